@@ -1,0 +1,176 @@
+/*
+ * mudg_hip.h — C-ABI of libmudg_hip.so: the MI355X (gfx950) kernels under MuDG's
+ * video-diffusion denoising path (3D-UNet + DDIM update + AutoencoderKL decode).
+ *
+ * The reference (heiheishuang/MuDG) has no FFI layer: its hot path is PyTorch
+ * module code whose arithmetic is dispatched implicitly to ATen/cuDNN/cuBLAS.
+ * Each entry point below replaces one such implicit kernel class; the reference
+ * call sites it stands in for are cited as file:line (relative to the reference
+ * tree).  SURVEY.md §2.1 numbers the classes K1..K16.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless
+ *     named host_*; the caller owns and allocates all buffers (outputs too);
+ *   - activations are channels-last: a tensor (F, H, W, C) is a row-major
+ *     matrix of F*H*W rows ("pixels"/"tokens") by C channels, bf16;
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*; NULL = the
+ *     default stream) and returns immediately;
+ *   - return value: 0 on success, a negative MUDG_E* code on error; nothing is
+ *     thrown across the ABI and no call synchronises the device;
+ *   - no hidden global state apart from the optional event profiler.
+ */
+#ifndef MUDG_HIP_H
+#define MUDG_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MUDG_OK          0
+#define MUDG_EINVAL     -1   /* bad argument (shape / alignment / null pointer) */
+#define MUDG_ELAUNCH    -2   /* the HIP runtime rejected a launch */
+#define MUDG_EUNSUPPORTED -3 /* shape outside what the kernels implement */
+
+/* ABI version; bumped whenever a struct below changes. */
+int mudg_version(void);
+/* Text for the most recent non-zero return on this thread. */
+const char* mudg_last_error(void);
+
+/* ------------------------------------------------------------------ GEMM / conv
+ * Y[m][n] = epilogue( alpha * sum_k X[m][k] * W[n][k] )          (bf16 in, fp32 accumulate)
+ *
+ * One MFMA kernel serves every dense contraction on the path:
+ *   mode 0  plain GEMM           nn.Linear / 1x1 Conv / Conv1d k=1
+ *                                (attention.py:53-57,424,447,493,519,582,602; openaimodel3d.py:168-174,187;
+ *                                 ae_modules.py:31-50 q/k/v/proj_out, :181 nin_shortcut; autoencoder.py:35)
+ *   mode 1  3x3 conv, pad 1      implicit GEMM over 9 taps on NHWC input, stride 1|2, optional
+ *                                nearest-2x upsample fused into the read
+ *                                (openaimodel3d.py:66-70,96,103,154,179,401,564; ae_modules.py:117-127,162-175,499,535)
+ *   mode 2  temporal (3,1,1) conv implicit GEMM over 3 taps along T on (B,T,H,W,C)
+ *                                (openaimodel3d.py:255-266)
+ * W is always [N][K] row-major with K = taps*Cin ordered tap-major (the host packs it once).
+ * X may be split over two sources along channels (skip-concat, openaimodel3d.py:621):
+ * channels [0,csplit) come from X, [csplit,Cin) from X2.
+ */
+typedef struct MudgGemmDesc {
+    const void* X;        /* bf16 activations */
+    const void* X2;       /* second channel source or NULL */
+    const void* W;        /* bf16 packed weights [N][K] */
+    void*       Y;        /* bf16 (or fp32 if out_fp32) [M][ldy] */
+    const float* bias;    /* fp32 [N] or NULL (packed like W's rows) */
+    const float* gbias;   /* fp32 [M/rows_per_group][Nout] or NULL: per-row-group bias
+                             (timestep-embedding add, openaimodel3d.py:219-228) */
+    const void* R;        /* bf16 residual [M][ldr] or NULL, added last */
+    int M, N, K;
+    int ldx, ldx2, ldw, ldy, ldr;   /* row strides in elements */
+    int csplit;           /* channels served by X (== Cin when X2 is NULL) */
+    int batch;            /* blockIdx.z count (>=1) */
+    int64_t sX, sW, sY, sR;         /* per-batch strides in elements */
+    int rows_per_group;   /* for gbias; 0 = unused */
+    int out_fp32;         /* 1: Y is fp32 */
+    int geglu;            /* 1: W rows are packed [32 value | 32 gate] blocks and
+                             Y[m][j] = v_j * gelu_erf(g_j), Nout = N/2 (attention.py:579-586) */
+    float alpha;
+    int mode;             /* 0 | 1 | 2 */
+    /* mode 1 */
+    int Hin, Win, Hout, Wout, Cin, stride, upsample;
+    /* mode 2 */
+    int T, HW;
+} MudgGemmDesc;
+int mudg_gemm(const MudgGemmDesc* d, void* stream);
+
+/* ------------------------------------------------------------------ attention
+ * Flash-style softmax(scale * Q K^T) V for head dim 64, never materialising the score matrix.
+ *   spatial self-attention  attention.py:81-144 (attn1, 393)     Nq = Nk = H*W
+ *   text / image cross-attn attention.py:89-94,128-142 (attn2)   Nk = 77 / 16; `accumulate` adds
+ *                                                                 the second softmax's output
+ * Q : rows (f*Nq + i), head h at columns [h*64, h*64+64), row stride ldq
+ * K : rows ((f / kv_div)*Nk + j), same column convention, row stride ldk
+ * Vt: V transposed per (kv batch, head): row (h*64 + d), column j, row stride ldvt,
+ *     batch stride svt elements (the producing GEMM writes it in this layout)
+ * O : like Q with row stride ldo
+ */
+typedef struct MudgAttnDesc {
+    const void* Q; const void* K; const void* Vt; void* O;
+    int F, heads, Nq, Nk;
+    int ldq, ldk, ldvt, ldo;
+    int64_t svt;
+    int kv_div;          /* frames sharing one K/V batch entry (T for text context, 1 otherwise) */
+    float scale;         /* dim_head**-0.5 */
+    int accumulate;      /* 1: O += result */
+} MudgAttnDesc;
+int mudg_attention(const MudgAttnDesc* d, void* stream);
+
+/* Temporal self-attention over T <= 32 frames per pixel (attention.py:529-576 via 81-144):
+ * QKV rows are ((b*T + t)*HW + p); q at columns [h*64..], k at C + h*64, v at 2C + h*64. */
+int mudg_temporal_attention(const void* QKV, void* O, int B, int T, int HW, int heads,
+                            int ldqkv, int ldo, float scale, void* stream);
+
+/* ------------------------------------------------------------------ normalisation
+ * GroupNorm(32 groups) on channels-last data with optional fused SiLU / swish
+ * (basics.py:76-87 GroupNormSpecific eps 1e-5; openaimodel3d.py:256-265; attention.py:420,488 eps 1e-6;
+ *  ae_modules.py:10-16 eps 1e-6).  Statistics are per (sample, group) over `rows` pixels, where a
+ * sample is one frame (2D norms) or one clip of T frames (the 5-D norms).  Two sources as in GEMM.
+ * `ws` is fp32 scratch of at least mudg_groupnorm_ws_floats(samples, groups, rows).
+ */
+int64_t mudg_groupnorm_ws_floats(int samples, int groups, int rows);
+int mudg_groupnorm(const void* X, const void* X2, int csplit, int ldx, int ldx2,
+                   const float* gamma, const float* beta, void* Y, int ldy,
+                   int samples, int rows, int C, int groups, float eps, int silu,
+                   float* ws, void* stream);
+
+/* LayerNorm over the last dim (attention.py:363-365, eps 1e-5). */
+int mudg_layernorm(const void* X, int ldx, const float* gamma, const float* beta,
+                   void* Y, int ldy, int rows, int C, float eps, void* stream);
+
+/* Row softmax of fp32 scores (already scaled) to bf16 probabilities
+ * (ae_modules.py:64-68: the VAE's single-head d=512 attention). */
+int mudg_softmax_rows(const float* S, int lds, void* P, int ldp, int rows, int cols, void* stream);
+
+/* ------------------------------------------------------------------ embeddings / small linears
+ * Sinusoidal embedding (utils_diffusion.py:8-28): out[i][:] = [cos(t_i f_j), sin(t_i f_j)], fp32.
+ * freqs: device fp32 [dim/2] table exp(-ln(max_period) j / (dim/2)), built on the host as the reference does. */
+int mudg_timestep_embedding(const int64_t* t, const float* freqs, float* out, int n, int dim, void* stream);
+/* y[m][n] = act_out( sum_k act_in(x[m][k]) * W[n][k] + b[n] ), fp32 I/O, bf16 or fp32 weights, m <= 64
+ * (time/class/fps MLPs openaimodel3d.py:377-397,569-602; ResBlock emb_layers 168-174). act: 0 none, 1 SiLU. */
+int mudg_small_linear(const float* x, const void* W, int w_is_bf16, const float* b, float* y,
+                      int M, int N, int K, int act_in, int act_out, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------ layout changes at the API boundary
+ * (b c t h w) fp32/bf16 -> channels-last bf16 rows ((b t) h w) with channel offset/stride
+ * (openaimodel3d.py:591; ddpm3d.py:1317-1319 channel concat of x and c_concat), and back (openaimodel3d.py:627). */
+int mudg_ncthw_to_rows(const void* src, int src_is_fp32, void* dst, int B, int C, int T, int HW,
+                       int ld, int coff, void* stream);
+int mudg_rows_to_ncthw(const void* src, int ld, int coff, void* dst, int dst_is_fp32,
+                       int B, int C, int T, int HW, float scale, void* stream);
+/* Zero the channel range [c0, c1) of a rows buffer (padding lanes of the stem input). */
+int mudg_zero_channels(void* dst, int rows, int ld, int c0, int c1, void* stream);
+
+/* ------------------------------------------------------------------ DDIM update (ddim.py:205-279)
+ * One call per step on fp32 latents, n elements per sample:
+ *   v  = e_u + cfg*(e_c - e_u);  v = phi*v*std(e_c)/std(v) + (1-phi)*v   (utils_diffusion.py:147-157)
+ *   e  = sqrt_ac*v + sqrt_1mac*x ;  x0 = sqrt_ac*x - sqrt_1mac*v          (ddpm3d.py:239-251)
+ *   x0 *= rescale ;  x_prev = sqrt(a_prev)*x0 + dir_coef*e + sigma*noise
+ * host_coef = {cfg, phi, sqrt_ac, sqrt_1mac, rescale, sqrt_a_prev, dir_coef, sigma} (HOST pointer, 8 floats).
+ * ws: fp64 device scratch of mudg_ddim_ws_doubles(B) doubles. e_u may be NULL (no guidance: v = e_c);
+ * noise may be NULL (eta = 0). */
+int64_t mudg_ddim_ws_doubles(int B);
+int mudg_ddim_step(const float* x, const float* e_c, const float* e_u, const float* noise,
+                   float* x_prev, float* pred_x0, int B, int64_t n, const float* host_coef,
+                   double* ws, void* stream);
+
+/* ------------------------------------------------------------------ event profiler (bench.py roofline)
+ * When enabled, every launch of kernel family `fam` is bracketed by hipEvents on its own stream. */
+enum { MUDG_FAM_GEMM = 0, MUDG_FAM_CONV = 1, MUDG_FAM_TCONV = 2, MUDG_FAM_ATTN = 3, MUDG_FAM_TATTN = 4,
+       MUDG_FAM_GNORM = 5, MUDG_FAM_LNORM = 6, MUDG_FAM_MISC = 7, MUDG_FAM_COUNT = 8 };
+int mudg_prof_enable(int family_mask);       /* 0 disables and drops pending events */
+/* Synchronises the recorded events and returns totals since the last reset. */
+int mudg_prof_collect(int fam, double* total_ms, int64_t* launches, double* flops, double* bytes);
+int mudg_prof_reset(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

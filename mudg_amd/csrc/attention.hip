@@ -1,0 +1,330 @@
+// attention.hip — softmax(scale * Q K^T) V for head dim 64 on gfx950.
+//
+// mudg_attention: flash-style (online softmax, score matrix never leaves registers).
+//   Workgroup = 4 waves = 128 query rows; each wave owns 32 query rows for the whole key loop.
+//   Scores are produced TRANSPOSED: S^T = K Q^T via v_mfma_f32_32x32x16_bf16 with A = K tile, B = Q fragments, so
+//   lane (q = lane&31, half = lane>>5) holds 16 of the 32 keys of a sub-tile for ITS query row: row max / row sum
+//   are in-lane reductions plus one lane<->lane^32 exchange.  O^T = V^T P^T is accumulated the same way
+//   (A = V^T tile rows = head-dim, B = P of the lane's own keys), which needs no cross-lane movement of P at all:
+//   the contraction index of the second MFMA is simply enumerated in the key order the first MFMA left in the
+//   registers (keys {0-3, 8-11} / {4-7, 12-15} per half), and the V^T fragment is gathered with two 8-byte LDS
+//   reads in that same order.  V arrives already transposed (the projection GEMM writes V^T), so both LDS tiles
+//   are filled with plain 16-byte row copies.
+//   K/V tiles (64 keys) are staged global -> registers -> LDS with two LDS buffers and one barrier per tile.
+//   Workgroups are numbered so that the query tiles of one (frame, head) run on one XCD and share its L2.
+//
+// mudg_temporal_attention: T <= 32 keys per pixel — a bandwidth problem.  One wave per (pixel, head), fp32 VALU
+//   dot products with K/V of that pixel in LDS; no MFMA.
+#include "common.h"
+
+namespace {
+
+constexpr int QB = 128;     // query rows per workgroup
+constexpr int KB = 64;      // keys per tile
+constexpr int ALD = 72;     // LDS row stride in bf16 (64 + 8 pad -> 144 B)
+constexpr int ATILE = 64 * ALD;
+
+__global__ __launch_bounds__(256, 2) void attn_kernel(const MudgAttnDesc p, const int nqt, const int total) {
+    __shared__ __attribute__((aligned(16))) bf16 Ks[2 * ATILE];
+    __shared__ __attribute__((aligned(16))) bf16 Vs[2 * ATILE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    // XCD-aware numbering: hardware places block b on XCD b % 8; give each XCD a contiguous range of work items.
+    int w;
+    {
+        const int q8 = total >> 3, r8 = total & 7;
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        w = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    }
+    const int pair = w / nqt, qt = w - pair * nqt;
+    const int f = pair / p.heads, h = pair - f * p.heads;
+    const int kvb = f / p.kv_div;
+
+    const bf16* Qp = reinterpret_cast<const bf16*>(p.Q) + (int64_t)f * p.Nq * p.ldq + h * 64;
+    const bf16* Kp = reinterpret_cast<const bf16*>(p.K) + (int64_t)kvb * p.Nk * p.ldk + h * 64;
+    const bf16* Vp = reinterpret_cast<const bf16*>(p.Vt) + (int64_t)kvb * p.svt + (int64_t)(h * 64) * p.ldvt;
+    bf16* Op = reinterpret_cast<bf16*>(p.O) + (int64_t)f * p.Nq * p.ldo + h * 64;
+
+    const int q = qt * QB + wave * 32 + l31;
+    const bool qok = q < p.Nq;
+
+    bf16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+        qf[ks] = as_bf16x8(qok ? ld16(Qp + (int64_t)q * p.ldq + ks * 16 + hi * 8) : zero16());
+
+    const int lrow = tid >> 3, kc = tid & 7;   // staging: rows lrow, lrow+32; 16-byte chunk kc
+    u32x4 kr[2], vr[2];
+    auto load_tiles = [&](int kt) {
+        const int j0 = kt * KB;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = lrow + 32 * i;
+            const int j = j0 + row;                       // key index for the K tile row
+            kr[i] = (j < p.Nk) ? ld16(Kp + (int64_t)j * p.ldk + kc * 8) : zero16();
+            const int jc = j0 + kc * 8;                   // first key of this V^T chunk (row = head-dim index)
+            u32x4 v = zero16();
+            if (jc < p.Nk) {
+                v = ld16(Vp + (int64_t)row * p.ldvt + jc);
+                if (jc + 8 > p.Nk) {                       // ragged tail: keys >= Nk must contribute exactly 0
+                    bf16x8 hv = as_bf16x8(v);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) if (jc + e >= p.Nk) hv[e] = (bf16)0.f;
+                    v = as_u32x4(hv);
+                }
+            }
+            vr[i] = v;
+        }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            st16(&Ks[buf * ATILE + (lrow + 32 * i) * ALD + kc * 8], kr[i]);
+            st16(&Vs[buf * ATILE + (lrow + 32 * i) * ALD + kc * 8], vr[i]);
+        }
+    };
+
+    f32x16 o[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;
+    const float c = p.scale * 1.4426950408889634f;   // scores are exponentiated in base 2
+
+    const int nkt = (p.Nk + KB - 1) / KB;
+    load_tiles(0);
+    stage(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        const bool more = kt + 1 < nkt;
+        if (more) load_tiles(kt + 1);
+
+        // ---- S^T = K Q^T for the two 32-key sub-tiles
+        f32x16 s[2];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[sub][r] = 0.f;
+            const bf16* kp = Ks + cur * ATILE + (sub * 32 + l31) * ALD + hi * 8;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kp + ks * 16);
+                s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[sub], 0, 0, 0);
+            }
+        }
+        if (kt * KB + KB > p.Nk) {   // ragged last tile
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int j = kt * KB + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (j >= p.Nk) s[sub][r] = -INFINITY;
+                }
+        }
+
+        // ---- online softmax (per query row = per lane; halves exchange once)
+        float mx = s[0][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = exp2f((m_run - m_new) * c);
+        const float mc = m_new * c;
+        m_run = m_new;
+        float ps = 0.f;
+        bf16x8 pk[2][2];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = exp2f(s[sub][r] * c - mc);
+                ps += e;
+                pk[sub][r >> 3][r & 7] = (bf16)e;
+            }
+        l_run = l_run * alpha + ps;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+
+        // ---- O^T += V^T P^T ; contraction slots follow the key order the score MFMA left in registers
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            const bf16* vp = Vs + cur * ATILE + (dt * 32 + l31) * ALD + 4 * hi;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int kk = sub * 32 + jj * 16;
+                    const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vp + kk);
+                    const bf16x4 up = *reinterpret_cast<const bf16x4*>(vp + kk + 8);
+                    bf16x8 vf;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { vf[e] = lo[e]; vf[4 + e] = up[e]; }
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pk[sub][jj], o[dt], 0, 0, 0);
+                }
+        }
+
+        if (more) stage(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- normalise and store: lane holds, for its query row, head-dim columns dt*32 + 8g + 4*hi + {0..3}
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.f / l_tot;
+    if (qok) {
+        bf16* orow = Op + (int64_t)q * p.ldo;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bf16* dst = orow + dt * 32 + 8 * g + 4 * hi;
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = o[dt][4 * g + j] * inv;
+                if (p.accumulate) {
+                    Pack8 old; old.u = *reinterpret_cast<const u32x2*>(dst);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] += (float)old.h[j];
+                }
+                Pack8 nw;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) nw.h[j] = (bf16)v[j];
+                *reinterpret_cast<u32x2*>(dst) = nw.u;
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ temporal
+// TP = padded sequence length (16 or 32); DP = 64 / TP lanes share one query row, each owning DW = 64 / DP dims.
+template <int TP>
+__global__ __launch_bounds__(256) void tattn_kernel(const bf16* __restrict__ QKV, bf16* __restrict__ O,
+                                                     int B, int T, int HW, int heads, int ldqkv, int ldo,
+                                                     float scale, int total) {
+    constexpr int DP = 64 / TP, DW = 64 / DP;
+    __shared__ __attribute__((aligned(16))) bf16 Ks[4][TP * 64];
+    __shared__ __attribute__((aligned(16))) bf16 Vs[4][TP * 64];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tq = lane / DP, dp = lane % DP;
+    const int w = blockIdx.x * 4 + wave;
+    const bool wok = w < total;
+    const int bp = wok ? w / heads : 0, h = wok ? w - bp * heads : 0;
+    const int b = bp / HW, px = bp - b * HW;
+    const int C = heads * 64;
+    const bool rok = wok && tq < T;
+
+    const int64_t row = ((int64_t)(b * T + tq) * HW + px);
+    const bf16* src = QKV + row * ldqkv + h * 64 + dp * DW;
+
+    float qv[DW];
+#pragma unroll
+    for (int i = 0; i < DW / 8; ++i) {
+        const bf16x8 t = as_bf16x8(rok ? ld16(src + i * 8) : zero16());
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qv[i * 8 + e] = (float)t[e];
+    }
+#pragma unroll
+    for (int i = 0; i < DW / 8; ++i) {
+        st16(&Ks[wave][tq * 64 + dp * DW + i * 8], rok ? ld16(src + C + i * 8) : zero16());
+        st16(&Vs[wave][tq * 64 + dp * DW + i * 8], rok ? ld16(src + 2 * C + i * 8) : zero16());
+    }
+    __syncthreads();
+
+    float sc[TP];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < TP; ++j) {
+        float a = 0.f;
+#pragma unroll
+        for (int i = 0; i < DW / 8; ++i) {
+            const bf16x8 kk = *reinterpret_cast<const bf16x8*>(&Ks[wave][j * 64 + dp * DW + i * 8]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a = fmaf(qv[i * 8 + e], (float)kk[e], a);
+        }
+#pragma unroll
+        for (int o = 1; o < DP; o <<= 1) a += __shfl_xor(a, o, 64);
+        a = (j < T) ? a * scale : -INFINITY;
+        sc[j] = a;
+        mx = fmaxf(mx, a);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < TP; ++j) { sc[j] = __expf(sc[j] - mx); sum += sc[j]; }
+    const float inv = 1.f / sum;
+
+    float ov[DW];
+#pragma unroll
+    for (int d = 0; d < DW; ++d) ov[d] = 0.f;
+#pragma unroll
+    for (int j = 0; j < TP; ++j) {
+        const float pj = sc[j] * inv;
+#pragma unroll
+        for (int i = 0; i < DW / 8; ++i) {
+            const bf16x8 vv = *reinterpret_cast<const bf16x8*>(&Vs[wave][j * 64 + dp * DW + i * 8]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ov[i * 8 + e] = fmaf(pj, (float)vv[e], ov[i * 8 + e]);
+        }
+    }
+    if (rok) {
+        bf16* dst = O + row * ldo + h * 64 + dp * DW;
+#pragma unroll
+        for (int i = 0; i < DW / 8; ++i) {
+            bf16x8 t;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] = (bf16)ov[i * 8 + e];
+            st16(dst + i * 8, as_u32x4(t));
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int mudg_attention(const MudgAttnDesc* dp, void* stream) {
+    MUDG_REQUIRE(dp, "mudg_attention: null descriptor");
+    const MudgAttnDesc d = *dp;
+    MUDG_REQUIRE(d.Q && d.K && d.Vt && d.O, "mudg_attention: null pointer");
+    MUDG_REQUIRE(d.F > 0 && d.heads > 0 && d.Nq > 0 && d.Nk > 0, "mudg_attention: empty problem");
+    MUDG_REQUIRE(d.kv_div >= 1 && d.F % d.kv_div == 0, "mudg_attention: kv_div=%d F=%d", d.kv_div, d.F);
+    MUDG_REQUIRE((d.ldq & 7) == 0 && (d.ldk & 7) == 0 && (d.ldvt & 7) == 0 && (d.ldo & 3) == 0 && (d.svt & 7) == 0,
+                 "mudg_attention: row strides must be multiples of 8 (ldo of 4)");
+    MUDG_REQUIRE(d.ldvt >= d.Nk, "mudg_attention: ldvt=%d < Nk=%d", d.ldvt, d.Nk);
+    MUDG_REQUIRE(aligned16(d.Q) && aligned16(d.K) && aligned16(d.Vt) && aligned16(d.O), "mudg_attention: alignment");
+    const int nqt = (d.Nq + QB - 1) / QB;
+    const int64_t total = (int64_t)nqt * d.F * d.heads;
+    MUDG_REQUIRE(total < (1ll << 31), "mudg_attention: grid too large");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int slot = mudg_prof_begin(MUDG_FAM_ATTN, s);
+    hipLaunchKernelGGL(attn_kernel, dim3((unsigned)total), dim3(256), 0, s, d, nqt, (int)total);
+    const int rc = mudg_check_launch("mudg_attention");
+    const double bh = (double)d.F * d.heads;
+    mudg_prof_end(slot, s, 4.0 * bh * d.Nq * (double)d.Nk * 64.0,
+                  bh * (2.0 * d.Nq + 2.0 * d.Nk / d.kv_div) * 64.0 * 2.0);
+    return rc;
+}
+
+extern "C" int mudg_temporal_attention(const void* QKV, void* O, int B, int T, int HW, int heads,
+                                       int ldqkv, int ldo, float scale, void* stream) {
+    MUDG_REQUIRE(QKV && O, "mudg_temporal_attention: null pointer");
+    MUDG_REQUIRE(B > 0 && HW > 0 && heads > 0, "mudg_temporal_attention: empty problem");
+    MUDG_REQUIRE(T >= 1 && T <= 32, "mudg_temporal_attention: T=%d outside [1,32]", T);
+    MUDG_REQUIRE((ldqkv & 7) == 0 && (ldo & 7) == 0 && aligned16(QKV) && aligned16(O), "mudg_temporal_attention: alignment");
+    MUDG_REQUIRE(ldqkv >= 3 * heads * 64 && ldo >= heads * 64, "mudg_temporal_attention: row strides too small");
+    const int64_t total = (int64_t)B * HW * heads;
+    MUDG_REQUIRE(total < (1ll << 31), "mudg_temporal_attention: grid too large");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int slot = mudg_prof_begin(MUDG_FAM_TATTN, s);
+    const unsigned grid = (unsigned)((total + 3) / 4);
+    if (T <= 16)
+        hipLaunchKernelGGL(tattn_kernel<16>, dim3(grid), dim3(256), 0, s, (const bf16*)QKV, (bf16*)O, B, T, HW, heads,
+                           ldqkv, ldo, scale, (int)total);
+    else
+        hipLaunchKernelGGL(tattn_kernel<32>, dim3(grid), dim3(256), 0, s, (const bf16*)QKV, (bf16*)O, B, T, HW, heads,
+                           ldqkv, ldo, scale, (int)total);
+    const int rc = mudg_check_launch("mudg_temporal_attention");
+    mudg_prof_end(slot, s, 4.0 * total * (double)T * T * 64.0, (double)total * T * 64.0 * 2.0 * 4.0);
+    return rc;
+}

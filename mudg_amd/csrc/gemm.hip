@@ -1,0 +1,316 @@
+// gemm.hip — the one MFMA contraction kernel of the path (plain GEMM, 3x3 conv and temporal 3-tap conv as
+// implicit GEMMs on channels-last activations).  See include/mudg_hip.h (MudgGemmDesc) for semantics.
+//
+// Tiling (gfx950, wave64): 128x128 output tile per 256-thread workgroup, BK = 64, four waves as 2(M) x 2(N),
+// each wave owns 64x64 = 2x2 v_mfma_f32_32x32x16_bf16 tiles (64 fp32 accumulators per lane).
+// The MFMA is issued "transposed" (A operand = weight rows, B operand = activation rows) so that each lane ends
+// up with 4 consecutive output channels of one pixel — the epilogue then moves 16-byte pieces.
+// Staging: global -> registers -> LDS, two LDS buffers, one barrier per K-tile; rows padded to 72 bf16 (144 B),
+// which makes both the 16-B staging writes and the ds_read_b128 fragment reads bank-conflict free.
+// Epilogue: accumulators (+bias, GEGLU) -> fp32 LDS tile -> coalesced 16-B rows (+group bias, +residual) -> HBM.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int LDSLD = 72;                       // bf16 elements per LDS row (64 + 8 pad)
+constexpr int STGLD = 132;                      // fp32 per staging row (128 + 4 pad)
+constexpr int TILE = BM * LDSLD;                // elements per operand per buffer
+constexpr int SMEM_MAIN = 4 * TILE * 2;         // X[2] + W[2], bytes
+constexpr int SMEM_STG = BM * STGLD * 4 + BN * 4;
+constexpr int SMEM_BYTES = SMEM_MAIN > SMEM_STG ? SMEM_MAIN : SMEM_STG;
+
+constexpr int VF_Y = 1, VF_R = 2;               // 16-byte access allowed on Y / R
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const MudgGemmDesc p, const int vflags) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16* Xs = reinterpret_cast<bf16*>(smem);
+    bf16* Ws = Xs + 2 * TILE;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    const int ntn = (p.N + BN - 1) / BN;
+    const int tm = blockIdx.x / ntn, tn = blockIdx.x - tm * ntn;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int64_t bz = blockIdx.z;
+    const bf16* X = reinterpret_cast<const bf16*>(p.X) + bz * p.sX;
+    const bf16* X2 = p.X2 ? reinterpret_cast<const bf16*>(p.X2) + bz * p.sX : nullptr;
+    const bf16* W = reinterpret_cast<const bf16*>(p.W) + bz * p.sW;
+
+    const int lrow = tid >> 3, kc = tid & 7;
+
+    // Loader state for the four activation rows this thread stages.
+    int rm[4], ra[4], rb[4], rc[4];
+    bool rv[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + lrow + 32 * i;
+        rm[i] = m;
+        rv[i] = m < p.M;
+        ra[i] = rb[i] = rc[i] = 0;
+        if (MODE == 1) {
+            const int hw = p.Hout * p.Wout;
+            const int f = m / hw, r = m - f * hw;
+            const int oy = r / p.Wout, ox = r - oy * p.Wout;
+            ra[i] = f * p.Hin * p.Win;
+            rb[i] = oy * p.stride - 1;
+            rc[i] = ox * p.stride - 1;
+        } else if (MODE == 2) {
+            rb[i] = (m / p.HW) % p.T;
+        }
+    }
+
+    u32x4 xr[4], wr[4];
+
+    auto load_tiles = [&](int kt) {
+        const int k = kt * BK + kc * 8;
+        const bool kv = k < p.K;
+        // ---- activations
+        if (MODE == 0) {
+            const bf16* base = X; int kk = k, ld = p.ldx;
+            if (k >= p.csplit) { base = X2; kk = k - p.csplit; ld = p.ldx2; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                xr[i] = (rv[i] && kv) ? ld16(base + (int64_t)rm[i] * ld + kk) : zero16();
+        } else {
+            const int tap = k / p.Cin;
+            const int c = k - tap * p.Cin;
+            const bf16* base = X; int cc = c, ld = p.ldx;
+            if (c >= p.csplit) { base = X2; cc = c - p.csplit; ld = p.ldx2; }
+            if (MODE == 1) {
+                const int dy = tap / 3, dx = tap - dy * 3;
+                const int hlim = p.upsample ? 2 * p.Hin : p.Hin;
+                const int wlim = p.upsample ? 2 * p.Win : p.Win;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    int iy = rb[i] + dy, ix = rc[i] + dx;
+                    const bool ok = rv[i] && kv && iy >= 0 && iy < hlim && ix >= 0 && ix < wlim;
+                    if (p.upsample) { iy >>= 1; ix >>= 1; }
+                    xr[i] = ok ? ld16(base + (int64_t)(ra[i] + iy * p.Win + ix) * ld + cc) : zero16();
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int it = rb[i] + tap - 1;
+                    const bool ok = rv[i] && kv && it >= 0 && it < p.T;
+                    xr[i] = ok ? ld16(base + ((int64_t)rm[i] + (int64_t)(tap - 1) * p.HW) * ld + cc) : zero16();
+                }
+            }
+        }
+        // ---- weights
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = n0 + lrow + 32 * i;
+            wr[i] = (n < p.N && kv) ? ld16(W + (int64_t)n * p.ldw + k) : zero16();
+        }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            st16(&Xs[buf * TILE + (lrow + 32 * i) * LDSLD + kc * 8], xr[i]);
+            st16(&Ws[buf * TILE + (lrow + 32 * i) * LDSLD + kc * 8], wr[i]);
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int nk = (p.K + BK - 1) / BK;
+    load_tiles(0);
+    stage(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const bool more = kt + 1 < nk;
+        if (more) load_tiles(kt + 1);
+        const bf16* xs = Xs + cur * TILE + (wm * 64 + l31) * LDSLD + hi * 8;
+        const bf16* ws = Ws + cur * TILE + (wn * 64 + l31) * LDSLD + hi * 8;
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            bf16x8 wf[2], xf[2];
+            wf[0] = *reinterpret_cast<const bf16x8*>(ws + ks * 16);
+            wf[1] = *reinterpret_cast<const bf16x8*>(ws + 32 * LDSLD + ks * 16);
+            xf[0] = *reinterpret_cast<const bf16x8*>(xs + ks * 16);
+            xf[1] = *reinterpret_cast<const bf16x8*>(xs + 32 * LDSLD + ks * 16);
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
+        }
+        if (more) stage(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ------------------------------------------------------------------ epilogue
+    float* stg = reinterpret_cast<float*>(smem);
+    float* sbias = stg + BM * STGLD;
+    if (tid < BN) sbias[tid] = (p.bias && n0 + tid < p.N) ? p.bias[n0 + tid] : 0.f;
+    __syncthreads();
+
+    const float alpha = p.alpha;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        const int ml = wm * 64 + mi * 32 + l31;
+        if (!p.geglu) {
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int nl = wn * 64 + ni * 32 + 8 * g + 4 * hi;
+                    f32x4 v;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = alpha * acc[ni][mi][4 * g + j] + sbias[nl + j];
+                    *reinterpret_cast<f32x4*>(&stg[ml * STGLD + nl]) = v;
+                }
+        } else {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int nl = wn * 64 + 8 * g + 4 * hi;      // value columns; gates sit 32 further
+                f32x4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float val = alpha * acc[0][mi][4 * g + j] + sbias[nl + j];
+                    const float gate = alpha * acc[1][mi][4 * g + j] + sbias[nl + 32 + j];
+                    v[j] = val * gelu_erf_f(gate);
+                }
+                *reinterpret_cast<f32x4*>(&stg[ml * STGLD + wn * 32 + 8 * g + 4 * hi]) = v;
+            }
+        }
+    }
+    __syncthreads();
+
+    const int NT = p.geglu ? BN / 2 : BN;
+    const int Nout = p.geglu ? p.N / 2 : p.N;
+    const int nout0 = p.geglu ? n0 / 2 : n0;
+    const int cpr = NT / 8;
+    const bf16* R = p.R ? reinterpret_cast<const bf16*>(p.R) + bz * p.sR : nullptr;
+    for (int c = tid; c < BM * cpr; c += 256) {
+        const int row = c / cpr, cc = c - row * cpr;
+        const int m = m0 + row, n = nout0 + cc * 8;
+        if (m >= p.M || n >= Nout) continue;
+        const int nvalid = (Nout - n) < 8 ? (Nout - n) : 8;
+        float v[8];
+        {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(&stg[row * STGLD + cc * 8]);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(&stg[row * STGLD + cc * 8 + 4]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[j] = a[j]; v[4 + j] = b[j]; }
+        }
+        if (p.gbias) {
+            const float* gb = p.gbias + (int64_t)(m / p.rows_per_group) * Nout + n;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (j < nvalid) v[j] += gb[j];
+        }
+        if (R) {
+            const bf16* rp = R + (int64_t)m * p.ldr + n;
+            if (nvalid == 8 && (vflags & VF_R)) {
+                const bf16x8 rr = as_bf16x8(ld16(rp));
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += (float)rr[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (j < nvalid) v[j] += (float)rp[j];
+            }
+        }
+        if (p.out_fp32) {
+            float* yp = reinterpret_cast<float*>(p.Y) + bz * p.sY + (int64_t)m * p.ldy + n;
+            if (nvalid == 8 && (vflags & VF_Y)) {
+                f32x4 a, b;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { a[j] = v[j]; b[j] = v[4 + j]; }
+                *reinterpret_cast<f32x4*>(yp) = a;
+                *reinterpret_cast<f32x4*>(yp + 4) = b;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (j < nvalid) yp[j] = v[j];
+            }
+        } else {
+            bf16* yp = reinterpret_cast<bf16*>(p.Y) + bz * p.sY + (int64_t)m * p.ldy + n;
+            if (nvalid == 8 && (vflags & VF_Y)) {
+                bf16x8 o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (bf16)v[j];
+                st16(yp, as_u32x4(o));
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (j < nvalid) yp[j] = (bf16)v[j];
+            }
+        }
+    }
+}
+
+template <int MODE>
+int launch(const MudgGemmDesc& d, int vflags, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<MODE>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+        if (e != hipSuccess) MUDG_FAIL(MUDG_ELAUNCH, "gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    const int tiles = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
+    dim3 grid(tiles, 1, d.batch);
+    hipLaunchKernelGGL(gemm_kernel<MODE>, grid, dim3(256), SMEM_BYTES, s, d, vflags);
+    return mudg_check_launch("mudg_gemm");
+}
+
+}  // namespace
+
+extern "C" int mudg_gemm(const MudgGemmDesc* dp, void* stream) {
+    MUDG_REQUIRE(dp, "mudg_gemm: null descriptor");
+    MudgGemmDesc d = *dp;
+    MUDG_REQUIRE(d.X && d.W && d.Y, "mudg_gemm: null X/W/Y");
+    MUDG_REQUIRE(d.M > 0 && d.N > 0 && d.K > 0, "mudg_gemm: empty problem M=%d N=%d K=%d", d.M, d.N, d.K);
+    MUDG_REQUIRE(d.mode >= 0 && d.mode <= 2, "mudg_gemm: mode %d", d.mode);
+    MUDG_REQUIRE((d.K & 7) == 0, "mudg_gemm: K=%d must be a multiple of 8", d.K);
+    MUDG_REQUIRE((d.ldx & 7) == 0 && (d.ldw & 7) == 0, "mudg_gemm: ldx=%d ldw=%d must be multiples of 8", d.ldx, d.ldw);
+    MUDG_REQUIRE(aligned16(d.X) && aligned16(d.W), "mudg_gemm: X/W must be 16-byte aligned");
+    MUDG_REQUIRE((d.sX & 7) == 0 && (d.sW & 7) == 0, "mudg_gemm: batch strides must be multiples of 8");
+    if (d.batch < 1) d.batch = 1;
+    const int cin = d.mode == 0 ? d.K : d.Cin;
+    if (!d.X2) d.csplit = cin;
+    else {
+        MUDG_REQUIRE(aligned16(d.X2) && (d.ldx2 & 7) == 0, "mudg_gemm: X2 alignment");
+        MUDG_REQUIRE(d.csplit > 0 && d.csplit < cin && (d.csplit & 7) == 0, "mudg_gemm: csplit=%d", d.csplit);
+    }
+    if (d.mode == 1) {
+        MUDG_REQUIRE(d.Cin > 0 && (d.Cin & 7) == 0 && d.K == 9 * d.Cin, "mudg_gemm: conv K=%d Cin=%d", d.K, d.Cin);
+        MUDG_REQUIRE(d.stride == 1 || d.stride == 2, "mudg_gemm: stride %d", d.stride);
+        MUDG_REQUIRE(!(d.upsample && d.stride != 1), "mudg_gemm: upsample needs stride 1");
+        MUDG_REQUIRE(d.Hin > 0 && d.Win > 0 && d.Hout > 0 && d.Wout > 0, "mudg_gemm: conv geometry");
+        MUDG_REQUIRE(d.M % (d.Hout * d.Wout) == 0, "mudg_gemm: M not a whole number of frames");
+    } else if (d.mode == 2) {
+        MUDG_REQUIRE(d.Cin > 0 && (d.Cin & 7) == 0 && d.K == 3 * d.Cin, "mudg_gemm: tconv K=%d Cin=%d", d.K, d.Cin);
+        MUDG_REQUIRE(d.T > 0 && d.HW > 0 && d.M % (d.T * d.HW) == 0, "mudg_gemm: tconv geometry");
+    }
+    if (d.geglu) MUDG_REQUIRE((d.N & 63) == 0, "mudg_gemm: geglu needs N %% 64 == 0");
+    if (d.gbias) MUDG_REQUIRE(d.rows_per_group > 0 && d.batch == 1, "mudg_gemm: gbias needs rows_per_group");
+    if (d.alpha == 0.f) d.alpha = 1.f;
+    int vflags = 0;
+    const int ybytes = d.out_fp32 ? 4 : 2;
+    if (aligned16(d.Y) && ((int64_t)d.ldy * ybytes) % 16 == 0 && ((int64_t)d.sY * ybytes) % 16 == 0) vflags |= VF_Y;
+    if (d.R && aligned16(d.R) && (d.ldr & 7) == 0 && (d.sR & 7) == 0) vflags |= VF_R;
+
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int fam = d.mode == 0 ? MUDG_FAM_GEMM : (d.mode == 1 ? MUDG_FAM_CONV : MUDG_FAM_TCONV);
+    const int slot = mudg_prof_begin(fam, s);
+    int rc;
+    if (d.mode == 0) rc = launch<0>(d, vflags, s);
+    else if (d.mode == 1) rc = launch<1>(d, vflags, s);
+    else rc = launch<2>(d, vflags, s);
+    const double flops = 2.0 * d.M * (double)d.N * d.K * d.batch;
+    const double bytes = ((double)d.M * cin + (double)d.N * d.K + (double)d.M * (d.geglu ? d.N / 2 : d.N)) * 2.0 * d.batch;
+    mudg_prof_end(slot, s, flops, bytes);
+    return rc;
+}

@@ -1,0 +1,220 @@
+// misc.hip — the small kernels around the UNet: sinusoidal embeddings, the tiny fp32 MLPs on them, the
+// (b c t h w) <-> channels-last conversions at the API boundary and the fused DDIM update.
+#include "common.h"
+
+namespace {
+
+__global__ void temb_kernel(const int64_t* __restrict__ t, const float* __restrict__ freqs, float* __restrict__ out, int n,
+                            int dim) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int half = dim / 2;
+    if (i >= n * half) return;
+    const int r = i / half, j = i - r * half;
+    // freqs[j] = exp(-log(max_period) * j / half) is a host-made table (utils_diffusion.py:19-22 builds it on the CPU
+    // too); the product with the timestep and the cos/sin happen here, as they do on the device in the reference.
+    const float a = (float)t[r] * freqs[j];
+    out[(int64_t)r * dim + j] = cosf(a);
+    out[(int64_t)r * dim + half + j] = sinf(a);
+    if ((dim & 1) && j == 0) out[(int64_t)r * dim + dim - 1] = 0.f;
+}
+
+template <typename WT>
+__global__ __launch_bounds__(256) void small_linear_kernel(const float* __restrict__ x, const WT* __restrict__ W,
+                                                            const float* __restrict__ b, float* __restrict__ y, int M, int N,
+                                                            int K, int act_in, int act_out, int accumulate) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int m = blockIdx.y;
+    if (n >= N) return;
+    const float* xr = x + (int64_t)m * K;
+    const WT* wr = W + (int64_t)n * K;
+    float a = 0.f;
+    for (int k = lane; k < K; k += 64) {
+        float xv = xr[k];
+        if (act_in) xv = silu_f(xv);
+        a = fmaf(xv, (float)wr[k], a);
+    }
+    a = wave_sum(a);
+    if (lane == 0) {
+        if (b) a += b[n];
+        if (act_out) a = silu_f(a);
+        float* o = y + (int64_t)m * N + n;
+        *o = accumulate ? *o + a : a;
+    }
+}
+
+template <typename ST>
+__global__ void ncthw_to_rows_kernel(const ST* __restrict__ src, bf16* __restrict__ dst, int B, int C, int T, int HW,
+                                     int ld, int coff) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over (b, t, p)
+    const int64_t n = (int64_t)B * T * HW;
+    if (i >= n) return;
+    const int p = (int)(i % HW);
+    const int64_t bt = i / HW;
+    const int t = (int)(bt % T), b = (int)(bt / T);
+    for (int c = 0; c < C; ++c)
+        dst[i * ld + coff + c] = (bf16)(float)src[(((int64_t)b * C + c) * T + t) * HW + p];
+}
+
+template <typename DT>
+__global__ void rows_to_ncthw_kernel(const bf16* __restrict__ src, int ld, int coff, DT* __restrict__ dst, int B, int C,
+                                     int T, int HW, float scale) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t n = (int64_t)B * T * HW;
+    if (i >= n) return;
+    const int p = (int)(i % HW);
+    const int64_t bt = i / HW;
+    const int t = (int)(bt % T), b = (int)(bt / T);
+    for (int c = 0; c < C; ++c)
+        dst[(((int64_t)b * C + c) * T + t) * HW + p] = (DT)((float)src[i * ld + coff + c] * scale);
+}
+
+__global__ void zero_channels_kernel(bf16* __restrict__ dst, int64_t rows, int ld, int c0, int c1) {
+    const int w = c1 - c0;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * w) return;
+    dst[(i / w) * ld + c0 + (int)(i % w)] = (bf16)0.f;
+}
+
+// ---- DDIM -------------------------------------------------------------------------------------------------
+constexpr int DDIM_BLK = 64;   // partial-sum blocks per sample
+
+__global__ __launch_bounds__(256) void ddim_stats_kernel(const float* __restrict__ ec, const float* __restrict__ eu,
+                                                          int64_t n, float cfg, double* __restrict__ ws) {
+    __shared__ double red[4][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y;
+    const float* c = ec + (int64_t)b * n;
+    const float* u = eu ? eu + (int64_t)b * n : nullptr;
+    const int64_t per = (n + DDIM_BLK - 1) / DDIM_BLK;
+    const int64_t i0 = blockIdx.x * per, i1 = (i0 + per < n) ? i0 + per : n;
+    double sc = 0, qc = 0, sv = 0, qv = 0;
+    for (int64_t i = i0 + tid; i < i1; i += 256) {
+        const float a = c[i];
+        const float v = u ? u[i] + cfg * (a - u[i]) : a;
+        sc += a; qc += (double)a * a; sv += v; qv += (double)v * v;
+    }
+    sc = wave_sum_d(sc); qc = wave_sum_d(qc); sv = wave_sum_d(sv); qv = wave_sum_d(qv);
+    if (lane == 0) { red[wave][0] = sc; red[wave][1] = qc; red[wave][2] = sv; red[wave][3] = qv; }
+    __syncthreads();
+    if (tid < 4)
+        ws[((int64_t)b * DDIM_BLK + blockIdx.x) * 4 + tid] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+}
+
+struct DdimCoef { float cfg, phi, sqrt_ac, sqrt_1mac, rescale, sqrt_a_prev, dir_coef, sigma; };
+
+__global__ __launch_bounds__(256) void ddim_update_kernel(const float* __restrict__ x, const float* __restrict__ ec,
+                                                           const float* __restrict__ eu, const float* __restrict__ noise,
+                                                           float* __restrict__ x_prev, float* __restrict__ pred_x0, int64_t n,
+                                                           DdimCoef k, const double* __restrict__ ws) {
+    __shared__ float s_ratio;
+    const int b = blockIdx.y;
+    if (threadIdx.x == 0) {
+        float ratio = 1.f;
+        if (k.phi > 0.f) {
+            double sc = 0, qc = 0, sv = 0, qv = 0;
+            for (int i = 0; i < DDIM_BLK; ++i) {
+                const double* p = ws + ((int64_t)b * DDIM_BLK + i) * 4;
+                sc += p[0]; qc += p[1]; sv += p[2]; qv += p[3];
+            }
+            const double dn = (double)n;
+            const double var_c = (qc - sc * sc / dn) / (dn - 1.0);   // unbiased, as torch.std
+            const double var_v = (qv - sv * sv / dn) / (dn - 1.0);
+            const float std_c = (float)sqrt(var_c > 0 ? var_c : 0.0), std_v = (float)sqrt(var_v > 0 ? var_v : 0.0);
+            ratio = std_c / std_v;
+        }
+        s_ratio = ratio;
+    }
+    __syncthreads();
+    const float ratio = s_ratio;
+    const int64_t off = (int64_t)b * n;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float xv = x[off + i], a = ec[off + i];
+        float v = eu ? eu[off + i] + k.cfg * (a - eu[off + i]) : a;
+        if (k.phi > 0.f) {
+            const float resc = v * ratio;
+            v = k.phi * resc + (1.f - k.phi) * v;
+        }
+        const float e = k.sqrt_ac * v + k.sqrt_1mac * xv;
+        float x0 = k.sqrt_ac * xv - k.sqrt_1mac * v;
+        x0 *= k.rescale;
+        const float dir = k.dir_coef * e;
+        const float nz = noise ? k.sigma * noise[off + i] : 0.f;
+        pred_x0[off + i] = x0;
+        x_prev[off + i] = k.sqrt_a_prev * x0 + dir + nz;
+    }
+}
+
+}  // namespace
+
+extern "C" int mudg_timestep_embedding(const int64_t* t, const float* freqs, float* out, int n, int dim, void* stream) {
+    MUDG_REQUIRE(t && freqs && out && n > 0 && dim >= 2, "mudg_timestep_embedding: bad arguments");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int tot = n * (dim / 2);
+    hipLaunchKernelGGL(temb_kernel, dim3((tot + 255) / 256), dim3(256), 0, s, t, freqs, out, n, dim);
+    return mudg_check_launch("mudg_timestep_embedding");
+}
+
+extern "C" int mudg_small_linear(const float* x, const void* W, int w_is_bf16, const float* b, float* y, int M, int N, int K,
+                                 int act_in, int act_out, int accumulate, void* stream) {
+    MUDG_REQUIRE(x && W && y && M > 0 && N > 0 && K > 0, "mudg_small_linear: bad arguments");
+    MUDG_REQUIRE(M <= 65535, "mudg_small_linear: M too large");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const dim3 grid((N + 3) / 4, M);
+    if (w_is_bf16)
+        hipLaunchKernelGGL(small_linear_kernel<bf16>, grid, dim3(256), 0, s, x, (const bf16*)W, b, y, M, N, K, act_in, act_out, accumulate);
+    else
+        hipLaunchKernelGGL(small_linear_kernel<float>, grid, dim3(256), 0, s, x, (const float*)W, b, y, M, N, K, act_in, act_out, accumulate);
+    return mudg_check_launch("mudg_small_linear");
+}
+
+extern "C" int mudg_ncthw_to_rows(const void* src, int src_is_fp32, void* dst, int B, int C, int T, int HW, int ld, int coff,
+                                  void* stream) {
+    MUDG_REQUIRE(src && dst && B > 0 && C > 0 && T > 0 && HW > 0 && coff >= 0 && coff + C <= ld, "mudg_ncthw_to_rows: bad arguments");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int64_t n = (int64_t)B * T * HW;
+    const dim3 grid((unsigned)((n + 255) / 256));
+    if (src_is_fp32) hipLaunchKernelGGL(ncthw_to_rows_kernel<float>, grid, dim3(256), 0, s, (const float*)src, (bf16*)dst, B, C, T, HW, ld, coff);
+    else hipLaunchKernelGGL(ncthw_to_rows_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)src, (bf16*)dst, B, C, T, HW, ld, coff);
+    return mudg_check_launch("mudg_ncthw_to_rows");
+}
+
+extern "C" int mudg_rows_to_ncthw(const void* src, int ld, int coff, void* dst, int dst_is_fp32, int B, int C, int T, int HW,
+                                  float scale, void* stream) {
+    MUDG_REQUIRE(src && dst && B > 0 && C > 0 && T > 0 && HW > 0 && coff >= 0 && coff + C <= ld, "mudg_rows_to_ncthw: bad arguments");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int64_t n = (int64_t)B * T * HW;
+    const dim3 grid((unsigned)((n + 255) / 256));
+    if (dst_is_fp32) hipLaunchKernelGGL(rows_to_ncthw_kernel<float>, grid, dim3(256), 0, s, (const bf16*)src, ld, coff, (float*)dst, B, C, T, HW, scale);
+    else hipLaunchKernelGGL(rows_to_ncthw_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)src, ld, coff, (bf16*)dst, B, C, T, HW, scale);
+    return mudg_check_launch("mudg_rows_to_ncthw");
+}
+
+extern "C" int mudg_zero_channels(void* dst, int rows, int ld, int c0, int c1, void* stream) {
+    MUDG_REQUIRE(dst && rows > 0 && c0 >= 0 && c1 > c0 && c1 <= ld, "mudg_zero_channels: bad arguments");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int64_t n = (int64_t)rows * (c1 - c0);
+    hipLaunchKernelGGL(zero_channels_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (bf16*)dst, (int64_t)rows, ld, c0, c1);
+    return mudg_check_launch("mudg_zero_channels");
+}
+
+extern "C" int64_t mudg_ddim_ws_doubles(int B) { return B > 0 ? (int64_t)B * DDIM_BLK * 4 : 0; }
+
+extern "C" int mudg_ddim_step(const float* x, const float* e_c, const float* e_u, const float* noise, float* x_prev,
+                              float* pred_x0, int B, int64_t n, const float* host_coef, double* ws, void* stream) {
+    MUDG_REQUIRE(x && e_c && x_prev && pred_x0 && host_coef && ws, "mudg_ddim_step: null pointer");
+    MUDG_REQUIRE(B > 0 && B <= 65535 && n > 1, "mudg_ddim_step: bad sizes");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    DdimCoef k;
+    k.cfg = host_coef[0]; k.phi = host_coef[1]; k.sqrt_ac = host_coef[2]; k.sqrt_1mac = host_coef[3];
+    k.rescale = host_coef[4]; k.sqrt_a_prev = host_coef[5]; k.dir_coef = host_coef[6]; k.sigma = host_coef[7];
+    const int slot = mudg_prof_begin(MUDG_FAM_MISC, s);
+    if (k.phi > 0.f)
+        hipLaunchKernelGGL(ddim_stats_kernel, dim3(DDIM_BLK, B), dim3(256), 0, s, e_c, e_u, n, k.cfg, ws);
+    int gx = (int)((n + 255) / 256);
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(ddim_update_kernel, dim3(gx, B), dim3(256), 0, s, x, e_c, e_u, noise, x_prev, pred_x0, n, k, ws);
+    const int rc = mudg_check_launch("mudg_ddim_step");
+    mudg_prof_end(slot, s, 0.0, (double)B * n * 4.0 * 8.0);
+    return rc;
+}

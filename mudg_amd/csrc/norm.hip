@@ -1,0 +1,268 @@
+// norm.hip — GroupNorm(+SiLU), LayerNorm and row softmax on channels-last bf16 data.  All HBM-bound:
+// every pass moves 16 bytes per lane, statistics are fp32 partials combined in fp64 in a fixed order
+// (no atomics: results are bit-reproducible run to run).
+#include "common.h"
+
+namespace {
+
+constexpr int GN_CMAX = 4096;
+
+__host__ __device__ inline int gn_chunks(int samples, int rows) {
+    int want = 2048 / (samples > 0 ? samples : 1);
+    if (want < 1) want = 1;
+    int most = (rows + 15) / 16;
+    if (want > most) want = most;
+    if (want > 1024) want = 1024;
+    return want < 1 ? 1 : want;
+}
+
+// Pass 1: per (sample, row-chunk) per-group partial sum / sum of squares.
+__global__ __launch_bounds__(256) void gn_stats_kernel(const bf16* __restrict__ X, const bf16* __restrict__ X2,
+                                                        int csplit, int ldx, int ldx2, int rows, int C, int groups,
+                                                        int nchunks, float* __restrict__ part_out) {
+    __shared__ float part[4][64][16];
+    __shared__ float chsum[GN_CMAX * 2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int chunk = blockIdx.x, smp = blockIdx.y;
+    const int rpc = (rows + nchunks - 1) / nchunks;
+    const int r0 = chunk * rpc, r1 = (r0 + rpc < rows) ? r0 + rpc : rows;
+    const int nvec = C >> 3;
+    const int64_t srow = (int64_t)smp * rows;
+
+    for (int vbase = 0; vbase < nvec; vbase += 64) {
+        const int v = vbase + lane;
+        float s[8], q[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
+        if (v < nvec) {
+            const int c0 = v * 8;
+            const bf16* base = X; int cc = c0, ld = ldx;
+            if (c0 >= csplit) { base = X2; cc = c0 - csplit; ld = ldx2; }
+            for (int r = r0 + wave; r < r1; r += 4) {
+                const bf16x8 t = as_bf16x8(ld16(base + (srow + r) * ld + cc));
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float x = (float)t[e]; s[e] += x; q[e] = fmaf(x, x, q[e]); }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { part[wave][lane][e] = s[e]; part[wave][lane][8 + e] = q[e]; }
+        __syncthreads();
+        for (int i = tid; i < 64 * 16; i += 256) {
+            const int ln = i >> 4, j = i & 15;
+            const int vv = vbase + ln;
+            if (vv < nvec) {
+                const float t = ((part[0][ln][j] + part[1][ln][j]) + part[2][ln][j]) + part[3][ln][j];
+                const int ch = vv * 8 + (j & 7);
+                chsum[ch * 2 + (j >> 3)] = t;
+            }
+        }
+        __syncthreads();
+    }
+    if (tid < groups) {
+        const int cpg = C / groups;
+        float a = 0.f, b = 0.f;
+        for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { a += chsum[c * 2]; b += chsum[c * 2 + 1]; }
+        float* o = part_out + (((int64_t)smp * nchunks + chunk) * groups + tid) * 2;
+        o[0] = a; o[1] = b;
+    }
+}
+
+// Pass 2: fold the chunk partials (fp64, fixed order) into mean / rstd per (sample, group).
+__global__ void gn_finalize_kernel(const float* __restrict__ part, float* __restrict__ stat, int samples, int groups,
+                                   int nchunks, double count, float eps) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= samples * groups) return;
+    const int smp = i / groups, g = i - smp * groups;
+    double a = 0.0, b = 0.0;
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const float* p = part + (((int64_t)smp * nchunks + ch) * groups + g) * 2;
+        a += (double)p[0]; b += (double)p[1];
+    }
+    const double mean = a / count;
+    double var = b / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stat[i * 2] = (float)mean;
+    stat[i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+// Pass 3: y = (x - mean) * rstd * gamma + beta, optional SiLU.
+__global__ __launch_bounds__(256) void gn_apply_kernel(const bf16* __restrict__ X, const bf16* __restrict__ X2,
+                                                        int csplit, int ldx, int ldx2, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, bf16* __restrict__ Y, int ldy,
+                                                        int rows, int C, int groups, int nblk, int silu,
+                                                        const float* __restrict__ stat) {
+    __shared__ float sc[GN_CMAX], sh[GN_CMAX];
+    const int tid = threadIdx.x;
+    const int smp = blockIdx.y;
+    const int cpg = C / groups;
+    for (int c = tid; c < C; c += 256) {
+        const int g = c / cpg;
+        const float mean = stat[(smp * groups + g) * 2], rstd = stat[(smp * groups + g) * 2 + 1];
+        const float a = rstd * gamma[c];
+        sc[c] = a;
+        sh[c] = beta[c] - mean * a;
+    }
+    __syncthreads();
+    const int nvec = C >> 3;
+    const int rpb = (rows + nblk - 1) / nblk;
+    const int r0 = blockIdx.x * rpb, r1 = (r0 + rpb < rows) ? r0 + rpb : rows;
+    const int64_t srow = (int64_t)smp * rows;
+    const int n = (r1 - r0) * nvec;
+    for (int i = tid; i < n; i += 256) {
+        const int r = r0 + i / nvec, v = i % nvec;
+        const int c0 = v * 8;
+        const bf16* base = X; int cc = c0, ld = ldx;
+        if (c0 >= csplit) { base = X2; cc = c0 - csplit; ld = ldx2; }
+        const bf16x8 t = as_bf16x8(ld16(base + (srow + r) * ld + cc));
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float y = fmaf((float)t[e], sc[c0 + e], sh[c0 + e]);
+            if (silu) y = silu_f(y);
+            o[e] = (bf16)y;
+        }
+        st16(Y + (srow + r) * ldy + c0, as_u32x4(o));
+    }
+}
+
+// LayerNorm: one wave per row, up to VMAX 16-byte vectors per lane kept in registers (C <= 512 * VMAX).
+template <int VMAX>
+__global__ __launch_bounds__(256) void ln_kernel(const bf16* __restrict__ X, int ldx, const float* __restrict__ gamma,
+                                                  const float* __restrict__ beta, bf16* __restrict__ Y, int ldy,
+                                                  int rows, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nvec = C >> 3;
+    float x[VMAX][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VMAX; ++i) {
+        const int v = lane + 64 * i;
+        if (v < nvec) {
+            const bf16x8 t = as_bf16x8(ld16(X + row * ldx + v * 8));
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { x[i][e] = (float)t[e]; s += x[i][e]; }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[i][e] = 0.f;
+        }
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < VMAX; ++i) {
+        const int v = lane + 64 * i;
+        if (v < nvec) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = x[i][e] - mean; q = fmaf(d, d, q); }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+#pragma unroll
+    for (int i = 0; i < VMAX; ++i) {
+        const int v = lane + 64 * i;
+        if (v < nvec) {
+            const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + v * 8);
+            const f32x4 g1 = *reinterpret_cast<const f32x4*>(gamma + v * 8 + 4);
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + v * 8);
+            const f32x4 b1 = *reinterpret_cast<const f32x4*>(beta + v * 8 + 4);
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o[e] = (bf16)fmaf((x[i][e] - mean) * rstd, g0[e], b0[e]);
+                o[4 + e] = (bf16)fmaf((x[i][4 + e] - mean) * rstd, g1[e], b1[e]);
+            }
+            st16(Y + row * ldy + v * 8, as_u32x4(o));
+        }
+    }
+}
+
+// Row softmax fp32 -> bf16, one workgroup per row, three passes over the row (second and third hit L2).
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ S, int lds, bf16* __restrict__ P,
+                                                            int ldp, int cols) {
+    __shared__ float red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* s = S + (int64_t)blockIdx.x * lds;
+    bf16* p = P + (int64_t)blockIdx.x * ldp;
+    float mx = -INFINITY;
+    for (int c = tid; c < cols; c += 256) mx = fmaxf(mx, s[c]);
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float sum = 0.f;
+    for (int c = tid; c < cols; c += 256) sum += __expf(s[c] - mx);
+    sum = wave_sum(sum);
+    if (lane == 0) red[wave] = sum;
+    __syncthreads();
+    sum = ((red[0] + red[1]) + red[2]) + red[3];
+    const float inv = 1.f / sum;
+    for (int c = tid; c < cols; c += 256) p[c] = (bf16)(__expf(s[c] - mx) * inv);
+}
+
+}  // namespace
+
+extern "C" int64_t mudg_groupnorm_ws_floats(int samples, int groups, int rows) {
+    if (samples <= 0 || groups <= 0 || rows <= 0) return 0;
+    return (int64_t)samples * groups * 2 * (gn_chunks(samples, rows) + 1);
+}
+
+extern "C" int mudg_groupnorm(const void* X, const void* X2, int csplit, int ldx, int ldx2, const float* gamma,
+                              const float* beta, void* Y, int ldy, int samples, int rows, int C, int groups, float eps,
+                              int silu, float* ws, void* stream) {
+    MUDG_REQUIRE(X && Y && gamma && beta && ws, "mudg_groupnorm: null pointer");
+    MUDG_REQUIRE(samples > 0 && rows > 0 && C > 0 && groups > 0, "mudg_groupnorm: empty problem");
+    MUDG_REQUIRE(C % groups == 0 && (C & 7) == 0 && C <= GN_CMAX, "mudg_groupnorm: C=%d groups=%d unsupported", C, groups);
+    MUDG_REQUIRE(groups <= 256, "mudg_groupnorm: groups=%d > 256", groups);
+    MUDG_REQUIRE((ldx & 7) == 0 && (ldy & 7) == 0 && aligned16(X) && aligned16(Y), "mudg_groupnorm: alignment");
+    MUDG_REQUIRE(samples <= 65535, "mudg_groupnorm: too many samples");
+    if (!X2) { csplit = C; ldx2 = ldx; }
+    else MUDG_REQUIRE(csplit > 0 && csplit < C && (csplit & 7) == 0 && (ldx2 & 7) == 0 && aligned16(X2), "mudg_groupnorm: X2/csplit");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int nchunks = gn_chunks(samples, rows);
+    float* part = ws;
+    float* stat = ws + (int64_t)samples * nchunks * groups * 2;
+    const int slot = mudg_prof_begin(MUDG_FAM_GNORM, s);
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunks, samples), dim3(256), 0, s, (const bf16*)X, (const bf16*)X2, csplit,
+                       ldx, ldx2, rows, C, groups, nchunks, part);
+    const int ng = samples * groups;
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((ng + 255) / 256), dim3(256), 0, s, part, stat, samples, groups, nchunks,
+                       (double)rows * (C / groups), eps);
+    const int nblk = nchunks;
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(nblk, samples), dim3(256), 0, s, (const bf16*)X, (const bf16*)X2, csplit, ldx,
+                       ldx2, gamma, beta, (bf16*)Y, ldy, rows, C, groups, nblk, silu, stat);
+    const int rc = mudg_check_launch("mudg_groupnorm");
+    mudg_prof_end(slot, s, 0.0, (double)samples * rows * C * 2.0 * 3.0);
+    return rc;
+}
+
+extern "C" int mudg_layernorm(const void* X, int ldx, const float* gamma, const float* beta, void* Y, int ldy, int rows,
+                              int C, float eps, void* stream) {
+    MUDG_REQUIRE(X && Y && gamma && beta, "mudg_layernorm: null pointer");
+    MUDG_REQUIRE(rows > 0 && C > 0 && (C & 7) == 0 && C <= 4096, "mudg_layernorm: rows=%d C=%d unsupported", rows, C);
+    MUDG_REQUIRE((ldx & 7) == 0 && (ldy & 7) == 0 && aligned16(X) && aligned16(Y) && aligned16(gamma) && aligned16(beta),
+                 "mudg_layernorm: alignment");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int slot = mudg_prof_begin(MUDG_FAM_LNORM, s);
+    const dim3 grid((rows + 3) / 4);
+    const int nvec = C >> 3;
+    if (nvec <= 64 * 3)
+        hipLaunchKernelGGL(ln_kernel<3>, grid, dim3(256), 0, s, (const bf16*)X, ldx, gamma, beta, (bf16*)Y, ldy, rows, C, eps);
+    else
+        hipLaunchKernelGGL(ln_kernel<8>, grid, dim3(256), 0, s, (const bf16*)X, ldx, gamma, beta, (bf16*)Y, ldy, rows, C, eps);
+    const int rc = mudg_check_launch("mudg_layernorm");
+    mudg_prof_end(slot, s, 0.0, (double)rows * C * 2.0 * 2.0);
+    return rc;
+}
+
+extern "C" int mudg_softmax_rows(const float* S, int lds, void* P, int ldp, int rows, int cols, void* stream) {
+    MUDG_REQUIRE(S && P && rows > 0 && cols > 0, "mudg_softmax_rows: bad arguments");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int slot = mudg_prof_begin(MUDG_FAM_MISC, s);
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, s, S, lds, (bf16*)P, ldp, cols);
+    const int rc = mudg_check_launch("mudg_softmax_rows");
+    mudg_prof_end(slot, s, 0.0, (double)rows * cols * 6.0);
+    return rc;
+}

@@ -1,0 +1,110 @@
+"""ctypes binding of libmudg_hip.so — the only door from Python to the gfx950 kernels.
+
+Nothing here computes: every function marshals raw device pointers into the C-ABI declared in
+include/mudg_hip.h and raises on a non-zero return.  If the shared library is missing the import of `lib()`
+fails loudly — there is no CPU or eager-PyTorch fallback anywhere in the product path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmudg_hip.so")
+
+FAM_GEMM, FAM_CONV, FAM_TCONV, FAM_ATTN, FAM_TATTN, FAM_GNORM, FAM_LNORM, FAM_MISC = range(8)
+FAM_NAMES = ["gemm", "conv3x3", "tconv3", "attention", "temporal_attention", "groupnorm", "layernorm", "misc"]
+
+
+class MudgError(RuntimeError):
+    pass
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("X", C.c_void_p), ("X2", C.c_void_p), ("W", C.c_void_p), ("Y", C.c_void_p),
+        ("bias", C.c_void_p), ("gbias", C.c_void_p), ("R", C.c_void_p),
+        ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+        ("ldx", C.c_int), ("ldx2", C.c_int), ("ldw", C.c_int), ("ldy", C.c_int), ("ldr", C.c_int),
+        ("csplit", C.c_int), ("batch", C.c_int),
+        ("sX", C.c_int64), ("sW", C.c_int64), ("sY", C.c_int64), ("sR", C.c_int64),
+        ("rows_per_group", C.c_int), ("out_fp32", C.c_int), ("geglu", C.c_int),
+        ("alpha", C.c_float), ("mode", C.c_int),
+        ("Hin", C.c_int), ("Win", C.c_int), ("Hout", C.c_int), ("Wout", C.c_int),
+        ("Cin", C.c_int), ("stride", C.c_int), ("upsample", C.c_int),
+        ("T", C.c_int), ("HW", C.c_int),
+    ]
+
+
+class AttnDesc(C.Structure):
+    _fields_ = [
+        ("Q", C.c_void_p), ("K", C.c_void_p), ("Vt", C.c_void_p), ("O", C.c_void_p),
+        ("F", C.c_int), ("heads", C.c_int), ("Nq", C.c_int), ("Nk", C.c_int),
+        ("ldq", C.c_int), ("ldk", C.c_int), ("ldvt", C.c_int), ("ldo", C.c_int),
+        ("svt", C.c_int64), ("kv_div", C.c_int), ("scale", C.c_float), ("accumulate", C.c_int),
+    ]
+
+
+# name -> (restype, argtypes); this table is also what tests check against include/mudg_hip.h
+_P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
+SIGNATURES = {
+    "mudg_version": (_I, []),
+    "mudg_last_error": (C.c_char_p, []),
+    "mudg_gemm": (_I, [C.POINTER(GemmDesc), _P]),
+    "mudg_attention": (_I, [C.POINTER(AttnDesc), _P]),
+    "mudg_temporal_attention": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _F, _P]),
+    "mudg_groupnorm_ws_floats": (_L, [_I, _I, _I]),
+    "mudg_groupnorm": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P, _P]),
+    "mudg_layernorm": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _F, _P]),
+    "mudg_softmax_rows": (_I, [_P, _I, _P, _I, _I, _I, _P]),
+    "mudg_timestep_embedding": (_I, [_P, _P, _P, _I, _I, _P]),
+    "mudg_small_linear": (_I, [_P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "mudg_ncthw_to_rows": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "mudg_rows_to_ncthw": (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _I, _F, _P]),
+    "mudg_zero_channels": (_I, [_P, _I, _I, _I, _I, _P]),
+    "mudg_ddim_ws_doubles": (_L, [_I]),
+    "mudg_ddim_step": (_I, [_P, _P, _P, _P, _P, _P, _I, _L, C.POINTER(C.c_float), _P, _P]),
+    "mudg_prof_enable": (_I, [_I]),
+    "mudg_prof_collect": (_I, [_I, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
+                               C.POINTER(C.c_double)]),
+    "mudg_prof_reset": (_I, []),
+}
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load libmudg_hip.so (once).  Raises MudgError when it has not been built — never falls back."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise MudgError(
+                f"{LIB_PATH} is missing: build it with `python -m mudg_amd.build` (hipcc, gfx950). "
+                "mudg_amd has no CPU or eager fallback.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)      # AttributeError = symbol missing = broken build
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().mudg_last_error()
+        raise MudgError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+
+def prof_enable(mask: int) -> None:
+    check(lib().mudg_prof_enable(mask), "mudg_prof_enable")
+
+
+def prof_reset() -> None:
+    check(lib().mudg_prof_reset(), "mudg_prof_reset")
+
+
+def prof_collect(fam: int):
+    ms, n, fl, by = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
+    check(lib().mudg_prof_collect(fam, C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)), "mudg_prof_collect")
+    return {"family": FAM_NAMES[fam], "ms": ms.value, "launches": n.value, "flops": fl.value, "bytes": by.value}

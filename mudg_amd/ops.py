@@ -1,0 +1,231 @@
+"""Tensor-level wrappers over the C-ABI: torch tensors are used purely as device buffers (pointer, stride,
+stream); every arithmetic result on the hot path comes out of a HIP kernel in libmudg_hip.so.
+
+Activations are "rows" matrices: 2-D bf16 tensors [pixels, channels] whose row stride may exceed the channel
+count (views into wider buffers are fine as long as stride(1) == 1 and rows are 16-byte aligned).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional
+
+import torch
+
+from . import hip
+
+BF16 = torch.bfloat16
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _rows(t: torch.Tensor, dtype=BF16) -> torch.Tensor:
+    if t.dim() != 2 or t.stride(1) != 1 or t.dtype != dtype or not t.is_cuda:
+        raise hip.MudgError(f"expected a cuda {dtype} rows matrix with unit channel stride, got "
+                            f"{tuple(t.shape)} {t.dtype} strides {t.stride()} on {t.device}")
+    return t
+
+
+def empty_rows(rows: int, cols: int, dtype=BF16, device=None) -> torch.Tensor:
+    return torch.empty((rows, cols), dtype=dtype, device=device or "cuda")
+
+
+# ------------------------------------------------------------------------------------------------ GEMM family
+def gemm(x, w, *, out=None, bias=None, gbias=None, rows_per_group=0, residual=None, x2=None, geglu=False,
+         out_fp32=False, alpha=1.0, batch=1, sx=0, sw=0, sy=0, sr=0, M=None, N=None, K=None, ldy=None):
+    """out[m, n] = epilogue(alpha * sum_k x[m, k] w[n, k]); see MudgGemmDesc."""
+    _rows(x); _rows(w)
+    if M is None:
+        M = x.shape[0]
+    if N is None:
+        N = w.shape[0]
+    if K is None:
+        K = w.shape[1]
+    nout = N // 2 if geglu else N
+    if out is None:
+        out = empty_rows(M, nout, torch.float32 if out_fp32 else BF16, x.device)
+    d = hip.GemmDesc()
+    d.X, d.X2, d.W, d.Y = x.data_ptr(), _ptr(x2), w.data_ptr(), out.data_ptr()
+    d.bias, d.gbias, d.R = _ptr(bias), _ptr(gbias), _ptr(residual)
+    d.M, d.N, d.K = M, N, K
+    d.ldx, d.ldw = x.stride(0), w.stride(0)
+    d.ldx2 = x2.stride(0) if x2 is not None else 0
+    d.ldy = ldy if ldy is not None else out.stride(0)
+    d.ldr = residual.stride(0) if residual is not None else 0
+    d.csplit = x.shape[1] if x2 is not None else K
+    d.batch, d.sX, d.sW, d.sY, d.sR = batch, sx, sw, sy, sr
+    d.rows_per_group, d.out_fp32, d.geglu, d.alpha, d.mode = rows_per_group, int(out_fp32), int(geglu), alpha, 0
+    hip.check(hip.lib().mudg_gemm(C.byref(d), _stream()), "mudg_gemm")
+    return out
+
+
+def conv3x3(x, w, *, frames, hin, win, cin, stride=1, upsample=False, out=None, bias=None, gbias=None,
+            rows_per_group=0, residual=None, x2=None):
+    """3x3 / pad 1 convolution on channels-last rows; w is packed [Cout][9*cin] tap-major."""
+    _rows(x); _rows(w)
+    if upsample:
+        hout, wout = 2 * hin, 2 * win
+    else:
+        hout, wout = (hin - 1) // stride + 1, (win - 1) // stride + 1
+    M, N = frames * hout * wout, w.shape[0]
+    if out is None:
+        out = empty_rows(M, N, BF16, x.device)
+    d = hip.GemmDesc()
+    d.X, d.X2, d.W, d.Y = x.data_ptr(), _ptr(x2), w.data_ptr(), out.data_ptr()
+    d.bias, d.gbias, d.R = _ptr(bias), _ptr(gbias), _ptr(residual)
+    d.M, d.N, d.K = M, N, 9 * cin
+    d.ldx, d.ldw, d.ldy = x.stride(0), w.stride(0), out.stride(0)
+    d.ldx2 = x2.stride(0) if x2 is not None else 0
+    d.ldr = residual.stride(0) if residual is not None else 0
+    d.csplit = x.shape[1] if x2 is not None else cin
+    d.batch, d.rows_per_group, d.alpha, d.mode = 1, rows_per_group, 1.0, 1
+    d.Hin, d.Win, d.Hout, d.Wout, d.Cin, d.stride, d.upsample = hin, win, hout, wout, cin, stride, int(upsample)
+    hip.check(hip.lib().mudg_gemm(C.byref(d), _stream()), "mudg_gemm[conv3x3]")
+    return out
+
+
+def tconv3(x, w, *, clips, t, hw, cin, out=None, bias=None, residual=None):
+    """(3,1,1) temporal convolution, pad (1,0,0), on rows ordered ((b t) hw); w packed [Cout][3*cin]."""
+    _rows(x); _rows(w)
+    M, N = clips * t * hw, w.shape[0]
+    if out is None:
+        out = empty_rows(M, N, BF16, x.device)
+    d = hip.GemmDesc()
+    d.X, d.W, d.Y = x.data_ptr(), w.data_ptr(), out.data_ptr()
+    d.bias, d.R = _ptr(bias), _ptr(residual)
+    d.M, d.N, d.K = M, N, 3 * cin
+    d.ldx, d.ldw, d.ldy = x.stride(0), w.stride(0), out.stride(0)
+    d.ldr = residual.stride(0) if residual is not None else 0
+    d.csplit, d.batch, d.alpha, d.mode = cin, 1, 1.0, 2
+    d.Cin, d.T, d.HW = cin, t, hw
+    hip.check(hip.lib().mudg_gemm(C.byref(d), _stream()), "mudg_gemm[tconv3]")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def attention(q, k, vt, out, *, frames, heads, nq, nk, ldvt, svt, kv_div=1, scale=0.125, accumulate=False):
+    d = hip.AttnDesc()
+    d.Q, d.K, d.Vt, d.O = q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr()
+    d.F, d.heads, d.Nq, d.Nk = frames, heads, nq, nk
+    d.ldq, d.ldk, d.ldvt, d.ldo = q.stride(0), k.stride(0), ldvt, out.stride(0)
+    d.svt, d.kv_div, d.scale, d.accumulate = svt, kv_div, scale, int(accumulate)
+    hip.check(hip.lib().mudg_attention(C.byref(d), _stream()), "mudg_attention")
+    return out
+
+
+def temporal_attention(qkv, out, *, clips, t, hw, heads, scale=0.125):
+    hip.check(hip.lib().mudg_temporal_attention(qkv.data_ptr(), out.data_ptr(), clips, t, hw, heads,
+                                                qkv.stride(0), out.stride(0), scale, _stream()),
+              "mudg_temporal_attention")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ norms
+def groupnorm(x, gamma, beta, *, samples, rows, eps, silu, groups=32, x2=None, out=None):
+    _rows(x)
+    c = x.shape[1] + (x2.shape[1] if x2 is not None else 0)
+    if out is None:
+        out = empty_rows(samples * rows, c, BF16, x.device)
+    n = hip.lib().mudg_groupnorm_ws_floats(samples, groups, rows)
+    ws = torch.empty(n, dtype=torch.float32, device=x.device)
+    hip.check(hip.lib().mudg_groupnorm(x.data_ptr(), _ptr(x2), x.shape[1], x.stride(0),
+                                       x2.stride(0) if x2 is not None else 0, gamma.data_ptr(), beta.data_ptr(),
+                                       out.data_ptr(), out.stride(0), samples, rows, c, groups, eps, int(silu),
+                                       ws.data_ptr(), _stream()), "mudg_groupnorm")
+    return out
+
+
+def layernorm(x, gamma, beta, *, eps=1e-5, out=None):
+    _rows(x)
+    if out is None:
+        out = empty_rows(x.shape[0], x.shape[1], BF16, x.device)
+    hip.check(hip.lib().mudg_layernorm(x.data_ptr(), x.stride(0), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(),
+                                       out.stride(0), x.shape[0], x.shape[1], eps, _stream()), "mudg_layernorm")
+    return out
+
+
+def softmax_rows(s, out=None):
+    if out is None:
+        out = empty_rows(s.shape[0], s.shape[1], BF16, s.device)
+    hip.check(hip.lib().mudg_softmax_rows(s.data_ptr(), s.stride(0), out.data_ptr(), out.stride(0), s.shape[0],
+                                          s.shape[1], _stream()), "mudg_softmax_rows")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ small stuff
+_FREQS = {}
+
+
+def sinusoid_freqs(dim, max_period, device):
+    """exp(-ln(max_period) * arange(dim/2) / (dim/2)) in fp32 on the HOST, op for op as utils_diffusion.py:19-22."""
+    key = (dim, float(max_period), str(device))
+    if key not in _FREQS:
+        half = dim // 2
+        f = torch.exp(-math.log(max_period) * torch.arange(start=0, end=half, dtype=torch.float32) / half)
+        _FREQS[key] = f.to(device)
+    return _FREQS[key]
+
+
+def timestep_embedding(t, dim, max_period=10000):
+    t = t.to(torch.int64).contiguous()
+    out = torch.empty((t.shape[0], dim), dtype=torch.float32, device=t.device)
+    freqs = sinusoid_freqs(dim, max_period, t.device)
+    hip.check(hip.lib().mudg_timestep_embedding(t.data_ptr(), freqs.data_ptr(), out.data_ptr(), t.shape[0], dim,
+                                                _stream()), "mudg_timestep_embedding")
+    return out
+
+
+def small_linear(x, w, b=None, *, act_in=False, act_out=False, out=None, accumulate=False):
+    """fp32 x [M, K] times w [N, K] (fp32 or bf16) plus bias, optional SiLU before / after."""
+    if x.dtype != torch.float32 or not x.is_contiguous() or not w.is_contiguous():
+        raise hip.MudgError("small_linear expects contiguous fp32 x and contiguous w")
+    m, k = x.shape
+    n = w.shape[0]
+    if out is None:
+        out = torch.empty((m, n), dtype=torch.float32, device=x.device)
+    hip.check(hip.lib().mudg_small_linear(x.data_ptr(), w.data_ptr(), int(w.dtype == BF16), _ptr(b), out.data_ptr(),
+                                          m, n, k, int(act_in), int(act_out), int(accumulate), _stream()),
+              "mudg_small_linear")
+    return out
+
+
+def ncthw_to_rows(src, dst, coff=0):
+    """(B, C, T, H, W) fp32|bf16 -> dst rows ((b t) h w) channels [coff, coff + C)."""
+    b, c, t, h, w = src.shape
+    src = src.contiguous()
+    hip.check(hip.lib().mudg_ncthw_to_rows(src.data_ptr(), int(src.dtype == torch.float32), dst.data_ptr(), b, c, t,
+                                           h * w, dst.stride(0), coff, _stream()), "mudg_ncthw_to_rows")
+    return dst
+
+
+def rows_to_ncthw(src, shape, coff=0, dtype=torch.float32, scale=1.0):
+    b, c, t, h, w = shape
+    out = torch.empty(shape, dtype=dtype, device=src.device)
+    hip.check(hip.lib().mudg_rows_to_ncthw(src.data_ptr(), src.stride(0), coff, out.data_ptr(),
+                                           int(dtype == torch.float32), b, c, t, h * w, scale, _stream()),
+              "mudg_rows_to_ncthw")
+    return out
+
+
+def zero_channels(dst, c0, c1):
+    hip.check(hip.lib().mudg_zero_channels(dst.data_ptr(), dst.shape[0], dst.stride(0), c0, c1, _stream()),
+              "mudg_zero_channels")
+    return dst
+
+
+def ddim_step(x, e_c, e_u, noise, coef):
+    """Fused DDIM update on fp32 latents (B, ...). coef = 8 host floats, see mudg_ddim_step."""
+    b = x.shape[0]
+    n = x.numel() // b
+    x_prev, pred_x0 = torch.empty_like(x), torch.empty_like(x)
+    ws = torch.empty(hip.lib().mudg_ddim_ws_doubles(b), dtype=torch.float64, device=x.device)
+    arr = (C.c_float * 8)(*[float(v) for v in coef])
+    hip.check(hip.lib().mudg_ddim_step(x.data_ptr(), e_c.data_ptr(), _ptr(e_u), _ptr(noise), x_prev.data_ptr(),
+                                       pred_x0.data_ptr(), b, n, arr, ws.data_ptr(), _stream()), "mudg_ddim_step")
+    return x_prev, pred_x0

@@ -1,0 +1,330 @@
+"""Per-kernel parity on the GPU: each C-ABI entry point against plain fp32 PyTorch ops on the CPU, fed the same
+bf16-rounded inputs.  Tolerances: a bf16 result carries one rounding (relative 2^-9, rms ~1.1e-3), so bf16 outputs
+are held to rel-L2 <= 3e-3; fp32 outputs to 2e-5 (accumulation order only)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+TOL_BF16 = 3e-3
+TOL_F32 = 2e-5
+
+
+def rel_l2(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(BF)
+
+
+def pack_geglu(w, b):
+    """Reference layout [value rows | gate rows] -> blocks of 32 value rows followed by their 32 gate rows."""
+    n2 = w.shape[0] // 2
+    idx = []
+    for blk in range(n2 // 32):
+        idx += list(range(blk * 32, blk * 32 + 32)) + list(range(n2 + blk * 32, n2 + blk * 32 + 32))
+    idx = torch.tensor(idx)
+    return w[idx].contiguous(), (b[idx].contiguous() if b is not None else None)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 96, 72), (1000, 320, 320), (77, 1280, 1024), (300, 4, 320),
+                                   (129, 200, 8)])
+def test_gemm_plain(cuda, M, N, K):
+    from mudg_amd import ops
+    x, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05)
+    b = torch.randn(N, generator=torch.Generator().manual_seed(3))
+    r = rnd(M, N, seed=4)
+    ref = x.float() @ w.float().t() + b + r.float()
+    y = ops.gemm(x.to(cuda), w.to(cuda), bias=b.to(cuda), residual=r.to(cuda))
+    assert y.dtype == BF and tuple(y.shape) == (M, N)
+    assert rel_l2(y, ref) < TOL_BF16
+    y32 = ops.gemm(x.to(cuda), w.to(cuda), bias=b.to(cuda), out_fp32=True, alpha=0.5)
+    assert rel_l2(y32, 0.5 * (x.float() @ w.float().t()) + b) < TOL_F32
+
+
+def test_gemm_transpose_detecting(cuda):
+    """A = I with an asymmetric B catches a swapped row/column mapping in the MFMA epilogue."""
+    from mudg_amd import ops
+    n = 128
+    x = torch.eye(n).to(BF)
+    w = (torch.arange(n * n).reshape(n, n) % 251).float().to(BF)
+    y = ops.gemm(x.to(cuda), w.to(cuda), out_fp32=True)
+    assert torch.equal(y.cpu(), w.float().t())
+
+
+def test_gemm_group_bias_and_two_sources(cuda):
+    from mudg_amd import ops
+    M, N, K1, K2 = 6 * 40, 96, 64, 128
+    x1, x2, w = rnd(M, K1, seed=1), rnd(M, K2, seed=2), rnd(N, K1 + K2, seed=3, scale=0.05)
+    gb = torch.randn(6, N, generator=torch.Generator().manual_seed(4))
+    ref = torch.cat([x1, x2], 1).float() @ w.float().t() + gb.repeat_interleave(40, 0)
+    y = ops.gemm(x1.to(cuda), w.to(cuda), x2=x2.to(cuda), gbias=gb.to(cuda), rows_per_group=40)
+    assert rel_l2(y, ref) < TOL_BF16
+
+
+def test_gemm_geglu(cuda):
+    from mudg_amd import ops
+    M, C = 300, 64
+    x, w = rnd(M, C, seed=1), rnd(8 * C, C, seed=2, scale=0.1)
+    b = torch.randn(8 * C, generator=torch.Generator().manual_seed(3)) * 0.1
+    h = x.float() @ w.float().t() + b
+    val, gate = h.chunk(2, dim=-1)
+    ref = val * F.gelu(gate)
+    wp, bp = pack_geglu(w, b)
+    y = ops.gemm(x.to(cuda), wp.to(cuda), bias=bp.to(cuda), geglu=True)
+    assert tuple(y.shape) == (M, 4 * C)
+    assert rel_l2(y, ref) < TOL_BF16
+
+
+def test_gemm_batched_swapped_gives_v_transposed(cuda):
+    """The V projection is issued with operands swapped so that it writes V^T per frame (ld padded to 8)."""
+    from mudg_amd import ops
+    frames, hw, C = 3, 77, 128
+    x, wv = rnd(frames * hw, C, seed=1), rnd(C, C, seed=2, scale=0.1)
+    ld = (hw + 7) // 8 * 8
+    out = torch.zeros(frames * C, ld, dtype=BF, device=cuda)
+    ops.gemm(wv.to(cuda), x.to(cuda), out=out, batch=frames, sx=0, sw=hw * C, sy=C * ld, M=C, N=hw, K=C, ldy=ld)
+    v = (x.float() @ wv.float().t()).reshape(frames, hw, C)
+    got = out.reshape(frames, C, ld)[:, :, :hw]
+    assert rel_l2(got, v.transpose(1, 2)) < TOL_BF16
+
+
+def pack_conv(w):
+    """(Cout, Cin, 3, 3) -> [Cout][tap][Cin]"""
+    return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous()
+
+
+def to_rows(x):       # (F, C, H, W) -> rows
+    return x.permute(0, 2, 3, 1).reshape(-1, x.shape[1]).contiguous()
+
+
+def from_rows(y, f, h, w):
+    return y.reshape(f, h, w, -1).permute(0, 3, 1, 2)
+
+
+@pytest.mark.parametrize("cin,cout,h,w,stride,ups", [(64, 96, 9, 16, 1, False), (64, 64, 10, 16, 2, False),
+                                                     (72, 40, 5, 7, 2, False), (64, 128, 5, 8, 1, True),
+                                                     (16, 320, 9, 16, 1, False), (320, 4, 9, 16, 1, False)])
+def test_conv3x3(cuda, cin, cout, h, w, stride, ups):
+    from mudg_amd import ops
+    frames = 3
+    x = rnd(frames, cin, h, w, seed=1)
+    wt = rnd(cout, cin, 3, 3, seed=2, scale=0.05)
+    b = torch.randn(cout, generator=torch.Generator().manual_seed(3))
+    xin = F.interpolate(x.float(), scale_factor=2, mode="nearest") if ups else x.float()
+    ref = F.conv2d(xin, wt.float(), b, stride=stride, padding=1)
+    y = ops.conv3x3(to_rows(x).to(cuda), pack_conv(wt).to(cuda), frames=frames, hin=h, win=w, cin=cin, stride=stride,
+                    upsample=ups, bias=b.to(cuda))
+    got = from_rows(y.cpu().float(), frames, ref.shape[2], ref.shape[3])
+    assert rel_l2(got, ref) < TOL_BF16
+
+
+def test_conv3x3_fused_epilogue_and_concat(cuda):
+    from mudg_amd import ops
+    frames, c1, c2, cout, h, w = 4, 64, 32, 64, 6, 8
+    xa, xb = rnd(frames, c1, h, w, seed=1), rnd(frames, c2, h, w, seed=2)
+    wt = rnd(cout, c1 + c2, 3, 3, seed=3, scale=0.05)
+    b = torch.randn(cout, generator=torch.Generator().manual_seed(4))
+    emb = torch.randn(2, cout, generator=torch.Generator().manual_seed(5))      # one row per clip of 2 frames
+    res = rnd(frames, cout, h, w, seed=6)
+    ref = F.conv2d(torch.cat([xa, xb], 1).float(), wt.float(), b, padding=1)
+    ref = ref + emb.repeat_interleave(2, 0)[:, :, None, None] + res.float()
+    y = ops.conv3x3(to_rows(xa).to(cuda), pack_conv(wt).to(cuda), frames=frames, hin=h, win=w, cin=c1 + c2,
+                    x2=to_rows(xb).to(cuda), bias=b.to(cuda), gbias=emb.to(cuda), rows_per_group=2 * h * w,
+                    residual=to_rows(res).to(cuda))
+    assert rel_l2(from_rows(y.cpu().float(), frames, h, w), ref) < TOL_BF16
+
+
+def test_tconv3(cuda):
+    from mudg_amd import ops
+    clips, t, h, w, c = 2, 5, 3, 4, 64
+    x = rnd(clips, c, t, h, w, seed=1)
+    wt = rnd(c, c, 3, 1, 1, seed=2, scale=0.05)
+    b = torch.randn(c, generator=torch.Generator().manual_seed(3))
+    ref = F.conv3d(x.float(), wt.float(), b, padding=(1, 0, 0)) + x.float()
+    rows = x.permute(0, 2, 3, 4, 1).reshape(-1, c).contiguous()
+    wp = wt[:, :, :, 0, 0].permute(0, 2, 1).reshape(c, 3 * c).contiguous()
+    y = ops.tconv3(rows.to(cuda), wp.to(cuda), clips=clips, t=t, hw=h * w, cin=c, bias=b.to(cuda),
+                   residual=rows.to(cuda))
+    got = y.cpu().float().reshape(clips, t, h, w, c).permute(0, 4, 1, 2, 3)
+    assert rel_l2(got, ref) < TOL_BF16
+
+
+def attn_ref(q, k, v, heads, scale):
+    """q [F, Nq, C], k/v [Fk, Nk, C] fp32, frames share k/v in blocks."""
+    f, nq, c = q.shape
+    rep = f // k.shape[0]
+    k, v = k.repeat_interleave(rep, 0), v.repeat_interleave(rep, 0)
+    qh = q.reshape(f, nq, heads, 64).transpose(1, 2)
+    kh = k.reshape(f, -1, heads, 64).transpose(1, 2)
+    vh = v.reshape(f, -1, heads, 64).transpose(1, 2)
+    p = torch.softmax(qh @ kh.transpose(-1, -2) * scale, dim=-1)
+    return (p @ vh).transpose(1, 2).reshape(f, nq, c)
+
+
+def make_vt(v, heads):
+    fk, nk, c = v.shape
+    ld = (nk + 7) // 8 * 8
+    vt = torch.full((fk, c, ld), float("nan"), dtype=BF)     # padding must never be read as data
+    vt[:, :, :nk] = v.transpose(1, 2)
+    return vt, ld
+
+
+@pytest.mark.parametrize("frames,heads,nq,nk,kv_div", [(2, 2, 200, 200, 1), (1, 5, 384, 384, 1), (4, 2, 150, 77, 2),
+                                                       (3, 1, 70, 16, 1), (1, 1, 128, 64, 1)])
+def test_attention(cuda, frames, heads, nq, nk, kv_div):
+    from mudg_amd import ops
+    c = heads * 64
+    q = rnd(frames, nq, c, seed=1)
+    k = rnd(frames // kv_div, nk, c, seed=2)
+    v = rnd(frames // kv_div, nk, c, seed=3)
+    ref = attn_ref(q.float(), k.float(), v.float(), heads, 0.125)
+    vt, ld = make_vt(v, heads)
+    out = torch.zeros(frames * nq, c, dtype=BF, device=cuda)
+    ops.attention(q.reshape(-1, c).to(cuda), k.reshape(-1, c).to(cuda), vt.to(cuda), out, frames=frames, heads=heads,
+                  nq=nq, nk=nk, ldvt=ld, svt=c * ld, kv_div=kv_div)
+    assert rel_l2(out.cpu().reshape(frames, nq, c), ref) < TOL_BF16
+    # second softmax accumulated on top (text + image cross-attention)
+    ops.attention(q.reshape(-1, c).to(cuda), k.reshape(-1, c).to(cuda), vt.to(cuda), out, frames=frames, heads=heads,
+                  nq=nq, nk=nk, ldvt=ld, svt=c * ld, kv_div=kv_div, accumulate=True)
+    assert rel_l2(out.cpu().reshape(frames, nq, c), 2 * ref) < 2 * TOL_BF16
+
+
+def test_attention_rescale_branch(cuda):
+    """Spike one key per 64-key tile so that the running max jumps at every tile (online-softmax rescale path)."""
+    from mudg_amd import ops
+    heads, n = 1, 512
+    q = rnd(1, n, 64, seed=1)
+    k = rnd(1, n, 64, seed=2)
+    v = rnd(1, n, 64, seed=3)
+    for tile in range(n // 64):
+        k[0, tile * 64 + 5] = (q[0, 7].float() * (1.0 + 0.5 * tile)).to(BF)
+    ref = attn_ref(q.float(), k.float(), v.float(), heads, 0.125)
+    vt, ld = make_vt(v, heads)
+    out = torch.zeros(n, 64, dtype=BF, device=cuda)
+    ops.attention(q.reshape(-1, 64).to(cuda), k.reshape(-1, 64).to(cuda), vt.to(cuda), out, frames=1, heads=1, nq=n,
+                  nk=n, ldvt=ld, svt=64 * ld)
+    assert rel_l2(out.cpu().reshape(1, n, 64), ref) < TOL_BF16
+    assert float((out.cpu().float().reshape(1, n, 64) - ref).abs().max()) < 0.05
+
+
+@pytest.mark.parametrize("clips,t,hw,heads", [(2, 16, 10, 3), (1, 5, 7, 2), (1, 20, 5, 1), (1, 16, 33, 8)])
+def test_temporal_attention(cuda, clips, t, hw, heads):
+    from mudg_amd import ops
+    c = heads * 64
+    qkv = rnd(clips * t * hw, 3 * c, seed=1)
+    x = qkv.float().reshape(clips, t, hw, 3, heads, 64)
+    q, k, v = (x[:, :, :, i].permute(0, 2, 3, 1, 4) for i in range(3))        # (b, hw, heads, t, 64)
+    p = torch.softmax(q @ k.transpose(-1, -2) * 0.125, dim=-1)
+    ref = (p @ v).permute(0, 3, 1, 2, 4).reshape(clips * t * hw, c)
+    out = torch.zeros(clips * t * hw, c, dtype=BF, device=cuda)
+    ops.temporal_attention(qkv.to(cuda), out, clips=clips, t=t, hw=hw, heads=heads)
+    assert rel_l2(out, ref) < TOL_BF16
+
+
+@pytest.mark.parametrize("samples,rows,c,silu,eps", [(2, 50, 64, True, 1e-5), (3, 144, 320, True, 1e-5),
+                                                     (1, 700, 960, False, 1e-6), (2, 33, 2560, True, 1e-5),
+                                                     (1, 5000, 128, True, 1e-6), (2, 20, 32, True, 1e-5)])
+def test_groupnorm(cuda, samples, rows, c, silu, eps):
+    from mudg_amd import ops
+    x = (rnd(samples * rows, c, seed=1).float() * 2 + 0.7).to(BF)
+    g = 1 + 0.1 * torch.randn(c, generator=torch.Generator().manual_seed(2))
+    b = 0.1 * torch.randn(c, generator=torch.Generator().manual_seed(3))
+    xr = x.float().reshape(samples, rows, c).transpose(1, 2)               # (N, C, L)
+    ref = F.group_norm(xr, 32, g, b, eps)
+    if silu:
+        ref = F.silu(ref)
+    ref = ref.transpose(1, 2).reshape(samples * rows, c)
+    y = ops.groupnorm(x.to(cuda), g.to(cuda), b.to(cuda), samples=samples, rows=rows, eps=eps, silu=silu)
+    assert rel_l2(y, ref) < TOL_BF16
+
+
+def test_groupnorm_two_sources(cuda):
+    from mudg_amd import ops
+    samples, rows, c1, c2 = 2, 40, 320, 640
+    x1, x2 = rnd(samples * rows, c1, seed=1), rnd(samples * rows, c2, seed=2, scale=3.0)
+    g = 1 + 0.1 * torch.randn(c1 + c2, generator=torch.Generator().manual_seed(3))
+    b = 0.1 * torch.randn(c1 + c2, generator=torch.Generator().manual_seed(4))
+    x = torch.cat([x1, x2], 1).float().reshape(samples, rows, -1).transpose(1, 2)
+    ref = F.silu(F.group_norm(x, 32, g, b, 1e-5)).transpose(1, 2).reshape(samples * rows, -1)
+    y = ops.groupnorm(x1.to(cuda), g.to(cuda), b.to(cuda), samples=samples, rows=rows, eps=1e-5, silu=True,
+                      x2=x2.to(cuda))
+    assert rel_l2(y, ref) < TOL_BF16
+
+
+@pytest.mark.parametrize("rows,c", [(10, 320), (77, 1280), (5, 2048), (3, 64), (9, 512)])
+def test_layernorm(cuda, rows, c):
+    from mudg_amd import ops
+    x = (rnd(rows, c, seed=1).float() * 3 - 1).to(BF)
+    g = 1 + 0.1 * torch.randn(c, generator=torch.Generator().manual_seed(2))
+    b = 0.1 * torch.randn(c, generator=torch.Generator().manual_seed(3))
+    ref = F.layer_norm(x.float(), (c,), g, b, 1e-5)
+    y = ops.layernorm(x.to(cuda), g.to(cuda), b.to(cuda))
+    assert rel_l2(y, ref) < TOL_BF16
+
+
+def test_softmax_rows(cuda):
+    from mudg_amd import ops
+    s = torch.randn(37, 1000, generator=torch.Generator().manual_seed(1)) * 4
+    y = ops.softmax_rows(s.to(cuda))
+    assert rel_l2(y, torch.softmax(s, -1)) < TOL_BF16
+
+
+def test_timestep_embedding_known_answers(cuda):
+    """SURVEY Appendix C values captured from the reference's timestep_embedding([999,19,10,500], 320)."""
+    from mudg_amd import ops
+    e = ops.timestep_embedding(torch.tensor([999, 19, 10, 500], device=cuda), 320).cpu()
+    assert torch.allclose(e[0, :3], torch.tensor([0.9996498, 0.8026775, -0.27806213]), atol=2e-5)
+    assert torch.allclose(e[0, 160:163], torch.tensor([-0.026460752, 0.5964133, -0.9605631]), atol=2e-5)
+    assert torch.allclose(e.sum(1), torch.tensor([57.183205, 125.40709, 136.76776, 69.293144]), atol=2e-3)
+
+
+def test_small_linear(cuda):
+    from mudg_amd import ops
+    g = torch.Generator().manual_seed(1)
+    x, w, b = torch.randn(3, 320, generator=g), torch.randn(1280, 320, generator=g) * 0.05, torch.randn(1280, generator=g)
+    y = ops.small_linear(x.to(cuda), w.to(cuda), b.to(cuda), act_out=True)
+    assert rel_l2(y, F.silu(x @ w.t() + b)) < TOL_F32
+    y2 = ops.small_linear(x.to(cuda), w.to(cuda), b.to(cuda), act_in=True)
+    assert rel_l2(y2, F.silu(x) @ w.t() + b) < TOL_F32
+
+
+def test_layout_round_trip(cuda):
+    from mudg_amd import ops
+    x = torch.randn(2, 4, 3, 5, 6, generator=torch.Generator().manual_seed(1))
+    c = torch.randn(2, 8, 3, 5, 6, generator=torch.Generator().manual_seed(2))
+    rows = torch.full((2 * 3 * 30, 16), 7.0, dtype=BF, device=cuda)
+    ops.ncthw_to_rows(x.to(cuda), rows, 0)
+    ops.ncthw_to_rows(c.to(cuda), rows, 4)
+    ops.zero_channels(rows, 12, 16)
+    want = torch.cat([x, c, torch.zeros(2, 4, 3, 5, 6)], 1).permute(0, 2, 3, 4, 1).reshape(-1, 16).to(BF)
+    assert torch.equal(rows.cpu(), want)
+    back = ops.rows_to_ncthw(rows, (2, 4, 3, 5, 6), coff=4)
+    assert torch.equal(back.cpu(), c[:, :4].to(BF).float())
+
+
+@pytest.mark.parametrize("phi,with_uncond,with_noise", [(0.7, True, True), (0.0, True, False), (0.7, False, True)])
+def test_ddim_step(cuda, phi, with_uncond, with_noise):
+    from mudg_amd import ops
+    g = torch.Generator().manual_seed(1)
+    shape = (3, 4, 16, 9, 16)
+    x, ec, eu, nz = (torch.randn(shape, generator=g) for _ in range(4))
+    ec = ec * torch.tensor([1.0, 2.0, 0.5]).view(3, 1, 1, 1, 1)
+    cfg, sac, s1m, resc, sap, dirc, sig = 7.5, 0.6, 0.8, 1.03, 0.9, 0.3, 0.31
+    v = eu + cfg * (ec - eu) if with_uncond else ec
+    if phi > 0:
+        dims = list(range(1, v.ndim))
+        v = phi * (v * (ec.std(dim=dims, keepdim=True) / v.std(dim=dims, keepdim=True))) + (1 - phi) * v
+    e = sac * v + s1m * x
+    x0 = (sac * x - s1m * v) * resc
+    xp = sap * x0 + dirc * e + (sig * nz if with_noise else 0)
+    got_xp, got_x0 = ops.ddim_step(x.to(cuda), ec.to(cuda), eu.to(cuda) if with_uncond else None,
+                                   nz.to(cuda) if with_noise else None, [cfg, phi, sac, s1m, resc, sap, dirc, sig])
+    assert rel_l2(got_x0, x0) < TOL_F32 and rel_l2(got_xp, xp) < TOL_F32
