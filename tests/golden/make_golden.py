@@ -1,0 +1,255 @@
+#!/usr/bin/env python3
+"""Capture golden vectors from the REFERENCE implementation (read-only at /root/reference).
+
+Run in the build container only:   python tests/golden/make_golden.py
+The reference is imported with /root/reference on sys.path and /root/repo NOT on it (both trees own a package
+called `lvdm`); missing third-party packages (cv2, pytorch_lightning, torchvision) are replaced by harness stubs
+that carry no arithmetic.  Only inputs, outputs and a weight checksum are stored — weights are re-derived from
+seeding.py on both sides.  The fixtures written next to this file are data, not code.
+"""
+import importlib.util
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = os.environ.get("MUDG_REFERENCE", "/root/reference")
+assert os.path.isdir(REF), "the reference tree is required to regenerate goldens"
+sys.path = [p for p in sys.path if os.path.abspath(p or ".") != os.path.abspath(os.path.join(HERE, "..", ".."))]
+sys.path.insert(0, REF)
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+torch.set_grad_enabled(False)
+torch.set_num_threads(max(1, os.cpu_count() or 1))
+
+
+def _load(name):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(HERE, name + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+seeding = _load("seeding")
+cfgs = _load("configs")
+
+# ---------------------------------------------------------------------------------------------- stubs (no math)
+sys.modules["cv2"] = types.ModuleType("cv2")
+pl = types.ModuleType("pytorch_lightning")
+
+
+class _LightningModule(nn.Module):
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    def log(self, *a, **k):
+        pass
+
+    def log_dict(self, *a, **k):
+        pass
+
+
+pl.LightningModule = _LightningModule
+plu = types.ModuleType("pytorch_lightning.utilities")
+plu.rank_zero_only = lambda f: f
+pl.utilities = plu
+sys.modules["pytorch_lightning"] = pl
+sys.modules["pytorch_lightning.utilities"] = plu
+tv = types.ModuleType("torchvision")
+tvu = types.ModuleType("torchvision.utils")
+tvu.make_grid = lambda *a, **k: None
+tv.utils = tvu
+sys.modules["torchvision"] = tv
+sys.modules["torchvision.utils"] = tvu
+
+stubs = types.ModuleType("golden_stubs")
+
+
+class DummyEmbedder(nn.Module):
+    """Stands in for the CLIP text/image encoders, which are outside the path."""
+
+    def __init__(self, **kw):
+        super().__init__()
+        self.p = nn.Parameter(torch.zeros(1))
+
+    def encode(self, x):
+        raise RuntimeError("conditioning is injected as tensors in the goldens")
+
+    def forward(self, x):
+        raise RuntimeError("conditioning is injected as tensors in the goldens")
+
+
+stubs.DummyEmbedder = DummyEmbedder
+sys.modules["golden_stubs"] = stubs
+
+
+class AttrDict(dict):
+    def __getattr__(self, k):
+        try:
+            v = self[k]
+        except KeyError:
+            raise AttributeError(k)
+        return AttrDict(v) if isinstance(v, dict) else v
+
+
+from lvdm.modules.networks.openaimodel3d import UNetModel           # noqa: E402  (the reference's)
+from lvdm.models.utils_diffusion import timestep_embedding          # noqa: E402
+from lvdm.models.samplers import ddim as ref_ddim                   # noqa: E402
+from lvdm.models.ddpm3d import LatentVisualDiffusion                # noqa: E402
+
+
+def reseed(module, seed):
+    shapes = {k: tuple(v.shape) for k, v in module.state_dict().items() if v.dtype.is_floating_point}
+    sd = seeding.seeded_state_dict(shapes, seed)
+    full = module.state_dict()
+    full.update(sd)
+    module.load_state_dict(full, strict=True)
+    return shapes, seeding.checksum(sd)
+
+
+def save(name, obj):
+    path = os.path.join(HERE, name)
+    torch.save(obj, path)
+    print(f"wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
+# ---------------------------------------------------------------------------------------------- 1. schedule KATs
+def golden_schedule():
+    out = {}
+    for base in (0.3, 0.7):
+        cfg = dict(cfgs.DIFFUSION, base_scale=base)
+        model = build_diffusion(cfgs.UNET_B, cfg)
+        sampler = CPUSampler(model)
+        entry = {"betas": model.betas.clone(), "alphas_cumprod": model.alphas_cumprod.clone(),
+                 "sqrt_alphas_cumprod": model.sqrt_alphas_cumprod.clone(),
+                 "sqrt_one_minus_alphas_cumprod": model.sqrt_one_minus_alphas_cumprod.clone(),
+                 "scale_arr": model.scale_arr.clone()}
+        for steps in (50, 2):
+            for spacing in ("uniform_trailing", "uniform"):
+                sampler.make_schedule(steps, ddim_discretize=spacing, ddim_eta=1.0, verbose=False)
+                entry[f"ddim_{steps}_{spacing}"] = {
+                    "timesteps": torch.as_tensor(np.ascontiguousarray(sampler.ddim_timesteps)),
+                    "alphas": torch.as_tensor(sampler.ddim_alphas).clone(),
+                    "alphas_prev": torch.as_tensor(np.asarray(sampler.ddim_alphas_prev, dtype=np.float64)),
+                    "sigmas": torch.as_tensor(sampler.ddim_sigmas).double().clone(),
+                    "sqrt_one_minus_alphas": torch.as_tensor(sampler.ddim_sqrt_one_minus_alphas).clone(),
+                    "scale_arr": sampler.ddim_scale_arr.clone(), "scale_arr_prev": sampler.ddim_scale_arr_prev.clone()}
+        out[f"base_{base}"] = entry
+    t = torch.tensor([999, 19, 10, 500, 0, 1])
+    out["timestep_embedding_320"] = {"t": t, "emb": timestep_embedding(t, 320)}
+    out["timestep_embedding_64"] = {"t": t, "emb": timestep_embedding(t, 64)}
+    save("schedule.pt", out)
+
+
+# ---------------------------------------------------------------------------------------------- 2. UNet forward
+def unet_inputs(cfg, shp, seed):
+    B, T, H, W = shp["B"], shp["T"], shp["H"], shp["W"]
+    x = seeding.seeded_input("x", (B, cfg["in_channels"], T, H, W), seed)
+    ctx = seeding.seeded_input("context", (B, 77 + 16 * T, cfg["context_dim"]), seed)
+    return x, ctx
+
+
+def golden_unet(tag, cfg, shp):
+    net = UNetModel(**cfg).eval()
+    shapes, cks = reseed(net, cfgs.SEED)
+    x, ctx = unet_inputs(cfg, shp, cfgs.SEED)
+    B = shp["B"]
+    cases = []
+    for t, labels in ((999, [0, 500, 1]), (19, [1, 0, 500])):
+        ts = torch.full((B,), t, dtype=torch.long)
+        lab = torch.tensor(labels[:B], dtype=torch.long)
+        fs = torch.full((B,), 10, dtype=torch.long)
+        y = net(x, ts, c_label=lab, context=ctx, fs=fs)
+        cases.append({"t": ts, "c_label": lab, "fs": fs, "y": y.clone()})
+    save(f"unet_{tag}.pt", {"cfg": cfg, "shape": shp, "seed": cfgs.SEED, "checksum": cks,
+                           "param_shapes": shapes, "cases": cases})
+
+
+# ---------------------------------------------------------------------------------------------- 3. sampler + decode
+class CPUSampler(ref_ddim.DDIMSampler):
+    """The reference sampler with its hard-coded .to('cuda') removed (ddim.py:18-22); arithmetic untouched."""
+
+    def register_buffer(self, name, attr):
+        setattr(self, name, attr)
+
+
+def build_diffusion(unet_cfg, diff_cfg):
+    dummy = {"target": "golden_stubs.DummyEmbedder", "params": {}}
+    model = LatentVisualDiffusion(
+        img_cond_stage_config=dummy, image_proj_stage_config=dummy,
+        first_stage_config=AttrDict({"target": "lvdm.models.autoencoder.AutoencoderKL",
+                                     "params": {"embed_dim": 4, "ddconfig": cfgs.VAE_DD,
+                                                "lossconfig": {"target": "torch.nn.Identity"}}}),
+        cond_stage_config=dummy,
+        unet_config=AttrDict({"target": "lvdm.modules.networks.openaimodel3d.UNetModel", "params": unet_cfg}),
+        **diff_cfg)
+    return model.eval()
+
+
+def golden_pipeline():
+    s = cfgs.SAMPLER
+    model = build_diffusion(cfgs.UNET_B, cfgs.DIFFUSION)
+    unet_shapes, unet_cks = reseed(model.model.diffusion_model, cfgs.SEED)
+    vae_shapes, vae_cks = reseed(model.first_stage_model, cfgs.SEED + 1)
+    shp = cfgs.UNET_B_SHAPE
+    B, T, H, W = shp["B"], shp["T"], shp["H"], shp["W"]
+    seed = cfgs.SEED + 2
+    ctx_c = seeding.seeded_input("ctx_cond", (B, 77 + 16 * T, cfgs.UNET_B["context_dim"]), seed)
+    ctx_u = seeding.seeded_input("ctx_uncond", (B, 77 + 16 * T, cfgs.UNET_B["context_dim"]), seed)
+    concat = seeding.seeded_input("c_concat", (B, 8, T, H, W), seed, 0.18215 * 5)
+    x_T = seeding.seeded_input("x_T", (B, 4, T, H, W), seed)
+    noises = [seeding.seeded_input(f"noise{i}", (B, 4, T, H, W), seed) for i in range(s["steps"])]
+    class_label = torch.tensor(s["class_labels"], dtype=torch.long)[:, None]
+    fs = torch.full((B,), s["fs"], dtype=torch.long)
+    cond = {"c_crossattn": [ctx_c], "c_concat": [concat]}
+    uc = {"c_crossattn": [ctx_u], "c_concat": [concat]}
+
+    trace, it = [], iter(noises)
+    ref_ddim.noise_like = lambda shape, device, repeat=False: next(it)          # inject recorded noise
+    orig_apply = model.apply_model
+    outs = []
+
+    def tapped(x, t, c, **kw):
+        y = orig_apply(x, t, c, **kw)
+        outs.append(y.clone())
+        return y
+
+    model.apply_model = tapped
+    sampler = CPUSampler(model)
+    orig_p = sampler.p_sample_ddim
+
+    def p_tapped(x, c, t, index, **kw):
+        xp, x0 = orig_p(x, c, t, index=index, **kw)
+        trace.append({"t": t.clone(), "index": index, "e_c": outs[-2], "e_u": outs[-1], "x_prev": xp.clone(),
+                      "pred_x0": x0.clone()})
+        return xp, x0
+
+    sampler.p_sample_ddim = p_tapped
+    samples, _ = sampler.sample(S=s["steps"], conditioning=cond, batch_size=B, shape=[4, T, H, W], verbose=False,
+                                unconditional_guidance_scale=s["cfg_scale"], unconditional_conditioning=uc,
+                                eta=s["eta"], cfg_img=None, mask=None, x0=None, fs=fs, x_T=x_T,
+                                timestep_spacing=s["spacing"], guidance_rescale=s["guidance_rescale"],
+                                sparse_x=concat[:, :4], class_label=class_label,
+                                unconditional_conditioning_img_nonetext=None)
+    decoded = model.decode_first_stage(samples)
+    z1 = seeding.seeded_input("z_dec", (2, 4, 8, 8), seed)
+    dec_direct = model.first_stage_model.decode(z1)
+    save("pipeline.pt", {
+        "unet_cfg": cfgs.UNET_B, "diffusion_cfg": cfgs.DIFFUSION, "vae_ddconfig": cfgs.VAE_DD, "sampler": s,
+        "shape": shp, "seed": cfgs.SEED, "unet_checksum": unet_cks, "vae_checksum": vae_cks,
+        "unet_param_shapes": unet_shapes, "vae_param_shapes": vae_shapes,
+        "ddim_timesteps": torch.as_tensor(np.ascontiguousarray(sampler.ddim_timesteps)),
+        "trace": trace, "samples": samples.clone(), "decoded": decoded.clone(),
+        "decode_direct": {"z": z1, "out": dec_direct.clone()}})
+
+
+if __name__ == "__main__":
+    golden_schedule()
+    golden_unet("a", cfgs.UNET_A, cfgs.UNET_A_SHAPE)
+    golden_unet("b", cfgs.UNET_B, cfgs.UNET_B_SHAPE)
+    golden_pipeline()

@@ -1,0 +1,104 @@
+"""Pin the CPU oracle to vectors captured from the reference itself (tests/golden/make_golden.py).
+fp32 on both sides: tolerance is rel-L2 <= 1e-5 per forward and <= 1e-4 after two sampler steps + decode."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import golden, pipeline_inputs, rel_l2, seeded_sd, unet_inputs
+
+from oracle import ddim as o_ddim
+from oracle import schedule as o_sched
+from oracle import unet as o_unet
+from oracle import vae as o_vae
+
+
+def test_schedule_known_answers_survey_appendix_c():
+    """The literal values SURVEY.md Appendix C records from the reference."""
+    s = o_sched.model_schedule(base_scale=0.3)
+    assert torch.allclose(s["betas"][[0, 1, 500, 998, 999]].double(),
+                          torch.tensor([8.5e-04, 9.1733359337e-04, 5.5305677845e-03, 7.5113700418e-01, 1.0]).double(),
+                          rtol=1e-6)
+    assert torch.allclose(s["alphas_cumprod"][[0, 19, 499, 979, 998]].double(),
+                          torch.tensor([0.99915, 0.98101045693, 0.24235916656, 8.5787843401e-05, 1.9678880566e-07]).double(),
+                          rtol=1e-6)
+    assert float(s["alphas_cumprod"][999]) == 0.0
+    ts = o_sched.ddim_timesteps("uniform_trailing", 50, 1000)
+    assert list(ts[:3]) == [19, 39, 59] and list(ts[-3:]) == [959, 979, 999]
+    assert list(o_sched.ddim_timesteps("uniform_trailing", 2, 1000)) == [499, 999]
+    dd = o_sched.ddim_schedule(s, 50, "uniform_trailing", 1.0)
+    sig = torch.as_tensor(dd["sigmas"]).double()
+    assert torch.allclose(sig[[0, 1, 25, 48, 49]], torch.tensor([0.0285072528, 0.1005311182, 0.3224573905,
+                                                                 0.8781245652, 0.9999571052]).double(), rtol=1e-7)
+    a_prev, sigma = torch.full((1,), float(dd["alphas_prev"][49])), torch.full((1,), float(dd["sigmas"][49]))
+    assert float(1. - a_prev - sigma ** 2) == pytest.approx(5.9604645e-08, rel=1e-6)   # one ulp above zero
+    assert float(s["scale_arr"][19]) == pytest.approx(0.9666666667, rel=1e-6) and s["scale_arr"].shape[0] == 1400
+
+
+@pytest.mark.parametrize("base", [0.3, 0.7])
+def test_schedule_matches_reference_buffers(base):
+    g = golden("schedule.pt")[f"base_{base}"]
+    s = o_sched.model_schedule(base_scale=base)
+    for k in ("betas", "alphas_cumprod", "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod", "scale_arr"):
+        assert torch.equal(s[k], g[k]), k
+    for steps in (50, 2):
+        for spacing in ("uniform_trailing", "uniform"):
+            ref = g[f"ddim_{steps}_{spacing}"]
+            dd = o_sched.ddim_schedule(s, steps, spacing, 1.0)
+            assert np.array_equal(np.asarray(dd["timesteps"]), ref["timesteps"].numpy())
+            assert torch.equal(torch.as_tensor(dd["alphas"]), ref["alphas"])
+            assert torch.equal(torch.as_tensor(np.asarray(dd["alphas_prev"], dtype=np.float64)), ref["alphas_prev"])
+            assert torch.equal(torch.as_tensor(dd["sigmas"]).double(), ref["sigmas"])
+            assert torch.equal(dd["scale_arr"], ref["scale_arr"]) and torch.equal(dd["scale_arr_prev"], ref["scale_arr_prev"])
+
+
+def test_sinusoid_matches_reference():
+    g = golden("schedule.pt")
+    for dim in (320, 64):
+        e = g[f"timestep_embedding_{dim}"]
+        assert torch.equal(o_unet.sinusoid(e["t"], dim), e["emb"])
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_unet_forward_matches_reference(tag):
+    g = golden(f"unet_{tag}.pt")
+    sd = seeded_sd(g["param_shapes"], g["seed"], g["checksum"])
+    x, ctx = unet_inputs(g["cfg"], g["shape"], g["seed"])
+    for case in g["cases"]:
+        y = o_unet.unet_forward(sd, g["cfg"], x, case["t"], case["c_label"], ctx, case["fs"])
+        assert y.shape == case["y"].shape
+        assert rel_l2(y, case["y"]) < 1e-5
+        assert float(case["y"].abs().max()) > 1e-3        # a dead (all-zero) golden would pin nothing
+
+
+def test_sampler_and_decode_match_reference():
+    g = golden("pipeline.pt")
+    usd = seeded_sd(g["unet_param_shapes"], g["seed"], g["unet_checksum"])
+    vsd = seeded_sd(g["vae_param_shapes"], g["seed"] + 1, g["vae_checksum"])
+    inp, s, dc = pipeline_inputs(g), g["sampler"], g["diffusion_cfg"]
+    sched = o_sched.model_schedule(dc["timesteps"], dc["linear_start"], dc["linear_end"], dc["rescale_betas_zero_snr"],
+                                   dc["base_scale"])
+    lab = inp["class_label"][:, 0]
+
+    def apply_model(x, t, ctx):
+        xc = torch.cat([x, inp["concat"]], dim=1)                      # DiffusionWrapper 'hybrid', ddpm3d.py:1317-1319
+        return o_unet.unet_forward(usd, g["unet_cfg"], xc, t, lab, ctx, inp["fs"])
+
+    trace = []
+    samples = o_ddim.ddim_sample(apply_model, sched, inp["x_T"], inp["ctx_c"], inp["ctx_u"], s["steps"], inp["noises"],
+                                 s["eta"], s["cfg_scale"], s["guidance_rescale"], s["spacing"], trace)
+    for got, ref in zip(trace, g["trace"]):
+        assert rel_l2(got["e_c"], ref["e_c"]) < 1e-4 and rel_l2(got["e_u"], ref["e_u"]) < 1e-4
+        assert rel_l2(got["pred_x0"], ref["pred_x0"]) < 1e-4 and rel_l2(got["x_prev"], ref["x_prev"]) < 1e-4
+    assert rel_l2(samples, g["samples"]) < 1e-4
+    # the update alone, fed the reference's own UNet outputs: isolates p_sample_ddim arithmetic
+    dd = o_sched.ddim_schedule(sched, s["steps"], s["spacing"], s["eta"])
+    x = inp["x_T"]
+    for i, ref in enumerate(g["trace"]):
+        coef = o_ddim.step_coefficients(sched, dd, ref["index"])
+        xp, x0 = o_ddim.p_sample_ddim(x, ref["e_c"], ref["e_u"], inp["noises"][i], coef, s["cfg_scale"], s["guidance_rescale"])
+        assert rel_l2(x0, ref["pred_x0"]) < 2e-6 and rel_l2(xp, ref["x_prev"]) < 2e-6
+        x = ref["x_prev"]
+    dec = o_vae.decode_first_stage(vsd, g["vae_ddconfig"], g["samples"], dc["scale_factor"])
+    assert rel_l2(dec, g["decoded"]) < 1e-5
+    d2 = o_vae.decode(vsd, g["vae_ddconfig"], g["decode_direct"]["z"])
+    assert rel_l2(d2, g["decode_direct"]["out"]) < 1e-5
