@@ -142,9 +142,18 @@ int mudg_small_linear(const float* x, const void* W, int w_is_bf16, const float*
  * (b c t h w) fp32/bf16 -> channels-last bf16 rows ((b t) h w) with channel offset/stride
  * (openaimodel3d.py:591; ddpm3d.py:1317-1319 channel concat of x and c_concat), and back (openaimodel3d.py:627). */
 int mudg_ncthw_to_rows(const void* src, int src_is_fp32, void* dst, int B, int C, int T, int HW,
-                       int ld, int coff, void* stream);
+                       int ld, int coff, int Ttot, int t0, void* stream);
 int mudg_rows_to_ncthw(const void* src, int ld, int coff, void* dst, int dst_is_fp32,
-                       int B, int C, int T, int HW, float scale, void* stream);
+                       int B, int C, int T, int HW, float scale, int Ttot, int t0, void* stream);
+/* Ttot/t0: the (b c t h w) tensor holds Ttot frames and frames [t0, t0+T) are converted (Ttot <= 0: Ttot = T). */
+/* Strided 2-D copy of bf16 rows (context token split, openaimodel3d.py:582-585) and y += alpha * x on fp32
+ * vectors (summing the time / class / fps embeddings, openaimodel3d.py:576,602). */
+int mudg_copy_rows(const void* src, int64_t lds, void* dst, int64_t ldd, int64_t rows, int64_t cols, void* stream);
+int mudg_axpy_f32(float* y, const float* x, int64_t n, float alpha, void* stream);
+/* out[b][:] = ca[b] x[b][:] + cb[b] y[b][:] on fp32 (B, n): q_sample / predict_start_from_z_and_v /
+ * predict_eps_from_z_and_v (ddpm3d.py:239-251) with ca, cb gathered per sample (device fp32 [B]). */
+int mudg_lincomb(float* out, const float* x, const float* y, const float* ca, const float* cb, int B, int64_t n,
+                 void* stream);
 /* Zero the channel range [c0, c1) of a rows buffer (padding lanes of the stem input). */
 int mudg_zero_channels(void* dst, int rows, int ld, int c0, int c1, void* stream);
 

@@ -1,0 +1,283 @@
+"""Latent video diffusion model at the drop-in boundary (reference: lvdm/models/ddpm3d.py).
+
+What the denoising path needs from the reference's Lightning classes, without Lightning: the schedule buffers
+(DDPM.register_schedule 123-186, scale_arr 522-527), the conditioning plumbing (LatentDiffusion.apply_model 723-739,
+DiffusionWrapper.forward 1309-1324), the v-parameterisation helpers (239-251), first-stage decode (646-671) and the
+constructor surface of LatentVisualDiffusion (1033-1055) so MuDG's YAML configs instantiate it unchanged and its
+checkpoints load with the same key prefixes (model.diffusion_model.*, first_stage_model.*, image_proj_model.*).
+Training (p_losses, optimisers, logging) is outside the hot path — those methods say so when called.
+"""
+from functools import partial
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from lvdm.basics import disabled_train
+from lvdm.common import default, extract_into_tensor
+from lvdm.models.utils_diffusion import make_beta_schedule, rescale_zero_terminal_snr
+from utils.utils import instantiate_from_config
+
+
+def _cfg_get(cfg, key, fallback=None):
+    """Configs arrive as OmegaConf nodes, dicts or attr-dicts."""
+    if cfg is None:
+        return fallback
+    if isinstance(cfg, dict) or hasattr(cfg, "keys"):
+        try:
+            return cfg[key]
+        except (KeyError, TypeError):
+            return fallback
+    return getattr(cfg, key, fallback)
+
+
+class DiffusionWrapper(nn.Module):
+    """Routes conditioning into the UNet.  'hybrid' (MuDG): latent channels = [x | c_concat...] and context =
+    cat(c_crossattn).  The channel concat is not materialised: the pieces go to the UNet as a list and are written
+    side by side by the layout kernel."""
+
+    def __init__(self, diff_model_config, conditioning_key):
+        super().__init__()
+        self.diffusion_model = instantiate_from_config(diff_model_config)
+        self.conditioning_key = conditioning_key
+
+    def forward(self, x, t, c_label=None, c_concat: list = None, c_crossattn: list = None, c_adm=None, s=None,
+                mask=None, **kwargs):
+        key = self.conditioning_key
+        ctx = None
+        if c_crossattn is not None:
+            ctx = c_crossattn[0] if len(c_crossattn) == 1 else torch.cat(list(c_crossattn), 1)
+        if key is None:
+            return self.diffusion_model(x, t)
+        if key == "concat":
+            return self.diffusion_model([x] + list(c_concat), t, **kwargs)
+        if key == "crossattn":
+            return self.diffusion_model(x, t, context=ctx, **kwargs)
+        if key == "hybrid":
+            return self.diffusion_model([x] + list(c_concat), t, c_label=c_label, context=ctx, **kwargs)
+        raise NotImplementedError(f"conditioning_key '{key}' is not on the MuDG path")
+
+
+class DDPM(nn.Module):
+    def __init__(self, unet_config, timesteps=1000, beta_schedule="linear", loss_type="l2", ckpt_path=None,
+                 ignore_keys=[], load_only_unet=False, monitor=None, use_ema=True, first_stage_key="image",
+                 image_size=256, channels=3, log_every_t=100, clip_denoised=True, linear_start=1e-4, linear_end=2e-2,
+                 cosine_s=8e-3, given_betas=None, original_elbo_weight=0., v_posterior=0., l_simple_weight=1.,
+                 conditioning_key=None, parameterization="eps", scheduler_config=None, use_positional_encodings=False,
+                 learn_logvar=False, logvar_init=0., rescale_betas_zero_snr=False):
+        super().__init__()
+        assert parameterization in ["eps", "x0", "v"], 'currently only supporting "eps" and "x0" and "v"'
+        if use_ema:
+            raise NotImplementedError("EMA weights (use_ema) are disabled in every MuDG config and not implemented")
+        self.parameterization = parameterization
+        self.cond_stage_model = None
+        self.clip_denoised, self.log_every_t = clip_denoised, log_every_t
+        self.first_stage_key, self.channels = first_stage_key, channels
+        self.temporal_length = _cfg_get(_cfg_get(unet_config, "params"), "temporal_length")
+        self.image_size = [image_size, image_size] if isinstance(image_size, int) else image_size
+        self.use_positional_encodings = use_positional_encodings
+        self.model = DiffusionWrapper(unet_config, conditioning_key)
+        self.use_ema = False
+        self.rescale_betas_zero_snr = rescale_betas_zero_snr
+        self.v_posterior, self.original_elbo_weight, self.l_simple_weight = v_posterior, original_elbo_weight, l_simple_weight
+        if monitor is not None:
+            self.monitor = monitor
+        self.register_schedule(given_betas=given_betas, beta_schedule=beta_schedule, timesteps=timesteps,
+                               linear_start=linear_start, linear_end=linear_end, cosine_s=cosine_s)
+        self.given_betas, self.beta_schedule, self.timesteps, self.cosine_s = given_betas, beta_schedule, timesteps, cosine_s
+        self.loss_type = loss_type
+        if ckpt_path is not None:
+            self.init_from_ckpt(ckpt_path, ignore_keys=ignore_keys, only_model=load_only_unet)
+
+    @property
+    def device(self):
+        return self.betas.device
+
+    def register_schedule(self, given_betas=None, beta_schedule="linear", timesteps=1000, linear_start=1e-4,
+                          linear_end=2e-2, cosine_s=8e-3):
+        betas = given_betas if given_betas is not None else make_beta_schedule(
+            beta_schedule, timesteps, linear_start=linear_start, linear_end=linear_end, cosine_s=cosine_s)
+        if self.rescale_betas_zero_snr:
+            betas = rescale_zero_terminal_snr(betas)
+        abar = np.cumprod(1. - betas, axis=0)
+        self.num_timesteps = int(betas.shape[0])
+        self.linear_start, self.linear_end = linear_start, linear_end
+        f32 = partial(torch.tensor, dtype=torch.float32)
+        for name, val in (("betas", betas), ("alphas_cumprod", abar),
+                          ("alphas_cumprod_prev", np.append(1., abar[:-1])),
+                          ("sqrt_alphas_cumprod", np.sqrt(abar)),
+                          ("sqrt_one_minus_alphas_cumprod", np.sqrt(1. - abar)),
+                          ("log_one_minus_alphas_cumprod", np.log(np.maximum(1. - abar, 1e-300)))):
+            self.register_buffer(name, f32(val))
+        # kept for state_dict compatibility with the reference's checkpoints (not used by v-prediction sampling)
+        prev = np.append(1., abar[:-1])
+        with np.errstate(divide="ignore", invalid="ignore"):
+            post_var = (1 - self.v_posterior) * betas * (1. - prev) / (1. - abar) + self.v_posterior * betas
+            coef1 = betas * np.sqrt(prev) / (1. - abar)
+            coef2 = (1. - prev) * np.sqrt(1. - betas) / (1. - abar)
+        zeros = torch.zeros(self.num_timesteps)
+        if self.parameterization != "v":
+            self.register_buffer("sqrt_recip_alphas_cumprod", f32(np.sqrt(1. / abar)))
+            self.register_buffer("sqrt_recipm1_alphas_cumprod", f32(np.sqrt(1. / abar - 1)))
+        else:
+            self.register_buffer("sqrt_recip_alphas_cumprod", zeros.clone())
+            self.register_buffer("sqrt_recipm1_alphas_cumprod", zeros.clone())
+        self.register_buffer("posterior_variance", f32(post_var))
+        self.register_buffer("posterior_log_variance_clipped", f32(np.log(np.maximum(post_var, 1e-20))))
+        self.register_buffer("posterior_mean_coef1", f32(coef1))
+        self.register_buffer("posterior_mean_coef2", f32(coef2))
+
+    def init_from_ckpt(self, path, ignore_keys=list(), only_model=False):
+        sd = torch.load(path, map_location="cpu")
+        sd = sd.get("state_dict", sd)
+        for k in list(sd.keys()):
+            if any(k.startswith(ik) for ik in ignore_keys):
+                del sd[k]
+        return (self.model if only_model else self).load_state_dict(sd, strict=False)
+
+    # ---- v-parameterisation (ddpm3d.py:239-251): elementwise with per-sample schedule scalars -> one HIP launch each
+    def _combine(self, ca, x, cb, y, t):
+        from mudg_amd import ops
+        return ops.lincomb(x, y, ca.to(x.device)[t], cb.to(x.device)[t])
+
+    def predict_start_from_z_and_v(self, x_t, t, v):
+        return self._combine(self.sqrt_alphas_cumprod, x_t, -self.sqrt_one_minus_alphas_cumprod, v, t)
+
+    def predict_eps_from_z_and_v(self, x_t, t, v):
+        return self._combine(self.sqrt_alphas_cumprod, v, self.sqrt_one_minus_alphas_cumprod, x_t, t)
+
+    def q_sample(self, x_start, t, noise=None):
+        if noise is None:
+            noise = torch.randn_like(x_start)
+        return self._combine(self.sqrt_alphas_cumprod, x_start, self.sqrt_one_minus_alphas_cumprod, noise, t)
+
+    def training_step(self, *a, **k):
+        raise NotImplementedError("training is outside the MI355X denoising path (SURVEY §8(f) rank 4)")
+
+    p_losses = shared_step = configure_optimizers = training_step
+
+
+class LatentDiffusion(DDPM):
+    def __init__(self, first_stage_config, cond_stage_config, num_timesteps_cond=None, cond_stage_key="caption",
+                 cond_stage_trainable=False, cond_stage_forward=None, conditioning_key=None, uncond_prob=0.2,
+                 uncond_type="empty_seq", scale_factor=1.0, scale_by_std=False, encoder_type="2d", only_model=False,
+                 noise_strength=0, use_dynamic_rescale=False, base_scale=0.7, turning_step=400, interp_mode=False,
+                 fps_condition_type="fs", perframe_ae=False, logdir=None, rand_cond_frame=False,
+                 en_and_decode_n_samples_a_time=None, *args, **kwargs):
+        self.num_timesteps_cond = default(num_timesteps_cond, 1)
+        self.scale_by_std = scale_by_std
+        assert self.num_timesteps_cond <= kwargs["timesteps"]
+        if self.num_timesteps_cond != 1:
+            raise NotImplementedError("num_timesteps_cond > 1 is not on the MuDG path")
+        ckpt_path = kwargs.pop("ckpt_path", None)
+        ignore_keys = kwargs.pop("ignore_keys", [])
+        super().__init__(conditioning_key=default(conditioning_key, "crossattn"), *args, **kwargs)
+        self.cond_stage_trainable, self.cond_stage_key = cond_stage_trainable, cond_stage_key
+        self.noise_strength, self.use_dynamic_rescale = noise_strength, use_dynamic_rescale
+        self.interp_mode, self.fps_condition_type, self.perframe_ae = interp_mode, fps_condition_type, perframe_ae
+        self.logdir, self.rand_cond_frame = logdir, rand_cond_frame
+        self.en_and_decode_n_samples_a_time = en_and_decode_n_samples_a_time
+        ddc = _cfg_get(_cfg_get(first_stage_config, "params"), "ddconfig")
+        mult = _cfg_get(ddc, "ch_mult")
+        self.num_downs = len(mult) - 1 if mult is not None else 0
+        if scale_by_std:
+            self.register_buffer("scale_factor", torch.tensor(scale_factor))
+        else:
+            self.scale_factor = scale_factor
+        self.base_scale, self.turning_step = base_scale, turning_step
+        if use_dynamic_rescale:
+            self._register_scale_arr()
+        self.instantiate_first_stage(first_stage_config)
+        self.instantiate_cond_stage(cond_stage_config)
+        self.first_stage_config, self.cond_stage_config = first_stage_config, cond_stage_config
+        self.clip_denoised = False
+        self.cond_stage_forward = cond_stage_forward
+        assert encoder_type in ["2d", "3d"]
+        self.encoder_type = encoder_type
+        self.uncond_prob, self.classifier_free_guidance = uncond_prob, uncond_prob > 0
+        assert uncond_type in ["zero_embed", "empty_seq"]
+        self.uncond_type = uncond_type
+        self.restarted_from_ckpt = False
+        if ckpt_path is not None:
+            self.init_from_ckpt(ckpt_path, ignore_keys, only_model=only_model)
+            self.restarted_from_ckpt = True
+
+    def _register_scale_arr(self):
+        # ddpm3d.py:522-527: 1 -> base_scale over `turning_step` steps, then flat (length turning_step + T)
+        arr = np.concatenate((np.linspace(1.0, self.base_scale, self.turning_step),
+                              np.full(self.num_timesteps, self.base_scale)))
+        self.register_buffer("scale_arr", torch.tensor(arr, dtype=torch.float32))
+
+    def rebuild_schedules(self, device=None):
+        """Recompute every schedule buffer from the stored hyper-parameters (they are pure functions of the config).
+        Needed after constructing under torch.device('meta') + to_empty(), where buffers carry no data."""
+        with torch.device("cpu"):
+            self.register_schedule(given_betas=self.given_betas, beta_schedule=self.beta_schedule,
+                                   timesteps=self.timesteps, linear_start=self.linear_start,
+                                   linear_end=self.linear_end, cosine_s=self.cosine_s)
+            if self.use_dynamic_rescale:
+                self._register_scale_arr()
+        if device is not None:
+            for name, buf in list(self.named_buffers(recurse=False)):
+                self.register_buffer(name, buf.to(device))
+        return self
+
+    def _freeze(self, model):
+        model = model.eval()
+        model.train = disabled_train.__get__(model)
+        for p in model.parameters():
+            p.requires_grad = False
+        return model
+
+    def instantiate_first_stage(self, config):
+        self.first_stage_model = self._freeze(instantiate_from_config(config))
+
+    def instantiate_cond_stage(self, config):
+        model = instantiate_from_config(config)
+        self.cond_stage_model = model if self.cond_stage_trainable else self._freeze(model)
+
+    def get_learned_conditioning(self, c):
+        """Text embedding via the configured cond stage (OpenCLIP in MuDG's configs — outside this path's scope; any
+        module with .encode / __call__ returning (B, 77, D) works)."""
+        m = self.cond_stage_model
+        if self.cond_stage_forward is None:
+            return m.encode(c) if callable(getattr(m, "encode", None)) else m(c)
+        return getattr(m, self.cond_stage_forward)(c)
+
+    def encode_first_stage(self, x):
+        raise NotImplementedError("AutoencoderKL encode is the next row of the scope table (SURVEY §8(f) rank 1)")
+
+    @torch.no_grad()
+    def decode_core(self, z, **kwargs):
+        """z (B, C, T, h, w) or (N, C, h, w) latents -> pixels; divides by scale_factor and decodes frame by frame
+        (perframe_ae) — every frame is independent, so batching only changes launch counts."""
+        from mudg_amd.engine import vae
+        return vae.decode_latents(self.first_stage_model, z, 1.0 / float(self.scale_factor), self.perframe_ae)
+
+    def decode_first_stage(self, z, **kwargs):
+        return self.decode_core(z, **kwargs)
+
+    differentiable_decode_first_stage = decode_first_stage
+
+    def apply_model(self, x_noisy, t, cond, **kwargs):
+        if not isinstance(cond, dict):
+            cond = {("c_concat" if self.model.conditioning_key == "concat" else "c_crossattn"):
+                    cond if isinstance(cond, list) else [cond]}
+        label = kwargs.get("class_label", None)
+        if label is None:
+            raise TypeError("apply_model needs class_label=(B, 1) (0 colour / 500 depth / 1 semantic)")
+        out = self.model(x_noisy, t, label[:, 0], **cond, **kwargs)
+        return out[0] if isinstance(out, tuple) else out
+
+
+class LatentVisualDiffusion(LatentDiffusion):
+    def __init__(self, img_cond_stage_config, image_proj_stage_config, freeze_embedder=True,
+                 image_proj_model_trainable=True, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.image_proj_model_trainable = image_proj_model_trainable
+        self.embedder = instantiate_from_config(img_cond_stage_config)
+        if freeze_embedder:
+            self.embedder = self._freeze(self.embedder)
+        self.image_proj_model = instantiate_from_config(image_proj_stage_config)
+        if not image_proj_model_trainable:
+            self.image_proj_model = self._freeze(self.image_proj_model)

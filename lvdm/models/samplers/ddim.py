@@ -1,0 +1,150 @@
+"""DDIM sampler at the drop-in boundary (reference: lvdm/models/samplers/ddim.py, DDIMSampler 10-317).
+
+Same constructor, `make_schedule`, `sample`, `ddim_sampling` and `p_sample_ddim` signatures and return values.
+What differs is where the arithmetic runs: the schedule is derived once on the host (same float64/float32 mix as
+the reference, see utils_diffusion), each step's scalars are kept as host floats instead of 1-element device
+tensors, and the whole per-step update — classifier-free guidance, guidance rescale (per-sample std), v -> (eps, x0),
+dynamic rescale and the x_{t-1} formula — is ONE fused HIP launch (mudg_ddim_step) after the two UNet passes.
+Options MuDG's drivers never use (mask blending, x0 quantisation, score correctors, noise dropout, the full
+1000-step "original steps" mode) raise NotImplementedError instead of falling back to eager PyTorch.
+"""
+import numpy as np
+import torch
+
+from lvdm.common import noise_like
+from lvdm.models.utils_diffusion import make_ddim_sampling_parameters, make_ddim_timesteps
+
+
+class DDIMSampler(object):
+    def __init__(self, model, schedule="linear", **kwargs):
+        super().__init__()
+        self.model = model
+        self.ddpm_num_timesteps = model.num_timesteps
+        self.schedule = schedule
+        self.counter = 0
+
+    def register_buffer(self, name, attr):
+        setattr(self, name, attr)
+
+    # ------------------------------------------------------------------ schedule (host)
+    def make_schedule(self, ddim_num_steps, ddim_discretize="uniform", ddim_eta=0., verbose=True):
+        self.ddim_timesteps = make_ddim_timesteps(ddim_discretize, ddim_num_steps, self.ddpm_num_timesteps,
+                                                  verbose=verbose)
+        ac = self.model.alphas_cumprod.detach().float().cpu()
+        assert ac.shape[0] == self.ddpm_num_timesteps, "alphas have to be defined for each timestep"
+        if self.model.use_dynamic_rescale:
+            sa = self.model.scale_arr.detach().float().cpu()[self.ddim_timesteps]
+            self.ddim_scale_arr = sa
+            self.ddim_scale_arr_prev = torch.cat([sa[0:1], sa[:-1]])
+        self.register_buffer("alphas_cumprod", ac)
+        self.register_buffer("sqrt_alphas_cumprod", self.model.sqrt_alphas_cumprod.detach().float().cpu())
+        self.register_buffer("sqrt_one_minus_alphas_cumprod",
+                             self.model.sqrt_one_minus_alphas_cumprod.detach().float().cpu())
+        sigmas, alphas, alphas_prev = make_ddim_sampling_parameters(ac, self.ddim_timesteps, ddim_eta, verbose=verbose)
+        self.register_buffer("ddim_sigmas", sigmas)
+        self.register_buffer("ddim_alphas", alphas)
+        self.register_buffer("ddim_alphas_prev", alphas_prev)
+        self.register_buffer("ddim_sqrt_one_minus_alphas", torch.sqrt(1. - alphas))
+
+    def step_coefficients(self, index, cfg_scale, guidance_rescale, temperature=1.0):
+        """The eight host scalars of mudg_ddim_step for DDIM index `index`, each rounded to fp32 where the reference
+        rounds it (torch.full((b,1,1,1,1), value) of a python/np/tensor scalar, ddim.py:251-254,262-266)."""
+        f32 = lambda v: torch.full((1,), float(v), dtype=torch.float32)
+        t = int(self.ddim_timesteps[index])
+        a_prev, sigma = f32(self.ddim_alphas_prev[index]), f32(self.ddim_sigmas[index])
+        rescale = torch.ones(1)
+        if self.model.use_dynamic_rescale:
+            rescale = f32(self.ddim_scale_arr_prev[index]) / f32(self.ddim_scale_arr[index])
+        dir_coef = (1. - a_prev - sigma ** 2).sqrt()
+        if self.model.parameterization != "v":
+            raise NotImplementedError("the MI355X sampler implements the v-parameterisation MuDG uses")
+        return [float(cfg_scale), float(guidance_rescale), float(self.sqrt_alphas_cumprod[t]),
+                float(self.sqrt_one_minus_alphas_cumprod[t]), float(rescale), float(a_prev.sqrt()), float(dir_coef),
+                float(sigma * temperature)]
+
+    # ------------------------------------------------------------------ sampling
+    @torch.no_grad()
+    def sample(self, S, batch_size, shape, conditioning=None, callback=None, normals_sequence=None, img_callback=None,
+               quantize_x0=False, eta=0., mask=None, x0=None, temperature=1., noise_dropout=0., score_corrector=None,
+               corrector_kwargs=None, verbose=True, schedule_verbose=False, x_T=None, log_every_t=100,
+               unconditional_guidance_scale=1., unconditional_conditioning=None, precision=None, fs=None,
+               timestep_spacing="uniform", guidance_rescale=0.0, **kwargs):
+        if conditioning is not None:
+            first = conditioning[list(conditioning.keys())[0]] if isinstance(conditioning, dict) else conditioning
+            cbs = (first[0] if isinstance(first, (list, tuple)) else first).shape[0]
+            if cbs != batch_size:
+                print(f"Warning: Got {cbs} conditionings but batch-size is {batch_size}")
+        self.make_schedule(ddim_num_steps=S, ddim_discretize=timestep_spacing, ddim_eta=eta, verbose=schedule_verbose)
+        if len(shape) not in (3, 4):
+            raise ValueError(f"shape must be (C, H, W) or (C, T, H, W), got {shape}")
+        size = (batch_size, *shape)
+        return self.ddim_sampling(conditioning, size, callback=callback, img_callback=img_callback,
+                                  quantize_denoised=quantize_x0, mask=mask, x0=x0, ddim_use_original_steps=False,
+                                  noise_dropout=noise_dropout, temperature=temperature,
+                                  score_corrector=score_corrector, corrector_kwargs=corrector_kwargs, x_T=x_T,
+                                  log_every_t=log_every_t, unconditional_guidance_scale=unconditional_guidance_scale,
+                                  unconditional_conditioning=unconditional_conditioning, verbose=verbose,
+                                  precision=precision, fs=fs, guidance_rescale=guidance_rescale, **kwargs)
+
+    @torch.no_grad()
+    def ddim_sampling(self, cond, shape, x_T=None, ddim_use_original_steps=False, callback=None, timesteps=None,
+                      quantize_denoised=False, mask=None, x0=None, img_callback=None, log_every_t=100, temperature=1.,
+                      noise_dropout=0., score_corrector=None, corrector_kwargs=None, unconditional_guidance_scale=1.,
+                      unconditional_conditioning=None, verbose=True, precision=None, fs=None, guidance_rescale=0.0,
+                      **kwargs):
+        if ddim_use_original_steps or timesteps is not None:
+            raise NotImplementedError("sampling on the full DDPM schedule / a timestep subset is not on the MuDG path")
+        if mask is not None:
+            raise NotImplementedError("mask blending (inpainting-style sampling) is not on the MuDG path")
+        kwargs.pop("clean_cond", None)
+        device = self.model.betas.device
+        b = shape[0]
+        img = torch.randn(shape, device=device) if x_T is None else x_T.to(device=device, dtype=torch.float32)
+        steps = self.ddim_timesteps
+        total = steps.shape[0]
+        intermediates = {"x_inter": [img], "pred_x0": [img]}
+        iterator = np.flip(steps)
+        if verbose:
+            from tqdm import tqdm
+            iterator = tqdm(iterator, desc="DDIM Sampler", total=total)
+        for i, step in enumerate(iterator):
+            index = total - i - 1
+            ts = torch.full((b,), int(step), device=device, dtype=torch.long)
+            img, pred_x0 = self.p_sample_ddim(img, cond, ts, index=index, quantize_denoised=quantize_denoised,
+                                              temperature=temperature, noise_dropout=noise_dropout,
+                                              score_corrector=score_corrector, corrector_kwargs=corrector_kwargs,
+                                              unconditional_guidance_scale=unconditional_guidance_scale,
+                                              unconditional_conditioning=unconditional_conditioning, mask=mask, x0=x0,
+                                              fs=fs, guidance_rescale=guidance_rescale, **kwargs)
+            if callback:
+                callback(i)
+            if img_callback:
+                img_callback(pred_x0, i)
+            if index % log_every_t == 0 or index == total - 1:
+                intermediates["x_inter"].append(img)
+                intermediates["pred_x0"].append(pred_x0)
+        return img, intermediates
+
+    @torch.no_grad()
+    def p_sample_ddim(self, x, c, t, index, repeat_noise=False, use_original_steps=False, quantize_denoised=False,
+                      temperature=1., noise_dropout=0., score_corrector=None, corrector_kwargs=None,
+                      unconditional_guidance_scale=1., unconditional_conditioning=None, uc_type=None,
+                      conditional_guidance_scale_temporal=None, mask=None, x0=None, guidance_rescale=0.0, **kwargs):
+        if use_original_steps or quantize_denoised or score_corrector is not None or noise_dropout > 0.:
+            raise NotImplementedError("original-steps / quantised x0 / score corrector / noise dropout are not on the "
+                                      "MuDG path")
+        from mudg_amd import ops
+        e_c = self.model.apply_model(x, t, c, **kwargs)
+        guided = unconditional_conditioning is not None and unconditional_guidance_scale != 1.
+        e_u = self.model.apply_model(x, t, unconditional_conditioning, **kwargs) if guided else None
+        coef = self.step_coefficients(index, unconditional_guidance_scale if guided else 1.0,
+                                      guidance_rescale if guided else 0.0, temperature)
+        noise = noise_like(x.shape, x.device, repeat_noise) if coef[7] != 0.0 else None
+        return ops.ddim_step(x.float().contiguous(), e_c.float().contiguous(),
+                             None if e_u is None else e_u.float().contiguous(), noise, coef)
+
+    def decode(self, *a, **k):
+        raise NotImplementedError("DDIM latent re-decoding is not on the MuDG path")
+
+    def stochastic_encode(self, *a, **k):
+        raise NotImplementedError("DDIM stochastic encoding is not on the MuDG path")

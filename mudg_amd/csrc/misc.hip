@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void small_linear_kernel(const float* __restri
 
 template <typename ST>
 __global__ void ncthw_to_rows_kernel(const ST* __restrict__ src, bf16* __restrict__ dst, int B, int C, int T, int HW,
-                                     int ld, int coff) {
+                                     int ld, int coff, int Ttot, int t0) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over (b, t, p)
     const int64_t n = (int64_t)B * T * HW;
     if (i >= n) return;
@@ -53,12 +53,12 @@ __global__ void ncthw_to_rows_kernel(const ST* __restrict__ src, bf16* __restric
     const int64_t bt = i / HW;
     const int t = (int)(bt % T), b = (int)(bt / T);
     for (int c = 0; c < C; ++c)
-        dst[i * ld + coff + c] = (bf16)(float)src[(((int64_t)b * C + c) * T + t) * HW + p];
+        dst[i * ld + coff + c] = (bf16)(float)src[(((int64_t)b * C + c) * Ttot + t0 + t) * HW + p];
 }
 
 template <typename DT>
 __global__ void rows_to_ncthw_kernel(const bf16* __restrict__ src, int ld, int coff, DT* __restrict__ dst, int B, int C,
-                                     int T, int HW, float scale) {
+                                     int T, int HW, float scale, int Ttot, int t0) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t n = (int64_t)B * T * HW;
     if (i >= n) return;
@@ -66,7 +66,7 @@ __global__ void rows_to_ncthw_kernel(const bf16* __restrict__ src, int ld, int c
     const int64_t bt = i / HW;
     const int t = (int)(bt % T), b = (int)(bt / T);
     for (int c = 0; c < C; ++c)
-        dst[(((int64_t)b * C + c) * T + t) * HW + p] = (DT)((float)src[i * ld + coff + c] * scale);
+        dst[(((int64_t)b * C + c) * Ttot + t0 + t) * HW + p] = (DT)((float)src[i * ld + coff + c] * scale);
 }
 
 __global__ void zero_channels_kernel(bf16* __restrict__ dst, int64_t rows, int ld, int c0, int c1) {
@@ -74,6 +74,36 @@ __global__ void zero_channels_kernel(bf16* __restrict__ dst, int64_t rows, int l
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows * w) return;
     dst[(i / w) * ld + c0 + (int)(i % w)] = (bf16)0.f;
+}
+
+__global__ void copy_rows_kernel(const bf16* __restrict__ src, int64_t lds, bf16* __restrict__ dst, int64_t ldd, int64_t rows,
+                                 int64_t cols, int vec) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (vec) {
+        const int64_t cv = cols >> 3;
+        if (i >= rows * cv) return;
+        const int64_t r = i / cv, c = (i - r * cv) << 3;
+        st16(dst + r * ldd + c, ld16(src + r * lds + c));
+    } else {
+        if (i >= rows * cols) return;
+        const int64_t r = i / cols, c = i - r * cols;
+        dst[r * ldd + c] = src[r * lds + c];
+    }
+}
+
+__global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, int64_t n, float alpha) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] += alpha * x[i];
+}
+
+// out[b][i] = ca[b] * x[b][i] + cb[b] * y[b][i]  (per-sample schedule coefficients gathered on the host side)
+__global__ void lincomb_kernel(float* __restrict__ out, const float* __restrict__ x, const float* __restrict__ y,
+                               const float* __restrict__ ca, const float* __restrict__ cb, int64_t n) {
+    const int b = blockIdx.y;
+    const float a = ca[b], c = cb[b];
+    const int64_t off = (int64_t)b * n;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+        out[off + i] = a * x[off + i] + c * y[off + i];
 }
 
 // ---- DDIM -------------------------------------------------------------------------------------------------
@@ -169,24 +199,28 @@ extern "C" int mudg_small_linear(const float* x, const void* W, int w_is_bf16, c
 }
 
 extern "C" int mudg_ncthw_to_rows(const void* src, int src_is_fp32, void* dst, int B, int C, int T, int HW, int ld, int coff,
-                                  void* stream) {
+                                  int Ttot, int t0, void* stream) {
     MUDG_REQUIRE(src && dst && B > 0 && C > 0 && T > 0 && HW > 0 && coff >= 0 && coff + C <= ld, "mudg_ncthw_to_rows: bad arguments");
+    if (Ttot <= 0) { Ttot = T; t0 = 0; }
+    MUDG_REQUIRE(t0 >= 0 && t0 + T <= Ttot, "mudg_ncthw_to_rows: frame window [%d, %d) outside %d", t0, t0 + T, Ttot);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int64_t n = (int64_t)B * T * HW;
     const dim3 grid((unsigned)((n + 255) / 256));
-    if (src_is_fp32) hipLaunchKernelGGL(ncthw_to_rows_kernel<float>, grid, dim3(256), 0, s, (const float*)src, (bf16*)dst, B, C, T, HW, ld, coff);
-    else hipLaunchKernelGGL(ncthw_to_rows_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)src, (bf16*)dst, B, C, T, HW, ld, coff);
+    if (src_is_fp32) hipLaunchKernelGGL(ncthw_to_rows_kernel<float>, grid, dim3(256), 0, s, (const float*)src, (bf16*)dst, B, C, T, HW, ld, coff, Ttot, t0);
+    else hipLaunchKernelGGL(ncthw_to_rows_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)src, (bf16*)dst, B, C, T, HW, ld, coff, Ttot, t0);
     return mudg_check_launch("mudg_ncthw_to_rows");
 }
 
 extern "C" int mudg_rows_to_ncthw(const void* src, int ld, int coff, void* dst, int dst_is_fp32, int B, int C, int T, int HW,
-                                  float scale, void* stream) {
+                                  float scale, int Ttot, int t0, void* stream) {
     MUDG_REQUIRE(src && dst && B > 0 && C > 0 && T > 0 && HW > 0 && coff >= 0 && coff + C <= ld, "mudg_rows_to_ncthw: bad arguments");
+    if (Ttot <= 0) { Ttot = T; t0 = 0; }
+    MUDG_REQUIRE(t0 >= 0 && t0 + T <= Ttot, "mudg_rows_to_ncthw: frame window [%d, %d) outside %d", t0, t0 + T, Ttot);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int64_t n = (int64_t)B * T * HW;
     const dim3 grid((unsigned)((n + 255) / 256));
-    if (dst_is_fp32) hipLaunchKernelGGL(rows_to_ncthw_kernel<float>, grid, dim3(256), 0, s, (const bf16*)src, ld, coff, (float*)dst, B, C, T, HW, scale);
-    else hipLaunchKernelGGL(rows_to_ncthw_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)src, ld, coff, (bf16*)dst, B, C, T, HW, scale);
+    if (dst_is_fp32) hipLaunchKernelGGL(rows_to_ncthw_kernel<float>, grid, dim3(256), 0, s, (const bf16*)src, ld, coff, (float*)dst, B, C, T, HW, scale, Ttot, t0);
+    else hipLaunchKernelGGL(rows_to_ncthw_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)src, ld, coff, (bf16*)dst, B, C, T, HW, scale, Ttot, t0);
     return mudg_check_launch("mudg_rows_to_ncthw");
 }
 
@@ -196,6 +230,33 @@ extern "C" int mudg_zero_channels(void* dst, int rows, int ld, int c0, int c1, v
     const int64_t n = (int64_t)rows * (c1 - c0);
     hipLaunchKernelGGL(zero_channels_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (bf16*)dst, (int64_t)rows, ld, c0, c1);
     return mudg_check_launch("mudg_zero_channels");
+}
+
+extern "C" int mudg_copy_rows(const void* src, int64_t lds, void* dst, int64_t ldd, int64_t rows, int64_t cols, void* stream) {
+    MUDG_REQUIRE(src && dst && rows > 0 && cols > 0 && lds >= cols && ldd >= cols, "mudg_copy_rows: bad arguments");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int vec = aligned16(src) && aligned16(dst) && !(lds & 7) && !(ldd & 7) && !(cols & 7);
+    const int64_t n = vec ? rows * (cols >> 3) : rows * cols;
+    hipLaunchKernelGGL(copy_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const bf16*)src, lds, (bf16*)dst,
+                       ldd, rows, cols, vec);
+    return mudg_check_launch("mudg_copy_rows");
+}
+
+extern "C" int mudg_axpy_f32(float* y, const float* x, int64_t n, float alpha, void* stream) {
+    MUDG_REQUIRE(y && x && n > 0, "mudg_axpy_f32: bad arguments");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(axpy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, y, x, n, alpha);
+    return mudg_check_launch("mudg_axpy_f32");
+}
+
+extern "C" int mudg_lincomb(float* out, const float* x, const float* y, const float* ca, const float* cb, int B, int64_t n,
+                            void* stream) {
+    MUDG_REQUIRE(out && x && y && ca && cb && B > 0 && B <= 65535 && n > 0, "mudg_lincomb: bad arguments");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    int gx = (int)((n + 255) / 256);
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(lincomb_kernel, dim3(gx, B), dim3(256), 0, s, out, x, y, ca, cb, n);
+    return mudg_check_launch("mudg_lincomb");
 }
 
 extern "C" int64_t mudg_ddim_ws_doubles(int B) { return B > 0 ? (int64_t)B * DDIM_BLK * 4 : 0; }

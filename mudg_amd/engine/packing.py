@@ -1,0 +1,99 @@
+"""Weight caches for the kernels: bf16, GEMM-ready layouts derived from the nn.Parameters the boundary modules own.
+
+The parameters stay the single source of truth (fp32 nn.Parameter, reference names).  A packed copy is rebuilt
+whenever the parameter object or its in-place version counter changes — load_state_dict, optimizer steps and module
+surgery all invalidate it — so the caches never need manual flushing.  Packing is one-off layout work (torch ops on
+the device), not part of the per-step path.
+"""
+import torch
+
+BF16 = torch.bfloat16
+
+
+def _key(params):
+    return tuple((p.data_ptr(), p._version, p.dtype, tuple(p.shape)) for p in params)
+
+
+def cached(module, name, params, build):
+    store = module.__dict__.setdefault("_mudg_packed", {})
+    key = _key(params)
+    hit = store.get(name)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    with torch.no_grad():
+        val = build()
+    store[name] = (key, val)
+    return val
+
+
+def _need_cuda(p, what):
+    if not p.is_cuda:
+        raise RuntimeError(f"{what}: parameters must live on the GPU (got {p.device}); the MI355X path has no CPU "
+                           "fallback — move the model with .cuda() first")
+
+
+def f32(module, name):
+    """A parameter as contiguous fp32 (biases, norm scales): usually the parameter's own storage."""
+    p = getattr(module, name)
+    if p is None:
+        return None
+    _need_cuda(p, type(module).__name__)
+    if p.dtype == torch.float32 and p.is_contiguous():
+        return p.detach()
+    return cached(module, "f32:" + name, (p,), lambda: p.detach().float().contiguous())
+
+
+def linear(mod):
+    """[N, K] bf16 from nn.Linear / 1x1 Conv2d / k=1 Conv1d weights."""
+    w = mod.weight
+    _need_cuda(w, type(mod).__name__)
+    return cached(mod, "w", (w,), lambda: w.detach().reshape(w.shape[0], -1).to(BF16).contiguous())
+
+
+def linear_cat(owner, name, mods):
+    """Rows of several bias-free Linears stacked into one [sum N, K] bf16 matrix (fused q/k or q/k/v projection)."""
+    ws = tuple(m.weight for m in mods)
+    for w in ws:
+        _need_cuda(w, name)
+    return cached(owner, name, ws, lambda: torch.cat([w.detach().to(BF16) for w in ws], 0).contiguous())
+
+
+def conv3x3(mod):
+    """(Cout, Cin, 3, 3) -> [Cout][tap][Cin padded to a multiple of 8] bf16; returns (matrix, padded Cin)."""
+    w = mod.weight
+    _need_cuda(w, type(mod).__name__)
+    cin = w.shape[1]
+    cpad = (cin + 7) // 8 * 8
+
+    def build():
+        t = w.detach().permute(0, 2, 3, 1)                       # Cout, ky, kx, Cin
+        if cpad != cin:
+            t = torch.nn.functional.pad(t, (0, cpad - cin))
+        return t.reshape(w.shape[0], 9 * cpad).to(BF16).contiguous()
+
+    return cached(mod, "w3x3", (w,), build), cpad
+
+
+def tconv(mod):
+    """(Cout, Cin, 3, 1, 1) -> [Cout][tap][Cin] bf16."""
+    w = mod.weight
+    _need_cuda(w, type(mod).__name__)
+    return cached(mod, "wt", (w,), lambda: w.detach()[:, :, :, 0, 0].permute(0, 2, 1).reshape(w.shape[0], -1)
+                  .to(BF16).contiguous())
+
+
+def geglu(mod):
+    """GEGLU projection [2I, K] (+bias) reordered into blocks of 32 value rows followed by their 32 gate rows,
+    the order mudg_gemm's fused GEGLU epilogue expects.  Returns (weight bf16, bias fp32)."""
+    w, b = mod.weight, mod.bias
+    _need_cuda(w, "GEGLU")
+    inner = w.shape[0] // 2
+    if inner % 32:
+        raise RuntimeError(f"GEGLU inner width {inner} must be a multiple of 32")
+
+    def build():
+        idx = torch.arange(inner, device=w.device).reshape(-1, 32)
+        order = torch.cat([idx, idx + inner], dim=1).reshape(-1)
+        return (w.detach()[order].to(BF16).contiguous(), b.detach()[order].float().contiguous())
+
+    return cached(mod, "geglu", (w, b), build)

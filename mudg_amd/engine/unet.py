@@ -1,0 +1,298 @@
+"""Executor of the 3D-UNet on MI355X: walks a boundary UNetModel (lvdm.modules.networks.openaimodel3d) and runs it
+as a sequence of HIP kernel launches on channels-last bf16 "rows" (pixels x channels) — no permutes, no eager ops.
+
+Reference semantics reproduced (file:line in the reference tree):
+  UNetModel.forward                     openaimodel3d.py:567-628
+  ResBlock._forward / TemporalConvBlock openaimodel3d.py:210-236 / 272-279
+  SpatialTransformer / TemporalTransformer / BasicTransformerBlock / CrossAttention / GEGLU
+                                        attention.py:451-467 / 529-576 / 392-400 / 81-144 / 579-606
+Layout: the reference flips between (b t) c h w, b c t h w, (b hw) t c ...; here every activation is one matrix
+whose rows are ordered ((b t) h w) with channels contiguous, so all of those rearranges are no-ops.  Fusions:
+bias / timestep-embedding add / residual add / GEGLU ride in GEMM epilogues, nearest-upsample, stride-2 and the
+skip-concat ride in the implicit-GEMM loader, V is produced already transposed for the flash kernel.
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from . import packing as pk
+
+BF16 = torch.bfloat16
+
+
+class _Ctx:
+    """Per-forward state shared by all blocks."""
+    __slots__ = ("B", "T", "emb", "text", "img", "n_text", "n_img", "img_div", "kv_cache")
+
+
+# ------------------------------------------------------------------------------------------------ building blocks
+def _gn(mod, x, x2, samples, rows, silu):
+    return ops.groupnorm(x, pk.f32(mod, "weight"), pk.f32(mod, "bias"), samples=samples, rows=rows, eps=mod.eps,
+                         silu=silu, groups=mod.num_groups, x2=x2)
+
+
+def _ln(mod, x):
+    return ops.layernorm(x, pk.f32(mod, "weight"), pk.f32(mod, "bias"), eps=mod.eps)
+
+
+def _linear(mod, x, residual=None, x2=None):
+    return ops.gemm(x, pk.linear(mod), bias=pk.f32(mod, "bias"), residual=residual, x2=x2)
+
+
+def _conv3x3(mod, x, frames, h, w, *, stride=1, upsample=False, gbias=None, rows_per_group=0, residual=None, x2=None):
+    wmat, cpad = pk.conv3x3(mod)
+    return ops.conv3x3(x, wmat, frames=frames, hin=h, win=w, cin=cpad, stride=stride, upsample=upsample,
+                       bias=pk.f32(mod, "bias"), gbias=gbias, rows_per_group=rows_per_group, residual=residual, x2=x2)
+
+
+def _vt_projection(mod, src_rows, batches, n_per_batch):
+    """V^T per batch entry: out[b] = W_v (C x K) @ src[b]^T (K x n) -> [batches * C, ld] with ld = n rounded to 8."""
+    w = pk.linear(mod)
+    c, k = w.shape
+    ld = (n_per_batch + 7) // 8 * 8
+    out = ops.empty_rows(batches * c, ld, BF16, src_rows.device)
+    ops.gemm(w, src_rows, out=out, batch=batches, sx=0, sw=n_per_batch * src_rows.stride(0), sy=c * ld,
+             M=c, N=n_per_batch, K=k, ldy=ld)
+    return out, ld
+
+
+def _feed_forward(ff, x_norm, residual):
+    wg, bg = pk.geglu(ff.net[0].proj)
+    hidden = ops.gemm(x_norm, wg, bias=bg, geglu=True)
+    return _linear(ff.net[2], hidden, residual=residual)
+
+
+def temporal_conv_block(mod, x, ctx, hw):
+    """identity + conv4(conv3(conv2(conv1(x)))); GroupNorm statistics span (C/32, T, H, W) of each clip."""
+    y = x
+    stages = (mod.conv1, mod.conv2, mod.conv3, mod.conv4)
+    for i, seq in enumerate(stages):
+        norm, conv = seq[0], seq[-1]
+        y = _gn(norm, y, None, ctx.B, ctx.T * hw, True)
+        y = ops.tconv3(y, pk.tconv(conv), clips=ctx.B, t=ctx.T, hw=hw, cin=conv.weight.shape[1],
+                       bias=pk.f32(conv, "bias"), residual=x if i == len(stages) - 1 else None)
+    return y
+
+
+def res_block(mod, x, x2, h, w, ctx):
+    """x (+ x2: the skip tensor of a decoder stage, read in place of torch.cat) -> rows [F*h*w, out_channels]."""
+    frames, hw = ctx.B * ctx.T, h * w
+    a = _gn(mod.in_layers[0], x, x2, frames, hw, True)
+    lin = mod.emb_layers[1]
+    emb_out = ops.small_linear(ctx.emb, pk.f32(lin, "weight"), pk.f32(lin, "bias"), act_in=True)     # (B, Cout) fp32
+    a = _conv3x3(mod.in_layers[2], a, frames, h, w, gbias=emb_out, rows_per_group=ctx.T * hw)
+    a = _gn(mod.out_layers[0], a, None, frames, hw, True)
+    if isinstance(mod.skip_connection, nn.Identity):
+        if x2 is not None:
+            raise RuntimeError("identity skip with a concatenated input")
+        skip = x
+    else:
+        skip = _linear(mod.skip_connection, x, x2=x2)
+    out = _conv3x3(mod.out_layers[3], a, frames, h, w, residual=skip)
+    if mod.use_temporal_conv:
+        out = temporal_conv_block(mod.temopral_conv, out, ctx, hw)
+    return out
+
+
+def _cross_kv(attn, ctx):
+    """K and V^T of the text tokens (shared by a clip's frames) and of the image tokens for one attn2 layer."""
+    k_text = ops.gemm(ctx.text, pk.linear(attn.to_k))
+    vt_text, ld_text = _vt_projection(attn.to_v, ctx.text, ctx.B, ctx.n_text)
+    if ctx.img is None or not attn.image_cross_attention:
+        return k_text, vt_text, ld_text, None, None, 0
+    k_img = ops.gemm(ctx.img, pk.linear(attn.to_k_ip))
+    vt_img, ld_img = _vt_projection(attn.to_v_ip, ctx.img, ctx.img.shape[0] // ctx.n_img, ctx.n_img)
+    return k_text, vt_text, ld_text, k_img, vt_img, ld_img
+
+
+def spatial_block(blk, hcur, frames, hw, ctx):
+    a1, a2 = blk.attn1, blk.attn2
+    c, heads = hcur.shape[1], a1.heads
+    # self-attention over the hw tokens of each frame
+    n1 = _ln(blk.norm1, hcur)
+    qk = ops.gemm(n1, pk.linear_cat(a1, "qk", (a1.to_q, a1.to_k)))
+    vt, ldv = _vt_projection(a1.to_v, n1, frames, hw)
+    att = ops.empty_rows(frames * hw, c, BF16, hcur.device)
+    ops.attention(qk[:, :c], qk[:, c:], vt, att, frames=frames, heads=heads, nq=hw, nk=hw, ldvt=ldv, svt=c * ldv,
+                  scale=a1.scale)
+    hcur = _linear(a1.to_out[0], att, residual=hcur)
+    # text (+ image) cross-attention: two softmaxes, outputs summed (image_cross_attention_scale == 1)
+    n2 = _ln(blk.norm2, hcur)
+    q2 = ops.gemm(n2, pk.linear(a2.to_q))
+    key = id(a2)
+    if key not in ctx.kv_cache:
+        ctx.kv_cache[key] = _cross_kv(a2, ctx)
+    k_text, vt_text, ld_text, k_img, vt_img, ld_img = ctx.kv_cache[key]
+    att2 = ops.empty_rows(frames * hw, c, BF16, hcur.device)
+    ops.attention(q2, k_text, vt_text, att2, frames=frames, heads=heads, nq=hw, nk=ctx.n_text, ldvt=ld_text,
+                  svt=c * ld_text, kv_div=ctx.T, scale=a2.scale)
+    if k_img is not None:
+        if a2.image_cross_attention_scale != 1.0:
+            raise NotImplementedError("image_cross_attention_scale != 1.0")
+        ops.attention(q2, k_img, vt_img, att2, frames=frames, heads=heads, nq=hw, nk=ctx.n_img, ldvt=ld_img,
+                      svt=c * ld_img, kv_div=ctx.img_div, scale=a2.scale, accumulate=True)
+    hcur = _linear(a2.to_out[0], att2, residual=hcur)
+    return _feed_forward(blk.ff, _ln(blk.norm3, hcur), hcur)
+
+
+def spatial_transformer(mod, x, h, w, ctx):
+    frames, hw = ctx.B * ctx.T, h * w
+    cur = _linear(mod.proj_in, _gn(mod.norm, x, None, frames, hw, False))
+    for blk in mod.transformer_blocks:
+        cur = spatial_block(blk, cur, frames, hw, ctx)
+    return _linear(mod.proj_out, cur, residual=x)
+
+
+def temporal_block(blk, hcur, hw, ctx):
+    for attn, norm in ((blk.attn1, blk.norm1), (blk.attn2, blk.norm2)):     # both are self-attention over T
+        c = hcur.shape[1]
+        qkv = ops.gemm(_ln(norm, hcur), pk.linear_cat(attn, "qkv", (attn.to_q, attn.to_k, attn.to_v)))
+        att = ops.empty_rows(hcur.shape[0], c, BF16, hcur.device)
+        ops.temporal_attention(qkv, att, clips=ctx.B, t=ctx.T, hw=hw, heads=attn.heads, scale=attn.scale)
+        hcur = _linear(attn.to_out[0], att, residual=hcur)
+    return _feed_forward(blk.ff, _ln(blk.norm3, hcur), hcur)
+
+
+def temporal_transformer(mod, x, h, w, ctx):
+    hw = h * w
+    cur = _linear(mod.proj_in, _gn(mod.norm, x, None, ctx.B, ctx.T * hw, False))
+    for blk in mod.transformer_blocks:
+        cur = temporal_block(blk, cur, hw, ctx)
+    return _linear(mod.proj_out, cur, residual=x)
+
+
+def run_stage(seq, x, x2, h, w, ctx):
+    """One TimestepEmbedSequential.  Returns (rows, h, w)."""
+    frames = ctx.B * ctx.T
+    for m in seq:
+        name = type(m).__name__
+        if name == "ResBlock":
+            x, x2 = res_block(m, x, x2, h, w, ctx), None
+        elif name == "SpatialTransformer":
+            x = spatial_transformer(m, x, h, w, ctx)
+        elif name == "TemporalTransformer":
+            x = temporal_transformer(m, x, h, w, ctx)
+        elif name == "Downsample":
+            x = _conv3x3(m.op, x, frames, h, w, stride=2)
+            h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        elif name == "Upsample":
+            x = _conv3x3(m.conv, x, frames, h, w, upsample=True)
+            h, w = 2 * h, 2 * w
+        elif isinstance(m, nn.Conv2d):                      # the stem (possibly swapped in by training-time surgery)
+            x = _conv3x3(m, x, frames, h, w)
+        else:
+            raise NotImplementedError(f"no MI355X implementation for UNet stage member {name}")
+    return x, h, w
+
+
+# ------------------------------------------------------------------------------------------------ conditioning
+def _embed_mlp(seq, sin):
+    l0, l2 = seq[0], seq[2]
+    hid = ops.small_linear(sin, pk.f32(l0, "weight"), pk.f32(l0, "bias"), act_out=True)
+    return ops.small_linear(hid, pk.f32(l2, "weight"), pk.f32(l2, "bias"))
+
+
+def _to_long(v, n, device, what):
+    if v is None:
+        raise AssertionError(f"{what} is required")
+    v = torch.as_tensor(v, device=device)
+    if v.numel() != n:
+        raise ValueError(f"{what}: expected {n} entries, got {tuple(v.shape)}")
+    return v.reshape(n).to(torch.int64)
+
+
+def make_context(model, ctx, context, t_len, device):
+    """Split (B, L, D) context into text rows [B*77, D] and image rows, cast to bf16 by the layout kernel."""
+    if context is None:
+        raise AssertionError("context is required (text + per-frame image tokens)")
+    if context.dim() != 3 or context.shape[0] != ctx.B:
+        raise ValueError(f"context must be (B, L, D), got {tuple(context.shape)}")
+    if not context.is_cuda:
+        raise RuntimeError("context must be a GPU tensor")
+    L, D = context.shape[1], context.shape[2]
+    if L <= 77:
+        raise ValueError("context needs more than the 77 text tokens (image tokens follow them)")
+    flat = context.contiguous()
+    if flat.dtype not in (torch.float32, BF16):
+        flat = flat.float()
+    rows = ops.cast_bf16(flat.reshape(ctx.B * L, D))
+    ctx.n_text = 77
+    # openaimodel3d.py:581-587: per-frame image tokens when L == 77 + 16 T, otherwise the whole context per frame
+    if L == 77 + 16 * t_len:
+        ctx.n_img, ctx.img_div = 16, 1
+    else:
+        ctx.n_img, ctx.img_div = L - 77, t_len
+    rows3 = rows.reshape(ctx.B, L, D)
+    text = ops.empty_rows(ctx.B * 77, D, BF16, device)
+    img = ops.empty_rows(ctx.B * (L - 77), D, BF16, device)
+    ops.copy_rows(rows3[:, :77].reshape(ctx.B, 77 * D), text.reshape(ctx.B, 77 * D))
+    ops.copy_rows(rows3[:, 77:].reshape(ctx.B, (L - 77) * D), img.reshape(ctx.B, (L - 77) * D))
+    ctx.text, ctx.img = text, img
+
+
+@torch.no_grad()
+def forward(model, x, timesteps, c_label=None, context=None, features_adapter=None, fs=None):
+    if features_adapter is not None:
+        raise NotImplementedError("features_adapter is not used on the MuDG path")
+    parts = list(x) if isinstance(x, (list, tuple)) else [x]
+    first = parts[0]
+    if first.dim() != 5:
+        raise ValueError(f"x must be (B, C, T, H, W), got {tuple(first.shape)}")
+    if not first.is_cuda:
+        raise RuntimeError("UNetModel.forward: inputs must be on the GPU; the MI355X path has no CPU fallback")
+    B, _, T, H, W = first.shape
+    device = first.device
+    cin = sum(p.shape[1] for p in parts)
+    if cin != model.in_channels:
+        raise ValueError(f"expected {model.in_channels} input channels, got {cin}")
+    stem = model.input_blocks[0][0]
+    cpad = (stem.weight.shape[1] + 7) // 8 * 8
+
+    ctx = _Ctx()
+    ctx.B, ctx.T, ctx.kv_cache = B, T, {}
+    # ---- embeddings: time (+ class) then + fps, all per clip (openaimodel3d.py:569-602)
+    mc = model.model_channels
+    ts = _to_long(timesteps, B, device, "timesteps")
+    emb = _embed_mlp(model.time_embed, ops.timestep_embedding(ts, mc))
+    if model.class_label_condition:
+        lab = _to_long(c_label, B, device, "class_label")
+        ops.add_(emb, _embed_mlp(model.class_embed, ops.timestep_embedding(lab, mc)))
+    if model.fs_condition:
+        fsv = torch.full((B,), model.default_fs, dtype=torch.int64, device=device) if fs is None else _to_long(fs, B, device, "fs")
+        ops.add_(emb, _embed_mlp(model.fps_embedding, ops.timestep_embedding(fsv, mc)))
+    ctx.emb = emb
+    make_context(model, ctx, context, T, device)
+
+    # ---- input: (b c t h w) pieces -> rows with channels side by side (replaces torch.cat + rearrange, 591 / ddpm3d 1317)
+    rows = ops.empty_rows(B * T * H * W, cpad, BF16, device)
+    off = 0
+    for p in parts:
+        if p.shape[0] != B or p.shape[2:] != first.shape[2:]:
+            raise ValueError("all input pieces must share (B, T, H, W)")
+        src = p if p.dtype in (torch.float32, BF16) else p.float()
+        ops.ncthw_to_rows(src, rows, off)
+        off += p.shape[1]
+    if cpad > off:
+        ops.zero_channels(rows, off, cpad)
+
+    h, w = H, W
+    skips = []
+    cur = rows
+    for i, stage in enumerate(model.input_blocks):
+        cur, h, w = run_stage(stage, cur, None, h, w, ctx)
+        if i == 0 and model.addition_attention:
+            cur, h, w = run_stage(model.init_attn, cur, None, h, w, ctx)
+        skips.append((cur, h, w))
+    cur, h, w = run_stage(model.middle_block, cur, None, h, w, ctx)
+    for stage in model.output_blocks:
+        skip, sh, sw = skips.pop()
+        if (sh, sw) != (h, w):
+            raise RuntimeError(f"skip resolution {sh}x{sw} does not match {h}x{w}: H and W must be divisible by "
+                               f"{2 ** (len(model.channel_mult) - 1)}")
+        cur, h, w = run_stage(stage, cur, skip, h, w, ctx)
+    norm, conv = model.out[0], model.out[2]
+    cur = _gn(norm, cur, None, B * T, h * w, True)
+    y = _conv3x3(conv, cur, B * T, h, w)
+    out_dtype = first.dtype if first.dtype in (torch.float32, BF16) else torch.float32
+    out = ops.rows_to_ncthw(y, (B, model.out_channels, T, h, w), dtype=out_dtype)
+    return out if out.dtype == first.dtype else out.to(first.dtype)

@@ -1,0 +1,154 @@
+"""AutoencoderKL decode on MI355X (reference: lvdm/models/autoencoder.py:104-107, ae_modules.py Decoder.forward
+539-578, ResnetBlock 190-210, AttnBlock 52-78, Upsample 123-127; per-frame loop and 1/scale_factor ddpm3d.py:646-667).
+
+Frames are independent, so a whole clip is decoded as one batch of channels-last rows: 3x3 convs are implicit
+GEMMs (nearest-2x upsampling fused into the loader), GroupNorm(eps 1e-6)+swish is the fused norm kernel, and the
+single-head d=C attention of the mid block is two batched MFMA GEMMs around a row softmax (scores in fp32).
+The 1/scale_factor latent scaling is folded into the 1x1 post_quant_conv GEMM's alpha.
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from . import packing as pk
+
+BF16 = torch.bfloat16
+MAX_SCORE_BYTES = 8 << 30      # fp32 attention scores held at once (frames are chunked beyond this)
+
+
+def _gn(mod, x, frames, hw, swish):
+    return ops.groupnorm(x, pk.f32(mod, "weight"), pk.f32(mod, "bias"), samples=frames, rows=hw, eps=mod.eps,
+                         silu=swish, groups=mod.num_groups)
+
+
+def _conv3x3(mod, x, frames, h, w, upsample=False, residual=None):
+    wmat, cpad = pk.conv3x3(mod)
+    return ops.conv3x3(x, wmat, frames=frames, hin=h, win=w, cin=cpad, upsample=upsample, bias=pk.f32(mod, "bias"),
+                       residual=residual)
+
+
+def resnet_block(mod, x, frames, h, w):
+    a = _conv3x3(mod.conv1, _gn(mod.norm1, x, frames, h * w, True), frames, h, w)
+    a = _gn(mod.norm2, a, frames, h * w, True)
+    skip = x
+    if mod.in_channels != mod.out_channels:
+        skip = ops.gemm(x, pk.linear(mod.nin_shortcut), bias=pk.f32(mod.nin_shortcut, "bias"))
+    return _conv3x3(mod.conv2, a, frames, h, w, residual=skip)
+
+
+def attn_block(mod, x, frames, hw):
+    """x + proj_out(softmax(q k^T / sqrt(C)) v), one head of width C over the hw positions of each frame."""
+    c = mod.in_channels
+    hn = _gn(mod.norm, x, frames, hw, False)
+    wqk = pk.cached(mod, "qk", (mod.q.weight, mod.k.weight),
+                    lambda: torch.cat([mod.q.weight.detach().reshape(c, c), mod.k.weight.detach().reshape(c, c)], 0)
+                    .to(BF16).contiguous())
+    bqk = pk.cached(mod, "bqk", (mod.q.bias, mod.k.bias),
+                    lambda: torch.cat([mod.q.bias.detach(), mod.k.bias.detach()]).float().contiguous())
+    qk = ops.gemm(hn, wqk, bias=bqk)                                   # [frames*hw, 2C]
+    ldv = (hw + 7) // 8 * 8
+    vt = ops.empty_rows(frames * c, ldv, BF16, x.device)               # V^T per frame (bias added after P @ V)
+    ops.gemm(pk.linear(mod.v), hn, out=vt, batch=frames, sx=0, sw=hw * hn.stride(0), sy=c * ldv, M=c, N=hw, K=c,
+             ldy=ldv)
+    att = ops.empty_rows(frames * hw, c, BF16, x.device)
+    per = max(1, min(frames, MAX_SCORE_BYTES // (hw * hw * 4)))
+    scores = torch.empty((per * hw, hw), dtype=torch.float32, device=x.device)
+    probs = ops.empty_rows(per * hw, hw, BF16, x.device)
+    q, k = qk[:, :c], qk[:, c:]
+    for f0 in range(0, frames, per):
+        n = min(per, frames - f0)
+        rows = slice(f0 * hw, (f0 + n) * hw)
+        ops.gemm(q[rows], k[rows], out=scores, out_fp32=True, alpha=float(int(c) ** (-0.5)), batch=n,
+                 sx=hw * qk.stride(0), sw=hw * qk.stride(0), sy=hw * hw, M=hw, N=hw, K=c, ldy=hw)
+        ops.softmax_rows(scores[:n * hw], probs[:n * hw])
+        ops.gemm(probs, vt[f0 * c:(f0 + n) * c], out=att[rows], bias=pk.f32(mod.v, "bias"), batch=n, sx=hw * hw,
+                 sw=c * ldv, sy=hw * c, M=hw, N=c, K=hw, ldy=c)
+    return ops.gemm(att, pk.linear(mod.proj_out), bias=pk.f32(mod.proj_out, "bias"), residual=x)
+
+
+def decoder_rows(dec, x, frames, h, w):
+    """Decoder.forward on rows [frames*h*w, z-padded]; returns (rows [frames*H*W, out_ch], H, W)."""
+    x = _conv3x3(dec.conv_in, x, frames, h, w)
+    x = resnet_block(dec.mid.block_1, x, frames, h, w)
+    if not isinstance(dec.mid.attn_1, nn.Identity):
+        x = attn_block(dec.mid.attn_1, x, frames, h * w)
+    x = resnet_block(dec.mid.block_2, x, frames, h, w)
+    for lvl in reversed(range(dec.num_resolutions)):
+        level = dec.up[lvl]
+        for i in range(dec.num_res_blocks + 1):
+            x = resnet_block(level.block[i], x, frames, h, w)
+            if len(level.attn) > 0:
+                x = attn_block(level.attn[i], x, frames, h * w)
+        if lvl != 0:
+            x = _conv3x3(level.upsample.conv, x, frames, h, w, upsample=True)
+            h, w = 2 * h, 2 * w
+    x = _gn(dec.norm_out, x, frames, h * w, True)
+    return _conv3x3(dec.conv_out, x, frames, h, w), h, w
+
+
+def _check(z):
+    if not z.is_cuda:
+        raise RuntimeError("AutoencoderKL.decode: latents must be on the GPU; the MI355X path has no CPU fallback")
+    return z if z.dtype in (torch.float32, BF16) else z.float()
+
+
+def _decode_rows(ae, rows_z, frames, h, w, inv_scale):
+    """rows_z [frames*h*w, zc] bf16 latents -> decoded rows; post_quant_conv with the latent scale as GEMM alpha."""
+    pq = ae.post_quant_conv
+    zc = pq.weight.shape[0]
+    cpad = (zc + 7) // 8 * 8
+    lat = ops.empty_rows(rows_z.shape[0], cpad, BF16, rows_z.device)
+    if cpad > zc:
+        ops.zero_channels(lat, zc, cpad)
+    wpq = pk.cached(pq, "wpad", (pq.weight,), lambda: torch.nn.functional.pad(
+        pq.weight.detach().reshape(zc, -1), (0, rows_z.shape[1] - pq.weight.shape[1])).to(BF16).contiguous())
+    ops.gemm(rows_z, wpq, out=lat, bias=pk.f32(pq, "bias"), alpha=inv_scale, N=zc, ldy=cpad)
+    return decoder_rows(ae.decoder, lat, frames, h, w)
+
+
+@torch.no_grad()
+def decode_latents(ae, z, inv_scale=1.0, perframe=True, max_frames=16):
+    """(B, C, T, h, w) -> (B, 3, T, 8h, 8w) or (N, C, h, w) -> (N, 3, 8h, 8w); fp32 output like the reference.
+    Frames are decoded in batches of up to `max_frames` (they are independent: perframe_ae only trades launches for
+    memory in the reference); the layout kernels read / write frame windows of the NCTHW tensors in place."""
+    z = _check(z).contiguous()
+    five = z.dim() == 5
+    if not five:
+        z = z.unsqueeze(2)                           # (N, C, 1, h, w): each image a one-frame clip
+    b, c, t, h, w = z.shape
+    cin = (c + 7) // 8 * 8
+    out = None
+    # work list of (first clip, clips, first frame, frames) with clips * frames <= max_frames
+    if t >= max_frames:
+        jobs = [(b0, 1, t0, min(max_frames, t - t0)) for b0 in range(b) for t0 in range(0, t, max_frames)]
+    else:
+        per = max(1, max_frames // t)
+        jobs = [(b0, min(per, b - b0), 0, t) for b0 in range(0, b, per)]
+    for b0, nb, t0, nt in jobs:
+        rows = ops.empty_rows(nb * nt * h * w, cin, BF16, z.device)
+        ops.ncthw_to_rows(z[b0:b0 + nb], rows, 0, t0=t0, frames=nt)
+        if cin > c:
+            ops.zero_channels(rows, c, cin)
+        y, H, W = _decode_rows(ae, rows, nb * nt, h, w, inv_scale)
+        if out is None:
+            out = torch.empty((b, y.shape[1], t, H, W), dtype=torch.float32, device=z.device)
+        ops.rows_to_ncthw(y, (nb, y.shape[1], t, H, W), out=out[b0:b0 + nb], t0=t0, frames=nt)
+    return out if five else out[:, :, 0]
+
+
+def decode(ae, z):
+    """AutoencoderKL.decode: z (N, zc, h, w), no latent scaling."""
+    return decode_latents(ae, z, 1.0)
+
+
+def decoder_forward(dec, z):
+    """Decoder.forward on an already post-quant-convolved z (N, zc, h, w)."""
+    z = _check(z).contiguous()
+    n, c, h, w = z.shape
+    cin = (c + 7) // 8 * 8
+    rows = ops.empty_rows(n * h * w, cin, BF16, z.device)
+    ops.ncthw_to_rows(z.unsqueeze(2), rows, 0)
+    if cin > c:
+        ops.zero_channels(rows, c, cin)
+    y, H, W = decoder_rows(dec, rows, n, h, w)
+    return ops.rows_to_ncthw(y, (n, y.shape[1], 1, H, W), dtype=torch.float32)[:, :, 0]

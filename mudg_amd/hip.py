@@ -59,9 +59,12 @@ SIGNATURES = {
     "mudg_softmax_rows": (_I, [_P, _I, _P, _I, _I, _I, _P]),
     "mudg_timestep_embedding": (_I, [_P, _P, _P, _I, _I, _P]),
     "mudg_small_linear": (_I, [_P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
-    "mudg_ncthw_to_rows": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _P]),
-    "mudg_rows_to_ncthw": (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _I, _F, _P]),
+    "mudg_ncthw_to_rows": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "mudg_rows_to_ncthw": (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _I, _F, _I, _I, _P]),
     "mudg_zero_channels": (_I, [_P, _I, _I, _I, _I, _P]),
+    "mudg_copy_rows": (_I, [_P, _L, _P, _L, _L, _L, _P]),
+    "mudg_axpy_f32": (_I, [_P, _P, _L, _F, _P]),
+    "mudg_lincomb": (_I, [_P, _P, _P, _P, _P, _I, _L, _P]),
     "mudg_ddim_ws_doubles": (_L, [_I]),
     "mudg_ddim_step": (_I, [_P, _P, _P, _P, _P, _P, _I, _L, C.POINTER(C.c_float), _P, _P]),
     "mudg_prof_enable": (_I, [_I]),

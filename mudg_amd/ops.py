@@ -195,20 +195,27 @@ def small_linear(x, w, b=None, *, act_in=False, act_out=False, out=None, accumul
     return out
 
 
-def ncthw_to_rows(src, dst, coff=0):
-    """(B, C, T, H, W) fp32|bf16 -> dst rows ((b t) h w) channels [coff, coff + C)."""
+def ncthw_to_rows(src, dst, coff=0, t0=0, frames=None):
+    """(B, C, T, H, W) fp32|bf16 -> dst rows ((b t) h w) channels [coff, coff + C); optional frame window
+    [t0, t0 + frames) of the T axis."""
     b, c, t, h, w = src.shape
     src = src.contiguous()
-    hip.check(hip.lib().mudg_ncthw_to_rows(src.data_ptr(), int(src.dtype == torch.float32), dst.data_ptr(), b, c, t,
-                                           h * w, dst.stride(0), coff, _stream()), "mudg_ncthw_to_rows")
+    n = t if frames is None else frames
+    hip.check(hip.lib().mudg_ncthw_to_rows(src.data_ptr(), int(src.dtype == torch.float32), dst.data_ptr(), b, c, n,
+                                           h * w, dst.stride(0), coff, t, t0, _stream()), "mudg_ncthw_to_rows")
     return dst
 
 
-def rows_to_ncthw(src, shape, coff=0, dtype=torch.float32, scale=1.0):
+def rows_to_ncthw(src, shape, coff=0, dtype=torch.float32, scale=1.0, out=None, t0=0, frames=None):
+    """rows ((b t) h w) -> (B, C, T, H, W); with `out` given, writes frames [t0, t0 + frames) of an existing tensor."""
     b, c, t, h, w = shape
-    out = torch.empty(shape, dtype=dtype, device=src.device)
+    if out is None:
+        out = torch.empty(shape, dtype=dtype, device=src.device)
+    elif tuple(out.shape) != tuple(shape) or not out.is_contiguous():
+        raise hip.MudgError("rows_to_ncthw: `out` must be a contiguous tensor of the stated shape")
+    n = t if frames is None else frames
     hip.check(hip.lib().mudg_rows_to_ncthw(src.data_ptr(), src.stride(0), coff, out.data_ptr(),
-                                           int(dtype == torch.float32), b, c, t, h * w, scale, _stream()),
+                                           int(out.dtype == torch.float32), b, c, n, h * w, scale, t, t0, _stream()),
               "mudg_rows_to_ncthw")
     return out
 
@@ -217,6 +224,43 @@ def zero_channels(dst, c0, c1):
     hip.check(hip.lib().mudg_zero_channels(dst.data_ptr(), dst.shape[0], dst.stride(0), c0, c1, _stream()),
               "mudg_zero_channels")
     return dst
+
+
+def cast_bf16(src):
+    """fp32|bf16 2-D tensor -> bf16 rows (the layout kernel with a single channel is a plain cast)."""
+    src = src.contiguous()
+    out = torch.empty(src.shape, dtype=BF16, device=src.device)
+    n = src.numel()
+    hip.check(hip.lib().mudg_ncthw_to_rows(src.data_ptr(), int(src.dtype == torch.float32), out.data_ptr(), 1, 1, 1, n,
+                                           1, 0, 1, 0, _stream()), "mudg_ncthw_to_rows[cast]")
+    return out
+
+
+def copy_rows(src, dst):
+    """dst[r, :] = src[r, :] for bf16 2-D views with unit inner stride."""
+    _rows(src); _rows(dst)
+    hip.check(hip.lib().mudg_copy_rows(src.data_ptr(), src.stride(0), dst.data_ptr(), dst.stride(0), src.shape[0],
+                                       src.shape[1], _stream()), "mudg_copy_rows")
+    return dst
+
+
+def add_(y, x, alpha=1.0):
+    """y += alpha * x on contiguous fp32 tensors of equal size."""
+    if y.dtype != torch.float32 or x.dtype != torch.float32 or not (y.is_contiguous() and x.is_contiguous()):
+        raise hip.MudgError("add_ expects contiguous fp32 tensors")
+    hip.check(hip.lib().mudg_axpy_f32(y.data_ptr(), x.data_ptr(), y.numel(), alpha, _stream()), "mudg_axpy_f32")
+    return y
+
+
+def lincomb(x, y, ca, cb):
+    """ca[b] * x[b] + cb[b] * y[b] for fp32 (B, ...) tensors and fp32 [B] device coefficient vectors."""
+    x, y = x.float().contiguous(), y.float().contiguous()
+    ca, cb = ca.float().contiguous(), cb.float().contiguous()
+    out = torch.empty_like(x)
+    b = x.shape[0]
+    hip.check(hip.lib().mudg_lincomb(out.data_ptr(), x.data_ptr(), y.data_ptr(), ca.data_ptr(), cb.data_ptr(), b,
+                                     x.numel() // b, _stream()), "mudg_lincomb")
+    return out
 
 
 def ddim_step(x, e_c, e_u, noise, coef):
