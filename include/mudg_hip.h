@@ -62,7 +62,7 @@ typedef struct MudgGemmDesc {
     const float* bias;    /* fp32 [N] or NULL (packed like W's rows) */
     const float* gbias;   /* fp32 [M/rows_per_group][Nout] or NULL: per-row-group bias
                              (timestep-embedding add, openaimodel3d.py:219-228) */
-    const void* R;        /* bf16 residual [M][ldr] or NULL, added last */
+    const void* R;        /* residual [M][ldr] (bf16, or fp32 if res_fp32) or NULL, added last */
     int M, N, K;
     int ldx, ldx2, ldw, ldy, ldr;   /* row strides in elements */
     int csplit;           /* channels served by X (== Cin when X2 is NULL) */
@@ -70,6 +70,7 @@ typedef struct MudgGemmDesc {
     int64_t sX, sW, sY, sR;         /* per-batch strides in elements */
     int rows_per_group;   /* for gbias; 0 = unused */
     int out_fp32;         /* 1: Y is fp32 */
+    int res_fp32;         /* 1: R is fp32 (the residual stream is kept in fp32 between blocks) */
     int geglu;            /* 1: W rows are packed [32 value | 32 gate] blocks and
                              Y[m][j] = v_j * gelu_erf(g_j), Nout = N/2 (attention.py:579-586) */
     float alpha;
@@ -116,13 +117,14 @@ int mudg_temporal_attention(const void* QKV, void* O, int B, int T, int HW, int 
  * `ws` is fp32 scratch of at least mudg_groupnorm_ws_floats(samples, groups, rows).
  */
 int64_t mudg_groupnorm_ws_floats(int samples, int groups, int rows);
-int mudg_groupnorm(const void* X, const void* X2, int csplit, int ldx, int ldx2,
+int mudg_groupnorm(const void* X, const void* X2, int csplit, int ldx, int ldx2, int x_fp32,
                    const float* gamma, const float* beta, void* Y, int ldy,
                    int samples, int rows, int C, int groups, float eps, int silu,
                    float* ws, void* stream);
+/* x_fp32: X (and X2) hold fp32 instead of bf16; Y is always bf16 (it feeds an MFMA GEMM). */
 
 /* LayerNorm over the last dim (attention.py:363-365, eps 1e-5). */
-int mudg_layernorm(const void* X, int ldx, const float* gamma, const float* beta,
+int mudg_layernorm(const void* X, int ldx, int x_fp32, const float* gamma, const float* beta,
                    void* Y, int ldy, int rows, int C, float eps, void* stream);
 
 /* Row softmax of fp32 scores (already scaled) to bf16 probabilities
@@ -143,7 +145,7 @@ int mudg_small_linear(const float* x, const void* W, int w_is_bf16, const float*
  * (openaimodel3d.py:591; ddpm3d.py:1317-1319 channel concat of x and c_concat), and back (openaimodel3d.py:627). */
 int mudg_ncthw_to_rows(const void* src, int src_is_fp32, void* dst, int B, int C, int T, int HW,
                        int ld, int coff, int Ttot, int t0, void* stream);
-int mudg_rows_to_ncthw(const void* src, int ld, int coff, void* dst, int dst_is_fp32,
+int mudg_rows_to_ncthw(const void* src, int src_is_fp32, int ld, int coff, void* dst, int dst_is_fp32,
                        int B, int C, int T, int HW, float scale, int Ttot, int t0, void* stream);
 /* Ttot/t0: the (b c t h w) tensor holds Ttot frames and frames [t0, t0+T) are converted (Ttot <= 0: Ttot = T). */
 /* Strided 2-D copy of bf16 rows (context token split, openaimodel3d.py:582-585) and y += alpha * x on fp32
@@ -154,6 +156,8 @@ int mudg_axpy_f32(float* y, const float* x, int64_t n, float alpha, void* stream
  * predict_eps_from_z_and_v (ddpm3d.py:239-251) with ca, cb gathered per sample (device fp32 [B]). */
 int mudg_lincomb(float* out, const float* x, const float* y, const float* ca, const float* cb, int B, int64_t n,
                  void* stream);
+/* fp32 -> bf16 cast of n contiguous elements (a fp32 stream tensor entering an MFMA GEMM as an operand). */
+int mudg_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream);
 /* Zero the channel range [c0, c1) of a rows buffer (padding lanes of the stem input). */
 int mudg_zero_channels(void* dst, int rows, int ld, int c0, int c1, void* stream);
 

@@ -95,6 +95,10 @@ class DDPM(nn.Module):
 
     def register_schedule(self, given_betas=None, beta_schedule="linear", timesteps=1000, linear_start=1e-4,
                           linear_end=2e-2, cosine_s=8e-3):
+        with torch.device("cpu"):       # host math even when the model is being built under torch.device("meta")
+            self._register_schedule(given_betas, beta_schedule, timesteps, linear_start, linear_end, cosine_s)
+
+    def _register_schedule(self, given_betas, beta_schedule, timesteps, linear_start, linear_end, cosine_s):
         betas = given_betas if given_betas is not None else make_beta_schedule(
             beta_schedule, timesteps, linear_start=linear_start, linear_end=linear_end, cosine_s=cosine_s)
         if self.rescale_betas_zero_snr:
@@ -206,17 +210,16 @@ class LatentDiffusion(DDPM):
         # ddpm3d.py:522-527: 1 -> base_scale over `turning_step` steps, then flat (length turning_step + T)
         arr = np.concatenate((np.linspace(1.0, self.base_scale, self.turning_step),
                               np.full(self.num_timesteps, self.base_scale)))
-        self.register_buffer("scale_arr", torch.tensor(arr, dtype=torch.float32))
+        self.register_buffer("scale_arr", torch.tensor(arr, dtype=torch.float32, device="cpu"))
 
     def rebuild_schedules(self, device=None):
         """Recompute every schedule buffer from the stored hyper-parameters (they are pure functions of the config).
         Needed after constructing under torch.device('meta') + to_empty(), where buffers carry no data."""
-        with torch.device("cpu"):
-            self.register_schedule(given_betas=self.given_betas, beta_schedule=self.beta_schedule,
-                                   timesteps=self.timesteps, linear_start=self.linear_start,
-                                   linear_end=self.linear_end, cosine_s=self.cosine_s)
-            if self.use_dynamic_rescale:
-                self._register_scale_arr()
+        self.register_schedule(given_betas=self.given_betas, beta_schedule=self.beta_schedule,
+                               timesteps=self.timesteps, linear_start=self.linear_start,
+                               linear_end=self.linear_end, cosine_s=self.cosine_s)
+        if self.use_dynamic_rescale:
+            self._register_scale_arr()
         if device is not None:
             for name, buf in list(self.named_buffers(recurse=False)):
                 self.register_buffer(name, buf.to(device))

@@ -194,7 +194,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const MudgGemmDesc p, cons
     const int Nout = p.geglu ? p.N / 2 : p.N;
     const int nout0 = p.geglu ? n0 / 2 : n0;
     const int cpr = NT / 8;
-    const bf16* R = p.R ? reinterpret_cast<const bf16*>(p.R) + bz * p.sR : nullptr;
+    const bf16* R = (p.R && !p.res_fp32) ? reinterpret_cast<const bf16*>(p.R) + bz * p.sR : nullptr;
+    const float* Rf = (p.R && p.res_fp32) ? reinterpret_cast<const float*>(p.R) + bz * p.sR : nullptr;
     for (int c = tid; c < BM * cpr; c += 256) {
         const int row = c / cpr, cc = c - row * cpr;
         const int m = m0 + row, n = nout0 + cc * 8;
@@ -221,6 +222,17 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const MudgGemmDesc p, cons
             } else {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) if (j < nvalid) v[j] += (float)rp[j];
+            }
+        }
+        if (Rf) {
+            const float* rp = Rf + (int64_t)m * p.ldr + n;
+            if (nvalid == 8 && (vflags & VF_R)) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(rp), b = *reinterpret_cast<const f32x4*>(rp + 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { v[j] += a[j]; v[4 + j] += b[j]; }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (j < nvalid) v[j] += rp[j];
             }
         }
         if (p.out_fp32) {
@@ -300,7 +312,8 @@ extern "C" int mudg_gemm(const MudgGemmDesc* dp, void* stream) {
     int vflags = 0;
     const int ybytes = d.out_fp32 ? 4 : 2;
     if (aligned16(d.Y) && ((int64_t)d.ldy * ybytes) % 16 == 0 && ((int64_t)d.sY * ybytes) % 16 == 0) vflags |= VF_Y;
-    if (d.R && aligned16(d.R) && (d.ldr & 7) == 0 && (d.sR & 7) == 0) vflags |= VF_R;
+    const int rbytes = d.res_fp32 ? 4 : 2;
+    if (d.R && aligned16(d.R) && ((int64_t)d.ldr * rbytes) % 16 == 0 && ((int64_t)d.sR * rbytes) % 16 == 0) vflags |= VF_R;
 
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int fam = d.mode == 0 ? MUDG_FAM_GEMM : (d.mode == 1 ? MUDG_FAM_CONV : MUDG_FAM_TCONV);

@@ -56,8 +56,8 @@ __global__ void ncthw_to_rows_kernel(const ST* __restrict__ src, bf16* __restric
         dst[i * ld + coff + c] = (bf16)(float)src[(((int64_t)b * C + c) * Ttot + t0 + t) * HW + p];
 }
 
-template <typename DT>
-__global__ void rows_to_ncthw_kernel(const bf16* __restrict__ src, int ld, int coff, DT* __restrict__ dst, int B, int C,
+template <typename ST, typename DT>
+__global__ void rows_to_ncthw_kernel(const ST* __restrict__ src, int ld, int coff, DT* __restrict__ dst, int B, int C,
                                      int T, int HW, float scale, int Ttot, int t0) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t n = (int64_t)B * T * HW;
@@ -88,6 +88,19 @@ __global__ void copy_rows_kernel(const bf16* __restrict__ src, int64_t lds, bf16
         if (i >= rows * cols) return;
         const int64_t r = i / cols, c = i - r * cols;
         dst[r * ldd + c] = src[r * lds + c];
+    }
+}
+
+__global__ void cast_kernel(const float* __restrict__ src, bf16* __restrict__ dst, int64_t n8, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n8) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(src + i * 8), b = *reinterpret_cast<const f32x4*>(src + i * 8 + 4);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { o[e] = (bf16)a[e]; o[4 + e] = (bf16)b[e]; }
+        st16(dst + i * 8, as_u32x4(o));
+    } else if (i == n8) {
+        for (int64_t j = n8 * 8; j < n; ++j) dst[j] = (bf16)src[j];
     }
 }
 
@@ -211,16 +224,21 @@ extern "C" int mudg_ncthw_to_rows(const void* src, int src_is_fp32, void* dst, i
     return mudg_check_launch("mudg_ncthw_to_rows");
 }
 
-extern "C" int mudg_rows_to_ncthw(const void* src, int ld, int coff, void* dst, int dst_is_fp32, int B, int C, int T, int HW,
-                                  float scale, int Ttot, int t0, void* stream) {
+extern "C" int mudg_rows_to_ncthw(const void* src, int src_is_fp32, int ld, int coff, void* dst, int dst_is_fp32, int B, int C,
+                                  int T, int HW, float scale, int Ttot, int t0, void* stream) {
     MUDG_REQUIRE(src && dst && B > 0 && C > 0 && T > 0 && HW > 0 && coff >= 0 && coff + C <= ld, "mudg_rows_to_ncthw: bad arguments");
     if (Ttot <= 0) { Ttot = T; t0 = 0; }
     MUDG_REQUIRE(t0 >= 0 && t0 + T <= Ttot, "mudg_rows_to_ncthw: frame window [%d, %d) outside %d", t0, t0 + T, Ttot);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int64_t n = (int64_t)B * T * HW;
     const dim3 grid((unsigned)((n + 255) / 256));
-    if (dst_is_fp32) hipLaunchKernelGGL(rows_to_ncthw_kernel<float>, grid, dim3(256), 0, s, (const bf16*)src, ld, coff, (float*)dst, B, C, T, HW, scale, Ttot, t0);
-    else hipLaunchKernelGGL(rows_to_ncthw_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)src, ld, coff, (bf16*)dst, B, C, T, HW, scale, Ttot, t0);
+    if (src_is_fp32) {
+        if (dst_is_fp32) hipLaunchKernelGGL((rows_to_ncthw_kernel<float, float>), grid, dim3(256), 0, s, (const float*)src, ld, coff, (float*)dst, B, C, T, HW, scale, Ttot, t0);
+        else hipLaunchKernelGGL((rows_to_ncthw_kernel<float, bf16>), grid, dim3(256), 0, s, (const float*)src, ld, coff, (bf16*)dst, B, C, T, HW, scale, Ttot, t0);
+    } else {
+        if (dst_is_fp32) hipLaunchKernelGGL((rows_to_ncthw_kernel<bf16, float>), grid, dim3(256), 0, s, (const bf16*)src, ld, coff, (float*)dst, B, C, T, HW, scale, Ttot, t0);
+        else hipLaunchKernelGGL((rows_to_ncthw_kernel<bf16, bf16>), grid, dim3(256), 0, s, (const bf16*)src, ld, coff, (bf16*)dst, B, C, T, HW, scale, Ttot, t0);
+    }
     return mudg_check_launch("mudg_rows_to_ncthw");
 }
 
@@ -240,6 +258,14 @@ extern "C" int mudg_copy_rows(const void* src, int64_t lds, void* dst, int64_t l
     hipLaunchKernelGGL(copy_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const bf16*)src, lds, (bf16*)dst,
                        ldd, rows, cols, vec);
     return mudg_check_launch("mudg_copy_rows");
+}
+
+extern "C" int mudg_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream) {
+    MUDG_REQUIRE(src && dst && n > 0 && aligned16(src) && aligned16(dst), "mudg_cast_f32_bf16: bad arguments");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int64_t n8 = n >> 3;
+    hipLaunchKernelGGL(cast_kernel, dim3((unsigned)((n8 + 1 + 255) / 256)), dim3(256), 0, s, src, (bf16*)dst, n8, n);
+    return mudg_check_launch("mudg_cast_f32_bf16");
 }
 
 extern "C" int mudg_axpy_f32(float* y, const float* x, int64_t n, float alpha, void* stream) {

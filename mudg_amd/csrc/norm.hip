@@ -7,6 +7,23 @@ namespace {
 
 constexpr int GN_CMAX = 4096;
 
+// Eight consecutive channels of one pixel as fp32, from bf16 (16 B) or fp32 (32 B) storage.
+template <typename T> struct Load8;
+template <> struct Load8<bf16> {
+    static __device__ __forceinline__ void get(const bf16* p, float (&x)[8]) {
+        const bf16x8 t = as_bf16x8(ld16(p));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = (float)t[e];
+    }
+};
+template <> struct Load8<float> {
+    static __device__ __forceinline__ void get(const float* p, float (&x)[8]) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { x[e] = a[e]; x[4 + e] = b[e]; }
+    }
+};
+
 __host__ __device__ inline int gn_chunks(int samples, int rows) {
     int want = 2048 / (samples > 0 ? samples : 1);
     if (want < 1) want = 1;
@@ -17,7 +34,8 @@ __host__ __device__ inline int gn_chunks(int samples, int rows) {
 }
 
 // Pass 1: per (sample, row-chunk) per-group partial sum / sum of squares.
-__global__ __launch_bounds__(256) void gn_stats_kernel(const bf16* __restrict__ X, const bf16* __restrict__ X2,
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ X, const T* __restrict__ X2,
                                                         int csplit, int ldx, int ldx2, int rows, int C, int groups,
                                                         int nchunks, float* __restrict__ part_out) {
     __shared__ float part[4][64][16];
@@ -36,12 +54,13 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16* __restrict__ 
         for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
         if (v < nvec) {
             const int c0 = v * 8;
-            const bf16* base = X; int cc = c0, ld = ldx;
+            const T* base = X; int cc = c0, ld = ldx;
             if (c0 >= csplit) { base = X2; cc = c0 - csplit; ld = ldx2; }
             for (int r = r0 + wave; r < r1; r += 4) {
-                const bf16x8 t = as_bf16x8(ld16(base + (srow + r) * ld + cc));
+                float xv[8];
+                Load8<T>::get(base + (srow + r) * ld + cc, xv);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { const float x = (float)t[e]; s[e] += x; q[e] = fmaf(x, x, q[e]); }
+                for (int e = 0; e < 8; ++e) { s[e] += xv[e]; q[e] = fmaf(xv[e], xv[e], q[e]); }
             }
         }
 #pragma unroll
@@ -86,7 +105,8 @@ __global__ void gn_finalize_kernel(const float* __restrict__ part, float* __rest
 }
 
 // Pass 3: y = (x - mean) * rstd * gamma + beta, optional SiLU.
-__global__ __launch_bounds__(256) void gn_apply_kernel(const bf16* __restrict__ X, const bf16* __restrict__ X2,
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ X, const T* __restrict__ X2,
                                                         int csplit, int ldx, int ldx2, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, bf16* __restrict__ Y, int ldy,
                                                         int rows, int C, int groups, int nblk, int silu,
@@ -111,13 +131,14 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16* __restrict__ 
     for (int i = tid; i < n; i += 256) {
         const int r = r0 + i / nvec, v = i % nvec;
         const int c0 = v * 8;
-        const bf16* base = X; int cc = c0, ld = ldx;
+        const T* base = X; int cc = c0, ld = ldx;
         if (c0 >= csplit) { base = X2; cc = c0 - csplit; ld = ldx2; }
-        const bf16x8 t = as_bf16x8(ld16(base + (srow + r) * ld + cc));
+        float xv[8];
+        Load8<T>::get(base + (srow + r) * ld + cc, xv);
         bf16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            float y = fmaf((float)t[e], sc[c0 + e], sh[c0 + e]);
+            float y = fmaf(xv[e], sc[c0 + e], sh[c0 + e]);
             if (silu) y = silu_f(y);
             o[e] = (bf16)y;
         }
@@ -126,8 +147,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const bf16* __restrict__ 
 }
 
 // LayerNorm: one wave per row, up to VMAX 16-byte vectors per lane kept in registers (C <= 512 * VMAX).
-template <int VMAX>
-__global__ __launch_bounds__(256) void ln_kernel(const bf16* __restrict__ X, int ldx, const float* __restrict__ gamma,
+template <int VMAX, typename T>
+__global__ __launch_bounds__(256) void ln_kernel(const T* __restrict__ X, int ldx, const float* __restrict__ gamma,
                                                   const float* __restrict__ beta, bf16* __restrict__ Y, int ldy,
                                                   int rows, int C, float eps) {
     const int lane = threadIdx.x & 63;
@@ -140,9 +161,9 @@ __global__ __launch_bounds__(256) void ln_kernel(const bf16* __restrict__ X, int
     for (int i = 0; i < VMAX; ++i) {
         const int v = lane + 64 * i;
         if (v < nvec) {
-            const bf16x8 t = as_bf16x8(ld16(X + row * ldx + v * 8));
+            Load8<T>::get(X + row * ldx + v * 8, x[i]);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { x[i][e] = (float)t[e]; s += x[i][e]; }
+            for (int e = 0; e < 8; ++e) s += x[i][e];
         } else {
 #pragma unroll
             for (int e = 0; e < 8; ++e) x[i][e] = 0.f;
@@ -209,51 +230,63 @@ extern "C" int64_t mudg_groupnorm_ws_floats(int samples, int groups, int rows) {
     return (int64_t)samples * groups * 2 * (gn_chunks(samples, rows) + 1);
 }
 
-extern "C" int mudg_groupnorm(const void* X, const void* X2, int csplit, int ldx, int ldx2, const float* gamma,
+extern "C" int mudg_groupnorm(const void* X, const void* X2, int csplit, int ldx, int ldx2, int x_fp32, const float* gamma,
                               const float* beta, void* Y, int ldy, int samples, int rows, int C, int groups, float eps,
                               int silu, float* ws, void* stream) {
     MUDG_REQUIRE(X && Y && gamma && beta && ws, "mudg_groupnorm: null pointer");
     MUDG_REQUIRE(samples > 0 && rows > 0 && C > 0 && groups > 0, "mudg_groupnorm: empty problem");
     MUDG_REQUIRE(C % groups == 0 && (C & 7) == 0 && C <= GN_CMAX, "mudg_groupnorm: C=%d groups=%d unsupported", C, groups);
     MUDG_REQUIRE(groups <= 256, "mudg_groupnorm: groups=%d > 256", groups);
-    MUDG_REQUIRE((ldx & 7) == 0 && (ldy & 7) == 0 && aligned16(X) && aligned16(Y), "mudg_groupnorm: alignment");
+    const int xq = x_fp32 ? 3 : 7;      // row stride granule so that every 8-channel vector is 16-byte aligned
+    MUDG_REQUIRE((ldx & xq) == 0 && (ldy & 7) == 0 && aligned16(X) && aligned16(Y), "mudg_groupnorm: alignment");
     MUDG_REQUIRE(samples <= 65535, "mudg_groupnorm: too many samples");
     if (!X2) { csplit = C; ldx2 = ldx; }
-    else MUDG_REQUIRE(csplit > 0 && csplit < C && (csplit & 7) == 0 && (ldx2 & 7) == 0 && aligned16(X2), "mudg_groupnorm: X2/csplit");
+    else MUDG_REQUIRE(csplit > 0 && csplit < C && (csplit & 7) == 0 && (ldx2 & xq) == 0 && aligned16(X2), "mudg_groupnorm: X2/csplit");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int nchunks = gn_chunks(samples, rows);
     float* part = ws;
     float* stat = ws + (int64_t)samples * nchunks * groups * 2;
     const int slot = mudg_prof_begin(MUDG_FAM_GNORM, s);
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunks, samples), dim3(256), 0, s, (const bf16*)X, (const bf16*)X2, csplit,
-                       ldx, ldx2, rows, C, groups, nchunks, part);
+    if (x_fp32)
+        hipLaunchKernelGGL(gn_stats_kernel<float>, dim3(nchunks, samples), dim3(256), 0, s, (const float*)X, (const float*)X2,
+                           csplit, ldx, ldx2, rows, C, groups, nchunks, part);
+    else
+        hipLaunchKernelGGL(gn_stats_kernel<bf16>, dim3(nchunks, samples), dim3(256), 0, s, (const bf16*)X, (const bf16*)X2,
+                           csplit, ldx, ldx2, rows, C, groups, nchunks, part);
     const int ng = samples * groups;
     hipLaunchKernelGGL(gn_finalize_kernel, dim3((ng + 255) / 256), dim3(256), 0, s, part, stat, samples, groups, nchunks,
                        (double)rows * (C / groups), eps);
     const int nblk = nchunks;
-    hipLaunchKernelGGL(gn_apply_kernel, dim3(nblk, samples), dim3(256), 0, s, (const bf16*)X, (const bf16*)X2, csplit, ldx,
-                       ldx2, gamma, beta, (bf16*)Y, ldy, rows, C, groups, nblk, silu, stat);
+    if (x_fp32)
+        hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(nblk, samples), dim3(256), 0, s, (const float*)X, (const float*)X2,
+                           csplit, ldx, ldx2, gamma, beta, (bf16*)Y, ldy, rows, C, groups, nblk, silu, stat);
+    else
+        hipLaunchKernelGGL(gn_apply_kernel<bf16>, dim3(nblk, samples), dim3(256), 0, s, (const bf16*)X, (const bf16*)X2,
+                           csplit, ldx, ldx2, gamma, beta, (bf16*)Y, ldy, rows, C, groups, nblk, silu, stat);
     const int rc = mudg_check_launch("mudg_groupnorm");
-    mudg_prof_end(slot, s, 0.0, (double)samples * rows * C * 2.0 * 3.0);
+    mudg_prof_end(slot, s, 0.0, (double)samples * rows * C * (x_fp32 ? 10.0 : 6.0));
     return rc;
 }
 
-extern "C" int mudg_layernorm(const void* X, int ldx, const float* gamma, const float* beta, void* Y, int ldy, int rows,
-                              int C, float eps, void* stream) {
+extern "C" int mudg_layernorm(const void* X, int ldx, int x_fp32, const float* gamma, const float* beta, void* Y, int ldy,
+                              int rows, int C, float eps, void* stream) {
     MUDG_REQUIRE(X && Y && gamma && beta, "mudg_layernorm: null pointer");
     MUDG_REQUIRE(rows > 0 && C > 0 && (C & 7) == 0 && C <= 4096, "mudg_layernorm: rows=%d C=%d unsupported", rows, C);
-    MUDG_REQUIRE((ldx & 7) == 0 && (ldy & 7) == 0 && aligned16(X) && aligned16(Y) && aligned16(gamma) && aligned16(beta),
-                 "mudg_layernorm: alignment");
+    MUDG_REQUIRE((ldx & (x_fp32 ? 3 : 7)) == 0 && (ldy & 7) == 0 && aligned16(X) && aligned16(Y) && aligned16(gamma) &&
+                 aligned16(beta), "mudg_layernorm: alignment");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int slot = mudg_prof_begin(MUDG_FAM_LNORM, s);
     const dim3 grid((rows + 3) / 4);
     const int nvec = C >> 3;
-    if (nvec <= 64 * 3)
-        hipLaunchKernelGGL(ln_kernel<3>, grid, dim3(256), 0, s, (const bf16*)X, ldx, gamma, beta, (bf16*)Y, ldy, rows, C, eps);
-    else
-        hipLaunchKernelGGL(ln_kernel<8>, grid, dim3(256), 0, s, (const bf16*)X, ldx, gamma, beta, (bf16*)Y, ldy, rows, C, eps);
+    if (nvec <= 64 * 3) {
+        if (x_fp32) hipLaunchKernelGGL((ln_kernel<3, float>), grid, dim3(256), 0, s, (const float*)X, ldx, gamma, beta, (bf16*)Y, ldy, rows, C, eps);
+        else hipLaunchKernelGGL((ln_kernel<3, bf16>), grid, dim3(256), 0, s, (const bf16*)X, ldx, gamma, beta, (bf16*)Y, ldy, rows, C, eps);
+    } else {
+        if (x_fp32) hipLaunchKernelGGL((ln_kernel<8, float>), grid, dim3(256), 0, s, (const float*)X, ldx, gamma, beta, (bf16*)Y, ldy, rows, C, eps);
+        else hipLaunchKernelGGL((ln_kernel<8, bf16>), grid, dim3(256), 0, s, (const bf16*)X, ldx, gamma, beta, (bf16*)Y, ldy, rows, C, eps);
+    }
     const int rc = mudg_check_launch("mudg_layernorm");
-    mudg_prof_end(slot, s, 0.0, (double)rows * C * 2.0 * 2.0);
+    mudg_prof_end(slot, s, 0.0, (double)rows * C * (x_fp32 ? 6.0 : 4.0));
     return rc;
 }
 

@@ -21,10 +21,11 @@ def _gn(mod, x, frames, hw, swish):
                          silu=swish, groups=mod.num_groups)
 
 
-def _conv3x3(mod, x, frames, h, w, upsample=False, residual=None):
+def _conv3x3(mod, x, frames, h, w, upsample=False, residual=None, stream=False):
+    """stream=True: the output is a residual-stream tensor, kept in fp32 (same policy as the UNet executor)."""
     wmat, cpad = pk.conv3x3(mod)
     return ops.conv3x3(x, wmat, frames=frames, hin=h, win=w, cin=cpad, upsample=upsample, bias=pk.f32(mod, "bias"),
-                       residual=residual)
+                       residual=residual, out_fp32=stream)
 
 
 def resnet_block(mod, x, frames, h, w):
@@ -32,13 +33,16 @@ def resnet_block(mod, x, frames, h, w):
     a = _gn(mod.norm2, a, frames, h * w, True)
     skip = x
     if mod.in_channels != mod.out_channels:
-        skip = ops.gemm(x, pk.linear(mod.nin_shortcut), bias=pk.f32(mod.nin_shortcut, "bias"))
-    return _conv3x3(mod.conv2, a, frames, h, w, residual=skip)
+        skip = ops.gemm(ops.cast_bf16(x), pk.linear(mod.nin_shortcut), bias=pk.f32(mod.nin_shortcut, "bias"),
+                        out_fp32=True)
+    return _conv3x3(mod.conv2, a, frames, h, w, residual=skip, stream=True)
 
 
 def attn_block(mod, x, frames, hw):
     """x + proj_out(softmax(q k^T / sqrt(C)) v), one head of width C over the hw positions of each frame."""
     c = mod.in_channels
+    if hw % 8:
+        raise NotImplementedError(f"VAE attention needs h*w divisible by 8 (got {hw})")
     hn = _gn(mod.norm, x, frames, hw, False)
     wqk = pk.cached(mod, "qk", (mod.q.weight, mod.k.weight),
                     lambda: torch.cat([mod.q.weight.detach().reshape(c, c), mod.k.weight.detach().reshape(c, c)], 0)
@@ -63,12 +67,12 @@ def attn_block(mod, x, frames, hw):
         ops.softmax_rows(scores[:n * hw], probs[:n * hw])
         ops.gemm(probs, vt[f0 * c:(f0 + n) * c], out=att[rows], bias=pk.f32(mod.v, "bias"), batch=n, sx=hw * hw,
                  sw=c * ldv, sy=hw * c, M=hw, N=c, K=hw, ldy=c)
-    return ops.gemm(att, pk.linear(mod.proj_out), bias=pk.f32(mod.proj_out, "bias"), residual=x)
+    return ops.gemm(att, pk.linear(mod.proj_out), bias=pk.f32(mod.proj_out, "bias"), residual=x, out_fp32=True)
 
 
 def decoder_rows(dec, x, frames, h, w):
     """Decoder.forward on rows [frames*h*w, z-padded]; returns (rows [frames*H*W, out_ch], H, W)."""
-    x = _conv3x3(dec.conv_in, x, frames, h, w)
+    x = _conv3x3(dec.conv_in, x, frames, h, w, stream=True)
     x = resnet_block(dec.mid.block_1, x, frames, h, w)
     if not isinstance(dec.mid.attn_1, nn.Identity):
         x = attn_block(dec.mid.attn_1, x, frames, h * w)
@@ -80,10 +84,10 @@ def decoder_rows(dec, x, frames, h, w):
             if len(level.attn) > 0:
                 x = attn_block(level.attn[i], x, frames, h * w)
         if lvl != 0:
-            x = _conv3x3(level.upsample.conv, x, frames, h, w, upsample=True)
+            x = _conv3x3(level.upsample.conv, ops.cast_bf16(x), frames, h, w, upsample=True, stream=True)
             h, w = 2 * h, 2 * w
     x = _gn(dec.norm_out, x, frames, h * w, True)
-    return _conv3x3(dec.conv_out, x, frames, h, w), h, w
+    return _conv3x3(dec.conv_out, x, frames, h, w, stream=True), h, w
 
 
 def _check(z):

@@ -28,7 +28,7 @@ class GemmDesc(C.Structure):
         ("ldx", C.c_int), ("ldx2", C.c_int), ("ldw", C.c_int), ("ldy", C.c_int), ("ldr", C.c_int),
         ("csplit", C.c_int), ("batch", C.c_int),
         ("sX", C.c_int64), ("sW", C.c_int64), ("sY", C.c_int64), ("sR", C.c_int64),
-        ("rows_per_group", C.c_int), ("out_fp32", C.c_int), ("geglu", C.c_int),
+        ("rows_per_group", C.c_int), ("out_fp32", C.c_int), ("res_fp32", C.c_int), ("geglu", C.c_int),
         ("alpha", C.c_float), ("mode", C.c_int),
         ("Hin", C.c_int), ("Win", C.c_int), ("Hout", C.c_int), ("Wout", C.c_int),
         ("Cin", C.c_int), ("stride", C.c_int), ("upsample", C.c_int),
@@ -54,13 +54,14 @@ SIGNATURES = {
     "mudg_attention": (_I, [C.POINTER(AttnDesc), _P]),
     "mudg_temporal_attention": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _F, _P]),
     "mudg_groupnorm_ws_floats": (_L, [_I, _I, _I]),
-    "mudg_groupnorm": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P, _P]),
-    "mudg_layernorm": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _F, _P]),
+    "mudg_groupnorm": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P, _P]),
+    "mudg_layernorm": (_I, [_P, _I, _I, _P, _P, _P, _I, _I, _I, _F, _P]),
     "mudg_softmax_rows": (_I, [_P, _I, _P, _I, _I, _I, _P]),
     "mudg_timestep_embedding": (_I, [_P, _P, _P, _I, _I, _P]),
     "mudg_small_linear": (_I, [_P, _P, _I, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "mudg_ncthw_to_rows": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
-    "mudg_rows_to_ncthw": (_I, [_P, _I, _I, _P, _I, _I, _I, _I, _I, _F, _I, _I, _P]),
+    "mudg_rows_to_ncthw": (_I, [_P, _I, _I, _I, _P, _I, _I, _I, _I, _I, _F, _I, _I, _P]),
+    "mudg_cast_f32_bf16": (_I, [_P, _P, _L, _P]),
     "mudg_zero_channels": (_I, [_P, _I, _I, _I, _I, _P]),
     "mudg_copy_rows": (_I, [_P, _L, _P, _L, _L, _L, _P]),
     "mudg_axpy_f32": (_I, [_P, _P, _L, _F, _P]),
@@ -80,6 +81,9 @@ def lib() -> C.CDLL:
     """Load libmudg_hip.so (once).  Raises MudgError when it has not been built — never falls back."""
     global _lib
     if _lib is None:
+        # PyTorch-ROCm bundles its own libamdhip64; it must be the HIP runtime of the process (it owns the device
+        # contexts and streams we launch on), so make sure it is loaded before our library resolves the same SONAME.
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise MudgError(
                 f"{LIB_PATH} is missing: build it with `python -m mudg_amd.build` (hipcc, gfx950). "

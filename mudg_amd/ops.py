@@ -61,12 +61,13 @@ def gemm(x, w, *, out=None, bias=None, gbias=None, rows_per_group=0, residual=No
     d.csplit = x.shape[1] if x2 is not None else K
     d.batch, d.sX, d.sW, d.sY, d.sR = batch, sx, sw, sy, sr
     d.rows_per_group, d.out_fp32, d.geglu, d.alpha, d.mode = rows_per_group, int(out_fp32), int(geglu), alpha, 0
+    d.res_fp32 = int(residual is not None and residual.dtype == torch.float32)
     hip.check(hip.lib().mudg_gemm(C.byref(d), _stream()), "mudg_gemm")
     return out
 
 
 def conv3x3(x, w, *, frames, hin, win, cin, stride=1, upsample=False, out=None, bias=None, gbias=None,
-            rows_per_group=0, residual=None, x2=None):
+            rows_per_group=0, residual=None, x2=None, out_fp32=False):
     """3x3 / pad 1 convolution on channels-last rows; w is packed [Cout][9*cin] tap-major."""
     _rows(x); _rows(w)
     if upsample:
@@ -75,10 +76,12 @@ def conv3x3(x, w, *, frames, hin, win, cin, stride=1, upsample=False, out=None, 
         hout, wout = (hin - 1) // stride + 1, (win - 1) // stride + 1
     M, N = frames * hout * wout, w.shape[0]
     if out is None:
-        out = empty_rows(M, N, BF16, x.device)
+        out = empty_rows(M, N, torch.float32 if out_fp32 else BF16, x.device)
     d = hip.GemmDesc()
     d.X, d.X2, d.W, d.Y = x.data_ptr(), _ptr(x2), w.data_ptr(), out.data_ptr()
     d.bias, d.gbias, d.R = _ptr(bias), _ptr(gbias), _ptr(residual)
+    d.out_fp32 = int(out.dtype == torch.float32)
+    d.res_fp32 = int(residual is not None and residual.dtype == torch.float32)
     d.M, d.N, d.K = M, N, 9 * cin
     d.ldx, d.ldw, d.ldy = x.stride(0), w.stride(0), out.stride(0)
     d.ldx2 = x2.stride(0) if x2 is not None else 0
@@ -90,15 +93,17 @@ def conv3x3(x, w, *, frames, hin, win, cin, stride=1, upsample=False, out=None, 
     return out
 
 
-def tconv3(x, w, *, clips, t, hw, cin, out=None, bias=None, residual=None):
+def tconv3(x, w, *, clips, t, hw, cin, out=None, bias=None, residual=None, out_fp32=False):
     """(3,1,1) temporal convolution, pad (1,0,0), on rows ordered ((b t) hw); w packed [Cout][3*cin]."""
     _rows(x); _rows(w)
     M, N = clips * t * hw, w.shape[0]
     if out is None:
-        out = empty_rows(M, N, BF16, x.device)
+        out = empty_rows(M, N, torch.float32 if out_fp32 else BF16, x.device)
     d = hip.GemmDesc()
     d.X, d.W, d.Y = x.data_ptr(), w.data_ptr(), out.data_ptr()
     d.bias, d.R = _ptr(bias), _ptr(residual)
+    d.out_fp32 = int(out.dtype == torch.float32)
+    d.res_fp32 = int(residual is not None and residual.dtype == torch.float32)
     d.M, d.N, d.K = M, N, 3 * cin
     d.ldx, d.ldw, d.ldy = x.stride(0), w.stride(0), out.stride(0)
     d.ldr = residual.stride(0) if residual is not None else 0
@@ -127,25 +132,35 @@ def temporal_attention(qkv, out, *, clips, t, hw, heads, scale=0.125):
 
 
 # ------------------------------------------------------------------------------------------------ norms
+def _rows_any(t):
+    if t.dim() != 2 or t.stride(1) != 1 or t.dtype not in (BF16, torch.float32) or not t.is_cuda:
+        raise hip.MudgError(f"expected a cuda bf16/fp32 rows matrix, got {tuple(t.shape)} {t.dtype} on {t.device}")
+    return t
+
+
 def groupnorm(x, gamma, beta, *, samples, rows, eps, silu, groups=32, x2=None, out=None):
-    _rows(x)
+    _rows_any(x)
+    if x2 is not None and x2.dtype != x.dtype:
+        raise hip.MudgError("groupnorm: both channel sources must share a dtype")
     c = x.shape[1] + (x2.shape[1] if x2 is not None else 0)
     if out is None:
         out = empty_rows(samples * rows, c, BF16, x.device)
     n = hip.lib().mudg_groupnorm_ws_floats(samples, groups, rows)
     ws = torch.empty(n, dtype=torch.float32, device=x.device)
     hip.check(hip.lib().mudg_groupnorm(x.data_ptr(), _ptr(x2), x.shape[1], x.stride(0),
-                                       x2.stride(0) if x2 is not None else 0, gamma.data_ptr(), beta.data_ptr(),
+                                       x2.stride(0) if x2 is not None else 0, int(x.dtype == torch.float32),
+                                       gamma.data_ptr(), beta.data_ptr(),
                                        out.data_ptr(), out.stride(0), samples, rows, c, groups, eps, int(silu),
                                        ws.data_ptr(), _stream()), "mudg_groupnorm")
     return out
 
 
 def layernorm(x, gamma, beta, *, eps=1e-5, out=None):
-    _rows(x)
+    _rows_any(x)
     if out is None:
         out = empty_rows(x.shape[0], x.shape[1], BF16, x.device)
-    hip.check(hip.lib().mudg_layernorm(x.data_ptr(), x.stride(0), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(),
+    hip.check(hip.lib().mudg_layernorm(x.data_ptr(), x.stride(0), int(x.dtype == torch.float32), gamma.data_ptr(),
+                                       beta.data_ptr(), out.data_ptr(),
                                        out.stride(0), x.shape[0], x.shape[1], eps, _stream()), "mudg_layernorm")
     return out
 
@@ -214,8 +229,9 @@ def rows_to_ncthw(src, shape, coff=0, dtype=torch.float32, scale=1.0, out=None, 
     elif tuple(out.shape) != tuple(shape) or not out.is_contiguous():
         raise hip.MudgError("rows_to_ncthw: `out` must be a contiguous tensor of the stated shape")
     n = t if frames is None else frames
-    hip.check(hip.lib().mudg_rows_to_ncthw(src.data_ptr(), src.stride(0), coff, out.data_ptr(),
-                                           int(out.dtype == torch.float32), b, c, n, h * w, scale, t, t0, _stream()),
+    hip.check(hip.lib().mudg_rows_to_ncthw(src.data_ptr(), int(src.dtype == torch.float32), src.stride(0), coff,
+                                           out.data_ptr(), int(out.dtype == torch.float32), b, c, n, h * w, scale,
+                                           t, t0, _stream()),
               "mudg_rows_to_ncthw")
     return out
 
@@ -227,12 +243,14 @@ def zero_channels(dst, c0, c1):
 
 
 def cast_bf16(src):
-    """fp32|bf16 2-D tensor -> bf16 rows (the layout kernel with a single channel is a plain cast)."""
-    src = src.contiguous()
+    """fp32 tensor -> bf16 copy of the same shape (bf16 input is returned as is)."""
+    if src.dtype == BF16:
+        return src
+    if src.dtype != torch.float32 or not src.is_contiguous():
+        raise hip.MudgError("cast_bf16 expects a contiguous fp32 tensor")
     out = torch.empty(src.shape, dtype=BF16, device=src.device)
-    n = src.numel()
-    hip.check(hip.lib().mudg_ncthw_to_rows(src.data_ptr(), int(src.dtype == torch.float32), out.data_ptr(), 1, 1, 1, n,
-                                           1, 0, 1, 0, _stream()), "mudg_ncthw_to_rows[cast]")
+    hip.check(hip.lib().mudg_cast_f32_bf16(src.data_ptr(), out.data_ptr(), src.numel(), _stream()),
+              "mudg_cast_f32_bf16")
     return out
 
 
@@ -265,6 +283,10 @@ def lincomb(x, y, ca, cb):
 
 def ddim_step(x, e_c, e_u, noise, coef):
     """Fused DDIM update on fp32 latents (B, ...). coef = 8 host floats, see mudg_ddim_step."""
+    def dense(t):      # raw pointers are handed to the kernel: insist on dense fp32 (permuted views are copied)
+        return None if t is None else t.to(torch.float32).contiguous()
+
+    x, e_c, e_u, noise = dense(x), dense(e_c), dense(e_u), dense(noise)
     b = x.shape[0]
     n = x.numel() // b
     x_prev, pred_x0 = torch.empty_like(x), torch.empty_like(x)

@@ -328,3 +328,31 @@ def test_ddim_step(cuda, phi, with_uncond, with_noise):
     got_xp, got_x0 = ops.ddim_step(x.to(cuda), ec.to(cuda), eu.to(cuda) if with_uncond else None,
                                    nz.to(cuda) if with_noise else None, [cfg, phi, sac, s1m, resc, sap, dirc, sig])
     assert rel_l2(got_x0, x0) < TOL_F32 and rel_l2(got_xp, xp) < TOL_F32
+
+
+def test_fp32_residual_stream_variants(cuda):
+    """The residual stream is fp32: GroupNorm / LayerNorm read it in fp32, GEMM epilogues add an fp32 residual and
+    write fp32; the fp32 -> bf16 cast feeds raw-stream GEMM operands."""
+    from mudg_amd import ops
+    g = torch.Generator().manual_seed(11)
+    samples, rows, c = 2, 60, 320
+    x = torch.randn(samples * rows, c, generator=g) * 2 + 0.3
+    gam, bet = 1 + 0.1 * torch.randn(c, generator=g), 0.1 * torch.randn(c, generator=g)
+    ref = F.silu(F.group_norm(x.reshape(samples, rows, c).transpose(1, 2), 32, gam, bet, 1e-5)).transpose(1, 2).reshape(-1, c)
+    y = ops.groupnorm(x.to(cuda), gam.to(cuda), bet.to(cuda), samples=samples, rows=rows, eps=1e-5, silu=True)
+    assert y.dtype == BF and rel_l2(y, ref) < TOL_BF16
+    x2 = torch.randn(samples * rows, 64, generator=g)
+    gam2, bet2 = torch.cat([gam, gam[:64]]), torch.cat([bet, bet[:64]])
+    ref2 = F.group_norm(torch.cat([x, x2], 1).reshape(samples, rows, -1).transpose(1, 2), 32, gam2, bet2, 1e-6)
+    y2 = ops.groupnorm(x.to(cuda), gam2.to(cuda), bet2.to(cuda), samples=samples, rows=rows, eps=1e-6, silu=False,
+                       x2=x2.to(cuda))
+    assert rel_l2(y2, ref2.transpose(1, 2).reshape(-1, c + 64)) < TOL_BF16
+    yl = ops.layernorm(x.to(cuda), gam.to(cuda), bet.to(cuda))
+    assert rel_l2(yl, F.layer_norm(x, (c,), gam, bet, 1e-5)) < TOL_BF16
+    a, w = rnd(samples * rows, 64, seed=1), rnd(c, 64, seed=2, scale=0.1)
+    out = ops.gemm(a.to(cuda), w.to(cuda), residual=x.to(cuda), out_fp32=True)
+    assert out.dtype == torch.float32 and rel_l2(out, a.float() @ w.float().t() + x) < TOL_F32
+    xb = ops.cast_bf16(x.to(cuda))
+    assert torch.equal(xb.cpu(), x.to(BF))
+    odd = torch.randn(1003, generator=g)
+    assert torch.equal(ops.cast_bf16(odd.to(cuda)).cpu(), odd.to(BF))
