@@ -5,15 +5,21 @@
 // each wave owns 64x64 = 2x2 v_mfma_f32_32x32x16_bf16 tiles (64 fp32 accumulators per lane).
 // The MFMA is issued "transposed" (A operand = weight rows, B operand = activation rows) so that each lane ends
 // up with 4 consecutive output channels of one pixel — the epilogue then moves 16-byte pieces.
-// Staging: global -> registers -> LDS, two LDS buffers, one barrier per K-tile; rows padded to 72 bf16 (144 B),
-// which makes both the 16-B staging writes and the ds_read_b128 fragment reads bank-conflict free.
+// Staging: HBM/L2 -> LDS directly with global_load_lds_dwordx4 (no VGPR round trip, no ds_write pass: the first
+// version staged through registers and was LDS-write-bound at ~600 TFLOP/s).  The DMA writes lane-linear 1-KiB
+// pieces (8 rows x 128 B), so the LDS tile is unpadded [128][64] bf16 and bank conflicts are removed by an XOR
+// swizzle applied on the SOURCE side (which 16-byte chunk of the row a lane fetches) and mirrored on the fragment
+// reads: chunk c of row r lives in slot c ^ ((r >> 1) & 7); with that, every 16-lane ds_read_b128 group touches 16
+// distinct 16-byte slots of the 256-byte bank row.  Out-of-range rows / taps / K tail fetch from a 16-byte zero page.
+// Two LDS buffers, one barrier per K-tile: the DMA of tile k+1 flies under the MFMAs of tile k.
 // Epilogue: accumulators (+bias, GEGLU) -> fp32 LDS tile -> coalesced 16-B rows (+group bias, +residual) -> HBM.
+// Workgroups are numbered so that each XCD gets a contiguous run of tiles (neighbouring tiles share operand panels).
 #include "common.h"
 
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int LDSLD = 72;                       // bf16 elements per LDS row (64 + 8 pad)
+constexpr int LDSLD = 64;                       // bf16 elements per LDS row: unpadded, XOR-swizzled (see header)
 constexpr int STGLD = 132;                      // fp32 per staging row (128 + 4 pad)
 constexpr int TILE = BM * LDSLD;                // elements per operand per buffer
 constexpr int SMEM_MAIN = 4 * TILE * 2;         // X[2] + W[2], bytes
@@ -22,33 +28,60 @@ constexpr int SMEM_BYTES = SMEM_MAIN > SMEM_STG ? SMEM_MAIN : SMEM_STG;
 
 constexpr int VF_Y = 1, VF_R = 2;               // 16-byte access allowed on Y / R
 
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __forceinline__ float gelu_fast(float x) {
+    // 0.5 x (1 + erf(x / sqrt 2)) with Abramowitz-Stegun 7.1.26 for erf (|abs err| < 1.5e-7): the exact erff
+    // costs about as much as the whole K loop of a K = 320 tile; the result is rounded to bf16 anyway.
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = 1.0f - p * t * __expf(-z * z);          // erf(|x| / sqrt 2)
+    return 0.5f * x * (1.0f + copysignf(e, x));
+}
+
 template <int MODE>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const MudgGemmDesc p, const int vflags) {
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const MudgGemmDesc p, const int vflags, const bf16* __restrict__ zpage) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* Xs = reinterpret_cast<bf16*>(smem);
     bf16* Ws = Xs + 2 * TILE;
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave & 1, wn = wave >> 1;
     const int l31 = lane & 31, hi = lane >> 5;
 
+    // XCD-aware tile numbering: hardware puts workgroup b on XCD b % 8; give every XCD a contiguous tile range.
     const int ntn = (p.N + BN - 1) / BN;
-    const int tm = blockIdx.x / ntn, tn = blockIdx.x - tm * ntn;
+    int tile;
+    {
+        const int total = gridDim.x, q8 = total >> 3, r8 = total & 7;
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    }
+    const int tm = tile / ntn, tn = tile - tm * ntn;
     const int m0 = tm * BM, n0 = tn * BN;
     const int64_t bz = blockIdx.z;
     const bf16* X = reinterpret_cast<const bf16*>(p.X) + bz * p.sX;
     const bf16* X2 = p.X2 ? reinterpret_cast<const bf16*>(p.X2) + bz * p.sX : nullptr;
     const bf16* W = reinterpret_cast<const bf16*>(p.W) + bz * p.sW;
 
-    const int lrow = tid >> 3, kc = tid & 7;
-
-    // Loader state for the four activation rows this thread stages.
-    int rm[4], ra[4], rb[4], rc[4];
+    // DMA geometry: wave w stages rows [32w, 32w+32) of both operand tiles with four 1-KiB instructions each;
+    // in instruction i, lane l lands in row 32w + 8i + (l >> 3), slot l & 7, and therefore fetches the logical
+    // chunk (l & 7) ^ ((row >> 1) & 7) of that row.
+    const int rsub = lane >> 3, slot = lane & 7;
+    int rm[4], ra[4], rb[4], rc[4], ch[4];
     bool rv[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int m = m0 + lrow + 32 * i;
+        const int rl = 32 * wave + 8 * i + rsub;
+        ch[i] = slot ^ ((rl >> 1) & 7);
+        const int m = m0 + rl;
         rm[i] = m;
         rv[i] = m < p.M;
         ra[i] = rb[i] = rc[i] = 0;
@@ -63,56 +96,44 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const MudgGemmDesc p, cons
             rb[i] = (m / p.HW) % p.T;
         }
     }
+    const bool tap_uniform = MODE != 0 && (p.Cin & 63) == 0;     // a 64-wide K tile never straddles two taps
 
-    u32x4 xr[4], wr[4];
-
-    auto load_tiles = [&](int kt) {
-        const int k = kt * BK + kc * 8;
-        const bool kv = k < p.K;
-        // ---- activations
-        if (MODE == 0) {
-            const bf16* base = X; int kk = k, ld = p.ldx;
-            if (k >= p.csplit) { base = X2; kk = k - p.csplit; ld = p.ldx2; }
+    auto issue_tiles = [&](int kt, int buf) {
+        const int k0 = kt * BK;
+        int tap_u = 0, c_u = 0;
+        if (MODE != 0 && tap_uniform) { tap_u = k0 / p.Cin; c_u = k0 - tap_u * p.Cin; }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                xr[i] = (rv[i] && kv) ? ld16(base + (int64_t)rm[i] * ld + kk) : zero16();
-        } else {
-            const int tap = k / p.Cin;
-            const int c = k - tap * p.Cin;
-            const bf16* base = X; int cc = c, ld = p.ldx;
-            if (c >= p.csplit) { base = X2; cc = c - p.csplit; ld = p.ldx2; }
-            if (MODE == 1) {
-                const int dy = tap / 3, dx = tap - dy * 3;
-                const int hlim = p.upsample ? 2 * p.Hin : p.Hin;
-                const int wlim = p.upsample ? 2 * p.Win : p.Win;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 4; ++i) {
+            const int k = k0 + ch[i] * 8;
+            const bool kv = k < p.K;
+            const bf16* src = zpage;
+            if (MODE == 0) {
+                if (rv[i] && kv)
+                    src = (k < p.csplit) ? X + (int64_t)rm[i] * p.ldx + k : X2 + (int64_t)rm[i] * p.ldx2 + (k - p.csplit);
+            } else {
+                int tap, c;
+                if (tap_uniform) { tap = tap_u; c = c_u + ch[i] * 8; }
+                else { tap = k / p.Cin; c = k - tap * p.Cin; }
+                const bf16* base = X; int cc = c, ld = p.ldx;
+                if (c >= p.csplit) { base = X2; cc = c - p.csplit; ld = p.ldx2; }
+                if (MODE == 1) {
+                    const int dy = tap / 3, dx = tap - dy * 3;
+                    const int hlim = p.upsample ? 2 * p.Hin : p.Hin;
+                    const int wlim = p.upsample ? 2 * p.Win : p.Win;
                     int iy = rb[i] + dy, ix = rc[i] + dx;
                     const bool ok = rv[i] && kv && iy >= 0 && iy < hlim && ix >= 0 && ix < wlim;
                     if (p.upsample) { iy >>= 1; ix >>= 1; }
-                    xr[i] = ok ? ld16(base + (int64_t)(ra[i] + iy * p.Win + ix) * ld + cc) : zero16();
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                    if (ok) src = base + (int64_t)(ra[i] + iy * p.Win + ix) * ld + cc;
+                } else {
                     const int it = rb[i] + tap - 1;
-                    const bool ok = rv[i] && kv && it >= 0 && it < p.T;
-                    xr[i] = ok ? ld16(base + ((int64_t)rm[i] + (int64_t)(tap - 1) * p.HW) * ld + cc) : zero16();
+                    if (rv[i] && kv && it >= 0 && it < p.T)
+                        src = base + ((int64_t)rm[i] + (int64_t)(tap - 1) * p.HW) * ld + cc;
                 }
             }
-        }
-        // ---- weights
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int n = n0 + lrow + 32 * i;
-            wr[i] = (n < p.N && kv) ? ld16(W + (int64_t)n * p.ldw + k) : zero16();
-        }
-    };
-    auto stage = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            st16(&Xs[buf * TILE + (lrow + 32 * i) * LDSLD + kc * 8], xr[i]);
-            st16(&Ws[buf * TILE + (lrow + 32 * i) * LDSLD + kc * 8], wr[i]);
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Xs + buf * TILE + (32 * wave + 8 * i) * LDSLD), 16, 0, 0);
+            const int n = n0 + 32 * wave + 8 * i + rsub;
+            const bf16* wsrc = (n < p.N && kv) ? W + (int64_t)n * p.ldw + k : zpage;
+            __builtin_amdgcn_global_load_lds((gptr_t)wsrc, (lptr_t)(Ws + buf * TILE + (32 * wave + 8 * i) * LDSLD), 16, 0, 0);
         }
     };
 
@@ -125,30 +146,29 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const MudgGemmDesc p, cons
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     const int nk = (p.K + BK - 1) / BK;
-    load_tiles(0);
-    stage(0);
-    __syncthreads();
+    issue_tiles(0, 0);
+    __syncthreads();                     // drains the DMA (vmcnt(0)) before anyone reads the tile
 
+    const int sw = (l31 >> 1) & 7;       // read-side swizzle: the row bases are multiples of 32, so only lane bits count
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        const bool more = kt + 1 < nk;
-        if (more) load_tiles(kt + 1);
-        const bf16* xs = Xs + cur * TILE + (wm * 64 + l31) * LDSLD + hi * 8;
-        const bf16* ws = Ws + cur * TILE + (wn * 64 + l31) * LDSLD + hi * 8;
+        if (kt + 1 < nk) issue_tiles(kt + 1, cur ^ 1);
+        const bf16* xs = Xs + cur * TILE + (wm * 64 + l31) * LDSLD;
+        const bf16* ws = Ws + cur * TILE + (wn * 64 + l31) * LDSLD;
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
+            const int off = ((ks * 2 + hi) ^ sw) << 3;
             bf16x8 wf[2], xf[2];
-            wf[0] = *reinterpret_cast<const bf16x8*>(ws + ks * 16);
-            wf[1] = *reinterpret_cast<const bf16x8*>(ws + 32 * LDSLD + ks * 16);
-            xf[0] = *reinterpret_cast<const bf16x8*>(xs + ks * 16);
-            xf[1] = *reinterpret_cast<const bf16x8*>(xs + 32 * LDSLD + ks * 16);
+            wf[0] = *reinterpret_cast<const bf16x8*>(ws + off);
+            wf[1] = *reinterpret_cast<const bf16x8*>(ws + 32 * LDSLD + off);
+            xf[0] = *reinterpret_cast<const bf16x8*>(xs + off);
+            xf[1] = *reinterpret_cast<const bf16x8*>(xs + 32 * LDSLD + off);
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi)
                     acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
         }
-        if (more) stage(cur ^ 1);
         __syncthreads();
     }
 
@@ -182,7 +202,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const MudgGemmDesc p, cons
                 for (int j = 0; j < 4; ++j) {
                     const float val = alpha * acc[0][mi][4 * g + j] + sbias[nl + j];
                     const float gate = alpha * acc[1][mi][4 * g + j] + sbias[nl + 32 + j];
-                    v[j] = val * gelu_erf_f(gate);
+                    v[j] = val * gelu_fast(gate);
                 }
                 *reinterpret_cast<f32x4*>(&stg[ml * STGLD + wn * 32 + 8 * g + 4 * hi]) = v;
             }
@@ -262,9 +282,21 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const MudgGemmDesc p, cons
     }
 }
 
+const bf16* zero_page() {
+    static bf16* page = nullptr;
+    if (!page) {
+        void* ptr = nullptr;
+        if (hipMalloc(&ptr, 256) != hipSuccess || hipMemset(ptr, 0, 256) != hipSuccess) return nullptr;
+        page = static_cast<bf16*>(ptr);
+    }
+    return page;
+}
+
 template <int MODE>
 int launch(const MudgGemmDesc& d, int vflags, hipStream_t s) {
     static bool attr_set = false;
+    const bf16* zp = zero_page();
+    if (!zp) MUDG_FAIL(MUDG_ELAUNCH, "gemm: could not allocate the zero page");
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<MODE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
@@ -273,7 +305,7 @@ int launch(const MudgGemmDesc& d, int vflags, hipStream_t s) {
     }
     const int tiles = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
     dim3 grid(tiles, 1, d.batch);
-    hipLaunchKernelGGL(gemm_kernel<MODE>, grid, dim3(256), SMEM_BYTES, s, d, vflags);
+    hipLaunchKernelGGL(gemm_kernel<MODE>, grid, dim3(256), SMEM_BYTES, s, d, vflags, zp);
     return mudg_check_launch("mudg_gemm");
 }
 

@@ -86,22 +86,27 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ X, 
     }
 }
 
-// Pass 2: fold the chunk partials (fp64, fixed order) into mean / rstd per (sample, group).
-__global__ void gn_finalize_kernel(const float* __restrict__ part, float* __restrict__ stat, int samples, int groups,
-                                   int nchunks, double count, float eps) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// Pass 2: fold the chunk partials into mean / rstd per (sample, group): one wave per pair, lanes stride over the
+// chunks in fp64 and combine with a fixed butterfly, so the result does not depend on scheduling.
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ part, float* __restrict__ stat,
+                                                           int samples, int groups, int nchunks, double count, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= samples * groups) return;
     const int smp = i / groups, g = i - smp * groups;
     double a = 0.0, b = 0.0;
-    for (int ch = 0; ch < nchunks; ++ch) {
+    for (int ch = lane; ch < nchunks; ch += 64) {
         const float* p = part + (((int64_t)smp * nchunks + ch) * groups + g) * 2;
         a += (double)p[0]; b += (double)p[1];
     }
-    const double mean = a / count;
-    double var = b / count - mean * mean;
-    if (var < 0.0) var = 0.0;
-    stat[i * 2] = (float)mean;
-    stat[i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    a = wave_sum_d(a); b = wave_sum_d(b);
+    if (lane == 0) {
+        const double mean = a / count;
+        double var = b / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        stat[i * 2] = (float)mean;
+        stat[i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
 }
 
 // Pass 3: y = (x - mean) * rstd * gamma + beta, optional SiLU.
@@ -254,7 +259,7 @@ extern "C" int mudg_groupnorm(const void* X, const void* X2, int csplit, int ldx
         hipLaunchKernelGGL(gn_stats_kernel<bf16>, dim3(nchunks, samples), dim3(256), 0, s, (const bf16*)X, (const bf16*)X2,
                            csplit, ldx, ldx2, rows, C, groups, nchunks, part);
     const int ng = samples * groups;
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3((ng + 255) / 256), dim3(256), 0, s, part, stat, samples, groups, nchunks,
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((ng + 3) / 4), dim3(256), 0, s, part, stat, samples, groups, nchunks,
                        (double)rows * (C / groups), eps);
     const int nblk = nchunks;
     if (x_fp32)
