@@ -30,7 +30,8 @@ def _hipcc() -> str:
 
 def _stamp() -> str:
     h = hashlib.sha256()
-    for name in sorted(os.listdir(CSRC)) + ["../../include/mudg_hip.h"]:
+    names = [n for n in sorted(os.listdir(CSRC)) if n.endswith((".hip", ".h"))] + ["../../include/mudg_hip.h"]
+    for name in names:
         with open(os.path.join(CSRC, name), "rb") as f:
             h.update(name.encode())
             h.update(f.read())
