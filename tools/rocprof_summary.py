@@ -1,29 +1,48 @@
 #!/usr/bin/env python3
-"""Summarise a rocprofv3 results database (rocpd SQLite, the default output of `rocprofv3 --kernel-trace --stats`)
-into the per-kernel table committed under profiles/: calls, total / average / min / max duration, share of GPU time.
+"""Summarise rocprofv3 results databases (rocpd SQLite, the default output of `rocprofv3 --kernel-trace [--stats|--pmc ..]`)
+into the small markdown tables committed under profiles/.
 
-usage: python tools/rocprof_summary.py gpurun_out/prof_r1/r1_results.db > profiles/r1_kernel_stats.md
+  python tools/rocprof_summary.py trace  <results.db>            per-kernel calls / total / avg / min / max / share
+  python tools/rocprof_summary.py pmc    <results.db> [scale]    per-kernel sum and per-launch mean of each collected counter
+                                                                  (scale multiplies the values, e.g. 2 for FETCH_SIZE on gfx950)
 """
 import sqlite3
 import sys
 
 
-def main(path, top=40):
-    db = sqlite3.connect(path)
-    cur = db.cursor()
-    cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
-    name_col = "name" if "name" in cols else [c for c in cols if "name" in c][0]
-    rows = cur.execute(f"select {name_col}, count(*), sum(end - start), avg(end - start), min(end - start), "
-                       f"max(end - start) from kernels group by {name_col} order by 3 desc").fetchall()
+def short(name, n=88):
+    name = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    return name if len(name) <= n else name[:n - 3] + "..."
+
+
+def trace(path, top=40):
+    cur = sqlite3.connect(path).cursor()
+    rows = cur.execute("select name, count(*), sum(end - start), avg(end - start), min(end - start), max(end - start) "
+                       "from kernels group by name order by 3 desc").fetchall()
     total = sum(r[2] for r in rows) or 1
-    print(f"# rocprofv3 kernel-trace summary: {path}\n")
+    print(f"# rocprofv3 --kernel-trace summary ({path.split('/')[-1]})\n")
     print(f"total kernel time {total / 1e6:.3f} ms over {sum(r[1] for r in rows)} dispatches\n")
     print("| kernel | calls | total ms | avg us | min us | max us | % |")
     print("|---|---:|---:|---:|---:|---:|---:|")
     for name, n, tot, avg, mn, mx in rows[:top]:
-        short = name if len(name) <= 90 else name[:87] + "..."
-        print(f"| `{short}` | {n} | {tot / 1e6:.3f} | {avg / 1e3:.2f} | {mn / 1e3:.2f} | {mx / 1e3:.2f} | {100 * tot / total:.2f} |")
+        print(f"| `{short(name)}` | {n} | {tot / 1e6:.3f} | {avg / 1e3:.2f} | {mn / 1e3:.2f} | {mx / 1e3:.2f} | {100 * tot / total:.2f} |")
+
+
+def pmc(path, scale=1.0, top=25):
+    cur = sqlite3.connect(path).cursor()
+    rows = cur.execute("select kernel_name, counter_name, count(*), sum(value) from counters_collection "
+                       "group by kernel_name, counter_name order by 4 desc").fetchall()
+    print(f"# rocprofv3 --pmc summary ({path.split('/')[-1]}), values x {scale:g}\n")
+    print("| kernel | counter | launches | sum | mean per launch |")
+    print("|---|---|---:|---:|---:|")
+    for name, ctr, n, tot in rows[:top]:
+        tot = (tot or 0) * scale
+        print(f"| `{short(name)}` | {ctr} | {n} | {tot:.4g} | {tot / max(n, 1):.4g} |")
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 40)
+    mode, path = sys.argv[1], sys.argv[2]
+    if mode == "trace":
+        trace(path)
+    else:
+        pmc(path, float(sys.argv[3]) if len(sys.argv) > 3 else 1.0)
