@@ -77,6 +77,9 @@ typedef struct MudgGemmDesc {
     int mode;             /* 0 | 1 | 2 */
     /* mode 1 */
     int Hin, Win, Hout, Wout, Cin, stride, upsample;
+    int korder;           /* mode 1: 0 = W's K axis is [tap][Cin]; 1 = [Cin/64][tap][64] (needs Cin % 64 == 0): the nine
+                             taps of a 64-channel slab are consecutive K tiles, so the shifted re-reads of the input
+                             hit L2 instead of coming back after a whole sweep over Cin */
     /* mode 2 */
     int T, HW;
 } MudgGemmDesc;

@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const MudgAttnDesc p, cons
         for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx);
-        const float alpha = exp2f((m_run - m_new) * c);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
         const float mc = m_new * c;
         m_run = m_new;
         float ps = 0.f;
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const MudgAttnDesc p, cons
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float e = exp2f(s[sub][r] * c - mc);
+                const float e = __builtin_amdgcn_exp2f(s[sub][r] * c - mc);
                 ps += e;
                 pk[sub][r >> 3][r & 7] = (bf16)e;
             }

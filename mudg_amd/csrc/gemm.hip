@@ -15,6 +15,7 @@
 // Epilogue: accumulators (+bias, GEGLU) -> fp32 LDS tile -> coalesced 16-B rows (+group bias, +residual) -> HBM.
 // Workgroups are numbered so that each XCD gets a contiguous run of tiles (neighbouring tiles share operand panels).
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -101,7 +102,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const MudgGemmDesc p, cons
     auto issue_tiles = [&](int kt, int buf) {
         const int k0 = kt * BK;
         int tap_u = 0, c_u = 0;
-        if (MODE != 0 && tap_uniform) { tap_u = k0 / p.Cin; c_u = k0 - tap_u * p.Cin; }
+        if (MODE != 0 && tap_uniform) {
+            if (MODE == 1 && p.korder) { const int slab = kt / 9; tap_u = kt - slab * 9; c_u = slab * 64; }
+            else { tap_u = k0 / p.Cin; c_u = k0 - tap_u * p.Cin; }
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int k = k0 + ch[i] * 8;
@@ -309,7 +313,24 @@ int launch(const MudgGemmDesc& d, int vflags, hipStream_t s) {
     return mudg_check_launch("mudg_gemm");
 }
 
+// Large-tile path (gemm256.hip): opt-in while it is not faster than this kernel.  MUDG_GEMM256=1 forces it whenever
+// the shape allows, =2 selects it for shapes with enough 256x256 tiles to occupy the chip and little column padding.
+bool use_gemm256(const MudgGemmDesc& d) {
+    static int mode = -1;
+    if (mode < 0) {
+        const char* e = getenv("MUDG_GEMM256");
+        mode = e ? atoi(e) : 0;
+    }
+    if (mode == 0 || d.M < 256 || d.N < 256) return false;
+    if (mode == 1) return true;
+    const int64_t tn = (d.N + 255) / 256, tiles = ((d.M + 255) / 256) * tn * d.batch;
+    const double waste = (double)(tn * 256 - d.N) / (double)(tn * 256);
+    return tiles >= 192 && waste <= 0.13;
+}
+
 }  // namespace
+
+int mudg_gemm256_dispatch(const MudgGemmDesc& d, int vflags, const bf16* zpage, hipStream_t s);
 
 extern "C" int mudg_gemm(const MudgGemmDesc* dp, void* stream) {
     MUDG_REQUIRE(dp, "mudg_gemm: null descriptor");
@@ -333,6 +354,7 @@ extern "C" int mudg_gemm(const MudgGemmDesc* dp, void* stream) {
         MUDG_REQUIRE(d.stride == 1 || d.stride == 2, "mudg_gemm: stride %d", d.stride);
         MUDG_REQUIRE(!(d.upsample && d.stride != 1), "mudg_gemm: upsample needs stride 1");
         MUDG_REQUIRE(d.Hin > 0 && d.Win > 0 && d.Hout > 0 && d.Wout > 0, "mudg_gemm: conv geometry");
+        MUDG_REQUIRE(!d.korder || (d.Cin & 63) == 0, "mudg_gemm: korder=1 needs Cin %% 64 == 0");
         MUDG_REQUIRE(d.M % (d.Hout * d.Wout) == 0, "mudg_gemm: M not a whole number of frames");
     } else if (d.mode == 2) {
         MUDG_REQUIRE(d.Cin > 0 && (d.Cin & 7) == 0 && d.K == 3 * d.Cin, "mudg_gemm: tconv K=%d Cin=%d", d.K, d.Cin);
@@ -351,7 +373,11 @@ extern "C" int mudg_gemm(const MudgGemmDesc* dp, void* stream) {
     const int fam = d.mode == 0 ? MUDG_FAM_GEMM : (d.mode == 1 ? MUDG_FAM_CONV : MUDG_FAM_TCONV);
     const int slot = mudg_prof_begin(fam, s);
     int rc;
-    if (d.mode == 0) rc = launch<0>(d, vflags, s);
+    if (use_gemm256(d)) {
+        const bf16* zp = zero_page();
+        if (!zp) MUDG_FAIL(MUDG_ELAUNCH, "gemm: could not allocate the zero page");
+        rc = mudg_gemm256_dispatch(d, vflags, zp, s);
+    } else if (d.mode == 0) rc = launch<0>(d, vflags, s);
     else if (d.mode == 1) rc = launch<1>(d, vflags, s);
     else rc = launch<2>(d, vflags, s);
     const double flops = 2.0 * d.M * (double)d.N * d.K * d.batch;

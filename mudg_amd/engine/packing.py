@@ -59,19 +59,24 @@ def linear_cat(owner, name, mods):
 
 
 def conv3x3(mod):
-    """(Cout, Cin, 3, 3) -> [Cout][tap][Cin padded to a multiple of 8] bf16; returns (matrix, padded Cin)."""
+    """(Cout, Cin, 3, 3) -> bf16 [Cout][K]; returns (matrix, padded Cin, korder).  K is ordered [Cin/64][tap][64]
+    when Cin is a multiple of 64 (korder 1: the nine taps of a channel slab are adjacent K tiles, which keeps the
+    shifted input re-reads in L2), else [tap][Cin padded to a multiple of 8] (korder 0)."""
     w = mod.weight
     _need_cuda(w, type(mod).__name__)
-    cin = w.shape[1]
+    cout, cin = w.shape[0], w.shape[1]
     cpad = (cin + 7) // 8 * 8
+    korder = 1 if cin % 64 == 0 else 0
 
     def build():
         t = w.detach().permute(0, 2, 3, 1)                       # Cout, ky, kx, Cin
-        if cpad != cin:
+        if korder:
+            t = t.reshape(cout, 9, cin // 64, 64).permute(0, 2, 1, 3)
+        elif cpad != cin:
             t = torch.nn.functional.pad(t, (0, cpad - cin))
-        return t.reshape(w.shape[0], 9 * cpad).to(BF16).contiguous()
+        return t.reshape(cout, 9 * cpad).to(BF16).contiguous()
 
-    return cached(mod, "w3x3", (w,), build), cpad
+    return cached(mod, "w3x3", (w,), build), cpad, korder
 
 
 def tconv(mod):

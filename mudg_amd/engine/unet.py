@@ -47,10 +47,10 @@ def _linear(mod, x, residual=None, x2=None, stream=False):
 
 def _conv3x3(mod, x, frames, h, w, *, stride=1, upsample=False, gbias=None, rows_per_group=0, residual=None, x2=None,
              stream=False):
-    wmat, cpad = pk.conv3x3(mod)
+    wmat, cpad, korder = pk.conv3x3(mod)
     return ops.conv3x3(x, wmat, frames=frames, hin=h, win=w, cin=cpad, stride=stride, upsample=upsample,
                        bias=pk.f32(mod, "bias"), gbias=gbias, rows_per_group=rows_per_group, residual=residual, x2=x2,
-                       out_fp32=stream)
+                       out_fp32=stream, korder=korder)
 
 
 def _vt_projection(mod, src_rows, batches, n_per_batch):

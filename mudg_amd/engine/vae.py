@@ -23,9 +23,9 @@ def _gn(mod, x, frames, hw, swish):
 
 def _conv3x3(mod, x, frames, h, w, upsample=False, residual=None, stream=False):
     """stream=True: the output is a residual-stream tensor, kept in fp32 (same policy as the UNet executor)."""
-    wmat, cpad = pk.conv3x3(mod)
+    wmat, cpad, korder = pk.conv3x3(mod)
     return ops.conv3x3(x, wmat, frames=frames, hin=h, win=w, cin=cpad, upsample=upsample, bias=pk.f32(mod, "bias"),
-                       residual=residual, out_fp32=stream)
+                       residual=residual, out_fp32=stream, korder=korder)
 
 
 def resnet_block(mod, x, frames, h, w):

@@ -31,7 +31,7 @@ class GemmDesc(C.Structure):
         ("rows_per_group", C.c_int), ("out_fp32", C.c_int), ("res_fp32", C.c_int), ("geglu", C.c_int),
         ("alpha", C.c_float), ("mode", C.c_int),
         ("Hin", C.c_int), ("Win", C.c_int), ("Hout", C.c_int), ("Wout", C.c_int),
-        ("Cin", C.c_int), ("stride", C.c_int), ("upsample", C.c_int),
+        ("Cin", C.c_int), ("stride", C.c_int), ("upsample", C.c_int), ("korder", C.c_int),
         ("T", C.c_int), ("HW", C.c_int),
     ]
 

@@ -67,8 +67,9 @@ def gemm(x, w, *, out=None, bias=None, gbias=None, rows_per_group=0, residual=No
 
 
 def conv3x3(x, w, *, frames, hin, win, cin, stride=1, upsample=False, out=None, bias=None, gbias=None,
-            rows_per_group=0, residual=None, x2=None, out_fp32=False):
-    """3x3 / pad 1 convolution on channels-last rows; w is packed [Cout][9*cin] tap-major."""
+            rows_per_group=0, residual=None, x2=None, out_fp32=False, korder=0):
+    """3x3 / pad 1 convolution on channels-last rows; w is packed [Cout][9*cin], K axis tap-major (korder 0) or
+    64-channel-slab-major (korder 1, see MudgGemmDesc.korder)."""
     _rows(x); _rows(w)
     if upsample:
         hout, wout = 2 * hin, 2 * win
@@ -89,6 +90,7 @@ def conv3x3(x, w, *, frames, hin, win, cin, stride=1, upsample=False, out=None, 
     d.csplit = x.shape[1] if x2 is not None else cin
     d.batch, d.rows_per_group, d.alpha, d.mode = 1, rows_per_group, 1.0, 1
     d.Hin, d.Win, d.Hout, d.Wout, d.Cin, d.stride, d.upsample = hin, win, hout, wout, cin, stride, int(upsample)
+    d.korder = korder
     hip.check(hip.lib().mudg_gemm(C.byref(d), _stream()), "mudg_gemm[conv3x3]")
     return out
 

@@ -101,6 +101,12 @@ def pack_conv(w):
     return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous()
 
 
+def pack_conv_slab(w):
+    """(Cout, Cin, 3, 3) with Cin % 64 == 0 -> [Cout][Cin/64][tap][64] (korder 1)"""
+    co, ci = w.shape[:2]
+    return w.permute(0, 2, 3, 1).reshape(co, 9, ci // 64, 64).permute(0, 2, 1, 3).reshape(co, -1).contiguous()
+
+
 def to_rows(x):       # (F, C, H, W) -> rows
     return x.permute(0, 2, 3, 1).reshape(-1, x.shape[1]).contiguous()
 
@@ -124,6 +130,19 @@ def test_conv3x3(cuda, cin, cout, h, w, stride, ups):
                     upsample=ups, bias=b.to(cuda))
     got = from_rows(y.cpu().float(), frames, ref.shape[2], ref.shape[3])
     assert rel_l2(got, ref) < TOL_BF16
+
+
+@pytest.mark.parametrize("cin,cout,stride,ups", [(128, 96, 1, False), (192, 64, 2, False), (64, 64, 1, True)])
+def test_conv3x3_slab_major_k_order(cuda, cin, cout, stride, ups):
+    from mudg_amd import ops
+    frames, h, w = 2, 10, 12
+    x = rnd(frames, cin, h, w, seed=1)
+    wt = rnd(cout, cin, 3, 3, seed=2, scale=0.05)
+    xin = F.interpolate(x.float(), scale_factor=2, mode="nearest") if ups else x.float()
+    ref = F.conv2d(xin, wt.float(), None, stride=stride, padding=1)
+    y = ops.conv3x3(to_rows(x).to(cuda), pack_conv_slab(wt).to(cuda), frames=frames, hin=h, win=w, cin=cin,
+                    stride=stride, upsample=ups, korder=1)
+    assert rel_l2(from_rows(y.cpu().float(), frames, ref.shape[2], ref.shape[3]), ref) < TOL_BF16
 
 
 def test_conv3x3_fused_epilogue_and_concat(cuda):
@@ -356,3 +375,78 @@ def test_fp32_residual_stream_variants(cuda):
     assert torch.equal(xb.cpu(), x.to(BF))
     odd = torch.randn(1003, generator=g)
     assert torch.equal(ops.cast_bf16(odd.to(cuda)).cpu(), odd.to(BF))
+
+
+# ---- large-tile (256x256, 8-wave, counted-vmcnt) GEMM path: shapes with >= 192 tiles select it automatically
+def test_gemm256_plain_epilogues(cuda):
+    from mudg_amd import ops
+    M, N, K = 4096 + 40, 3072, 200                      # ragged M, K tail (200 = 3 tiles + 8)
+    x, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05)
+    b = torch.randn(N, generator=torch.Generator().manual_seed(3))
+    r32 = torch.randn(M, N, generator=torch.Generator().manual_seed(4))
+    ref = x.float() @ w.float().t() + b
+    y = ops.gemm(x.to(cuda), w.to(cuda), bias=b.to(cuda))
+    assert rel_l2(y, ref) < TOL_BF16
+    y32 = ops.gemm(x.to(cuda), w.to(cuda), bias=b.to(cuda), residual=r32.to(cuda), out_fp32=True)
+    assert rel_l2(y32, ref + r32) < TOL_F32
+    rb = rnd(M, N, seed=5)
+    gb = torch.randn(M // 8 + 1, N, generator=torch.Generator().manual_seed(6))
+    y3 = ops.gemm(x.to(cuda), w.to(cuda), residual=rb.to(cuda), gbias=gb.to(cuda), rows_per_group=8)
+    assert rel_l2(y3, x.float() @ w.float().t() + rb.float() + gb.repeat_interleave(8, 0)[:M]) < TOL_BF16
+
+
+def test_gemm256_transpose_detecting_and_two_sources(cuda):
+    from mudg_amd import ops
+    n = 4096
+    w = ((torch.arange(n * 256).reshape(n, 256) * 7) % 251).float().to(BF)      # asymmetric
+    x = torch.zeros(n, 256)
+    x[torch.arange(256) * 16, torch.arange(256)] = 1.0                          # row 16 j selects column j
+    y = ops.gemm(x.to(BF).to(cuda), w.to(cuda), out_fp32=True)                  # [4096, 4096]
+    want = torch.zeros(n, n)
+    want[torch.arange(256) * 16] = w.float().t()
+    assert torch.equal(y.cpu(), want)
+    M, N, K1, K2 = 4096, 3072, 64, 192
+    x1, x2, w2 = rnd(M, K1, seed=1), rnd(M, K2, seed=2), rnd(N, K1 + K2, seed=3, scale=0.05)
+    y2 = ops.gemm(x1.to(cuda), w2.to(cuda), x2=x2.to(cuda))
+    assert rel_l2(y2, torch.cat([x1, x2], 1).float() @ w2.float().t()) < TOL_BF16
+
+
+def test_gemm256_geglu(cuda):
+    from mudg_amd import ops
+    M, C = 8192, 192                                      # N = 8C = 1536: 32 x 6 = 192 tiles
+    x, w = rnd(M, C, seed=1), rnd(8 * C, C, seed=2, scale=0.1)
+    b = torch.randn(8 * C, generator=torch.Generator().manual_seed(3)) * 0.1
+    val, gate = (x.float() @ w.float().t() + b).chunk(2, dim=-1)
+    wp, bp = pack_geglu(w, b)
+    y = ops.gemm(x.to(cuda), wp.to(cuda), bias=bp.to(cuda), geglu=True)
+    assert tuple(y.shape) == (M, 4 * C) and rel_l2(y, val * F.gelu(gate)) < TOL_BF16
+
+
+@pytest.mark.parametrize("korder,stride,ups", [(0, 1, False), (1, 1, False), (1, 2, False), (1, 1, True)])
+def test_gemm256_conv3x3(cuda, korder, stride, ups):
+    from mudg_amd import ops
+    frames, h, w, cin, cout = (16, 32, 32, 64, 768) if not ups else (4, 32, 32, 64, 768)
+    if stride == 2:
+        frames, h, w = 16, 64, 64
+    x = rnd(frames, cin, h, w, seed=1)
+    wt = rnd(cout, cin, 3, 3, seed=2, scale=0.05)
+    b = torch.randn(cout, generator=torch.Generator().manual_seed(3))
+    xin = F.interpolate(x.float(), scale_factor=2, mode="nearest") if ups else x.float()
+    ref = F.conv2d(xin, wt.float(), b, stride=stride, padding=1)
+    packed = pack_conv_slab(wt) if korder else pack_conv(wt)
+    y = ops.conv3x3(to_rows(x).to(cuda), packed.to(cuda), frames=frames, hin=h, win=w, cin=cin, stride=stride,
+                    upsample=ups, bias=b.to(cuda), korder=korder)
+    assert rel_l2(from_rows(y.cpu().float(), frames, ref.shape[2], ref.shape[3]), ref) < TOL_BF16
+
+
+def test_gemm256_tconv3(cuda):
+    from mudg_amd import ops
+    clips, t, h, w, c = 2, 8, 32, 32, 256                 # M = 16384, N = 256 -> 64 tiles: forced below
+    x = rnd(clips, c, t, h, w, seed=1)
+    wt = rnd(3 * c, c, 3, 1, 1, seed=2, scale=0.05)        # Cout = 768 so that 64 x 3 = 192 tiles
+    ref = F.conv3d(x.float(), wt.float(), None, padding=(1, 0, 0))
+    rows = x.permute(0, 2, 3, 4, 1).reshape(-1, c).contiguous()
+    wp = wt[:, :, :, 0, 0].permute(0, 2, 1).reshape(3 * c, 3 * c).contiguous()
+    y = ops.tconv3(rows.to(cuda), wp.to(cuda), clips=clips, t=t, hw=h * w, cin=c)
+    got = y.cpu().float().reshape(clips, t, h, w, 3 * c).permute(0, 4, 1, 2, 3)
+    assert rel_l2(got, ref) < TOL_BF16

@@ -58,8 +58,9 @@ def main():
         for (h, w_, cin, cout) in [(72, 128, 320, 320), (72, 128, 640, 320), (72, 128, 960, 320), (36, 64, 640, 640),
                                    (36, 64, 1280, 640), (18, 32, 1280, 1280), (18, 32, 2560, 1280), (9, 16, 2560, 1280)]:
             x, wt = rn(T * h * w_, cin), rn(cout, 9 * cin)
-            report(f"conv3x3 {h}x{w_} {cin}->{cout}", timeit(lambda: ops.conv3x3(x, wt, frames=T, hin=h, win=w_, cin=cin)),
-                   2.0 * T * h * w_ * cout * 9 * cin)
+            for ko in (0, 1):
+                report(f"conv3x3 {h}x{w_} {cin}->{cout} korder={ko}", timeit(lambda: ops.conv3x3(x, wt, frames=T, hin=h, win=w_, cin=cin, korder=ko)),
+                       2.0 * T * h * w_ * cout * 9 * cin)
         for hw, c in levels:
             x, wt = rn(T * hw, c), rn(c, 3 * c)
             report(f"tconv3 hw={hw} C={c}", timeit(lambda: ops.tconv3(x, wt, clips=1, t=T, hw=hw, cin=c)), 2.0 * T * hw * c * 3 * c)
