@@ -18,8 +18,13 @@
 // STATUS (round 1): bit-correct, but not yet faster than the 128x128 kernel, so it is opt-in (MUDG_GEMM256=1|2).
 // Ablation on MI355X, conv 18x32 2560->1280 (K = 23040, 180 tiles): MFMA + barriers only 424 us, DMA + barriers only
 // 406-498 us (8.5-10.5 TB/s L2->LDS), ds_read + barriers only 274 us, everything 823 us: the MFMA stream and the DMA
-// stream do not overlap because all eight waves issue their DMA at the same barrier.  Next step: stagger the two
-// wave groups by one phase (loader/compute ping-pong) so one half computes while the other half issues.
+// stream do not overlap because all eight waves issue their DMA at the same barrier.  Tried and rejected this round:
+// (a) putting the whole next tile in flight at the tile boundary (DMA-only 406 us, full kernel unchanged);
+// (b) running the two wave groups one sub-phase apart with a barrier after every load / MFMA sub-phase (8 barriers
+// per K-tile): correct, but slower (conv 530 vs 660 TFLOP/s) — the load sub-phase (tap decode + 64-bit address
+// arithmetic + bounds tests per DMA instruction) is longer than the 8-MFMA sub-phase it should hide under.
+// Next: make the load sub-phase cheap (incremental per-lane offsets into a buffer descriptor instead of recomputed
+// 64-bit pointers) before staggering again.
 //
 // Epilogue: four passes (one per quadrant) through the same fp32 LDS tile as gemm.hip; GEGLU is applied in the
 // coalesced pass (value / gate columns of the usual [32 value | 32 gate] packing sit 32 apart in the staged tile).
