@@ -77,6 +77,8 @@ typedef struct MudgGemmDesc {
     int mode;             /* 0 | 1 | 2 */
     /* mode 1 */
     int Hin, Win, Hout, Wout, Cin, stride, upsample;
+    int pad;              /* mode 1: leading zero padding rows/cols (1 = the usual pad 1; 0 = AutoencoderKL's stride-2
+                             downsample, which pads (0,1,0,1): only bottom/right, ae_modules.py:104-106) */
     int korder;           /* mode 1: 0 = W's K axis is [tap][Cin]; 1 = [Cin/64][tap][64] (needs Cin % 64 == 0): the nine
                              taps of a 64-channel slab are consecutive K tiles, so the shifted re-reads of the input
                              hit L2 instead of coming back after a whole sweep over Cin */
@@ -176,6 +178,12 @@ int64_t mudg_ddim_ws_doubles(int B);
 int mudg_ddim_step(const float* x, const float* e_c, const float* e_u, const float* noise,
                    float* x_prev, float* pred_x0, int B, int64_t n, const float* host_coef,
                    double* ws, void* stream);
+
+/* ------------------------------------------------------------------ VAE posterior (distributions.py:24-40)
+ * moments (N, 2C, HW) fp32 planar: mean = [:, :C], logvar = clamp([:, C:], -30, 20);
+ * out (N, C, HW) = scale * (mean + exp(0.5 logvar) * noise); noise NULL = posterior mode. */
+int mudg_gaussian_sample(const float* moments, const float* noise, float* out, int N, int C, int HW, float scale,
+                         void* stream);
 
 /* ------------------------------------------------------------------ event profiler (bench.py roofline)
  * When enabled, every launch of kernel family `fam` is bracketed by hipEvents on its own stream. */

@@ -1,5 +1,5 @@
-"""AutoencoderKL at the drop-in boundary (reference: lvdm/models/autoencoder.py:13-107).  `decode` runs the
-decoder on the gfx950 kernels (mudg_amd.engine.vae); `encode` is the next scope row and refuses for now."""
+"""AutoencoderKL at the drop-in boundary (reference: lvdm/models/autoencoder.py:13-107).  `encode` and `decode` run
+the encoder / decoder on the gfx950 kernels (mudg_amd.engine.vae)."""
 import torch
 import torch.nn as nn
 
@@ -39,8 +39,12 @@ class AutoencoderKL(nn.Module):
                 del sd[k]
         self.load_state_dict(sd, strict=False)
 
+    @torch.no_grad()
     def encode(self, x, **kwargs):
-        raise NotImplementedError("AutoencoderKL.encode is the next row of the scope table (SURVEY §8(f) rank 1)")
+        """x (N, 3, H, W) in [-1, 1] -> DiagonalGaussianDistribution over (N, embed_dim, H/8, W/8): encoder +
+        quant_conv on the HIP kernels (reference autoencoder.py:97-102)."""
+        from mudg_amd.engine import vae
+        return DiagonalGaussianDistribution(vae.encode_moments(self, x))
 
     @torch.no_grad()
     def decode(self, z, **kwargs):

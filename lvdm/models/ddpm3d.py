@@ -247,8 +247,36 @@ class LatentDiffusion(DDPM):
             return m.encode(c) if callable(getattr(m, "encode", None)) else m(c)
         return getattr(m, self.cond_stage_forward)(c)
 
+    def get_first_stage_encoding(self, encoder_posterior, noise=None):
+        """scale_factor * posterior.sample() (ddpm3d.py:611-618); the scale rides in the sampling kernel."""
+        if isinstance(encoder_posterior, torch.Tensor):
+            from mudg_amd import ops
+            return ops.lincomb(encoder_posterior, encoder_posterior,
+                               torch.full((encoder_posterior.shape[0],), float(self.scale_factor), device=encoder_posterior.device),
+                               torch.zeros(encoder_posterior.shape[0], device=encoder_posterior.device))
+        return encoder_posterior.sample(noise=noise, scale=float(self.scale_factor))
+
+    @torch.no_grad()
     def encode_first_stage(self, x):
-        raise NotImplementedError("AutoencoderKL encode is the next row of the scope table (SURVEY §8(f) rank 1)")
+        """(B, 3, T, H, W) or (N, 3, H, W) pixels -> scaled latents (ddpm3d.py:620-644).  With perframe_ae the
+        reference encodes and samples frame by frame; the CPU noise draws happen in that same order here, while the
+        encoder itself runs on batches of frames (they are independent)."""
+        five = x.dim() == 5
+        if five:
+            b, c, t, h, w = x.shape
+            frames = x.permute(0, 2, 1, 3, 4).reshape(b * t, c, h, w)
+        else:
+            frames = x
+        posterior = self.first_stage_model.encode(frames)
+        n, c2, hh, ww = posterior.parameters.shape
+        if self.perframe_ae:
+            noise = torch.cat([torch.randn((1, c2 // 2, hh, ww)) for _ in range(n)], 0)
+        else:
+            noise = torch.randn((n, c2 // 2, hh, ww))
+        z = self.get_first_stage_encoding(posterior, noise=noise)
+        if five:
+            z = z.reshape(b, t, c2 // 2, hh, ww).permute(0, 2, 1, 3, 4)
+        return z
 
     @torch.no_grad()
     def decode_core(self, z, **kwargs):

@@ -111,7 +111,7 @@ class Encoder(nn.Module):
         self.conv_out = Conv2d(block_in, 2 * z_channels if double_z else z_channels, kernel_size=3, stride=1, padding=1)
 
     def forward(self, x):
-        raise NotImplementedError("AutoencoderKL encode is the next row of the scope table (SURVEY §8(f) rank 1)")
+        raise RuntimeError("Encoder runs inside AutoencoderKL.encode (mudg_amd.engine.vae.encode_moments)")
 
 
 class Decoder(nn.Module):

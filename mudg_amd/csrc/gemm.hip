@@ -91,8 +91,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const MudgGemmDesc p, cons
             const int f = m / hw, r = m - f * hw;
             const int oy = r / p.Wout, ox = r - oy * p.Wout;
             ra[i] = f * p.Hin * p.Win;
-            rb[i] = oy * p.stride - 1;
-            rc[i] = ox * p.stride - 1;
+            rb[i] = oy * p.stride - p.pad;
+            rc[i] = ox * p.stride - p.pad;
         } else if (MODE == 2) {
             rb[i] = (m / p.HW) % p.T;
         }
@@ -354,6 +354,7 @@ extern "C" int mudg_gemm(const MudgGemmDesc* dp, void* stream) {
         MUDG_REQUIRE(d.stride == 1 || d.stride == 2, "mudg_gemm: stride %d", d.stride);
         MUDG_REQUIRE(!(d.upsample && d.stride != 1), "mudg_gemm: upsample needs stride 1");
         MUDG_REQUIRE(d.Hin > 0 && d.Win > 0 && d.Hout > 0 && d.Wout > 0, "mudg_gemm: conv geometry");
+        MUDG_REQUIRE(d.pad == 0 || d.pad == 1, "mudg_gemm: pad %d", d.pad);
         MUDG_REQUIRE(!d.korder || (d.Cin & 63) == 0, "mudg_gemm: korder=1 needs Cin %% 64 == 0");
         MUDG_REQUIRE(d.M % (d.Hout * d.Wout) == 0, "mudg_gemm: M not a whole number of frames");
     } else if (d.mode == 2) {

@@ -113,8 +113,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const MudgGemmDesc p, c
                 const int f = m / hw, r = m - f * hw;
                 const int oy = r / p.Wout, ox = r - oy * p.Wout;
                 ra[h][i] = f * p.Hin * p.Win;
-                rb[h][i] = oy * p.stride - 1;
-                rc[h][i] = ox * p.stride - 1;
+                rb[h][i] = oy * p.stride - p.pad;
+                rc[h][i] = ox * p.stride - p.pad;
             } else if (MODE == 2) {
                 rb[h][i] = (m / p.HW) % p.T;
             }

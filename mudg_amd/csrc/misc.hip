@@ -119,6 +119,20 @@ __global__ void lincomb_kernel(float* __restrict__ out, const float* __restrict_
         out[off + i] = a * x[off + i] + c * y[off + i];
 }
 
+__global__ void gaussian_sample_kernel(const float* __restrict__ mom, const float* __restrict__ noise, float* __restrict__ out,
+                                       int C, int HW, float scale, int64_t total) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;       // over (n, c, p)
+    if (i >= total) return;
+    const int64_t chw = (int64_t)C * HW;
+    const int64_t n = i / chw, r = i - n * chw;
+    const float mean = mom[n * 2 * chw + r];
+    float lv = mom[n * 2 * chw + chw + r];
+    lv = fminf(fmaxf(lv, -30.f), 20.f);
+    float z = mean;
+    if (noise) z = mean + expf(0.5f * lv) * noise[i];
+    out[i] = scale * z;
+}
+
 // ---- DDIM -------------------------------------------------------------------------------------------------
 constexpr int DDIM_BLK = 64;   // partial-sum blocks per sample
 
@@ -283,6 +297,16 @@ extern "C" int mudg_lincomb(float* out, const float* x, const float* y, const fl
     if (gx > 1024) gx = 1024;
     hipLaunchKernelGGL(lincomb_kernel, dim3(gx, B), dim3(256), 0, s, out, x, y, ca, cb, n);
     return mudg_check_launch("mudg_lincomb");
+}
+
+extern "C" int mudg_gaussian_sample(const float* moments, const float* noise, float* out, int N, int C, int HW, float scale,
+                                    void* stream) {
+    MUDG_REQUIRE(moments && out && N > 0 && C > 0 && HW > 0, "mudg_gaussian_sample: bad arguments");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int64_t total = (int64_t)N * C * HW;
+    hipLaunchKernelGGL(gaussian_sample_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, moments, noise, out, C, HW,
+                       scale, total);
+    return mudg_check_launch("mudg_gaussian_sample");
 }
 
 extern "C" int64_t mudg_ddim_ws_doubles(int B) { return B > 0 ? (int64_t)B * DDIM_BLK * 4 : 0; }

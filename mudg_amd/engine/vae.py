@@ -21,11 +21,11 @@ def _gn(mod, x, frames, hw, swish):
                          silu=swish, groups=mod.num_groups)
 
 
-def _conv3x3(mod, x, frames, h, w, upsample=False, residual=None, stream=False):
+def _conv3x3(mod, x, frames, h, w, upsample=False, residual=None, stream=False, stride=1, pad=1):
     """stream=True: the output is a residual-stream tensor, kept in fp32 (same policy as the UNet executor)."""
     wmat, cpad, korder = pk.conv3x3(mod)
     return ops.conv3x3(x, wmat, frames=frames, hin=h, win=w, cin=cpad, upsample=upsample, bias=pk.f32(mod, "bias"),
-                       residual=residual, out_fp32=stream, korder=korder)
+                       residual=residual, out_fp32=stream, korder=korder, stride=stride, pad=pad)
 
 
 def resnet_block(mod, x, frames, h, w):
@@ -88,6 +88,50 @@ def decoder_rows(dec, x, frames, h, w):
             h, w = 2 * h, 2 * w
     x = _gn(dec.norm_out, x, frames, h * w, True)
     return _conv3x3(dec.conv_out, x, frames, h, w, stream=True), h, w
+
+
+def encoder_rows(enc, x, frames, h, w):
+    """Encoder.forward (ae_modules.py:433-463) on rows [frames*h*w, in-padded]; returns (rows, h/8.., w/8..)."""
+    x = _conv3x3(enc.conv_in, x, frames, h, w, stream=True)
+    for lvl in range(enc.num_resolutions):
+        level = enc.down[lvl]
+        for i in range(enc.num_res_blocks):
+            x = resnet_block(level.block[i], x, frames, h, w)
+            if len(level.attn) > 0:
+                x = attn_block(level.attn[i], x, frames, h * w)
+        if lvl != enc.num_resolutions - 1:
+            # Downsample: zero-pad bottom/right by one, 3x3 stride 2, no other padding (ae_modules.py:102-107)
+            x = _conv3x3(level.downsample.conv, ops.cast_bf16(x), frames, h, w, stream=True, stride=2, pad=0)
+            h, w = (h + 1 - 3) // 2 + 1, (w + 1 - 3) // 2 + 1
+    x = resnet_block(enc.mid.block_1, x, frames, h, w)
+    if not isinstance(enc.mid.attn_1, nn.Identity):
+        x = attn_block(enc.mid.attn_1, x, frames, h * w)
+    x = resnet_block(enc.mid.block_2, x, frames, h, w)
+    x = _gn(enc.norm_out, x, frames, h * w, True)
+    return _conv3x3(enc.conv_out, x, frames, h, w), h, w
+
+
+@torch.no_grad()
+def encode_moments(ae, x, max_frames=8):
+    """AutoencoderKL.encode up to the posterior parameters: x (N, 3, H, W) -> moments (N, 2*embed, H/8, W/8) fp32
+    (encoder + 1x1 quant_conv).  Frames are independent and processed in batches."""
+    x = _check(x).contiguous()
+    n, c, h, w = x.shape
+    cin = (c + 7) // 8 * 8
+    qc = ae.quant_conv
+    out = None
+    for n0 in range(0, n, max_frames):
+        nb = min(max_frames, n - n0)
+        rows = ops.empty_rows(nb * h * w, cin, BF16, x.device)
+        ops.ncthw_to_rows(x[n0:n0 + nb].unsqueeze(2), rows, 0)
+        if cin > c:
+            ops.zero_channels(rows, c, cin)
+        y, hh, ww = encoder_rows(ae.encoder, rows, nb, h, w)
+        mom = ops.gemm(y, pk.linear(qc), bias=pk.f32(qc, "bias"), out_fp32=True)
+        if out is None:
+            out = torch.empty((n, mom.shape[1], 1, hh, ww), dtype=torch.float32, device=x.device)
+        ops.rows_to_ncthw(mom, (nb, mom.shape[1], 1, hh, ww), out=out[n0:n0 + nb])
+    return out[:, :, 0]
 
 
 def _check(z):

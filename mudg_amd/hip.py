@@ -31,7 +31,7 @@ class GemmDesc(C.Structure):
         ("rows_per_group", C.c_int), ("out_fp32", C.c_int), ("res_fp32", C.c_int), ("geglu", C.c_int),
         ("alpha", C.c_float), ("mode", C.c_int),
         ("Hin", C.c_int), ("Win", C.c_int), ("Hout", C.c_int), ("Wout", C.c_int),
-        ("Cin", C.c_int), ("stride", C.c_int), ("upsample", C.c_int), ("korder", C.c_int),
+        ("Cin", C.c_int), ("stride", C.c_int), ("upsample", C.c_int), ("pad", C.c_int), ("korder", C.c_int),
         ("T", C.c_int), ("HW", C.c_int),
     ]
 
@@ -68,6 +68,7 @@ SIGNATURES = {
     "mudg_lincomb": (_I, [_P, _P, _P, _P, _P, _I, _L, _P]),
     "mudg_ddim_ws_doubles": (_L, [_I]),
     "mudg_ddim_step": (_I, [_P, _P, _P, _P, _P, _P, _I, _L, C.POINTER(C.c_float), _P, _P]),
+    "mudg_gaussian_sample": (_I, [_P, _P, _P, _I, _I, _I, _F, _P]),
     "mudg_prof_enable": (_I, [_I]),
     "mudg_prof_collect": (_I, [_I, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                C.POINTER(C.c_double)]),

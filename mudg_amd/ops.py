@@ -67,14 +67,16 @@ def gemm(x, w, *, out=None, bias=None, gbias=None, rows_per_group=0, residual=No
 
 
 def conv3x3(x, w, *, frames, hin, win, cin, stride=1, upsample=False, out=None, bias=None, gbias=None,
-            rows_per_group=0, residual=None, x2=None, out_fp32=False, korder=0):
+            rows_per_group=0, residual=None, x2=None, out_fp32=False, korder=0, pad=1):
     """3x3 / pad 1 convolution on channels-last rows; w is packed [Cout][9*cin], K axis tap-major (korder 0) or
     64-channel-slab-major (korder 1, see MudgGemmDesc.korder)."""
     _rows(x); _rows(w)
     if upsample:
         hout, wout = 2 * hin, 2 * win
-    else:
+    elif pad == 1:
         hout, wout = (hin - 1) // stride + 1, (win - 1) // stride + 1
+    else:       # pad 0 with one trailing zero row / column: AutoencoderKL's downsample
+        hout, wout = (hin + 1 - 3) // stride + 1, (win + 1 - 3) // stride + 1
     M, N = frames * hout * wout, w.shape[0]
     if out is None:
         out = empty_rows(M, N, torch.float32 if out_fp32 else BF16, x.device)
@@ -90,7 +92,7 @@ def conv3x3(x, w, *, frames, hin, win, cin, stride=1, upsample=False, out=None, 
     d.csplit = x.shape[1] if x2 is not None else cin
     d.batch, d.rows_per_group, d.alpha, d.mode = 1, rows_per_group, 1.0, 1
     d.Hin, d.Win, d.Hout, d.Wout, d.Cin, d.stride, d.upsample = hin, win, hout, wout, cin, stride, int(upsample)
-    d.korder = korder
+    d.korder, d.pad = korder, pad
     hip.check(hip.lib().mudg_gemm(C.byref(d), _stream()), "mudg_gemm[conv3x3]")
     return out
 
@@ -280,6 +282,18 @@ def lincomb(x, y, ca, cb):
     b = x.shape[0]
     hip.check(hip.lib().mudg_lincomb(out.data_ptr(), x.data_ptr(), y.data_ptr(), ca.data_ptr(), cb.data_ptr(), b,
                                      x.numel() // b, _stream()), "mudg_lincomb")
+    return out
+
+
+def gaussian_sample(moments, noise=None, scale=1.0):
+    """moments (N, 2C, H, W) fp32 -> scale * (mean + std * noise) as (N, C, H, W); noise None = mode."""
+    moments = moments.float().contiguous()
+    n, c2, h, w = moments.shape
+    out = torch.empty((n, c2 // 2, h, w), dtype=torch.float32, device=moments.device)
+    if noise is not None:
+        noise = noise.to(device=moments.device, dtype=torch.float32).contiguous()
+    hip.check(hip.lib().mudg_gaussian_sample(moments.data_ptr(), _ptr(noise), out.data_ptr(), n, c2 // 2, h * w, scale,
+                                             _stream()), "mudg_gaussian_sample")
     return out
 
 

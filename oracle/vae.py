@@ -40,6 +40,32 @@ def attn_block(sd, p, x):
 
 
 @torch.no_grad()
+def encode(sd, ddconfig, x):
+    """AutoencoderKL.encode up to the posterior parameters (autoencoder.py:97-102; Encoder.forward ae_modules.py:
+    433-463; Downsample pads (0,1,0,1) then 3x3 stride 2, ae_modules.py:102-107).  Returns moments (N, 2*z, h, w)."""
+    nlev, nres = len(ddconfig["ch_mult"]), ddconfig["num_res_blocks"]
+    h = _conv(sd, "encoder.conv_in", x, 1)
+    for lvl in range(nlev):
+        for i in range(nres):
+            h = resnet_block(sd, f"encoder.down.{lvl}.block.{i}", h)
+        if lvl != nlev - 1:
+            h = F.conv2d(F.pad(h, (0, 1, 0, 1)), sd[f"encoder.down.{lvl}.downsample.conv.weight"],
+                         sd[f"encoder.down.{lvl}.downsample.conv.bias"], stride=2)
+    h = resnet_block(sd, "encoder.mid.block_1", h)
+    h = attn_block(sd, "encoder.mid.attn_1", h)
+    h = resnet_block(sd, "encoder.mid.block_2", h)
+    h = _conv(sd, "encoder.conv_out", _swish(_gn(sd, "encoder.norm_out", h)), 1)
+    return _conv(sd, "quant_conv", h)
+
+
+def posterior_sample(moments, noise, scale_factor=1.0):
+    """DiagonalGaussianDistribution.sample + get_first_stage_encoding (distributions.py:24-40, ddpm3d.py:611-618)."""
+    mean, logvar = torch.chunk(moments, 2, dim=1)
+    std = torch.exp(0.5 * torch.clamp(logvar, -30.0, 20.0))
+    return scale_factor * (mean + std * noise)
+
+
+@torch.no_grad()
 def decode(sd, ddconfig, z, prefix=""):
     """AutoencoderKL.decode: post_quant_conv then Decoder.forward.  z (N, z_channels, h, w) already divided by
     scale_factor.  sd keys: post_quant_conv.*, decoder.* (optionally under `prefix`)."""

@@ -248,8 +248,26 @@ def golden_pipeline():
         "decode_direct": {"z": z1, "out": dec_direct.clone()}})
 
 
+def golden_encode():
+    """AutoencoderKL.encode moments + encode_first_stage (perframe, CPU-generator noise) on the tiny VAE."""
+    model = build_diffusion(cfgs.UNET_B, cfgs.DIFFUSION)
+    shapes, cks = reseed(model.first_stage_model, cfgs.SEED + 1)
+    x = seeding.seeded_input("pixels", (2, 3, 3, 64, 64), cfgs.SEED + 3, 0.5).clamp(-1, 1)       # (B, 3, T, H, W)
+    frames = x.permute(0, 2, 1, 3, 4).reshape(6, 3, 64, 64)
+    moments = model.first_stage_model.encode(frames).parameters
+    torch.manual_seed(777)
+    z = model.encode_first_stage(x)
+    save("encode.pt", {"vae_ddconfig": cfgs.VAE_DD, "seed": cfgs.SEED, "vae_checksum": cks, "vae_param_shapes": shapes,
+                       "moments": moments.clone(), "z": z.clone(), "cpu_seed": 777,
+                       "scale_factor": cfgs.DIFFUSION["scale_factor"]})
+
+
 if __name__ == "__main__":
+    if "--only-encode" in sys.argv:
+        golden_encode()
+        sys.exit(0)
     golden_schedule()
     golden_unet("a", cfgs.UNET_A, cfgs.UNET_A_SHAPE)
     golden_unet("b", cfgs.UNET_B, cfgs.UNET_B_SHAPE)
     golden_pipeline()
+    golden_encode()

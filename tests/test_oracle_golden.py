@@ -102,3 +102,17 @@ def test_sampler_and_decode_match_reference():
     assert rel_l2(dec, g["decoded"]) < 1e-5
     d2 = o_vae.decode(vsd, g["vae_ddconfig"], g["decode_direct"]["z"])
     assert rel_l2(d2, g["decode_direct"]["out"]) < 1e-5
+
+
+def test_vae_encode_matches_reference():
+    from helpers import seeding
+    g = golden("encode.pt")
+    vsd = seeded_sd(g["vae_param_shapes"], g["seed"] + 1, g["vae_checksum"])
+    x = seeding.seeded_input("pixels", (2, 3, 3, 64, 64), g["seed"] + 3, 0.5).clamp(-1, 1)
+    frames = x.permute(0, 2, 1, 3, 4).reshape(6, 3, 64, 64)
+    mom = o_vae.encode(vsd, g["vae_ddconfig"], frames)
+    assert rel_l2(mom, g["moments"]) < 1e-5
+    torch.manual_seed(g["cpu_seed"])                       # perframe_ae: one CPU randn per frame, in frame order
+    noise = torch.cat([torch.randn(1, 4, 8, 8) for _ in range(6)], 0)
+    z = o_vae.posterior_sample(g["moments"], noise, g["scale_factor"]).reshape(2, 3, 4, 8, 8).permute(0, 2, 1, 3, 4)
+    assert rel_l2(z, g["z"]) < 1e-6

@@ -73,3 +73,26 @@ def test_single_step_with_reference_unet_outputs_is_fp32_exact(cuda):
         xp, x0 = ops.ddim_step(x.to(cuda), ref["e_c"].to(cuda), ref["e_u"].to(cuda), inp["noises"][i].to(cuda), coef)
         assert rel_l2(x0, ref["pred_x0"]) < 2e-6 and rel_l2(xp, ref["x_prev"]) < 2e-6
         x = ref["x_prev"]
+
+
+def test_vae_encode_matches_reference(cuda):
+    """AutoencoderKL.encode + encode_first_stage (perframe, CPU-generator posterior noise) against the reference."""
+    from helpers import seeding
+    g = golden("encode.pt")
+    gp = golden("pipeline.pt")
+    model = build_model(gp, cuda)
+    x = seeding.seeded_input("pixels", (2, 3, 3, 64, 64), g["seed"] + 3, 0.5).clamp(-1, 1)
+    frames = x.permute(0, 2, 1, 3, 4).reshape(6, 3, 64, 64)
+    post = model.first_stage_model.encode(frames.to(cuda))
+    e_m = rel_l2(post.parameters, g["moments"])
+    torch.manual_seed(g["cpu_seed"])
+    z = model.encode_first_stage(x.to(cuda))
+    e_z = rel_l2(z, g["z"])
+    print(f"vae encode rel-L2 vs reference: moments {e_m:.3e}  latents {e_z:.3e}")
+    assert z.shape == g["z"].shape and e_m < 2e-2 and e_z < 2e-2
+    # sampling arithmetic alone, fed the reference's own moments: fp32-exact
+    torch.manual_seed(g["cpu_seed"])
+    noise = torch.cat([torch.randn(1, 4, 8, 8) for _ in range(6)], 0)
+    from mudg_amd import ops
+    z2 = ops.gaussian_sample(g["moments"].to(cuda), noise, g["scale_factor"]).reshape(2, 3, 4, 8, 8).permute(0, 2, 1, 3, 4)
+    assert rel_l2(z2, g["z"]) < 2e-6
