@@ -37,6 +37,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="CPU-baseline time budget")
     ap.add_argument("--no-profile", action="store_true", help="skip hipEvent bracketing of kernel families")
+    ap.add_argument("--operand", default=os.environ.get("MUDG_OPERAND", "bf16"), choices=["bf16", "fp16"],
+                    help="16-bit MFMA operand type (bf16 is the BASELINE dtype; fp16 = the reference's autocast dtype)")
     return ap.parse_args()
 
 
@@ -103,6 +105,7 @@ def main():
 
     from mudg_amd import build as mbuild, configs, factory, hip
     mbuild.build(verbose=False)
+    hip.set_operand(args.operand)
     hip.lib()
     from lvdm.models.samplers.ddim import DDIMSampler
 
@@ -156,13 +159,14 @@ def main():
         if args.resolution == "1024" else "DDIM denoise steps/sec, MDM512 320x512x16f",
         "value": round(steps_per_s, 4), "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1000.0 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "vs_baseline": None, "dtype": args.operand, "data": "synthetic",
         "config": {"workload": f"MDM{args.resolution} latents (B={args.batch},4,16,"
                                f"{configs.LATENT_SHAPE[args.resolution][2]},{configs.LATENT_SHAPE[args.resolution][3]}) "
                                f"+ c_concat 8ch, context (B,333,1024), 50-step uniform_trailing DDIM schedule, "
                                f"cfg 7.5, guidance_rescale 0.7, eta 1.0, v-prediction, dynamic rescale",
                    "clips_per_gpu": args.batch, "parallelism": f"clip-DP x{world} (no in-step collective)",
-                   "weights": "seeded N(0,0.02^2) incl. zero-init tensors, fp32 params -> bf16 MFMA operands"},
+                   "weights": f"seeded N(0,0.02^2) incl. zero-init tensors, fp32 params -> {args.operand} MFMA operands, "
+                              "fp32 accumulate / norms / softmax / residual stream"},
         "algorithmic_tflop_per_step": step_tflop,
         "achieved_tflops_per_gpu": round(step_tflop * args.batch * args.steps / elapsed, 2),
         "frac_of_bf16_mfma_peak": round(step_tflop * args.batch * args.steps / elapsed / PEAK_TFLOPS_BF16, 4),

@@ -35,6 +35,9 @@ extern "C" {
 
 /* ABI version; bumped whenever a struct below changes. */
 int mudg_version(void);
+/* 16-bit MFMA operand type of this build: 0 = bfloat16 (libmudg_hip.so), 1 = IEEE fp16 (libmudg_hip_fp16.so).
+ * Wherever this header says "bf16" for an operand buffer, the fp16 build expects fp16 in its place. */
+int mudg_operand_dtype(void);
 /* Text for the most recent non-zero return on this thread. */
 const char* mudg_last_error(void);
 

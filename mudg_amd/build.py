@@ -16,6 +16,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libmudg_hip.so")
+OUT_FP16 = os.path.join(HERE, "libmudg_hip_fp16.so")
 SOURCES = ["capi.hip", "gemm.hip", "gemm256.hip", "attention.hip", "norm.hip", "misc.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-ffp-contract=off"]
@@ -39,20 +40,20 @@ def _stamp() -> str:
     return h.hexdigest()
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
-    stamp_file = OUT + ".stamp"
+def _build_one(out: str, extra, tag: str, force: bool, verbose: bool) -> str:
+    stamp_file = out + ".stamp"
     stamp = _stamp()
-    if not force and os.path.exists(OUT) and os.path.exists(stamp_file):
+    if not force and os.path.exists(out) and os.path.exists(stamp_file):
         with open(stamp_file) as f:
             if f.read().strip() == stamp:
-                return OUT
+                return out
     hipcc = _hipcc()
-    objdir = os.path.join(HERE, "build")
+    objdir = os.path.join(HERE, "build", tag)
     os.makedirs(objdir, exist_ok=True)
 
     def compile_one(src: str) -> str:
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, *FLAGS, *extra, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
@@ -60,13 +61,19 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 1)) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", OUT]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", out]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
     with open(stamp_file, "w") as f:
         f.write(stamp)
-    return OUT
+    return out
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    """Both operand-type builds of the same sources: bf16 (default) and fp16 (-DMUDG_OPERAND_FP16)."""
+    _build_one(OUT_FP16, ["-DMUDG_OPERAND_FP16"], "fp16", force, verbose)
+    return _build_one(OUT, [], "bf16", force, verbose)
 
 
 if __name__ == "__main__":

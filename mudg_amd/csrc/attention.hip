@@ -21,12 +21,12 @@ namespace {
 
 constexpr int QB = 128;     // query rows per workgroup
 constexpr int KB = 64;      // keys per tile
-constexpr int ALD = 72;     // LDS row stride in bf16 (64 + 8 pad -> 144 B)
+constexpr int ALD = 72;     // LDS row stride in h16 (64 + 8 pad -> 144 B)
 constexpr int ATILE = 64 * ALD;
 
 __global__ __launch_bounds__(256, 2) void attn_kernel(const MudgAttnDesc p, const int nqt, const int total) {
-    __shared__ __attribute__((aligned(16))) bf16 Ks[2 * ATILE];
-    __shared__ __attribute__((aligned(16))) bf16 Vs[2 * ATILE];
+    __shared__ __attribute__((aligned(16))) h16 Ks[2 * ATILE];
+    __shared__ __attribute__((aligned(16))) h16 Vs[2 * ATILE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
@@ -42,18 +42,18 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const MudgAttnDesc p, cons
     const int f = pair / p.heads, h = pair - f * p.heads;
     const int kvb = f / p.kv_div;
 
-    const bf16* Qp = reinterpret_cast<const bf16*>(p.Q) + (int64_t)f * p.Nq * p.ldq + h * 64;
-    const bf16* Kp = reinterpret_cast<const bf16*>(p.K) + (int64_t)kvb * p.Nk * p.ldk + h * 64;
-    const bf16* Vp = reinterpret_cast<const bf16*>(p.Vt) + (int64_t)kvb * p.svt + (int64_t)(h * 64) * p.ldvt;
-    bf16* Op = reinterpret_cast<bf16*>(p.O) + (int64_t)f * p.Nq * p.ldo + h * 64;
+    const h16* Qp = reinterpret_cast<const h16*>(p.Q) + (int64_t)f * p.Nq * p.ldq + h * 64;
+    const h16* Kp = reinterpret_cast<const h16*>(p.K) + (int64_t)kvb * p.Nk * p.ldk + h * 64;
+    const h16* Vp = reinterpret_cast<const h16*>(p.Vt) + (int64_t)kvb * p.svt + (int64_t)(h * 64) * p.ldvt;
+    h16* Op = reinterpret_cast<h16*>(p.O) + (int64_t)f * p.Nq * p.ldo + h * 64;
 
     const int q = qt * QB + wave * 32 + l31;
     const bool qok = q < p.Nq;
 
-    bf16x8 qf[4];
+    h16x8 qf[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
-        qf[ks] = as_bf16x8(qok ? ld16(Qp + (int64_t)q * p.ldq + ks * 16 + hi * 8) : zero16());
+        qf[ks] = as_h16x8(qok ? ld16(Qp + (int64_t)q * p.ldq + ks * 16 + hi * 8) : zero16());
 
     const int lrow = tid >> 3, kc = tid & 7;   // staging: rows lrow, lrow+32; 16-byte chunk kc
     u32x4 kr[2], vr[2];
@@ -69,9 +69,9 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const MudgAttnDesc p, cons
             if (jc < p.Nk) {
                 v = ld16(Vp + (int64_t)row * p.ldvt + jc);
                 if (jc + 8 > p.Nk) {                       // ragged tail: keys >= Nk must contribute exactly 0
-                    bf16x8 hv = as_bf16x8(v);
+                    h16x8 hv = as_h16x8(v);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) if (jc + e >= p.Nk) hv[e] = (bf16)0.f;
+                    for (int e = 0; e < 8; ++e) if (jc + e >= p.Nk) hv[e] = (h16)0.f;
                     v = as_u32x4(hv);
                 }
             }
@@ -108,11 +108,11 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const MudgAttnDesc p, cons
         for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[sub][r] = 0.f;
-            const bf16* kp = Ks + cur * ATILE + (sub * 32 + l31) * ALD + hi * 8;
+            const h16* kp = Ks + cur * ATILE + (sub * 32 + l31) * ALD + hi * 8;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(kp + ks * 16);
-                s[sub] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[sub], 0, 0, 0);
+                const h16x8 kf = *reinterpret_cast<const h16x8*>(kp + ks * 16);
+                s[sub] = MFMA_32x32x16(kf, qf[ks], s[sub]);
             }
         }
         if (kt * KB + KB > p.Nk) {   // ragged last tile
@@ -137,14 +137,14 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const MudgAttnDesc p, cons
         const float mc = m_new * c;
         m_run = m_new;
         float ps = 0.f;
-        bf16x8 pk[2][2];
+        h16x8 pk[2][2];
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float e = __builtin_amdgcn_exp2f(s[sub][r] * c - mc);
                 ps += e;
-                pk[sub][r >> 3][r & 7] = (bf16)e;
+                pk[sub][r >> 3][r & 7] = (h16)e;
             }
         l_run = l_run * alpha + ps;
 #pragma unroll
@@ -153,18 +153,18 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const MudgAttnDesc p, cons
         // ---- O^T += V^T P^T ; contraction slots follow the key order the score MFMA left in registers
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
-            const bf16* vp = Vs + cur * ATILE + (dt * 32 + l31) * ALD + 4 * hi;
+            const h16* vp = Vs + cur * ATILE + (dt * 32 + l31) * ALD + 4 * hi;
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
                 for (int jj = 0; jj < 2; ++jj) {
                     const int kk = sub * 32 + jj * 16;
-                    const bf16x4 lo = *reinterpret_cast<const bf16x4*>(vp + kk);
-                    const bf16x4 up = *reinterpret_cast<const bf16x4*>(vp + kk + 8);
-                    bf16x8 vf;
+                    const h16x4 lo = *reinterpret_cast<const h16x4*>(vp + kk);
+                    const h16x4 up = *reinterpret_cast<const h16x4*>(vp + kk + 8);
+                    h16x8 vf;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { vf[e] = lo[e]; vf[4 + e] = up[e]; }
-                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pk[sub][jj], o[dt], 0, 0, 0);
+                    o[dt] = MFMA_32x32x16(vf, pk[sub][jj], o[dt]);
                 }
         }
 
@@ -176,12 +176,12 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const MudgAttnDesc p, cons
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.f / l_tot;
     if (qok) {
-        bf16* orow = Op + (int64_t)q * p.ldo;
+        h16* orow = Op + (int64_t)q * p.ldo;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                bf16* dst = orow + dt * 32 + 8 * g + 4 * hi;
+                h16* dst = orow + dt * 32 + 8 * g + 4 * hi;
                 float v[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = o[dt][4 * g + j] * inv;
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const MudgAttnDesc p, cons
                 }
                 Pack8 nw;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) nw.h[j] = (bf16)v[j];
+                for (int j = 0; j < 4; ++j) nw.h[j] = (h16)v[j];
                 *reinterpret_cast<u32x2*>(dst) = nw.u;
             }
     }
@@ -201,12 +201,12 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const MudgAttnDesc p, cons
 // ------------------------------------------------------------------------------------------------ temporal
 // TP = padded sequence length (16 or 32); DP = 64 / TP lanes share one query row, each owning DW = 64 / DP dims.
 template <int TP>
-__global__ __launch_bounds__(256) void tattn_kernel(const bf16* __restrict__ QKV, bf16* __restrict__ O,
+__global__ __launch_bounds__(256) void tattn_kernel(const h16* __restrict__ QKV, h16* __restrict__ O,
                                                      int B, int T, int HW, int heads, int ldqkv, int ldo,
                                                      float scale, int total) {
     constexpr int DP = 64 / TP, DW = 64 / DP;
-    __shared__ __attribute__((aligned(16))) bf16 Ks[4][TP * 64];
-    __shared__ __attribute__((aligned(16))) bf16 Vs[4][TP * 64];
+    __shared__ __attribute__((aligned(16))) h16 Ks[4][TP * 64];
+    __shared__ __attribute__((aligned(16))) h16 Vs[4][TP * 64];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tq = lane / DP, dp = lane % DP;
@@ -218,12 +218,12 @@ __global__ __launch_bounds__(256) void tattn_kernel(const bf16* __restrict__ QKV
     const bool rok = wok && tq < T;
 
     const int64_t row = ((int64_t)(b * T + tq) * HW + px);
-    const bf16* src = QKV + row * ldqkv + h * 64 + dp * DW;
+    const h16* src = QKV + row * ldqkv + h * 64 + dp * DW;
 
     float qv[DW];
 #pragma unroll
     for (int i = 0; i < DW / 8; ++i) {
-        const bf16x8 t = as_bf16x8(rok ? ld16(src + i * 8) : zero16());
+        const h16x8 t = as_h16x8(rok ? ld16(src + i * 8) : zero16());
 #pragma unroll
         for (int e = 0; e < 8; ++e) qv[i * 8 + e] = (float)t[e];
     }
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void tattn_kernel(const bf16* __restrict__ QKV
         float a = 0.f;
 #pragma unroll
         for (int i = 0; i < DW / 8; ++i) {
-            const bf16x8 kk = *reinterpret_cast<const bf16x8*>(&Ks[wave][j * 64 + dp * DW + i * 8]);
+            const h16x8 kk = *reinterpret_cast<const h16x8*>(&Ks[wave][j * 64 + dp * DW + i * 8]);
 #pragma unroll
             for (int e = 0; e < 8; ++e) a = fmaf(qv[i * 8 + e], (float)kk[e], a);
         }
@@ -264,18 +264,18 @@ __global__ __launch_bounds__(256) void tattn_kernel(const bf16* __restrict__ QKV
         const float pj = sc[j] * inv;
 #pragma unroll
         for (int i = 0; i < DW / 8; ++i) {
-            const bf16x8 vv = *reinterpret_cast<const bf16x8*>(&Vs[wave][j * 64 + dp * DW + i * 8]);
+            const h16x8 vv = *reinterpret_cast<const h16x8*>(&Vs[wave][j * 64 + dp * DW + i * 8]);
 #pragma unroll
             for (int e = 0; e < 8; ++e) ov[i * 8 + e] = fmaf(pj, (float)vv[e], ov[i * 8 + e]);
         }
     }
     if (rok) {
-        bf16* dst = O + row * ldo + h * 64 + dp * DW;
+        h16* dst = O + row * ldo + h * 64 + dp * DW;
 #pragma unroll
         for (int i = 0; i < DW / 8; ++i) {
-            bf16x8 t;
+            h16x8 t;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) t[e] = (bf16)ov[i * 8 + e];
+            for (int e = 0; e < 8; ++e) t[e] = (h16)ov[i * 8 + e];
             st16(dst + i * 8, as_u32x4(t));
         }
     }
@@ -319,10 +319,10 @@ extern "C" int mudg_temporal_attention(const void* QKV, void* O, int B, int T, i
     const int slot = mudg_prof_begin(MUDG_FAM_TATTN, s);
     const unsigned grid = (unsigned)((total + 3) / 4);
     if (T <= 16)
-        hipLaunchKernelGGL(tattn_kernel<16>, dim3(grid), dim3(256), 0, s, (const bf16*)QKV, (bf16*)O, B, T, HW, heads,
+        hipLaunchKernelGGL(tattn_kernel<16>, dim3(grid), dim3(256), 0, s, (const h16*)QKV, (h16*)O, B, T, HW, heads,
                            ldqkv, ldo, scale, (int)total);
     else
-        hipLaunchKernelGGL(tattn_kernel<32>, dim3(grid), dim3(256), 0, s, (const bf16*)QKV, (bf16*)O, B, T, HW, heads,
+        hipLaunchKernelGGL(tattn_kernel<32>, dim3(grid), dim3(256), 0, s, (const h16*)QKV, (h16*)O, B, T, HW, heads,
                            ldqkv, ldo, scale, (int)total);
     const int rc = mudg_check_launch("mudg_temporal_attention");
     mudg_prof_end(slot, s, 4.0 * total * (double)T * T * 64.0, (double)total * T * 64.0 * 2.0 * 4.0);

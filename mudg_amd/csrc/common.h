@@ -1,13 +1,24 @@
-// common.h — shared device helpers for the gfx950 kernels (wave64, MFMA, bf16 storage / fp32 math).
+// common.h — shared device helpers for the gfx950 kernels (wave64, MFMA, h16 storage / fp32 math).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/mudg_hip.h"
 
-typedef __bf16 bf16;
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+// h16 = the 16-bit MFMA operand type of this build: bfloat16 by default (libmudg_hip.so), IEEE half when compiled
+// with -DMUDG_OPERAND_FP16 (libmudg_hip_fp16.so).  Same MFMA rate, same bytes; fp16 has three more mantissa bits
+// (operand rounding 2^-12 instead of 2^-9) and is what the reference itself computes in under torch.autocast.
+#ifdef MUDG_OPERAND_FP16
+typedef _Float16 h16;
+#define MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#define MUDG_OPERAND_CODE 1
+#else
+typedef __bf16 h16;
+#define MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#define MUDG_OPERAND_CODE 0
+#endif
+typedef __attribute__((ext_vector_type(8))) h16 h16x8;
+typedef __attribute__((ext_vector_type(4))) h16 h16x4;
+typedef __attribute__((ext_vector_type(2))) h16 h16x2;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
@@ -20,11 +31,11 @@ __device__ __forceinline__ u32x4 ld16(const void* p) { return *reinterpret_cast<
 __device__ __forceinline__ void st16(void* p, u32x4 v) { *reinterpret_cast<u32x4*>(p) = v; }
 __device__ __forceinline__ u32x4 zero16() { u32x4 z = {0u, 0u, 0u, 0u}; return z; }
 
-union Pack16 { u32x4 u; bf16x8 h; };
-union Pack8 { u32x2 u; bf16x4 h; };
+union Pack16 { u32x4 u; h16x8 h; };
+union Pack8 { u32x2 u; h16x4 h; };
 
-__device__ __forceinline__ bf16x8 as_bf16x8(u32x4 v) { Pack16 p; p.u = v; return p.h; }
-__device__ __forceinline__ u32x4 as_u32x4(bf16x8 v) { Pack16 p; p.h = v; return p.u; }
+__device__ __forceinline__ h16x8 as_h16x8(u32x4 v) { Pack16 p; p.u = v; return p.h; }
+__device__ __forceinline__ u32x4 as_u32x4(h16x8 v) { Pack16 p; p.h = v; return p.u; }
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }

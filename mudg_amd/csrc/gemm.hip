@@ -7,7 +7,7 @@
 // up with 4 consecutive output channels of one pixel — the epilogue then moves 16-byte pieces.
 // Staging: HBM/L2 -> LDS directly with global_load_lds_dwordx4 (no VGPR round trip, no ds_write pass: the first
 // version staged through registers and was LDS-write-bound at ~600 TFLOP/s).  The DMA writes lane-linear 1-KiB
-// pieces (8 rows x 128 B), so the LDS tile is unpadded [128][64] bf16 and bank conflicts are removed by an XOR
+// pieces (8 rows x 128 B), so the LDS tile is unpadded [128][64] h16 and bank conflicts are removed by an XOR
 // swizzle applied on the SOURCE side (which 16-byte chunk of the row a lane fetches) and mirrored on the fragment
 // reads: chunk c of row r lives in slot c ^ ((r >> 1) & 7); with that, every 16-lane ds_read_b128 group touches 16
 // distinct 16-byte slots of the 256-byte bank row.  Out-of-range rows / taps / K tail fetch from a 16-byte zero page.
@@ -20,7 +20,7 @@
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int LDSLD = 64;                       // bf16 elements per LDS row: unpadded, XOR-swizzled (see header)
+constexpr int LDSLD = 64;                       // h16 elements per LDS row: unpadded, XOR-swizzled (see header)
 constexpr int STGLD = 132;                      // fp32 per staging row (128 + 4 pad)
 constexpr int TILE = BM * LDSLD;                // elements per operand per buffer
 constexpr int SMEM_MAIN = 4 * TILE * 2;         // X[2] + W[2], bytes
@@ -34,7 +34,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 
 __device__ __forceinline__ float gelu_fast(float x) {
     // 0.5 x (1 + erf(x / sqrt 2)) with Abramowitz-Stegun 7.1.26 for erf (|abs err| < 1.5e-7): the exact erff
-    // costs about as much as the whole K loop of a K = 320 tile; the result is rounded to bf16 anyway.
+    // costs about as much as the whole K loop of a K = 320 tile; the result is rounded to h16 anyway.
     const float z = fabsf(x) * 0.70710678118654752440f;
     const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
     float p = fmaf(1.061405429f, t, -1.453152027f);
@@ -46,10 +46,10 @@ __device__ __forceinline__ float gelu_fast(float x) {
 }
 
 template <int MODE>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const MudgGemmDesc p, const int vflags, const bf16* __restrict__ zpage) {
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const MudgGemmDesc p, const int vflags, const h16* __restrict__ zpage) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    bf16* Xs = reinterpret_cast<bf16*>(smem);
-    bf16* Ws = Xs + 2 * TILE;
+    h16* Xs = reinterpret_cast<h16*>(smem);
+    h16* Ws = Xs + 2 * TILE;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -68,9 +68,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const MudgGemmDesc p, cons
     const int tm = tile / ntn, tn = tile - tm * ntn;
     const int m0 = tm * BM, n0 = tn * BN;
     const int64_t bz = blockIdx.z;
-    const bf16* X = reinterpret_cast<const bf16*>(p.X) + bz * p.sX;
-    const bf16* X2 = p.X2 ? reinterpret_cast<const bf16*>(p.X2) + bz * p.sX : nullptr;
-    const bf16* W = reinterpret_cast<const bf16*>(p.W) + bz * p.sW;
+    const h16* X = reinterpret_cast<const h16*>(p.X) + bz * p.sX;
+    const h16* X2 = p.X2 ? reinterpret_cast<const h16*>(p.X2) + bz * p.sX : nullptr;
+    const h16* W = reinterpret_cast<const h16*>(p.W) + bz * p.sW;
 
     // DMA geometry: wave w stages rows [32w, 32w+32) of both operand tiles with four 1-KiB instructions each;
     // in instruction i, lane l lands in row 32w + 8i + (l >> 3), slot l & 7, and therefore fetches the logical
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const MudgGemmDesc p, cons
         for (int i = 0; i < 4; ++i) {
             const int k = k0 + ch[i] * 8;
             const bool kv = k < p.K;
-            const bf16* src = zpage;
+            const h16* src = zpage;
             if (MODE == 0) {
                 if (rv[i] && kv)
                     src = (k < p.csplit) ? X + (int64_t)rm[i] * p.ldx + k : X2 + (int64_t)rm[i] * p.ldx2 + (k - p.csplit);
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const MudgGemmDesc p, cons
                 int tap, c;
                 if (tap_uniform) { tap = tap_u; c = c_u + ch[i] * 8; }
                 else { tap = k / p.Cin; c = k - tap * p.Cin; }
-                const bf16* base = X; int cc = c, ld = p.ldx;
+                const h16* base = X; int cc = c, ld = p.ldx;
                 if (c >= p.csplit) { base = X2; cc = c - p.csplit; ld = p.ldx2; }
                 if (MODE == 1) {
                     const int dy = tap / 3, dx = tap - dy * 3;
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const MudgGemmDesc p, cons
             }
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Xs + buf * TILE + (32 * wave + 8 * i) * LDSLD), 16, 0, 0);
             const int n = n0 + 32 * wave + 8 * i + rsub;
-            const bf16* wsrc = (n < p.N && kv) ? W + (int64_t)n * p.ldw + k : zpage;
+            const h16* wsrc = (n < p.N && kv) ? W + (int64_t)n * p.ldw + k : zpage;
             __builtin_amdgcn_global_load_lds((gptr_t)wsrc, (lptr_t)(Ws + buf * TILE + (32 * wave + 8 * i) * LDSLD), 16, 0, 0);
         }
     };
@@ -157,21 +157,21 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const MudgGemmDesc p, cons
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nk) issue_tiles(kt + 1, cur ^ 1);
-        const bf16* xs = Xs + cur * TILE + (wm * 64 + l31) * LDSLD;
-        const bf16* ws = Ws + cur * TILE + (wn * 64 + l31) * LDSLD;
+        const h16* xs = Xs + cur * TILE + (wm * 64 + l31) * LDSLD;
+        const h16* ws = Ws + cur * TILE + (wn * 64 + l31) * LDSLD;
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
             const int off = ((ks * 2 + hi) ^ sw) << 3;
-            bf16x8 wf[2], xf[2];
-            wf[0] = *reinterpret_cast<const bf16x8*>(ws + off);
-            wf[1] = *reinterpret_cast<const bf16x8*>(ws + 32 * LDSLD + off);
-            xf[0] = *reinterpret_cast<const bf16x8*>(xs + off);
-            xf[1] = *reinterpret_cast<const bf16x8*>(xs + 32 * LDSLD + off);
+            h16x8 wf[2], xf[2];
+            wf[0] = *reinterpret_cast<const h16x8*>(ws + off);
+            wf[1] = *reinterpret_cast<const h16x8*>(ws + 32 * LDSLD + off);
+            xf[0] = *reinterpret_cast<const h16x8*>(xs + off);
+            xf[1] = *reinterpret_cast<const h16x8*>(xs + 32 * LDSLD + off);
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi)
-                    acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ni], xf[mi], acc[ni][mi], 0, 0, 0);
+                    acc[ni][mi] = MFMA_32x32x16(wf[ni], xf[mi], acc[ni][mi]);
         }
         __syncthreads();
     }
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const MudgGemmDesc p, cons
     const int Nout = p.geglu ? p.N / 2 : p.N;
     const int nout0 = p.geglu ? n0 / 2 : n0;
     const int cpr = NT / 8;
-    const bf16* R = (p.R && !p.res_fp32) ? reinterpret_cast<const bf16*>(p.R) + bz * p.sR : nullptr;
+    const h16* R = (p.R && !p.res_fp32) ? reinterpret_cast<const h16*>(p.R) + bz * p.sR : nullptr;
     const float* Rf = (p.R && p.res_fp32) ? reinterpret_cast<const float*>(p.R) + bz * p.sR : nullptr;
     for (int c = tid; c < BM * cpr; c += 256) {
         const int row = c / cpr, cc = c - row * cpr;
@@ -238,9 +238,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const MudgGemmDesc p, cons
             for (int j = 0; j < 8; ++j) if (j < nvalid) v[j] += gb[j];
         }
         if (R) {
-            const bf16* rp = R + (int64_t)m * p.ldr + n;
+            const h16* rp = R + (int64_t)m * p.ldr + n;
             if (nvalid == 8 && (vflags & VF_R)) {
-                const bf16x8 rr = as_bf16x8(ld16(rp));
+                const h16x8 rr = as_h16x8(ld16(rp));
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] += (float)rr[j];
             } else {
@@ -272,26 +272,26 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const MudgGemmDesc p, cons
                 for (int j = 0; j < 8; ++j) if (j < nvalid) yp[j] = v[j];
             }
         } else {
-            bf16* yp = reinterpret_cast<bf16*>(p.Y) + bz * p.sY + (int64_t)m * p.ldy + n;
+            h16* yp = reinterpret_cast<h16*>(p.Y) + bz * p.sY + (int64_t)m * p.ldy + n;
             if (nvalid == 8 && (vflags & VF_Y)) {
-                bf16x8 o;
+                h16x8 o;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = (bf16)v[j];
+                for (int j = 0; j < 8; ++j) o[j] = (h16)v[j];
                 st16(yp, as_u32x4(o));
             } else {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) if (j < nvalid) yp[j] = (bf16)v[j];
+                for (int j = 0; j < 8; ++j) if (j < nvalid) yp[j] = (h16)v[j];
             }
         }
     }
 }
 
-const bf16* zero_page() {
-    static bf16* page = nullptr;
+const h16* zero_page() {
+    static h16* page = nullptr;
     if (!page) {
         void* ptr = nullptr;
         if (hipMalloc(&ptr, 256) != hipSuccess || hipMemset(ptr, 0, 256) != hipSuccess) return nullptr;
-        page = static_cast<bf16*>(ptr);
+        page = static_cast<h16*>(ptr);
     }
     return page;
 }
@@ -299,7 +299,7 @@ const bf16* zero_page() {
 template <int MODE>
 int launch(const MudgGemmDesc& d, int vflags, hipStream_t s) {
     static bool attr_set = false;
-    const bf16* zp = zero_page();
+    const h16* zp = zero_page();
     if (!zp) MUDG_FAIL(MUDG_ELAUNCH, "gemm: could not allocate the zero page");
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<MODE>),
@@ -330,7 +330,7 @@ bool use_gemm256(const MudgGemmDesc& d) {
 
 }  // namespace
 
-int mudg_gemm256_dispatch(const MudgGemmDesc& d, int vflags, const bf16* zpage, hipStream_t s);
+int mudg_gemm256_dispatch(const MudgGemmDesc& d, int vflags, const h16* zpage, hipStream_t s);
 
 extern "C" int mudg_gemm(const MudgGemmDesc* dp, void* stream) {
     MUDG_REQUIRE(dp, "mudg_gemm: null descriptor");
@@ -375,7 +375,7 @@ extern "C" int mudg_gemm(const MudgGemmDesc* dp, void* stream) {
     const int slot = mudg_prof_begin(fam, s);
     int rc;
     if (use_gemm256(d)) {
-        const bf16* zp = zero_page();
+        const h16* zp = zero_page();
         if (!zp) MUDG_FAIL(MUDG_ELAUNCH, "gemm: could not allocate the zero page");
         rc = mudg_gemm256_dispatch(d, vflags, zp, s);
     } else if (d.mode == 0) rc = launch<0>(d, vflags, s);

@@ -3,7 +3,7 @@
 // global_load_lds in HALF-TILE pieces that stay in flight across barriers (counted s_waitcnt vmcnt, raw s_barrier).
 //
 // Geometry.  Block rows (activations, "X") and block columns (weights, "W") are each split in two 128-row halves.
-// LDS holds two K-tile buffers of four half-tiles each ([128][64] bf16 = 16 KiB, XOR-swizzled exactly as in gemm.hip):
+// LDS holds two K-tile buffers of four half-tiles each ([128][64] h16 = 16 KiB, XOR-swizzled exactly as in gemm.hip):
 // 2 x 64 KiB = 128 KiB, one workgroup per CU, 2 waves per SIMD.  Waves form a 2 (M) x 4 (N) grid; wave (wm, wn) owns,
 // in EACH X half, rows wm*64 + [0,64) and, in EACH W half, rows wn*32 + [0,32): eight 32x32 MFMA tiles = 128 fp32
 // accumulators per lane.  A K-tile is computed in four quadrant phases (X half, W half) = (0,0) (0,1) (1,1) (1,0),
@@ -64,9 +64,9 @@ __device__ __forceinline__ float gelu_fast2(float x) {
 #define BARRIER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
 
 template <int MODE>
-__global__ __launch_bounds__(512, 2) void gemm256_kernel(const MudgGemmDesc p, const int vflags, const bf16* __restrict__ zpage, const int ablate) {
+__global__ __launch_bounds__(512, 2) void gemm256_kernel(const MudgGemmDesc p, const int vflags, const h16* __restrict__ zpage, const int ablate) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    bf16* L = reinterpret_cast<bf16*>(smem);
+    h16* L = reinterpret_cast<h16*>(smem);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -84,9 +84,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const MudgGemmDesc p, c
     const int tm = tile / ntn, tn = tile - tm * ntn;
     const int m0 = tm * 256, n0 = tn * 256;
     const int64_t bz = blockIdx.z;
-    const bf16* X = reinterpret_cast<const bf16*>(p.X) + bz * p.sX;
-    const bf16* X2 = p.X2 ? reinterpret_cast<const bf16*>(p.X2) + bz * p.sX : nullptr;
-    const bf16* W = reinterpret_cast<const bf16*>(p.W) + bz * p.sW;
+    const h16* X = reinterpret_cast<const h16*>(p.X) + bz * p.sX;
+    const h16* X2 = p.X2 ? reinterpret_cast<const h16*>(p.X2) + bz * p.sX : nullptr;
+    const h16* W = reinterpret_cast<const h16*>(p.W) + bz * p.sW;
 
     // DMA geometry: a half-tile is staged by all 8 waves, wave w rows [16w, 16w+16) with two instructions;
     // in instruction i lane l lands in row 16w + 8i + (l >> 3), slot l & 7 and fetches chunk slot ^ ((row >> 1) & 7).
@@ -128,12 +128,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const MudgGemmDesc p, c
             if (MODE == 1 && p.korder) { const int slab = kt / 9; tap_u = kt - slab * 9; c_u = slab * 64; }
             else { tap_u = k0 / p.Cin; c_u = k0 - tap_u * p.Cin; }
         }
-        bf16* dst = L + (kt & 1) * KBUF + h * HTILE;
+        h16* dst = L + (kt & 1) * KBUF + h * HTILE;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int k = k0 + ch[i] * 8;
             const bool kv = k < p.K;
-            const bf16* src = zpage;
+            const h16* src = zpage;
             if (MODE == 0) {
                 if (rv[h][i] && kv)
                     src = (k < p.csplit) ? X + (int64_t)rm[h][i] * p.ldx + k : X2 + (int64_t)rm[h][i] * p.ldx2 + (k - p.csplit);
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const MudgGemmDesc p, c
                 int tap, c;
                 if (tap_uniform) { tap = tap_u; c = c_u + ch[i] * 8; }
                 else { tap = k / p.Cin; c = k - tap * p.Cin; }
-                const bf16* base = X; int cc = c, ld = p.ldx;
+                const h16* base = X; int cc = c, ld = p.ldx;
                 if (c >= p.csplit) { base = X2; cc = c - p.csplit; ld = p.ldx2; }
                 if (MODE == 1) {
                     const int dy = tap / 3, dx = tap - dy * 3;
@@ -162,12 +162,12 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const MudgGemmDesc p, c
     };
     auto issue_w = [&](int kt, int g) {
         const int k0 = kt * BK;
-        bf16* dst = L + (kt & 1) * KBUF + (2 + g) * HTILE;
+        h16* dst = L + (kt & 1) * KBUF + (2 + g) * HTILE;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int k = k0 + ch[i] * 8;
             const int n = n0 + g * HROWS + rl[i];
-            const bf16* src = (n < p.N && k < p.K) ? W + (int64_t)n * p.ldw + k : zpage;
+            const h16* src = (n < p.N && k < p.K) ? W + (int64_t)n * p.ldw + k : zpage;
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + (16 * wave + 8 * i) * 64), 16, 0, 0);
         }
     };
@@ -186,20 +186,20 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const MudgGemmDesc p, c
     const int sw = (l31 >> 1) & 7;
     const int xrow = (wm * 64 + l31) * 64, wrow = (wn * 32 + l31) * 64;
 
-    bf16x8 xf[2][4], wf[4];
-    auto load_x = [&](const bf16* buf, int h) {
-        const bf16* base = buf + h * HTILE + xrow;
+    h16x8 xf[2][4], wf[4];
+    auto load_x = [&](const h16* buf, int h) {
+        const h16* base = buf + h * HTILE + xrow;
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
-                xf[mi][ks] = *reinterpret_cast<const bf16x8*>(base + mi * 32 * 64 + (((ks * 2 + hi) ^ sw) << 3));
+                xf[mi][ks] = *reinterpret_cast<const h16x8*>(base + mi * 32 * 64 + (((ks * 2 + hi) ^ sw) << 3));
     };
-    auto load_w = [&](const bf16* buf, int g) {
-        const bf16* base = buf + (2 + g) * HTILE + wrow;
+    auto load_w = [&](const h16* buf, int g) {
+        const h16* base = buf + (2 + g) * HTILE + wrow;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
-            wf[ks] = *reinterpret_cast<const bf16x8*>(base + (((ks * 2 + hi) ^ sw) << 3));
+            wf[ks] = *reinterpret_cast<const h16x8*>(base + (((ks * 2 + hi) ^ sw) << 3));
     };
     auto mma = [&](int g, int h) {
         WAIT_LGKM0();
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const MudgGemmDesc p, c
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
-                acc[g][h][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks], xf[mi][ks], acc[g][h][mi], 0, 0, 0);
+                acc[g][h][mi] = MFMA_32x32x16(wf[ks], xf[mi][ks], acc[g][h][mi]);
         __builtin_amdgcn_s_setprio(0);
     };
 
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const MudgGemmDesc p, c
     issue_x(0, 0); issue_w(0, 0); issue_w(0, 1); issue_x(0, 1);
 
     for (int kt = 0; kt < nk; ++kt) {
-        const bf16* buf = L + (kt & 1) * KBUF;
+        const h16* buf = L + (kt & 1) * KBUF;
         const bool more = (kt + 1 < nk) && !(ablate & 1);
         // ---- tile boundary: X0, W0 of this tile must have landed (W1, X1 may still fly); the barrier also retires
         // the other buffer (last read during tile kt-1), into which tile kt+1 is streamed one piece per phase.
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const MudgGemmDesc p, c
     float* sbias = stg + 128 * STGLD;
     const float alpha = p.alpha;
     const int Nout = p.geglu ? p.N / 2 : p.N;
-    const bf16* R = (p.R && !p.res_fp32) ? reinterpret_cast<const bf16*>(p.R) + bz * p.sR : nullptr;
+    const h16* R = (p.R && !p.res_fp32) ? reinterpret_cast<const h16*>(p.R) + bz * p.sR : nullptr;
     const float* Rf = (p.R && p.res_fp32) ? reinterpret_cast<const float*>(p.R) + bz * p.sR : nullptr;
 #pragma unroll
     for (int h = 0; h < 2; ++h)
@@ -302,9 +302,9 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const MudgGemmDesc p, c
                     for (int j = 0; j < 8; ++j) if (j < nvalid) v[j] += gb[j];
                 }
                 if (R) {
-                    const bf16* rp = R + (int64_t)m * p.ldr + n;
+                    const h16* rp = R + (int64_t)m * p.ldr + n;
                     if (nvalid == 8 && (vflags & VF_R)) {
-                        const bf16x8 rr = as_bf16x8(ld16(rp));
+                        const h16x8 rr = as_h16x8(ld16(rp));
 #pragma unroll
                         for (int j = 0; j < 8; ++j) v[j] += (float)rr[j];
                     } else {
@@ -336,15 +336,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const MudgGemmDesc p, c
                         for (int j = 0; j < 8; ++j) if (j < nvalid) yp[j] = v[j];
                     }
                 } else {
-                    bf16* yp = reinterpret_cast<bf16*>(p.Y) + bz * p.sY + (int64_t)m * p.ldy + n;
+                    h16* yp = reinterpret_cast<h16*>(p.Y) + bz * p.sY + (int64_t)m * p.ldy + n;
                     if (nvalid == 8 && (vflags & VF_Y)) {
-                        bf16x8 o;
+                        h16x8 o;
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) o[j] = (bf16)v[j];
+                        for (int j = 0; j < 8; ++j) o[j] = (h16)v[j];
                         st16(yp, as_u32x4(o));
                     } else {
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) if (j < nvalid) yp[j] = (bf16)v[j];
+                        for (int j = 0; j < 8; ++j) if (j < nvalid) yp[j] = (h16)v[j];
                     }
                 }
             }
@@ -353,7 +353,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const MudgGemmDesc p, c
 }
 
 template <int MODE>
-int launch256(const MudgGemmDesc& d, int vflags, const bf16* zp, hipStream_t s) {
+int launch256(const MudgGemmDesc& d, int vflags, const h16* zp, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<MODE>),
@@ -371,7 +371,7 @@ int launch256(const MudgGemmDesc& d, int vflags, const bf16* zp, hipStream_t s) 
 }  // namespace
 
 // Called by mudg_gemm (gemm.hip) once the descriptor is validated and the large-tile path is selected.
-int mudg_gemm256_dispatch(const MudgGemmDesc& d, int vflags, const bf16* zpage, hipStream_t s) {
+int mudg_gemm256_dispatch(const MudgGemmDesc& d, int vflags, const h16* zpage, hipStream_t s) {
     if (d.mode == 0) return launch256<0>(d, vflags, zpage, s);
     if (d.mode == 1) return launch256<1>(d, vflags, zpage, s);
     return launch256<2>(d, vflags, zpage, s);

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void small_linear_kernel(const float* __restri
 }
 
 template <typename ST>
-__global__ void ncthw_to_rows_kernel(const ST* __restrict__ src, bf16* __restrict__ dst, int B, int C, int T, int HW,
+__global__ void ncthw_to_rows_kernel(const ST* __restrict__ src, h16* __restrict__ dst, int B, int C, int T, int HW,
                                      int ld, int coff, int Ttot, int t0) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over (b, t, p)
     const int64_t n = (int64_t)B * T * HW;
@@ -53,7 +53,7 @@ __global__ void ncthw_to_rows_kernel(const ST* __restrict__ src, bf16* __restric
     const int64_t bt = i / HW;
     const int t = (int)(bt % T), b = (int)(bt / T);
     for (int c = 0; c < C; ++c)
-        dst[i * ld + coff + c] = (bf16)(float)src[(((int64_t)b * C + c) * Ttot + t0 + t) * HW + p];
+        dst[i * ld + coff + c] = (h16)(float)src[(((int64_t)b * C + c) * Ttot + t0 + t) * HW + p];
 }
 
 template <typename ST, typename DT>
@@ -69,14 +69,14 @@ __global__ void rows_to_ncthw_kernel(const ST* __restrict__ src, int ld, int cof
         dst[(((int64_t)b * C + c) * Ttot + t0 + t) * HW + p] = (DT)((float)src[i * ld + coff + c] * scale);
 }
 
-__global__ void zero_channels_kernel(bf16* __restrict__ dst, int64_t rows, int ld, int c0, int c1) {
+__global__ void zero_channels_kernel(h16* __restrict__ dst, int64_t rows, int ld, int c0, int c1) {
     const int w = c1 - c0;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows * w) return;
-    dst[(i / w) * ld + c0 + (int)(i % w)] = (bf16)0.f;
+    dst[(i / w) * ld + c0 + (int)(i % w)] = (h16)0.f;
 }
 
-__global__ void copy_rows_kernel(const bf16* __restrict__ src, int64_t lds, bf16* __restrict__ dst, int64_t ldd, int64_t rows,
+__global__ void copy_rows_kernel(const h16* __restrict__ src, int64_t lds, h16* __restrict__ dst, int64_t ldd, int64_t rows,
                                  int64_t cols, int vec) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (vec) {
@@ -91,16 +91,16 @@ __global__ void copy_rows_kernel(const bf16* __restrict__ src, int64_t lds, bf16
     }
 }
 
-__global__ void cast_kernel(const float* __restrict__ src, bf16* __restrict__ dst, int64_t n8, int64_t n) {
+__global__ void cast_kernel(const float* __restrict__ src, h16* __restrict__ dst, int64_t n8, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n8) {
         const f32x4 a = *reinterpret_cast<const f32x4*>(src + i * 8), b = *reinterpret_cast<const f32x4*>(src + i * 8 + 4);
-        bf16x8 o;
+        h16x8 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { o[e] = (bf16)a[e]; o[4 + e] = (bf16)b[e]; }
+        for (int e = 0; e < 4; ++e) { o[e] = (h16)a[e]; o[4 + e] = (h16)b[e]; }
         st16(dst + i * 8, as_u32x4(o));
     } else if (i == n8) {
-        for (int64_t j = n8 * 8; j < n; ++j) dst[j] = (bf16)src[j];
+        for (int64_t j = n8 * 8; j < n; ++j) dst[j] = (h16)src[j];
     }
 }
 
@@ -219,7 +219,7 @@ extern "C" int mudg_small_linear(const float* x, const void* W, int w_is_bf16, c
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const dim3 grid((N + 3) / 4, M);
     if (w_is_bf16)
-        hipLaunchKernelGGL(small_linear_kernel<bf16>, grid, dim3(256), 0, s, x, (const bf16*)W, b, y, M, N, K, act_in, act_out, accumulate);
+        hipLaunchKernelGGL(small_linear_kernel<h16>, grid, dim3(256), 0, s, x, (const h16*)W, b, y, M, N, K, act_in, act_out, accumulate);
     else
         hipLaunchKernelGGL(small_linear_kernel<float>, grid, dim3(256), 0, s, x, (const float*)W, b, y, M, N, K, act_in, act_out, accumulate);
     return mudg_check_launch("mudg_small_linear");
@@ -233,8 +233,8 @@ extern "C" int mudg_ncthw_to_rows(const void* src, int src_is_fp32, void* dst, i
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int64_t n = (int64_t)B * T * HW;
     const dim3 grid((unsigned)((n + 255) / 256));
-    if (src_is_fp32) hipLaunchKernelGGL(ncthw_to_rows_kernel<float>, grid, dim3(256), 0, s, (const float*)src, (bf16*)dst, B, C, T, HW, ld, coff, Ttot, t0);
-    else hipLaunchKernelGGL(ncthw_to_rows_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)src, (bf16*)dst, B, C, T, HW, ld, coff, Ttot, t0);
+    if (src_is_fp32) hipLaunchKernelGGL(ncthw_to_rows_kernel<float>, grid, dim3(256), 0, s, (const float*)src, (h16*)dst, B, C, T, HW, ld, coff, Ttot, t0);
+    else hipLaunchKernelGGL(ncthw_to_rows_kernel<h16>, grid, dim3(256), 0, s, (const h16*)src, (h16*)dst, B, C, T, HW, ld, coff, Ttot, t0);
     return mudg_check_launch("mudg_ncthw_to_rows");
 }
 
@@ -248,10 +248,10 @@ extern "C" int mudg_rows_to_ncthw(const void* src, int src_is_fp32, int ld, int 
     const dim3 grid((unsigned)((n + 255) / 256));
     if (src_is_fp32) {
         if (dst_is_fp32) hipLaunchKernelGGL((rows_to_ncthw_kernel<float, float>), grid, dim3(256), 0, s, (const float*)src, ld, coff, (float*)dst, B, C, T, HW, scale, Ttot, t0);
-        else hipLaunchKernelGGL((rows_to_ncthw_kernel<float, bf16>), grid, dim3(256), 0, s, (const float*)src, ld, coff, (bf16*)dst, B, C, T, HW, scale, Ttot, t0);
+        else hipLaunchKernelGGL((rows_to_ncthw_kernel<float, h16>), grid, dim3(256), 0, s, (const float*)src, ld, coff, (h16*)dst, B, C, T, HW, scale, Ttot, t0);
     } else {
-        if (dst_is_fp32) hipLaunchKernelGGL((rows_to_ncthw_kernel<bf16, float>), grid, dim3(256), 0, s, (const bf16*)src, ld, coff, (float*)dst, B, C, T, HW, scale, Ttot, t0);
-        else hipLaunchKernelGGL((rows_to_ncthw_kernel<bf16, bf16>), grid, dim3(256), 0, s, (const bf16*)src, ld, coff, (bf16*)dst, B, C, T, HW, scale, Ttot, t0);
+        if (dst_is_fp32) hipLaunchKernelGGL((rows_to_ncthw_kernel<h16, float>), grid, dim3(256), 0, s, (const h16*)src, ld, coff, (float*)dst, B, C, T, HW, scale, Ttot, t0);
+        else hipLaunchKernelGGL((rows_to_ncthw_kernel<h16, h16>), grid, dim3(256), 0, s, (const h16*)src, ld, coff, (h16*)dst, B, C, T, HW, scale, Ttot, t0);
     }
     return mudg_check_launch("mudg_rows_to_ncthw");
 }
@@ -260,7 +260,7 @@ extern "C" int mudg_zero_channels(void* dst, int rows, int ld, int c0, int c1, v
     MUDG_REQUIRE(dst && rows > 0 && c0 >= 0 && c1 > c0 && c1 <= ld, "mudg_zero_channels: bad arguments");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int64_t n = (int64_t)rows * (c1 - c0);
-    hipLaunchKernelGGL(zero_channels_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (bf16*)dst, (int64_t)rows, ld, c0, c1);
+    hipLaunchKernelGGL(zero_channels_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (h16*)dst, (int64_t)rows, ld, c0, c1);
     return mudg_check_launch("mudg_zero_channels");
 }
 
@@ -269,7 +269,7 @@ extern "C" int mudg_copy_rows(const void* src, int64_t lds, void* dst, int64_t l
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int vec = aligned16(src) && aligned16(dst) && !(lds & 7) && !(ldd & 7) && !(cols & 7);
     const int64_t n = vec ? rows * (cols >> 3) : rows * cols;
-    hipLaunchKernelGGL(copy_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const bf16*)src, lds, (bf16*)dst,
+    hipLaunchKernelGGL(copy_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const h16*)src, lds, (h16*)dst,
                        ldd, rows, cols, vec);
     return mudg_check_launch("mudg_copy_rows");
 }
@@ -278,7 +278,7 @@ extern "C" int mudg_cast_f32_bf16(const float* src, void* dst, int64_t n, void* 
     MUDG_REQUIRE(src && dst && n > 0 && aligned16(src) && aligned16(dst), "mudg_cast_f32_bf16: bad arguments");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int64_t n8 = n >> 3;
-    hipLaunchKernelGGL(cast_kernel, dim3((unsigned)((n8 + 1 + 255) / 256)), dim3(256), 0, s, src, (bf16*)dst, n8, n);
+    hipLaunchKernelGGL(cast_kernel, dim3((unsigned)((n8 + 1 + 255) / 256)), dim3(256), 0, s, src, (h16*)dst, n8, n);
     return mudg_check_launch("mudg_cast_f32_bf16");
 }
 

@@ -1,4 +1,4 @@
-// norm.hip — GroupNorm(+SiLU), LayerNorm and row softmax on channels-last bf16 data.  All HBM-bound:
+// norm.hip — GroupNorm(+SiLU), LayerNorm and row softmax on channels-last h16 data.  All HBM-bound:
 // every pass moves 16 bytes per lane, statistics are fp32 partials combined in fp64 in a fixed order
 // (no atomics: results are bit-reproducible run to run).
 #include "common.h"
@@ -7,11 +7,11 @@ namespace {
 
 constexpr int GN_CMAX = 4096;
 
-// Eight consecutive channels of one pixel as fp32, from bf16 (16 B) or fp32 (32 B) storage.
+// Eight consecutive channels of one pixel as fp32, from h16 (16 B) or fp32 (32 B) storage.
 template <typename T> struct Load8;
-template <> struct Load8<bf16> {
-    static __device__ __forceinline__ void get(const bf16* p, float (&x)[8]) {
-        const bf16x8 t = as_bf16x8(ld16(p));
+template <> struct Load8<h16> {
+    static __device__ __forceinline__ void get(const h16* p, float (&x)[8]) {
+        const h16x8 t = as_h16x8(ld16(p));
 #pragma unroll
         for (int e = 0; e < 8; ++e) x[e] = (float)t[e];
     }
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
 template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ X, const T* __restrict__ X2,
                                                         int csplit, int ldx, int ldx2, const float* __restrict__ gamma,
-                                                        const float* __restrict__ beta, bf16* __restrict__ Y, int ldy,
+                                                        const float* __restrict__ beta, h16* __restrict__ Y, int ldy,
                                                         int rows, int C, int groups, int nblk, int silu,
                                                         const float* __restrict__ stat) {
     __shared__ float sc[GN_CMAX], sh[GN_CMAX];
@@ -140,12 +140,12 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ X, 
         if (c0 >= csplit) { base = X2; cc = c0 - csplit; ld = ldx2; }
         float xv[8];
         Load8<T>::get(base + (srow + r) * ld + cc, xv);
-        bf16x8 o;
+        h16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             float y = fmaf(xv[e], sc[c0 + e], sh[c0 + e]);
             if (silu) y = silu_f(y);
-            o[e] = (bf16)y;
+            o[e] = (h16)y;
         }
         st16(Y + (srow + r) * ldy + c0, as_u32x4(o));
     }
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ X, 
 // LayerNorm: one wave per row, up to VMAX 16-byte vectors per lane kept in registers (C <= 512 * VMAX).
 template <int VMAX, typename T>
 __global__ __launch_bounds__(256) void ln_kernel(const T* __restrict__ X, int ldx, const float* __restrict__ gamma,
-                                                  const float* __restrict__ beta, bf16* __restrict__ Y, int ldy,
+                                                  const float* __restrict__ beta, h16* __restrict__ Y, int ldy,
                                                   int rows, int C, float eps) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -193,24 +193,24 @@ __global__ __launch_bounds__(256) void ln_kernel(const T* __restrict__ X, int ld
             const f32x4 g1 = *reinterpret_cast<const f32x4*>(gamma + v * 8 + 4);
             const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + v * 8);
             const f32x4 b1 = *reinterpret_cast<const f32x4*>(beta + v * 8 + 4);
-            bf16x8 o;
+            h16x8 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                o[e] = (bf16)fmaf((x[i][e] - mean) * rstd, g0[e], b0[e]);
-                o[4 + e] = (bf16)fmaf((x[i][4 + e] - mean) * rstd, g1[e], b1[e]);
+                o[e] = (h16)fmaf((x[i][e] - mean) * rstd, g0[e], b0[e]);
+                o[4 + e] = (h16)fmaf((x[i][4 + e] - mean) * rstd, g1[e], b1[e]);
             }
             st16(Y + row * ldy + v * 8, as_u32x4(o));
         }
     }
 }
 
-// Row softmax fp32 -> bf16, one workgroup per row, three passes over the row (second and third hit L2).
-__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ S, int lds, bf16* __restrict__ P,
+// Row softmax fp32 -> h16, one workgroup per row, three passes over the row (second and third hit L2).
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ S, int lds, h16* __restrict__ P,
                                                             int ldp, int cols) {
     __shared__ float red[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* s = S + (int64_t)blockIdx.x * lds;
-    bf16* p = P + (int64_t)blockIdx.x * ldp;
+    h16* p = P + (int64_t)blockIdx.x * ldp;
     float mx = -INFINITY;
     for (int c = tid; c < cols; c += 256) mx = fmaxf(mx, s[c]);
     mx = wave_max(mx);
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
     __syncthreads();
     sum = ((red[0] + red[1]) + red[2]) + red[3];
     const float inv = 1.f / sum;
-    for (int c = tid; c < cols; c += 256) p[c] = (bf16)(__expf(s[c] - mx) * inv);
+    for (int c = tid; c < cols; c += 256) p[c] = (h16)(__expf(s[c] - mx) * inv);
 }
 
 }  // namespace
@@ -256,7 +256,7 @@ extern "C" int mudg_groupnorm(const void* X, const void* X2, int csplit, int ldx
         hipLaunchKernelGGL(gn_stats_kernel<float>, dim3(nchunks, samples), dim3(256), 0, s, (const float*)X, (const float*)X2,
                            csplit, ldx, ldx2, rows, C, groups, nchunks, part);
     else
-        hipLaunchKernelGGL(gn_stats_kernel<bf16>, dim3(nchunks, samples), dim3(256), 0, s, (const bf16*)X, (const bf16*)X2,
+        hipLaunchKernelGGL(gn_stats_kernel<h16>, dim3(nchunks, samples), dim3(256), 0, s, (const h16*)X, (const h16*)X2,
                            csplit, ldx, ldx2, rows, C, groups, nchunks, part);
     const int ng = samples * groups;
     hipLaunchKernelGGL(gn_finalize_kernel, dim3((ng + 3) / 4), dim3(256), 0, s, part, stat, samples, groups, nchunks,
@@ -264,10 +264,10 @@ extern "C" int mudg_groupnorm(const void* X, const void* X2, int csplit, int ldx
     const int nblk = nchunks;
     if (x_fp32)
         hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(nblk, samples), dim3(256), 0, s, (const float*)X, (const float*)X2,
-                           csplit, ldx, ldx2, gamma, beta, (bf16*)Y, ldy, rows, C, groups, nblk, silu, stat);
+                           csplit, ldx, ldx2, gamma, beta, (h16*)Y, ldy, rows, C, groups, nblk, silu, stat);
     else
-        hipLaunchKernelGGL(gn_apply_kernel<bf16>, dim3(nblk, samples), dim3(256), 0, s, (const bf16*)X, (const bf16*)X2,
-                           csplit, ldx, ldx2, gamma, beta, (bf16*)Y, ldy, rows, C, groups, nblk, silu, stat);
+        hipLaunchKernelGGL(gn_apply_kernel<h16>, dim3(nblk, samples), dim3(256), 0, s, (const h16*)X, (const h16*)X2,
+                           csplit, ldx, ldx2, gamma, beta, (h16*)Y, ldy, rows, C, groups, nblk, silu, stat);
     const int rc = mudg_check_launch("mudg_groupnorm");
     mudg_prof_end(slot, s, 0.0, (double)samples * rows * C * (x_fp32 ? 10.0 : 6.0));
     return rc;
@@ -284,11 +284,11 @@ extern "C" int mudg_layernorm(const void* X, int ldx, int x_fp32, const float* g
     const dim3 grid((rows + 3) / 4);
     const int nvec = C >> 3;
     if (nvec <= 64 * 3) {
-        if (x_fp32) hipLaunchKernelGGL((ln_kernel<3, float>), grid, dim3(256), 0, s, (const float*)X, ldx, gamma, beta, (bf16*)Y, ldy, rows, C, eps);
-        else hipLaunchKernelGGL((ln_kernel<3, bf16>), grid, dim3(256), 0, s, (const bf16*)X, ldx, gamma, beta, (bf16*)Y, ldy, rows, C, eps);
+        if (x_fp32) hipLaunchKernelGGL((ln_kernel<3, float>), grid, dim3(256), 0, s, (const float*)X, ldx, gamma, beta, (h16*)Y, ldy, rows, C, eps);
+        else hipLaunchKernelGGL((ln_kernel<3, h16>), grid, dim3(256), 0, s, (const h16*)X, ldx, gamma, beta, (h16*)Y, ldy, rows, C, eps);
     } else {
-        if (x_fp32) hipLaunchKernelGGL((ln_kernel<8, float>), grid, dim3(256), 0, s, (const float*)X, ldx, gamma, beta, (bf16*)Y, ldy, rows, C, eps);
-        else hipLaunchKernelGGL((ln_kernel<8, bf16>), grid, dim3(256), 0, s, (const bf16*)X, ldx, gamma, beta, (bf16*)Y, ldy, rows, C, eps);
+        if (x_fp32) hipLaunchKernelGGL((ln_kernel<8, float>), grid, dim3(256), 0, s, (const float*)X, ldx, gamma, beta, (h16*)Y, ldy, rows, C, eps);
+        else hipLaunchKernelGGL((ln_kernel<8, h16>), grid, dim3(256), 0, s, (const h16*)X, ldx, gamma, beta, (h16*)Y, ldy, rows, C, eps);
     }
     const int rc = mudg_check_launch("mudg_layernorm");
     mudg_prof_end(slot, s, 0.0, (double)rows * C * (x_fp32 ? 6.0 : 4.0));
@@ -299,7 +299,7 @@ extern "C" int mudg_softmax_rows(const float* S, int lds, void* P, int ldp, int 
     MUDG_REQUIRE(S && P && rows > 0 && cols > 0, "mudg_softmax_rows: bad arguments");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int slot = mudg_prof_begin(MUDG_FAM_MISC, s);
-    hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, s, S, lds, (bf16*)P, ldp, cols);
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, s, S, lds, (h16*)P, ldp, cols);
     const int rc = mudg_check_launch("mudg_softmax_rows");
     mudg_prof_end(slot, s, 0.0, (double)rows * cols * 6.0);
     return rc;

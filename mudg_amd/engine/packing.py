@@ -7,7 +7,8 @@ the device), not part of the per-step path.
 """
 import torch
 
-BF16 = torch.bfloat16
+from .. import hip
+
 
 
 def _key(params):
@@ -47,7 +48,7 @@ def linear(mod):
     """[N, K] bf16 from nn.Linear / 1x1 Conv2d / k=1 Conv1d weights."""
     w = mod.weight
     _need_cuda(w, type(mod).__name__)
-    return cached(mod, "w", (w,), lambda: w.detach().reshape(w.shape[0], -1).to(BF16).contiguous())
+    return cached(mod, "w", (w,), lambda: w.detach().reshape(w.shape[0], -1).to(hip.operand_dtype()).contiguous())
 
 
 def linear_cat(owner, name, mods):
@@ -55,7 +56,7 @@ def linear_cat(owner, name, mods):
     ws = tuple(m.weight for m in mods)
     for w in ws:
         _need_cuda(w, name)
-    return cached(owner, name, ws, lambda: torch.cat([w.detach().to(BF16) for w in ws], 0).contiguous())
+    return cached(owner, name, ws, lambda: torch.cat([w.detach().to(hip.operand_dtype()) for w in ws], 0).contiguous())
 
 
 def conv3x3(mod):
@@ -74,7 +75,7 @@ def conv3x3(mod):
             t = t.reshape(cout, 9, cin // 64, 64).permute(0, 2, 1, 3)
         elif cpad != cin:
             t = torch.nn.functional.pad(t, (0, cpad - cin))
-        return t.reshape(cout, 9 * cpad).to(BF16).contiguous()
+        return t.reshape(cout, 9 * cpad).to(hip.operand_dtype()).contiguous()
 
     return cached(mod, "w3x3", (w,), build), cpad, korder
 
@@ -84,7 +85,7 @@ def tconv(mod):
     w = mod.weight
     _need_cuda(w, type(mod).__name__)
     return cached(mod, "wt", (w,), lambda: w.detach()[:, :, :, 0, 0].permute(0, 2, 1).reshape(w.shape[0], -1)
-                  .to(BF16).contiguous())
+                  .to(hip.operand_dtype()).contiguous())
 
 
 def geglu(mod):
@@ -99,6 +100,6 @@ def geglu(mod):
     def build():
         idx = torch.arange(inner, device=w.device).reshape(-1, 32)
         order = torch.cat([idx, idx + inner], dim=1).reshape(-1)
-        return (w.detach()[order].to(BF16).contiguous(), b.detach()[order].float().contiguous())
+        return (w.detach()[order].to(hip.operand_dtype()).contiguous(), b.detach()[order].float().contiguous())
 
     return cached(mod, "geglu", (w, b), build)

@@ -7,7 +7,6 @@ import torch
 from .. import ops
 from . import unet as U
 
-BF16 = torch.bfloat16
 
 
 def _to_rows(x4):
@@ -15,8 +14,8 @@ def _to_rows(x4):
     f, c, h, w = x4.shape
     if not x4.is_cuda:
         raise RuntimeError("the MI355X path has no CPU fallback: move inputs to the GPU")
-    src = x4 if x4.dtype in (torch.float32, BF16) else x4.float()
-    rows = ops.empty_rows(f * h * w, c, BF16, x4.device)
+    src = x4 if x4.dtype in (torch.float32, ops.H16()) else x4.float()
+    rows = ops.empty_rows(f * h * w, c, ops.H16(), x4.device)
     ops.ncthw_to_rows(src.permute(1, 0, 2, 3).unsqueeze(0), rows, 0)
     return rows
 
@@ -69,8 +68,8 @@ def spatial_transformer(mod, x, context):
 def temporal_transformer(mod, x):
     """x (B, C, T, H, W)."""
     b, c, t, h, w = x.shape
-    rows = ops.empty_rows(b * t * h * w, c, BF16, x.device)
-    ops.ncthw_to_rows(x if x.dtype in (torch.float32, BF16) else x.float(), rows, 0)
+    rows = ops.empty_rows(b * t * h * w, c, ops.H16(), x.device)
+    ops.ncthw_to_rows(x if x.dtype in (torch.float32, ops.H16()) else x.float(), rows, 0)
     ctx = _ctx(b, b * t)
     out = U.temporal_transformer(mod, rows, h, w, ctx)
     return ops.rows_to_ncthw(out, (b, c, t, h, w), dtype=torch.float32).to(x.dtype)

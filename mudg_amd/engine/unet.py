@@ -22,7 +22,6 @@ import torch.nn as nn
 from .. import ops
 from . import packing as pk
 
-BF16 = torch.bfloat16
 
 
 class _Ctx:
@@ -58,7 +57,7 @@ def _vt_projection(mod, src_rows, batches, n_per_batch):
     w = pk.linear(mod)
     c, k = w.shape
     ld = (n_per_batch + 7) // 8 * 8
-    out = ops.empty_rows(batches * c, ld, BF16, src_rows.device)
+    out = ops.empty_rows(batches * c, ld, ops.H16(), src_rows.device)
     ops.gemm(w, src_rows, out=out, batch=batches, sx=0, sw=n_per_batch * src_rows.stride(0), sy=c * ld,
              M=c, N=n_per_batch, K=k, ldy=ld)
     return out, ld
@@ -121,7 +120,7 @@ def spatial_block(blk, hcur, frames, hw, ctx, last):
     n1 = _ln(blk.norm1, hcur)
     qk = ops.gemm(n1, pk.linear_cat(a1, "qk", (a1.to_q, a1.to_k)))
     vt, ldv = _vt_projection(a1.to_v, n1, frames, hw)
-    att = ops.empty_rows(frames * hw, c, BF16, hcur.device)
+    att = ops.empty_rows(frames * hw, c, ops.H16(), hcur.device)
     ops.attention(qk[:, :c], qk[:, c:], vt, att, frames=frames, heads=heads, nq=hw, nk=hw, ldvt=ldv, svt=c * ldv,
                   scale=a1.scale)
     hcur = _linear(a1.to_out[0], att, residual=hcur, stream=True)
@@ -132,7 +131,7 @@ def spatial_block(blk, hcur, frames, hw, ctx, last):
     if key not in ctx.kv_cache:
         ctx.kv_cache[key] = _cross_kv(a2, ctx)
     k_text, vt_text, ld_text, k_img, vt_img, ld_img = ctx.kv_cache[key]
-    att2 = ops.empty_rows(frames * hw, c, BF16, hcur.device)
+    att2 = ops.empty_rows(frames * hw, c, ops.H16(), hcur.device)
     ops.attention(q2, k_text, vt_text, att2, frames=frames, heads=heads, nq=hw, nk=ctx.n_text, ldvt=ld_text,
                   svt=c * ld_text, kv_div=ctx.T, scale=a2.scale)
     if k_img is not None:
@@ -158,7 +157,7 @@ def temporal_block(blk, hcur, hw, ctx, last):
     for attn, norm in ((blk.attn1, blk.norm1), (blk.attn2, blk.norm2)):     # both are self-attention over T
         c = hcur.shape[1]
         qkv = ops.gemm(_ln(norm, hcur), pk.linear_cat(attn, "qkv", (attn.to_q, attn.to_k, attn.to_v)))
-        att = ops.empty_rows(hcur.shape[0], c, BF16, hcur.device)
+        att = ops.empty_rows(hcur.shape[0], c, ops.H16(), hcur.device)
         ops.temporal_attention(qkv, att, clips=ctx.B, t=ctx.T, hw=hw, heads=attn.heads, scale=attn.scale)
         hcur = _linear(attn.to_out[0], att, residual=hcur, stream=True)
     return _feed_forward(blk.ff, _ln(blk.norm3, hcur), hcur, stream=not last)
@@ -225,7 +224,7 @@ def make_context(model, ctx, context, t_len, device):
     if L <= 77:
         raise ValueError("context needs more than the 77 text tokens (image tokens follow them)")
     flat = context.contiguous()
-    if flat.dtype not in (torch.float32, BF16):
+    if flat.dtype not in (torch.float32, ops.H16()):
         flat = flat.float()
     rows = ops.cast_bf16(flat.reshape(ctx.B * L, D))
     ctx.n_text = 77
@@ -235,8 +234,8 @@ def make_context(model, ctx, context, t_len, device):
     else:
         ctx.n_img, ctx.img_div = L - 77, t_len
     rows3 = rows.reshape(ctx.B, L, D)
-    text = ops.empty_rows(ctx.B * 77, D, BF16, device)
-    img = ops.empty_rows(ctx.B * (L - 77), D, BF16, device)
+    text = ops.empty_rows(ctx.B * 77, D, ops.H16(), device)
+    img = ops.empty_rows(ctx.B * (L - 77), D, ops.H16(), device)
     ops.copy_rows(rows3[:, :77].reshape(ctx.B, 77 * D), text.reshape(ctx.B, 77 * D))
     ops.copy_rows(rows3[:, 77:].reshape(ctx.B, (L - 77) * D), img.reshape(ctx.B, (L - 77) * D))
     ctx.text, ctx.img = text, img
@@ -276,12 +275,12 @@ def forward(model, x, timesteps, c_label=None, context=None, features_adapter=No
     make_context(model, ctx, context, T, device)
 
     # ---- input: (b c t h w) pieces -> rows with channels side by side (replaces torch.cat + rearrange, 591 / ddpm3d 1317)
-    rows = ops.empty_rows(B * T * H * W, cpad, BF16, device)
+    rows = ops.empty_rows(B * T * H * W, cpad, ops.H16(), device)
     off = 0
     for p in parts:
         if p.shape[0] != B or p.shape[2:] != first.shape[2:]:
             raise ValueError("all input pieces must share (B, T, H, W)")
-        src = p if p.dtype in (torch.float32, BF16) else p.float()
+        src = p if p.dtype in (torch.float32, ops.H16()) else p.float()
         ops.ncthw_to_rows(src, rows, off)
         off += p.shape[1]
     if cpad > off:
@@ -305,6 +304,6 @@ def forward(model, x, timesteps, c_label=None, context=None, features_adapter=No
     norm, conv = model.out[0], model.out[2]
     cur = _gn(norm, cur, None, B * T, h * w, True)
     y = _conv3x3(conv, cur, B * T, h, w, stream=True)
-    out_dtype = first.dtype if first.dtype in (torch.float32, BF16) else torch.float32
+    out_dtype = first.dtype if first.dtype in (torch.float32, ops.H16()) else torch.float32
     out = ops.rows_to_ncthw(y, (B, model.out_channels, T, h, w), dtype=out_dtype)
     return out if out.dtype == first.dtype else out.to(first.dtype)

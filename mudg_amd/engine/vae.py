@@ -12,7 +12,6 @@ import torch.nn as nn
 from .. import ops
 from . import packing as pk
 
-BF16 = torch.bfloat16
 MAX_SCORE_BYTES = 8 << 30      # fp32 attention scores held at once (frames are chunked beyond this)
 
 
@@ -46,18 +45,18 @@ def attn_block(mod, x, frames, hw):
     hn = _gn(mod.norm, x, frames, hw, False)
     wqk = pk.cached(mod, "qk", (mod.q.weight, mod.k.weight),
                     lambda: torch.cat([mod.q.weight.detach().reshape(c, c), mod.k.weight.detach().reshape(c, c)], 0)
-                    .to(BF16).contiguous())
+                    .to(ops.H16()).contiguous())
     bqk = pk.cached(mod, "bqk", (mod.q.bias, mod.k.bias),
                     lambda: torch.cat([mod.q.bias.detach(), mod.k.bias.detach()]).float().contiguous())
     qk = ops.gemm(hn, wqk, bias=bqk)                                   # [frames*hw, 2C]
     ldv = (hw + 7) // 8 * 8
-    vt = ops.empty_rows(frames * c, ldv, BF16, x.device)               # V^T per frame (bias added after P @ V)
+    vt = ops.empty_rows(frames * c, ldv, ops.H16(), x.device)               # V^T per frame (bias added after P @ V)
     ops.gemm(pk.linear(mod.v), hn, out=vt, batch=frames, sx=0, sw=hw * hn.stride(0), sy=c * ldv, M=c, N=hw, K=c,
              ldy=ldv)
-    att = ops.empty_rows(frames * hw, c, BF16, x.device)
+    att = ops.empty_rows(frames * hw, c, ops.H16(), x.device)
     per = max(1, min(frames, MAX_SCORE_BYTES // (hw * hw * 4)))
     scores = torch.empty((per * hw, hw), dtype=torch.float32, device=x.device)
-    probs = ops.empty_rows(per * hw, hw, BF16, x.device)
+    probs = ops.empty_rows(per * hw, hw, ops.H16(), x.device)
     q, k = qk[:, :c], qk[:, c:]
     for f0 in range(0, frames, per):
         n = min(per, frames - f0)
@@ -122,7 +121,7 @@ def encode_moments(ae, x, max_frames=8):
     out = None
     for n0 in range(0, n, max_frames):
         nb = min(max_frames, n - n0)
-        rows = ops.empty_rows(nb * h * w, cin, BF16, x.device)
+        rows = ops.empty_rows(nb * h * w, cin, ops.H16(), x.device)
         ops.ncthw_to_rows(x[n0:n0 + nb].unsqueeze(2), rows, 0)
         if cin > c:
             ops.zero_channels(rows, c, cin)
@@ -137,7 +136,7 @@ def encode_moments(ae, x, max_frames=8):
 def _check(z):
     if not z.is_cuda:
         raise RuntimeError("AutoencoderKL.decode: latents must be on the GPU; the MI355X path has no CPU fallback")
-    return z if z.dtype in (torch.float32, BF16) else z.float()
+    return z if z.dtype in (torch.float32, ops.H16()) else z.float()
 
 
 def _decode_rows(ae, rows_z, frames, h, w, inv_scale):
@@ -145,11 +144,11 @@ def _decode_rows(ae, rows_z, frames, h, w, inv_scale):
     pq = ae.post_quant_conv
     zc = pq.weight.shape[0]
     cpad = (zc + 7) // 8 * 8
-    lat = ops.empty_rows(rows_z.shape[0], cpad, BF16, rows_z.device)
+    lat = ops.empty_rows(rows_z.shape[0], cpad, ops.H16(), rows_z.device)
     if cpad > zc:
         ops.zero_channels(lat, zc, cpad)
     wpq = pk.cached(pq, "wpad", (pq.weight,), lambda: torch.nn.functional.pad(
-        pq.weight.detach().reshape(zc, -1), (0, rows_z.shape[1] - pq.weight.shape[1])).to(BF16).contiguous())
+        pq.weight.detach().reshape(zc, -1), (0, rows_z.shape[1] - pq.weight.shape[1])).to(ops.H16()).contiguous())
     ops.gemm(rows_z, wpq, out=lat, bias=pk.f32(pq, "bias"), alpha=inv_scale, N=zc, ldy=cpad)
     return decoder_rows(ae.decoder, lat, frames, h, w)
 
@@ -173,7 +172,7 @@ def decode_latents(ae, z, inv_scale=1.0, perframe=True, max_frames=16):
         per = max(1, max_frames // t)
         jobs = [(b0, min(per, b - b0), 0, t) for b0 in range(0, b, per)]
     for b0, nb, t0, nt in jobs:
-        rows = ops.empty_rows(nb * nt * h * w, cin, BF16, z.device)
+        rows = ops.empty_rows(nb * nt * h * w, cin, ops.H16(), z.device)
         ops.ncthw_to_rows(z[b0:b0 + nb], rows, 0, t0=t0, frames=nt)
         if cin > c:
             ops.zero_channels(rows, c, cin)
@@ -194,7 +193,7 @@ def decoder_forward(dec, z):
     z = _check(z).contiguous()
     n, c, h, w = z.shape
     cin = (c + 7) // 8 * 8
-    rows = ops.empty_rows(n * h * w, cin, BF16, z.device)
+    rows = ops.empty_rows(n * h * w, cin, ops.H16(), z.device)
     ops.ncthw_to_rows(z.unsqueeze(2), rows, 0)
     if cin > c:
         ops.zero_channels(rows, c, cin)

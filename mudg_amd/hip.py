@@ -10,7 +10,32 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmudg_hip.so")
+LIB_PATHS = {"bf16": os.path.join(_HERE, "libmudg_hip.so"), "fp16": os.path.join(_HERE, "libmudg_hip_fp16.so")}
+# The 16-bit MFMA operand type is a property of the loaded library (one per process): bf16 unless MUDG_OPERAND=fp16
+# is set in the environment or set_operand("fp16") is called before the first kernel call.
+_operand = os.environ.get("MUDG_OPERAND", "bf16").lower()
+LIB_PATH = LIB_PATHS["bf16"]
+
+
+def set_operand(name: str) -> None:
+    global _operand
+    name = name.lower()
+    if name not in LIB_PATHS:
+        raise MudgError(f"unknown operand type {name!r} (bf16 | fp16)")
+    if _lib is not None and name != _operand:
+        raise MudgError("the operand type must be chosen before the first kernel call")
+    _operand = name
+
+
+def operand_name() -> str:
+    return _operand
+
+
+def operand_dtype():
+    import torch
+    return torch.float16 if _operand == "fp16" else torch.bfloat16
+
+_lib = None
 
 FAM_GEMM, FAM_CONV, FAM_TCONV, FAM_ATTN, FAM_TATTN, FAM_GNORM, FAM_LNORM, FAM_MISC = range(8)
 FAM_NAMES = ["gemm", "conv3x3", "tconv3", "attention", "temporal_attention", "groupnorm", "layernorm", "misc"]
@@ -49,6 +74,7 @@ class AttnDesc(C.Structure):
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 SIGNATURES = {
     "mudg_version": (_I, []),
+    "mudg_operand_dtype": (_I, []),
     "mudg_last_error": (C.c_char_p, []),
     "mudg_gemm": (_I, [C.POINTER(GemmDesc), _P]),
     "mudg_attention": (_I, [C.POINTER(AttnDesc), _P]),
@@ -75,7 +101,6 @@ SIGNATURES = {
     "mudg_prof_reset": (_I, []),
 }
 
-_lib = None
 
 
 def lib() -> C.CDLL:
@@ -85,15 +110,20 @@ def lib() -> C.CDLL:
         # PyTorch-ROCm bundles its own libamdhip64; it must be the HIP runtime of the process (it owns the device
         # contexts and streams we launch on), so make sure it is loaded before our library resolves the same SONAME.
         import torch  # noqa: F401
-        if not os.path.exists(LIB_PATH):
+        if _operand not in LIB_PATHS:
+            raise MudgError(f"MUDG_OPERAND={_operand!r}: expected bf16 or fp16")
+        path = LIB_PATHS[_operand]
+        if not os.path.exists(path):
             raise MudgError(
-                f"{LIB_PATH} is missing: build it with `python -m mudg_amd.build` (hipcc, gfx950). "
+                f"{path} is missing: build it with `python -m mudg_amd.build` (hipcc, gfx950). "
                 "mudg_amd has no CPU or eager fallback.")
-        handle = C.CDLL(LIB_PATH)
+        handle = C.CDLL(path)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)      # AttributeError = symbol missing = broken build
             fn.restype = res
             fn.argtypes = args
+        if handle.mudg_operand_dtype() != (1 if _operand == "fp16" else 0):
+            raise MudgError(f"{path} was not built for {_operand} operands")
         _lib = handle
     return _lib
 

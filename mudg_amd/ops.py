@@ -14,7 +14,11 @@ import torch
 
 from . import hip
 
-BF16 = torch.bfloat16
+
+
+def H16():
+    """torch dtype of the 16-bit MFMA operands of the loaded library (bf16 by default, fp16 with MUDG_OPERAND=fp16)."""
+    return hip.operand_dtype()
 
 
 def _stream() -> int:
@@ -25,14 +29,16 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
-def _rows(t: torch.Tensor, dtype=BF16) -> torch.Tensor:
+def _rows(t: torch.Tensor, dtype=None) -> torch.Tensor:
+    dtype = dtype or H16()
     if t.dim() != 2 or t.stride(1) != 1 or t.dtype != dtype or not t.is_cuda:
         raise hip.MudgError(f"expected a cuda {dtype} rows matrix with unit channel stride, got "
                             f"{tuple(t.shape)} {t.dtype} strides {t.stride()} on {t.device}")
     return t
 
 
-def empty_rows(rows: int, cols: int, dtype=BF16, device=None) -> torch.Tensor:
+def empty_rows(rows: int, cols: int, dtype=None, device=None) -> torch.Tensor:
+    dtype = dtype or H16()
     return torch.empty((rows, cols), dtype=dtype, device=device or "cuda")
 
 
@@ -49,7 +55,7 @@ def gemm(x, w, *, out=None, bias=None, gbias=None, rows_per_group=0, residual=No
         K = w.shape[1]
     nout = N // 2 if geglu else N
     if out is None:
-        out = empty_rows(M, nout, torch.float32 if out_fp32 else BF16, x.device)
+        out = empty_rows(M, nout, torch.float32 if out_fp32 else H16(), x.device)
     d = hip.GemmDesc()
     d.X, d.X2, d.W, d.Y = x.data_ptr(), _ptr(x2), w.data_ptr(), out.data_ptr()
     d.bias, d.gbias, d.R = _ptr(bias), _ptr(gbias), _ptr(residual)
@@ -79,7 +85,7 @@ def conv3x3(x, w, *, frames, hin, win, cin, stride=1, upsample=False, out=None, 
         hout, wout = (hin + 1 - 3) // stride + 1, (win + 1 - 3) // stride + 1
     M, N = frames * hout * wout, w.shape[0]
     if out is None:
-        out = empty_rows(M, N, torch.float32 if out_fp32 else BF16, x.device)
+        out = empty_rows(M, N, torch.float32 if out_fp32 else H16(), x.device)
     d = hip.GemmDesc()
     d.X, d.X2, d.W, d.Y = x.data_ptr(), _ptr(x2), w.data_ptr(), out.data_ptr()
     d.bias, d.gbias, d.R = _ptr(bias), _ptr(gbias), _ptr(residual)
@@ -102,7 +108,7 @@ def tconv3(x, w, *, clips, t, hw, cin, out=None, bias=None, residual=None, out_f
     _rows(x); _rows(w)
     M, N = clips * t * hw, w.shape[0]
     if out is None:
-        out = empty_rows(M, N, torch.float32 if out_fp32 else BF16, x.device)
+        out = empty_rows(M, N, torch.float32 if out_fp32 else H16(), x.device)
     d = hip.GemmDesc()
     d.X, d.W, d.Y = x.data_ptr(), w.data_ptr(), out.data_ptr()
     d.bias, d.R = _ptr(bias), _ptr(residual)
@@ -137,7 +143,7 @@ def temporal_attention(qkv, out, *, clips, t, hw, heads, scale=0.125):
 
 # ------------------------------------------------------------------------------------------------ norms
 def _rows_any(t):
-    if t.dim() != 2 or t.stride(1) != 1 or t.dtype not in (BF16, torch.float32) or not t.is_cuda:
+    if t.dim() != 2 or t.stride(1) != 1 or t.dtype not in (H16(), torch.float32) or not t.is_cuda:
         raise hip.MudgError(f"expected a cuda bf16/fp32 rows matrix, got {tuple(t.shape)} {t.dtype} on {t.device}")
     return t
 
@@ -148,7 +154,7 @@ def groupnorm(x, gamma, beta, *, samples, rows, eps, silu, groups=32, x2=None, o
         raise hip.MudgError("groupnorm: both channel sources must share a dtype")
     c = x.shape[1] + (x2.shape[1] if x2 is not None else 0)
     if out is None:
-        out = empty_rows(samples * rows, c, BF16, x.device)
+        out = empty_rows(samples * rows, c, H16(), x.device)
     n = hip.lib().mudg_groupnorm_ws_floats(samples, groups, rows)
     ws = torch.empty(n, dtype=torch.float32, device=x.device)
     hip.check(hip.lib().mudg_groupnorm(x.data_ptr(), _ptr(x2), x.shape[1], x.stride(0),
@@ -162,7 +168,7 @@ def groupnorm(x, gamma, beta, *, samples, rows, eps, silu, groups=32, x2=None, o
 def layernorm(x, gamma, beta, *, eps=1e-5, out=None):
     _rows_any(x)
     if out is None:
-        out = empty_rows(x.shape[0], x.shape[1], BF16, x.device)
+        out = empty_rows(x.shape[0], x.shape[1], H16(), x.device)
     hip.check(hip.lib().mudg_layernorm(x.data_ptr(), x.stride(0), int(x.dtype == torch.float32), gamma.data_ptr(),
                                        beta.data_ptr(), out.data_ptr(),
                                        out.stride(0), x.shape[0], x.shape[1], eps, _stream()), "mudg_layernorm")
@@ -171,7 +177,7 @@ def layernorm(x, gamma, beta, *, eps=1e-5, out=None):
 
 def softmax_rows(s, out=None):
     if out is None:
-        out = empty_rows(s.shape[0], s.shape[1], BF16, s.device)
+        out = empty_rows(s.shape[0], s.shape[1], H16(), s.device)
     hip.check(hip.lib().mudg_softmax_rows(s.data_ptr(), s.stride(0), out.data_ptr(), out.stride(0), s.shape[0],
                                           s.shape[1], _stream()), "mudg_softmax_rows")
     return out
@@ -208,7 +214,7 @@ def small_linear(x, w, b=None, *, act_in=False, act_out=False, out=None, accumul
     n = w.shape[0]
     if out is None:
         out = torch.empty((m, n), dtype=torch.float32, device=x.device)
-    hip.check(hip.lib().mudg_small_linear(x.data_ptr(), w.data_ptr(), int(w.dtype == BF16), _ptr(b), out.data_ptr(),
+    hip.check(hip.lib().mudg_small_linear(x.data_ptr(), w.data_ptr(), int(w.dtype == H16()), _ptr(b), out.data_ptr(),
                                           m, n, k, int(act_in), int(act_out), int(accumulate), _stream()),
               "mudg_small_linear")
     return out
@@ -248,11 +254,11 @@ def zero_channels(dst, c0, c1):
 
 def cast_bf16(src):
     """fp32 tensor -> bf16 copy of the same shape (bf16 input is returned as is)."""
-    if src.dtype == BF16:
+    if src.dtype == H16():
         return src
     if src.dtype != torch.float32 or not src.is_contiguous():
         raise hip.MudgError("cast_bf16 expects a contiguous fp32 tensor")
-    out = torch.empty(src.shape, dtype=BF16, device=src.device)
+    out = torch.empty(src.shape, dtype=H16(), device=src.device)
     hip.check(hip.lib().mudg_cast_f32_bf16(src.data_ptr(), out.data_ptr(), src.numel(), _stream()),
               "mudg_cast_f32_bf16")
     return out

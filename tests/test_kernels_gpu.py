@@ -9,7 +9,9 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-BF = torch.bfloat16
+from mudg_amd import hip as _hip
+
+BF = _hip.operand_dtype()       # bf16, or fp16 when the suite runs with MUDG_OPERAND=fp16
 TOL_BF16 = 3e-3
 TOL_F32 = 2e-5
 

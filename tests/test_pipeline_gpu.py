@@ -10,7 +10,13 @@ import torch
 
 from helpers import golden, pipeline_inputs, rel_l2, seeded_sd
 
+from mudg_amd import hip as _hip
+
 pytestmark = pytest.mark.gpu
+# With fp16 operands (MUDG_OPERAND=fp16) the same checks measure 4.7e-3 / 5.2e-3 end to end, 9e-4 ... 1.5e-3 for the
+# decoder alone and 1.3e-3 / 7e-4 for the encoder.
+FP16 = _hip.operand_name() == "fp16"
+TOL_E2E, TOL_DEC, TOL_ENC = (1e-2, 3e-3, 3e-3) if FP16 else (6e-2, 2e-2, 2e-2)
 
 
 def build_model(g, dev):
@@ -55,7 +61,7 @@ def test_sampler_steps_and_decode_match_reference(cuda, monkeypatch):
     err_v2 = rel_l2(d2, g["decode_direct"]["out"])
     print(f"pipeline rel-L2 vs reference: samples {err_s:.3e}  decoded {err_d:.3e}  decode-only {err_v:.3e} / {err_v2:.3e}")
     assert samples.shape == g["samples"].shape and decoded.shape == g["decoded"].shape
-    assert err_s < 6e-2 and err_d < 6e-2 and err_v < 2e-2 and err_v2 < 2e-2
+    assert err_s < TOL_E2E and err_d < TOL_E2E and err_v < TOL_DEC and err_v2 < TOL_DEC
 
 
 def test_single_step_with_reference_unet_outputs_is_fp32_exact(cuda):
@@ -89,7 +95,7 @@ def test_vae_encode_matches_reference(cuda):
     z = model.encode_first_stage(x.to(cuda))
     e_z = rel_l2(z, g["z"])
     print(f"vae encode rel-L2 vs reference: moments {e_m:.3e}  latents {e_z:.3e}")
-    assert z.shape == g["z"].shape and e_m < 2e-2 and e_z < 2e-2
+    assert z.shape == g["z"].shape and e_m < TOL_ENC and e_z < TOL_ENC
     # sampling arithmetic alone, fed the reference's own moments: fp32-exact
     torch.manual_seed(g["cpu_seed"])
     noise = torch.cat([torch.randn(1, 4, 8, 8) for _ in range(6)], 0)

@@ -10,8 +10,14 @@ import torch
 
 from helpers import golden, rel_l2, seeded_sd, unet_inputs
 
+from mudg_amd import hip as _hip
+
 pytestmark = pytest.mark.gpu
-TOL_UNET = 2.5e-2
+# fp16 operands (MUDG_OPERAND=fp16: three more mantissa bits, the reference's own autocast dtype) measure 8x lower:
+# 2.0e-3 per forward, 5-6e-4 per block.
+FP16 = _hip.operand_name() == "fp16"
+TOL_UNET = 4e-3 if FP16 else 2.5e-2
+TOL_BLOCK = 1.2e-3 if FP16 else 7e-3
 
 
 def build_unet(cfg, sd, device):
@@ -75,4 +81,4 @@ def test_unet_blocks_against_oracle(cuda):
     got = tt(x5.to(cuda))
     e3 = rel_l2(got, want)
     print(f"block rel-L2: res {e1:.3e}  spatial {e2:.3e}  temporal {e3:.3e}")
-    assert e1 < 7e-3 and e2 < 7e-3 and e3 < 7e-3
+    assert e1 < TOL_BLOCK and e2 < TOL_BLOCK and e3 < TOL_BLOCK
