@@ -64,6 +64,27 @@ def test_sampler_steps_and_decode_match_reference(cuda, monkeypatch):
     assert err_s < TOL_E2E and err_d < TOL_E2E and err_v < TOL_DEC and err_v2 < TOL_DEC
 
 
+def test_batched_cfg_equals_sequential_passes(cuda):
+    """cond + uncond in one doubled batch (default) vs the reference's two sequential passes: same numbers."""
+    from lvdm.models.samplers.ddim import DDIMSampler
+    g = golden("pipeline.pt")
+    model = build_model(g, cuda)
+    inp, s = pipeline_inputs(g), g["sampler"]
+    cond = {"c_crossattn": [inp["ctx_c"].to(cuda)], "c_concat": [inp["concat"].to(cuda)]}
+    uc = {"c_crossattn": [inp["ctx_u"].to(cuda)], "c_concat": [inp["concat"].to(cuda)]}
+    outs = []
+    for batched in (True, False):
+        sampler = DDIMSampler(model)
+        sampler.batch_cfg = batched
+        sampler.make_schedule(s["steps"], ddim_discretize=s["spacing"], ddim_eta=0.0, verbose=False)
+        ts = torch.full((3,), int(sampler.ddim_timesteps[-1]), device=cuda, dtype=torch.long)
+        outs.append(sampler.p_sample_ddim(inp["x_T"].to(cuda), cond, ts, index=s["steps"] - 1,
+                                          unconditional_guidance_scale=s["cfg_scale"], unconditional_conditioning=uc,
+                                          guidance_rescale=s["guidance_rescale"], fs=inp["fs"].to(cuda),
+                                          class_label=inp["class_label"].to(cuda), sparse_x=inp["concat"][:, :4].to(cuda)))
+    assert rel_l2(outs[0][0], outs[1][0]) < 1e-5 and rel_l2(outs[0][1], outs[1][1]) < 1e-5
+
+
 def test_single_step_with_reference_unet_outputs_is_fp32_exact(cuda):
     """The fused update kernel fed the reference's own e_cond / e_uncond reproduces x_prev / pred_x0 to fp32 rounding."""
     from lvdm.models.samplers.ddim import DDIMSampler
