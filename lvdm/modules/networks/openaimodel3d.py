@@ -212,5 +212,5 @@ class UNetModel(nn.Module):
         pass (sparse_x, class_label, cfg_img, ...) are accepted and ignored, as in the reference.  Returns
         (B, out_channels, T, H, W) in x's dtype."""
         from mudg_amd.engine import unet as engine
-        return engine.forward(self, x, timesteps, c_label=c_label, context=context,
-                              features_adapter=features_adapter, fs=fs)
+        return engine.forward_entry(self, x, timesteps, c_label=c_label, context=context,
+                                    features_adapter=features_adapter, fs=fs)

@@ -242,6 +242,23 @@ def make_context(model, ctx, context, t_len, device):
 
 
 @torch.no_grad()
+def forward_entry(model, x, timesteps, c_label=None, context=None, features_adapter=None, fs=None):
+    """UNetModel.forward: eager launch sequence, or hipGraph replay when `model.use_hip_graph` is set."""
+    if getattr(model, "use_hip_graph", False) and features_adapter is None and context is not None \
+            and not torch.cuda.is_current_stream_capturing():
+        from .graph import UNetGraphs
+        graphs = model.__dict__.get("_mudg_graphs")
+        if graphs is None:
+            graphs = model.__dict__["_mudg_graphs"] = UNetGraphs(model)
+        parts = list(x) if isinstance(x, (list, tuple)) else [x]
+        if all(p.is_cuda for p in parts):
+            from .. import hip
+            if not hip.prof_enabled():           # per-kernel hipEvents cannot be recorded inside a graph
+                return graphs(parts, timesteps, c_label, context, fs)
+    return forward(model, x, timesteps, c_label=c_label, context=context, features_adapter=features_adapter, fs=fs)
+
+
+@torch.no_grad()
 def forward(model, x, timesteps, c_label=None, context=None, features_adapter=None, fs=None):
     if features_adapter is not None:
         raise NotImplementedError("features_adapter is not used on the MuDG path")

@@ -134,8 +134,17 @@ def check(rc: int, what: str) -> None:
         raise MudgError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
 
 
+_prof_mask = 0
+
+
 def prof_enable(mask: int) -> None:
+    global _prof_mask
     check(lib().mudg_prof_enable(mask), "mudg_prof_enable")
+    _prof_mask = mask
+
+
+def prof_enabled() -> bool:
+    return _prof_mask != 0
 
 
 def prof_reset() -> None:

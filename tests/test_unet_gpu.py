@@ -82,3 +82,27 @@ def test_unet_blocks_against_oracle(cuda):
     e3 = rel_l2(got, want)
     print(f"block rel-L2: res {e1:.3e}  spatial {e2:.3e}  temporal {e3:.3e}")
     assert e1 < TOL_BLOCK and e2 < TOL_BLOCK and e3 < TOL_BLOCK
+
+
+def test_hip_graph_replay_matches_eager_and_tracks_weight_changes(cuda):
+    g = golden("unet_b.pt")
+    sd = seeded_sd(g["param_shapes"], g["seed"], g["checksum"])
+    net = build_unet(g["cfg"], sd, cuda)
+    x, ctx = unet_inputs(g["cfg"], g["shape"], g["seed"])
+    case = g["cases"][0]
+    args = (x.to(cuda), case["t"].to(cuda))
+    kw = dict(c_label=case["c_label"].to(cuda), context=ctx.to(cuda), fs=case["fs"].to(cuda))
+    eager = net(*args, **kw)
+    net.use_hip_graph = True
+    first = net(*args, **kw)                       # captures
+    second = net(*args, **kw)                      # replays
+    assert torch.equal(first, eager) and torch.equal(second, eager)
+    other = net(args[0] * 0.5, case["t"].to(cuda), **kw)          # same graph, new input values
+    net.use_hip_graph = False
+    assert torch.equal(other, net(args[0] * 0.5, case["t"].to(cuda), **kw))
+    net.use_hip_graph = True
+    with torch.no_grad():
+        net.out[2].weight.mul_(2.0)                # in-place parameter update must invalidate the captured graph
+    changed = net(*args, **kw)
+    net.use_hip_graph = False
+    assert torch.equal(changed, net(*args, **kw)) and not torch.equal(changed, eager)
