@@ -76,6 +76,7 @@ typedef struct MudgGemmDesc {
     int res_fp32;         /* 1: R is fp32 (the residual stream is kept in fp32 between blocks) */
     int geglu;            /* 1: W rows are packed [32 value | 32 gate] blocks and
                              Y[m][j] = v_j * gelu_erf(g_j), Nout = N/2 (attention.py:579-586) */
+    int act;              /* 1: Y = gelu_erf(.) applied after bias (Perceiver FeedForward, resampler.py:27-34); 0: none */
     float alpha;
     int mode;             /* 0 | 1 | 2 */
     /* mode 1 */

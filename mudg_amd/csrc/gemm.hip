@@ -195,6 +195,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const MudgGemmDesc p, cons
                     f32x4 v;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = alpha * acc[ni][mi][4 * g + j] + sbias[nl + j];
+                    if (p.act) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = gelu_fast(v[j]);
+                    }
                     *reinterpret_cast<f32x4*>(&stg[ml * STGLD + nl]) = v;
                 }
         } else {

@@ -271,6 +271,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const MudgGemmDesc p, c
                     f32x4 v;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = alpha * acc[g][h][mi][4 * q + j] + sbias[nl + j];
+                    if (p.act && !p.geglu) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = gelu_fast2(v[j]);
+                    }
                     *reinterpret_cast<f32x4*>(&stg[ml * STGLD + nl]) = v;
                 }
             }

@@ -1,0 +1,59 @@
+"""Perceiver Resampler on the gfx950 kernels (reference: lvdm/modules/encoders/resampler.py:48-145).
+
+Per layer: latents += to_out(softmax(q k^T / sqrt(64)) v) with q from LayerNorm(latents) and k, v from the
+concatenation [LayerNorm(x) ; LayerNorm(latents)] (the reference scales q and k by 64^-1/4 each, i.e. the usual
+1/sqrt(d) on the logits), then latents += W2 gelu(W1 LayerNorm(latents)).  Rows are (batch, token) with channels
+contiguous; the latent stream is fp32, MFMA operands are 16-bit, V^T comes straight out of a swapped GEMM."""
+import torch
+
+from .. import ops
+from . import packing as pk
+
+
+def _kv_weights(attn):
+    w = attn.to_kv.weight
+    inner = w.shape[0] // 2
+    wk = pk.cached(attn, "wk", (w,), lambda: w.detach()[:inner].to(ops.H16()).contiguous())
+    wv = pk.cached(attn, "wv", (w,), lambda: w.detach()[inner:].to(ops.H16()).contiguous())
+    return wk, wv, inner
+
+
+@torch.no_grad()
+def forward(mod, x):
+    if not x.is_cuda:
+        raise RuntimeError("Resampler: inputs must be on the GPU; the MI355X path has no CPU fallback")
+    b, n1, e = x.shape
+    dev = x.device
+    lat_p = mod.latents
+    n2, dim = lat_p.shape[1], lat_p.shape[2]
+    xin = ops.cast_bf16(x.reshape(b * n1, e).float().contiguous())
+    xs = ops.gemm(xin, pk.linear(mod.proj_in), bias=pk.f32(mod.proj_in, "bias"))            # (b*n1, dim) operand rows
+    # fp32 latent stream: the learned queries replicated per batch entry (resampler.py:134; a copy, no arithmetic)
+    lat = lat_p.detach().float().repeat(b, 1, 1).reshape(b * n2, dim).contiguous()
+    nk = n1 + n2
+    for attn, ff in mod.layers:
+        heads = attn.heads
+        kv_in = ops.empty_rows(b * nk, dim, None, dev)
+        for i in range(b):        # [LayerNorm1(x_i) ; LayerNorm2(latents_i)] per batch entry
+            ops.layernorm(xs[i * n1:(i + 1) * n1], pk.f32(attn.norm1, "weight"), pk.f32(attn.norm1, "bias"),
+                          eps=attn.norm1.eps, out=kv_in[i * nk:i * nk + n1])
+            ops.layernorm(lat[i * n2:(i + 1) * n2], pk.f32(attn.norm2, "weight"), pk.f32(attn.norm2, "bias"),
+                          eps=attn.norm2.eps, out=kv_in[i * nk + n1:(i + 1) * nk])
+        wk, wv, inner = _kv_weights(attn)
+        qin = ops.empty_rows(b * n2, dim, None, dev)
+        for i in range(b):
+            ops.copy_rows(kv_in[i * nk + n1:(i + 1) * nk], qin[i * n2:(i + 1) * n2])
+        q = ops.gemm(qin, pk.linear(attn.to_q))
+        k = ops.gemm(kv_in, wk)
+        ldv = (nk + 7) // 8 * 8
+        vt = ops.empty_rows(b * inner, ldv, None, dev)
+        ops.gemm(wv, kv_in, out=vt, batch=b, sx=0, sw=nk * dim, sy=inner * ldv, M=inner, N=nk, K=dim, ldy=ldv)
+        att = ops.empty_rows(b * n2, inner, None, dev)
+        ops.attention(q, k, vt, att, frames=b, heads=heads, nq=n2, nk=nk, ldvt=ldv, svt=inner * ldv, scale=attn.scale)
+        lat = ops.gemm(att, pk.linear(attn.to_out), residual=lat, out_fp32=True)
+        hid = ops.gemm(ops.layernorm(lat, pk.f32(ff[0], "weight"), pk.f32(ff[0], "bias"), eps=ff[0].eps),
+                       pk.linear(ff[1]), gelu=True)
+        lat = ops.gemm(hid, pk.linear(ff[3]), residual=lat, out_fp32=True)
+    out = ops.gemm(ops.cast_bf16(lat), pk.linear(mod.proj_out), bias=pk.f32(mod.proj_out, "bias"), out_fp32=True)
+    out = ops.layernorm(out, pk.f32(mod.norm_out, "weight"), pk.f32(mod.norm_out, "bias"), eps=mod.norm_out.eps)
+    return ops.to_f32(out).reshape(b, n2, -1)

@@ -53,7 +53,7 @@ class GemmDesc(C.Structure):
         ("ldx", C.c_int), ("ldx2", C.c_int), ("ldw", C.c_int), ("ldy", C.c_int), ("ldr", C.c_int),
         ("csplit", C.c_int), ("batch", C.c_int),
         ("sX", C.c_int64), ("sW", C.c_int64), ("sY", C.c_int64), ("sR", C.c_int64),
-        ("rows_per_group", C.c_int), ("out_fp32", C.c_int), ("res_fp32", C.c_int), ("geglu", C.c_int),
+        ("rows_per_group", C.c_int), ("out_fp32", C.c_int), ("res_fp32", C.c_int), ("geglu", C.c_int), ("act", C.c_int),
         ("alpha", C.c_float), ("mode", C.c_int),
         ("Hin", C.c_int), ("Win", C.c_int), ("Hout", C.c_int), ("Wout", C.c_int),
         ("Cin", C.c_int), ("stride", C.c_int), ("upsample", C.c_int), ("pad", C.c_int), ("korder", C.c_int),

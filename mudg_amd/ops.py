@@ -44,7 +44,7 @@ def empty_rows(rows: int, cols: int, dtype=None, device=None) -> torch.Tensor:
 
 # ------------------------------------------------------------------------------------------------ GEMM family
 def gemm(x, w, *, out=None, bias=None, gbias=None, rows_per_group=0, residual=None, x2=None, geglu=False,
-         out_fp32=False, alpha=1.0, batch=1, sx=0, sw=0, sy=0, sr=0, M=None, N=None, K=None, ldy=None):
+         out_fp32=False, alpha=1.0, batch=1, sx=0, sw=0, sy=0, sr=0, M=None, N=None, K=None, ldy=None, gelu=False):
     """out[m, n] = epilogue(alpha * sum_k x[m, k] w[n, k]); see MudgGemmDesc."""
     _rows(x); _rows(w)
     if M is None:
@@ -68,6 +68,7 @@ def gemm(x, w, *, out=None, bias=None, gbias=None, rows_per_group=0, residual=No
     d.batch, d.sX, d.sW, d.sY, d.sR = batch, sx, sw, sy, sr
     d.rows_per_group, d.out_fp32, d.geglu, d.alpha, d.mode = rows_per_group, int(out_fp32), int(geglu), alpha, 0
     d.res_fp32 = int(residual is not None and residual.dtype == torch.float32)
+    d.act = int(gelu)
     hip.check(hip.lib().mudg_gemm(C.byref(d), _stream()), "mudg_gemm")
     return out
 
@@ -261,6 +262,16 @@ def cast_bf16(src):
     out = torch.empty(src.shape, dtype=H16(), device=src.device)
     hip.check(hip.lib().mudg_cast_f32_bf16(src.data_ptr(), out.data_ptr(), src.numel(), _stream()),
               "mudg_cast_f32_bf16")
+    return out
+
+
+def to_f32(src):
+    """16-bit operand tensor -> fp32 copy of the same shape (the layout kernel with one channel is a plain cast)."""
+    src = src.contiguous()
+    out = torch.empty(src.shape, dtype=torch.float32, device=src.device)
+    n = src.numel()
+    hip.check(hip.lib().mudg_rows_to_ncthw(src.data_ptr(), int(src.dtype == torch.float32), 1, 0, out.data_ptr(), 1,
+                                           1, 1, 1, n, 1.0, 1, 0, _stream()), "mudg_rows_to_ncthw[cast]")
     return out
 
 

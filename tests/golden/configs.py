@@ -28,3 +28,6 @@ DIFFUSION = dict(rescale_betas_zero_snr=True, parameterization="v", linear_start
 SAMPLER = dict(steps=2, eta=1.0, cfg_scale=7.5, guidance_rescale=0.7, spacing="uniform_trailing", fs=10,
                class_labels=[0, 500, 1])
 SEED = 123
+
+RESAMPLER = dict(dim=128, depth=2, dim_head=64, heads=2, num_queries=16, embedding_dim=96, output_dim=64,
+                 ff_mult=4, video_length=4)

@@ -262,12 +262,25 @@ def golden_encode():
                        "scale_factor": cfgs.DIFFUSION["scale_factor"]})
 
 
+def golden_resampler():
+    from lvdm.modules.encoders.resampler import Resampler
+    net = Resampler(**cfgs.RESAMPLER).eval()
+    shapes, cks = reseed(net, cfgs.SEED + 4)
+    x = seeding.seeded_input("clip_tokens", (3, 257, cfgs.RESAMPLER["embedding_dim"]), cfgs.SEED + 4)
+    save("resampler.pt", {"cfg": cfgs.RESAMPLER, "seed": cfgs.SEED + 4, "checksum": cks, "param_shapes": shapes,
+                          "out": net(x).clone()})
+
+
 if __name__ == "__main__":
     if "--only-encode" in sys.argv:
         golden_encode()
+        sys.exit(0)
+    if "--only-resampler" in sys.argv:
+        golden_resampler()
         sys.exit(0)
     golden_schedule()
     golden_unet("a", cfgs.UNET_A, cfgs.UNET_A_SHAPE)
     golden_unet("b", cfgs.UNET_B, cfgs.UNET_B_SHAPE)
     golden_pipeline()
     golden_encode()
+    golden_resampler()

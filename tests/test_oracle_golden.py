@@ -116,3 +116,13 @@ def test_vae_encode_matches_reference():
     noise = torch.cat([torch.randn(1, 4, 8, 8) for _ in range(6)], 0)
     z = o_vae.posterior_sample(g["moments"], noise, g["scale_factor"]).reshape(2, 3, 4, 8, 8).permute(0, 2, 1, 3, 4)
     assert rel_l2(z, g["z"]) < 1e-6
+
+
+def test_resampler_matches_reference():
+    from helpers import seeding
+    from oracle import resampler as o_res
+    g = golden("resampler.pt")
+    sd = seeded_sd(g["param_shapes"], g["seed"], g["checksum"])
+    x = seeding.seeded_input("clip_tokens", (3, 257, g["cfg"]["embedding_dim"]), g["seed"])
+    out = o_res.forward(sd, x, g["cfg"]["heads"], g["cfg"]["depth"])
+    assert out.shape == g["out"].shape and rel_l2(out, g["out"]) < 1e-5

@@ -123,3 +123,19 @@ def test_vae_encode_matches_reference(cuda):
     from mudg_amd import ops
     z2 = ops.gaussian_sample(g["moments"].to(cuda), noise, g["scale_factor"]).reshape(2, 3, 4, 8, 8).permute(0, 2, 1, 3, 4)
     assert rel_l2(z2, g["z"]) < 2e-6
+
+
+def test_resampler_matches_reference(cuda):
+    """Perceiver Resampler (image-token projector) on the HIP kernels against the reference's output."""
+    from helpers import seeding
+    from lvdm.modules.encoders.resampler import Resampler
+    g = golden("resampler.pt")
+    net = Resampler(**g["cfg"])
+    assert {k: tuple(v.shape) for k, v in net.state_dict().items()} == {k: tuple(v) for k, v in g["param_shapes"].items()}
+    net.load_state_dict(seeded_sd(g["param_shapes"], g["seed"], g["checksum"]), strict=True)
+    net = net.to(cuda).eval()
+    x = seeding.seeded_input("clip_tokens", (3, 257, g["cfg"]["embedding_dim"]), g["seed"])
+    out = net(x.to(cuda))
+    err = rel_l2(out, g["out"])
+    print(f"resampler rel-L2 vs reference: {err:.3e}")
+    assert out.shape == g["out"].shape and err < (3e-3 if FP16 else 1.5e-2)
