@@ -172,14 +172,16 @@ int mudg_zero_channels(void* dst, int rows, int ld, int c0, int c1, void* stream
 
 /* ------------------------------------------------------------------ DDIM update (ddim.py:205-279)
  * One call per step on fp32 latents, n elements per sample:
- *   v  = e_u + cfg*(e_c - e_u);  v = phi*v*std(e_c)/std(v) + (1-phi)*v   (utils_diffusion.py:147-157)
+ *   v  = e_u + cfg*(e_c - e_u)                      two-way guidance, or with e_m (image-only conditioning) the
+ *        e_u + cfg_img*(e_m - e_u) + cfg*(e_c - e_m) three-way form of ddim_multiplecond.py:226-233;
+ *   v = phi*v*std(e_c)/std(v) + (1-phi)*v            (utils_diffusion.py:147-157)
  *   e  = sqrt_ac*v + sqrt_1mac*x ;  x0 = sqrt_ac*x - sqrt_1mac*v          (ddpm3d.py:239-251)
  *   x0 *= rescale ;  x_prev = sqrt(a_prev)*x0 + dir_coef*e + sigma*noise
- * host_coef = {cfg, phi, sqrt_ac, sqrt_1mac, rescale, sqrt_a_prev, dir_coef, sigma} (HOST pointer, 8 floats).
+ * host_coef = {cfg, phi, sqrt_ac, sqrt_1mac, rescale, sqrt_a_prev, dir_coef, sigma, cfg_img} (HOST pointer, 9 floats).
  * ws: fp64 device scratch of mudg_ddim_ws_doubles(B) doubles. e_u may be NULL (no guidance: v = e_c);
  * noise may be NULL (eta = 0). */
 int64_t mudg_ddim_ws_doubles(int B);
-int mudg_ddim_step(const float* x, const float* e_c, const float* e_u, const float* noise,
+int mudg_ddim_step(const float* x, const float* e_c, const float* e_u, const float* e_m, const float* noise,
                    float* x_prev, float* pred_x0, int B, int64_t n, const float* host_coef,
                    double* ws, void* stream);
 

@@ -154,22 +154,27 @@ class DDIMSampler(object):
 
     def _batched_cfg(self, x, t, c, uc, kwargs):
         """[cond | uncond] in one apply_model call; None when the conditionings cannot be stacked."""
-        if not (isinstance(c, dict) and isinstance(uc, dict) and set(c) == set(uc)):
+        return self._batched_passes(x, t, [c, uc], kwargs)
+
+    def _batched_passes(self, x, t, conds, kwargs):
+        """One apply_model call over len(conds) stacked copies of the batch; None if the dicts cannot be stacked."""
+        first = conds[0]
+        if not all(isinstance(cd, dict) and set(cd) == set(first) for cd in conds):
             return None
-        b = x.shape[0]
+        b, n = x.shape[0], len(conds)
         merged = {}
-        for key in c:
-            a_list, u_list = c[key], uc[key]
-            if not (isinstance(a_list, (list, tuple)) and len(a_list) == len(u_list)):
+        for key in first:
+            lists = [cd[key] for cd in conds]
+            if not all(isinstance(l, (list, tuple)) and len(l) == len(lists[0]) for l in lists):
                 return None
-            if any(a.shape != u.shape for a, u in zip(a_list, u_list)):
+            if any(v.shape != lists[0][i].shape for l in lists for i, v in enumerate(l)):
                 return None
-            merged[key] = [torch.cat([a, u], 0) for a, u in zip(a_list, u_list)]
+            merged[key] = [torch.cat([l[i] for l in lists], 0) for i in range(len(lists[0]))]
         kw = {}
-        for k, v in kwargs.items():          # per-sample tensors ride along twice; everything else is shared
-            kw[k] = torch.cat([v, v], 0) if (torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == b) else v
-        out = self.model.apply_model(torch.cat([x, x], 0), torch.cat([t, t], 0), merged, **kw)
-        return out[:b], out[b:]
+        for k, v in kwargs.items():          # per-sample tensors ride along n times; everything else is shared
+            kw[k] = torch.cat([v] * n, 0) if (torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == b) else v
+        out = self.model.apply_model(torch.cat([x] * n, 0), torch.cat([t] * n, 0), merged, **kw)
+        return tuple(out[i * b:(i + 1) * b] for i in range(n))
 
     def decode(self, *a, **k):
         raise NotImplementedError("DDIM latent re-decoding is not on the MuDG path")

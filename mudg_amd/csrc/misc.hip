@@ -137,18 +137,21 @@ __global__ void gaussian_sample_kernel(const float* __restrict__ mom, const floa
 constexpr int DDIM_BLK = 64;   // partial-sum blocks per sample
 
 __global__ __launch_bounds__(256) void ddim_stats_kernel(const float* __restrict__ ec, const float* __restrict__ eu,
-                                                          int64_t n, float cfg, double* __restrict__ ws) {
+                                                          const float* __restrict__ em, int64_t n, float cfg, float cfg_img,
+                                                          double* __restrict__ ws) {
     __shared__ double red[4][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.y;
     const float* c = ec + (int64_t)b * n;
     const float* u = eu ? eu + (int64_t)b * n : nullptr;
+    const float* mid = em ? em + (int64_t)b * n : nullptr;
     const int64_t per = (n + DDIM_BLK - 1) / DDIM_BLK;
     const int64_t i0 = blockIdx.x * per, i1 = (i0 + per < n) ? i0 + per : n;
     double sc = 0, qc = 0, sv = 0, qv = 0;
     for (int64_t i = i0 + tid; i < i1; i += 256) {
         const float a = c[i];
-        const float v = u ? u[i] + cfg * (a - u[i]) : a;
+        float v = a;
+        if (u) v = mid ? u[i] + cfg_img * (mid[i] - u[i]) + cfg * (a - mid[i]) : u[i] + cfg * (a - u[i]);
         sc += a; qc += (double)a * a; sv += v; qv += (double)v * v;
     }
     sc = wave_sum_d(sc); qc = wave_sum_d(qc); sv = wave_sum_d(sv); qv = wave_sum_d(qv);
@@ -158,10 +161,11 @@ __global__ __launch_bounds__(256) void ddim_stats_kernel(const float* __restrict
         ws[((int64_t)b * DDIM_BLK + blockIdx.x) * 4 + tid] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
 }
 
-struct DdimCoef { float cfg, phi, sqrt_ac, sqrt_1mac, rescale, sqrt_a_prev, dir_coef, sigma; };
+struct DdimCoef { float cfg, phi, sqrt_ac, sqrt_1mac, rescale, sqrt_a_prev, dir_coef, sigma, cfg_img; };
 
 __global__ __launch_bounds__(256) void ddim_update_kernel(const float* __restrict__ x, const float* __restrict__ ec,
-                                                           const float* __restrict__ eu, const float* __restrict__ noise,
+                                                           const float* __restrict__ eu, const float* __restrict__ em,
+                                                           const float* __restrict__ noise,
                                                            float* __restrict__ x_prev, float* __restrict__ pred_x0, int64_t n,
                                                            DdimCoef k, const double* __restrict__ ws) {
     __shared__ float s_ratio;
@@ -187,7 +191,11 @@ __global__ __launch_bounds__(256) void ddim_update_kernel(const float* __restric
     const int64_t off = (int64_t)b * n;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const float xv = x[off + i], a = ec[off + i];
-        float v = eu ? eu[off + i] + k.cfg * (a - eu[off + i]) : a;
+        float v = a;
+        if (eu) {
+            const float u = eu[off + i];
+            v = em ? u + k.cfg_img * (em[off + i] - u) + k.cfg * (a - em[off + i]) : u + k.cfg * (a - u);
+        }
         if (k.phi > 0.f) {
             const float resc = v * ratio;
             v = k.phi * resc + (1.f - k.phi) * v;
@@ -311,20 +319,23 @@ extern "C" int mudg_gaussian_sample(const float* moments, const float* noise, fl
 
 extern "C" int64_t mudg_ddim_ws_doubles(int B) { return B > 0 ? (int64_t)B * DDIM_BLK * 4 : 0; }
 
-extern "C" int mudg_ddim_step(const float* x, const float* e_c, const float* e_u, const float* noise, float* x_prev,
-                              float* pred_x0, int B, int64_t n, const float* host_coef, double* ws, void* stream) {
+extern "C" int mudg_ddim_step(const float* x, const float* e_c, const float* e_u, const float* e_m, const float* noise,
+                              float* x_prev, float* pred_x0, int B, int64_t n, const float* host_coef, double* ws,
+                              void* stream) {
     MUDG_REQUIRE(x && e_c && x_prev && pred_x0 && host_coef && ws, "mudg_ddim_step: null pointer");
     MUDG_REQUIRE(B > 0 && B <= 65535 && n > 1, "mudg_ddim_step: bad sizes");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     DdimCoef k;
     k.cfg = host_coef[0]; k.phi = host_coef[1]; k.sqrt_ac = host_coef[2]; k.sqrt_1mac = host_coef[3];
     k.rescale = host_coef[4]; k.sqrt_a_prev = host_coef[5]; k.dir_coef = host_coef[6]; k.sigma = host_coef[7];
+    k.cfg_img = host_coef[8];
+    MUDG_REQUIRE(!e_m || e_u, "mudg_ddim_step: e_m needs e_u");
     const int slot = mudg_prof_begin(MUDG_FAM_MISC, s);
     if (k.phi > 0.f)
-        hipLaunchKernelGGL(ddim_stats_kernel, dim3(DDIM_BLK, B), dim3(256), 0, s, e_c, e_u, n, k.cfg, ws);
+        hipLaunchKernelGGL(ddim_stats_kernel, dim3(DDIM_BLK, B), dim3(256), 0, s, e_c, e_u, e_m, n, k.cfg, k.cfg_img, ws);
     int gx = (int)((n + 255) / 256);
     if (gx > 1024) gx = 1024;
-    hipLaunchKernelGGL(ddim_update_kernel, dim3(gx, B), dim3(256), 0, s, x, e_c, e_u, noise, x_prev, pred_x0, n, k, ws);
+    hipLaunchKernelGGL(ddim_update_kernel, dim3(gx, B), dim3(256), 0, s, x, e_c, e_u, e_m, noise, x_prev, pred_x0, n, k, ws);
     const int rc = mudg_check_launch("mudg_ddim_step");
     mudg_prof_end(slot, s, 0.0, (double)B * n * 4.0 * 8.0);
     return rc;

@@ -452,3 +452,19 @@ def test_gemm256_tconv3(cuda):
     y = ops.tconv3(rows.to(cuda), wp.to(cuda), clips=clips, t=t, hw=h * w, cin=c)
     got = y.cpu().float().reshape(clips, t, h, w, 3 * c).permute(0, 4, 1, 2, 3)
     assert rel_l2(got, ref) < TOL_BF16
+
+
+def test_ddim_step_three_way_guidance(cuda):
+    from mudg_amd import ops
+    g = torch.Generator().manual_seed(2)
+    shape = (2, 4, 8, 9, 16)
+    x, ec, eu, em, nz = (torch.randn(shape, generator=g) for _ in range(5))
+    cfg, cimg, phi, sac, s1m, resc, sap, dirc, sig = 7.5, 2.0, 0.7, 0.6, 0.8, 1.03, 0.9, 0.3, 0.31
+    v = eu + cimg * (em - eu) + cfg * (ec - em)
+    dims = list(range(1, v.ndim))
+    v = phi * (v * (ec.std(dim=dims, keepdim=True) / v.std(dim=dims, keepdim=True))) + (1 - phi) * v
+    x0 = (sac * x - s1m * v) * resc
+    xp = sap * x0 + dirc * (sac * v + s1m * x) + sig * nz
+    got_xp, got_x0 = ops.ddim_step(x.to(cuda), ec.to(cuda), eu.to(cuda), nz.to(cuda),
+                                   [cfg, phi, sac, s1m, resc, sap, dirc, sig, cimg], e_m=em.to(cuda))
+    assert rel_l2(got_x0, x0) < TOL_F32 and rel_l2(got_xp, xp) < TOL_F32

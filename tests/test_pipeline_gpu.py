@@ -139,3 +139,50 @@ def test_resampler_matches_reference(cuda):
     err = rel_l2(out, g["out"])
     print(f"resampler rel-L2 vs reference: {err:.3e}")
     assert out.shape == g["out"].shape and err < (3e-3 if FP16 else 1.5e-2)
+
+
+class _FakeTower(torch.nn.Module):
+    """Stands in for the CLIP towers (outside the path): deterministic tensors of the right shapes."""
+
+    def __init__(self, tokens, dim, seed):
+        super().__init__()
+        self.tokens, self.dim, self.seed = tokens, dim, seed
+
+    def _make(self, n, salt, device):
+        g = torch.Generator().manual_seed(self.seed + salt)
+        return torch.randn(n, self.tokens, self.dim, generator=g).to(device)
+
+    def forward(self, img):
+        return self._make(img.shape[0], int(img.abs().sum().item() > 0), img.device)
+
+    def encode(self, prompts):
+        return self._make(len(prompts), sum(len(p) for p in prompts) > 0, self.dev)
+
+
+def test_driver_image_guided_synthesis_two_and_three_way(cuda):
+    """The reference driver's call sequence end to end on tensors: VAE encodes of the sparse RGB / depth clips,
+    Resampler, hybrid conditioning, guided sampling (two-way and three-way CFG), decode."""
+    from lvdm.modules.encoders.resampler import Resampler
+    from virtual_render.virtual_pose_render import image_guided_synthesis
+    g = golden("pipeline.pt")
+    model = build_model(g, cuda)
+    shp = g["shape"]
+    T, D = shp["T"], g["unet_cfg"]["context_dim"]
+    model.image_proj_model = Resampler(dim=128, depth=1, dim_head=64, heads=2, num_queries=16, embedding_dim=96,
+                                       output_dim=D, ff_mult=2, video_length=T).to(cuda)
+    model.embedder = _FakeTower(257, 96, 1)
+    model.cond_stage_model = _FakeTower(77, D, 2)
+    model.cond_stage_model.dev = cuda
+    gen = torch.Generator().manual_seed(9)
+    sparse = (torch.rand(3, 3, T, 64, 64, generator=gen) * 2 - 1).to(cuda)
+    depth = (torch.rand(3, 3, T, 64, 64, generator=gen) * 2 - 1).to(cuda)
+    labels = torch.tensor([[0], [500], [1]], device=cuda)
+    common = dict(ddim_steps=2, ddim_eta=1.0, unconditional_guidance_scale=7.5, fs=10, text_input=True,
+                  timestep_spacing="uniform_trailing", guidance_rescale=0.7)
+    torch.manual_seed(3)
+    out2 = image_guided_synthesis(model, ["a street"] * 3, sparse, depth, labels, [3, 4, T, 8, 8], **common)
+    torch.manual_seed(3)
+    out3 = image_guided_synthesis(model, ["a street"] * 3, sparse, depth, labels, [3, 4, T, 8, 8],
+                                  multiple_cond_cfg=True, cfg_img=2.0, **common)
+    assert out2.shape == (3, 1, 3, T, 64, 64) and out3.shape == out2.shape
+    assert torch.isfinite(out2).all() and torch.isfinite(out3).all() and not torch.equal(out2, out3)
