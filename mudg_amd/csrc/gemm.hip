@@ -317,19 +317,23 @@ int launch(const MudgGemmDesc& d, int vflags, hipStream_t s) {
     return mudg_check_launch("mudg_gemm");
 }
 
-// Large-tile path (gemm256.hip): opt-in while it is not faster than this kernel.  MUDG_GEMM256=1 forces it whenever
-// the shape allows, =2 selects it for shapes with enough 256x256 tiles to occupy the chip and little column padding.
+// Large-tile path (gemm256.hip): 256x256 tiles stage half the bytes per FLOP, which pays when the K loop is long
+// and the column padding of the last tile is small; short-K / narrow-N shapes stay on the 128x128 kernel (measured
+// per shape family on MI355X, tools/kernel_bench.py).  MUDG_GEMM256=0 disables it, =1 forces it whenever M, N >= 256.
 bool use_gemm256(const MudgGemmDesc& d) {
     static int mode = -1;
     if (mode < 0) {
         const char* e = getenv("MUDG_GEMM256");
-        mode = e ? atoi(e) : 0;
+        mode = e ? atoi(e) : 2;
     }
     if (mode == 0 || d.M < 256 || d.N < 256) return false;
     if (mode == 1) return true;
     const int64_t tn = (d.N + 255) / 256, tiles = ((d.M + 255) / 256) * tn * d.batch;
     const double waste = (double)(tn * 256 - d.N) / (double)(tn * 256);
-    return tiles >= 192 && waste <= 0.13;
+    if (tiles < 128) return false;
+    if (d.mode == 1) return d.N >= 512 && waste <= 0.2;                     // 3x3 convs: K = 9 Cin is always long
+    if (d.mode == 2) return d.N >= 1024 && waste <= 0.13;
+    return d.N >= 1024 && waste <= 0.13 && (d.K >= 2048 || (d.geglu && d.K >= 1024));
 }
 
 }  // namespace

@@ -1,42 +1,31 @@
 // gemm256.hip — the large-tile variant of the contraction kernel (same MudgGemmDesc semantics as gemm.hip) for
-// shapes with enough 256x256 tiles to fill the chip: 8 waves, 256x256x64 block tile, operands streamed into LDS by
-// global_load_lds in HALF-TILE pieces that stay in flight across barriers (counted s_waitcnt vmcnt, raw s_barrier).
+// shapes with enough 256x256 tiles to fill the chip.
 //
-// Geometry.  Block rows (activations, "X") and block columns (weights, "W") are each split in two 128-row halves.
-// LDS holds two K-tile buffers of four half-tiles each ([128][64] h16 = 16 KiB, XOR-swizzled exactly as in gemm.hip):
-// 2 x 64 KiB = 128 KiB, one workgroup per CU, 2 waves per SIMD.  Waves form a 2 (M) x 4 (N) grid; wave (wm, wn) owns,
-// in EACH X half, rows wm*64 + [0,64) and, in EACH W half, rows wn*32 + [0,32): eight 32x32 MFMA tiles = 128 fp32
-// accumulators per lane.  A K-tile is computed in four quadrant phases (X half, W half) = (0,0) (0,1) (1,1) (1,0),
-// 8 MFMAs each, re-using the fragments of the half that does not change.
+// Why: ablations on MI355X show the 128x128 kernel is bound by the L2 -> LDS DMA stream (it saturates at ~8.5-12 TB/s;
+// at 64 FLOP per staged byte that is ~600-750 TFLOP/s, which is where that kernel sits).  A 256x256x64 block tile
+// stages half the bytes per FLOP.  Sixteen waves (1024 threads, one workgroup per CU, 4 waves per SIMD) form a 4 x 4
+// grid and each keeps the 64x64 wave tile of gemm.hip (2x2 v_mfma_f32_32x32x16, 64 accumulators, ~125 VGPRs), so the
+// per-wave instruction stream is unchanged while each K-tile's 64 KiB arrive with four 1-KiB global_load_lds
+// instructions per wave.  Two K-tile buffers (2 x 64 KiB, XOR-swizzled [256][64] tiles as in gemm.hip), one barrier
+// per K-tile: the DMA of tile k+1 flies under 16 MFMAs x 4 waves per SIMD.
 //
-// Pipeline.  While tile t is computed, the four half-tiles of tile t+1 are issued one per phase in the order the
-// phases will need them (X0, W0, W1, X1), each wave contributing two 1-KiB DMA instructions per piece.  Nothing is
-// drained to zero in the steady state: before a phase that needs a new piece the wave waits with s_waitcnt vmcnt(4)
-// (its four most recent DMA instructions may stay in flight), then a raw s_barrier publishes the piece to the other
-// waves.  Three barriers per 32 MFMAs instead of one full drain per 16.
+// (An 8-wave variant with 128x64 wave tiles, half-tile pieces and counted vmcnt was tried first: correct, but its two
+// waves per SIMD ran in lock-step and the MFMA, ds_read and DMA streams did not overlap — MFMA-only 424 us, DMA-only
+// 406-498 us, ds_read-only 274 us, all together 823 us on conv 18x32 2560->1280 — and staggering the two wave groups
+// with a barrier per sub-phase made it slower still.  Four independent waves per SIMD give the scheduler that overlap
+// for free.)
 //
-// STATUS (round 1): bit-correct, but not yet faster than the 128x128 kernel, so it is opt-in (MUDG_GEMM256=1|2).
-// Ablation on MI355X, conv 18x32 2560->1280 (K = 23040, 180 tiles): MFMA + barriers only 424 us, DMA + barriers only
-// 406-498 us (8.5-10.5 TB/s L2->LDS), ds_read + barriers only 274 us, everything 823 us: the MFMA stream and the DMA
-// stream do not overlap because all eight waves issue their DMA at the same barrier.  Tried and rejected this round:
-// (a) putting the whole next tile in flight at the tile boundary (DMA-only 406 us, full kernel unchanged);
-// (b) running the two wave groups one sub-phase apart with a barrier after every load / MFMA sub-phase (8 barriers
-// per K-tile): correct, but slower (conv 530 vs 660 TFLOP/s) — the load sub-phase (tap decode + 64-bit address
-// arithmetic + bounds tests per DMA instruction) is longer than the 8-MFMA sub-phase it should hide under.
-// Next: make the load sub-phase cheap (incremental per-lane offsets into a buffer descriptor instead of recomputed
-// 64-bit pointers) before staggering again.
-//
-// Epilogue: four passes (one per quadrant) through the same fp32 LDS tile as gemm.hip; GEGLU is applied in the
-// coalesced pass (value / gate columns of the usual [32 value | 32 gate] packing sit 32 apart in the staged tile).
+// Epilogue: four passes (one 128x128 quadrant each) through the same fp32 LDS tile as gemm.hip; GEGLU is applied in
+// the coalesced pass (value / gate columns of the usual [32 value | 32 gate] packing sit 32 apart in the staged tile).
 #include "common.h"
 #include <cstdlib>
 
 namespace {
 
 constexpr int BK = 64;
-constexpr int HROWS = 128;                     // rows per half-tile
-constexpr int HTILE = HROWS * 64;              // elements per half-tile
-constexpr int KBUF = 4 * HTILE;                // elements per K-tile buffer: X0, X1, W0, W1
+constexpr int TROWS = 256;                     // rows per operand tile
+constexpr int OTILE = TROWS * 64;              // elements per operand tile
+constexpr int KBUF = 2 * OTILE;                // elements per K-tile buffer: X, W
 constexpr int SMEM_MAIN = 2 * KBUF * 2;        // bytes (131072)
 constexpr int STGLD = 132;
 constexpr int SMEM_STG = 128 * STGLD * 4 + 128 * 4;
@@ -64,14 +53,14 @@ __device__ __forceinline__ float gelu_fast2(float x) {
 #define BARRIER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
 
 template <int MODE>
-__global__ __launch_bounds__(512, 2) void gemm256_kernel(const MudgGemmDesc p, const int vflags, const h16* __restrict__ zpage, const int ablate) {
+__global__ __launch_bounds__(1024, 4) void gemm256_kernel(const MudgGemmDesc p, const int vflags, const h16* __restrict__ zpage, const int ablate) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     h16* L = reinterpret_cast<h16*>(smem);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave & 1, wn = wave >> 1;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // 0..15
+    const int wm = wave & 3, wn = wave >> 2;
     const int l31 = lane & 31, hi = lane >> 5;
 
     const int ntn = (p.N + 255) >> 8;
@@ -88,55 +77,49 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const MudgGemmDesc p, c
     const h16* X2 = p.X2 ? reinterpret_cast<const h16*>(p.X2) + bz * p.sX : nullptr;
     const h16* W = reinterpret_cast<const h16*>(p.W) + bz * p.sW;
 
-    // DMA geometry: a half-tile is staged by all 8 waves, wave w rows [16w, 16w+16) with two instructions;
-    // in instruction i lane l lands in row 16w + 8i + (l >> 3), slot l & 7 and fetches chunk slot ^ ((row >> 1) & 7).
+    // DMA geometry: wave w stages rows [16w, 16w+16) of both operand tiles with two 1-KiB instructions each; in
+    // instruction i lane l lands in row 16w + 8i + (l >> 3), slot l & 7 and fetches chunk slot ^ ((row >> 1) & 7).
     const int rsub = lane >> 3, slot = lane & 7;
-    int ch[2], rl[2];
+    int ch[2], rl[2], rm[2], ra[2], rb[2], rc[2];
+    bool rv[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         rl[i] = 16 * wave + 8 * i + rsub;
         ch[i] = slot ^ ((rl[i] >> 1) & 7);
-    }
-    // per (half h, instr i) activation row state
-    int rm[2][2], ra[2][2], rb[2][2], rc[2][2];
-    bool rv[2][2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int m = m0 + h * HROWS + rl[i];
-            rm[h][i] = m;
-            rv[h][i] = m < p.M;
-            ra[h][i] = rb[h][i] = rc[h][i] = 0;
-            if (MODE == 1) {
-                const int hw = p.Hout * p.Wout;
-                const int f = m / hw, r = m - f * hw;
-                const int oy = r / p.Wout, ox = r - oy * p.Wout;
-                ra[h][i] = f * p.Hin * p.Win;
-                rb[h][i] = oy * p.stride - p.pad;
-                rc[h][i] = ox * p.stride - p.pad;
-            } else if (MODE == 2) {
-                rb[h][i] = (m / p.HW) % p.T;
-            }
+        const int m = m0 + rl[i];
+        rm[i] = m;
+        rv[i] = m < p.M;
+        ra[i] = rb[i] = rc[i] = 0;
+        if (MODE == 1) {
+            const int hw = p.Hout * p.Wout;
+            const int f = m / hw, r = m - f * hw;
+            const int oy = r / p.Wout, ox = r - oy * p.Wout;
+            ra[i] = f * p.Hin * p.Win;
+            rb[i] = oy * p.stride - p.pad;
+            rc[i] = ox * p.stride - p.pad;
+        } else if (MODE == 2) {
+            rb[i] = (m / p.HW) % p.T;
         }
+    }
     const bool tap_uniform = MODE != 0 && (p.Cin & 63) == 0;
 
-    auto issue_x = [&](int kt, int h) {
+    auto issue_tiles = [&](int kt) {
         const int k0 = kt * BK;
         int tap_u = 0, c_u = 0;
         if (MODE != 0 && tap_uniform) {
             if (MODE == 1 && p.korder) { const int slab = kt / 9; tap_u = kt - slab * 9; c_u = slab * 64; }
             else { tap_u = k0 / p.Cin; c_u = k0 - tap_u * p.Cin; }
         }
-        h16* dst = L + (kt & 1) * KBUF + h * HTILE;
+        h16* xdst = L + (kt & 1) * KBUF;
+        h16* wdst = xdst + OTILE;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int k = k0 + ch[i] * 8;
             const bool kv = k < p.K;
             const h16* src = zpage;
             if (MODE == 0) {
-                if (rv[h][i] && kv)
-                    src = (k < p.csplit) ? X + (int64_t)rm[h][i] * p.ldx + k : X2 + (int64_t)rm[h][i] * p.ldx2 + (k - p.csplit);
+                if (rv[i] && kv)
+                    src = (k < p.csplit) ? X + (int64_t)rm[i] * p.ldx + k : X2 + (int64_t)rm[i] * p.ldx2 + (k - p.csplit);
             } else {
                 int tap, c;
                 if (tap_uniform) { tap = tap_u; c = c_u + ch[i] * 8; }
@@ -147,105 +130,54 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const MudgGemmDesc p, c
                     const int dy = tap / 3, dx = tap - dy * 3;
                     const int hlim = p.upsample ? 2 * p.Hin : p.Hin;
                     const int wlim = p.upsample ? 2 * p.Win : p.Win;
-                    int iy = rb[h][i] + dy, ix = rc[h][i] + dx;
-                    const bool ok = rv[h][i] && kv && iy >= 0 && iy < hlim && ix >= 0 && ix < wlim;
+                    int iy = rb[i] + dy, ix = rc[i] + dx;
+                    const bool ok = rv[i] && kv && iy >= 0 && iy < hlim && ix >= 0 && ix < wlim;
                     if (p.upsample) { iy >>= 1; ix >>= 1; }
-                    if (ok) src = base + (int64_t)(ra[h][i] + iy * p.Win + ix) * ld + cc;
+                    if (ok) src = base + (int64_t)(ra[i] + iy * p.Win + ix) * ld + cc;
                 } else {
-                    const int it = rb[h][i] + tap - 1;
-                    if (rv[h][i] && kv && it >= 0 && it < p.T)
-                        src = base + ((int64_t)rm[h][i] + (int64_t)(tap - 1) * p.HW) * ld + cc;
+                    const int it = rb[i] + tap - 1;
+                    if (rv[i] && kv && it >= 0 && it < p.T)
+                        src = base + ((int64_t)rm[i] + (int64_t)(tap - 1) * p.HW) * ld + cc;
                 }
             }
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + (16 * wave + 8 * i) * 64), 16, 0, 0);
-        }
-    };
-    auto issue_w = [&](int kt, int g) {
-        const int k0 = kt * BK;
-        h16* dst = L + (kt & 1) * KBUF + (2 + g) * HTILE;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int k = k0 + ch[i] * 8;
-            const int n = n0 + g * HROWS + rl[i];
-            const h16* src = (n < p.N && k < p.K) ? W + (int64_t)n * p.ldw + k : zpage;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + (16 * wave + 8 * i) * 64), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(xdst + (16 * wave + 8 * i) * 64), 16, 0, 0);
+            const int n = n0 + rl[i];
+            const h16* wsrc = (n < p.N && kv) ? W + (int64_t)n * p.ldw + k : zpage;
+            __builtin_amdgcn_global_load_lds((gptr_t)wsrc, (lptr_t)(wdst + (16 * wave + 8 * i) * 64), 16, 0, 0);
         }
     };
 
-    f32x16 acc[2][2][2];     // [g][h][mi]
+    f32x16 acc[2][2];     // [ni][mi]
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int c = 0; c < 2; ++c)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[a][b][c][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     const int nk = (p.K + BK - 1) / BK;
     const int sw = (l31 >> 1) & 7;
-    const int xrow = (wm * 64 + l31) * 64, wrow = (wn * 32 + l31) * 64;
-
-    h16x8 xf[2][4], wf[4];
-    auto load_x = [&](const h16* buf, int h) {
-        const h16* base = buf + h * HTILE + xrow;
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-                xf[mi][ks] = *reinterpret_cast<const h16x8*>(base + mi * 32 * 64 + (((ks * 2 + hi) ^ sw) << 3));
-    };
-    auto load_w = [&](const h16* buf, int g) {
-        const h16* base = buf + (2 + g) * HTILE + wrow;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-            wf[ks] = *reinterpret_cast<const h16x8*>(base + (((ks * 2 + hi) ^ sw) << 3));
-    };
-    auto mma = [&](int g, int h) {
-        WAIT_LGKM0();
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-                acc[g][h][mi] = MFMA_32x32x16(wf[ks], xf[mi][ks], acc[g][h][mi]);
-        __builtin_amdgcn_s_setprio(0);
-    };
-
-    // prologue: all four pieces of tile 0, in the order the phases consume them
-    issue_x(0, 0); issue_w(0, 0); issue_w(0, 1); issue_x(0, 1);
-
+    issue_tiles(0);
     for (int kt = 0; kt < nk; ++kt) {
-        const h16* buf = L + (kt & 1) * KBUF;
-        const bool more = (kt + 1 < nk) && !(ablate & 1);
-        // ---- tile boundary: X0, W0 of this tile must have landed (W1, X1 may still fly); the barrier also retires
-        // the other buffer (last read during tile kt-1), into which tile kt+1 is streamed one piece per phase.
-        WAIT_VM4();
-        BARRIER();
-        // phase (X0, W0)
-        if (more) issue_x(kt + 1, 0);
-        if (!(ablate & 2) || kt == 0) { load_x(buf, 0); load_w(buf, 0); }
-        if (!(ablate & 4)) mma(0, 0);
-        // phase (X0, W1): needs W1
-        if (more) { WAIT_VM4(); } else { WAIT_VM0(); }
-        BARRIER();
-        if (more) issue_w(kt + 1, 0);
-        if (!(ablate & 2)) load_w(buf, 1);
-        if (!(ablate & 4)) mma(1, 0);
-        // phase (X1, W1): needs X1
-        if (more) { WAIT_VM4(); } else { WAIT_VM0(); }
-        BARRIER();
-        if (more) issue_w(kt + 1, 1);
-        if (!(ablate & 2)) load_x(buf, 1);
-        if (!(ablate & 4)) mma(1, 1);
-        // phase (X1, W0)
-        if (more) issue_x(kt + 1, 1);
-        if (!(ablate & 2)) load_w(buf, 0);
-        if (!(ablate & 4)) mma(0, 1);
-        if (ablate & 4) { asm volatile("" :: "v"(xf[0][0]), "v"(xf[1][3]), "v"(wf[0]), "v"(wf[3])); }
+        __syncthreads();                       // vmcnt(0) + barrier: tile kt has landed, tile kt-1's buffer is free
+        if (kt + 1 < nk && !(ablate & 1)) issue_tiles(kt + 1);
+        const h16* xs = L + (kt & 1) * KBUF + (wm * 64 + l31) * 64;
+        const h16* ws = L + (kt & 1) * KBUF + OTILE + (wn * 64 + l31) * 64;
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            const int off = ((ks * 2 + hi) ^ sw) << 3;
+            h16x8 wf[2], xf[2];
+            wf[0] = *reinterpret_cast<const h16x8*>(ws + off);
+            wf[1] = *reinterpret_cast<const h16x8*>(ws + 32 * 64 + off);
+            xf[0] = *reinterpret_cast<const h16x8*>(xs + off);
+            xf[1] = *reinterpret_cast<const h16x8*>(xs + 32 * 64 + off);
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+                    acc[ni][mi] = MFMA_32x32x16(wf[ni], xf[mi], acc[ni][mi]);
+        }
     }
-    WAIT_VM0();
     __syncthreads();
 
     // ------------------------------------------------------------------ epilogue: one 128x128 quadrant at a time
@@ -262,27 +194,31 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const MudgGemmDesc p, c
             const int mq = m0 + h * 128, nq = n0 + g * 128;
             if (tid < 128) sbias[tid] = (p.bias && nq + tid < p.N) ? p.bias[nq + tid] : 0.f;
             __syncthreads();
+            if ((wm >> 1) == h && (wn >> 1) == g) {          // the four waves that own this quadrant stage it
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
-                const int ml = wm * 64 + mi * 32 + l31;
+                for (int mi = 0; mi < 2; ++mi) {
+                    const int ml = (wm & 1) * 64 + mi * 32 + l31;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int nl = wn * 32 + 8 * q + 4 * hi;
-                    f32x4 v;
+                    for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = alpha * acc[g][h][mi][4 * q + j] + sbias[nl + j];
-                    if (p.act && !p.geglu) {
+                        for (int q = 0; q < 4; ++q) {
+                            const int nl = (wn & 1) * 64 + ni * 32 + 8 * q + 4 * hi;
+                            f32x4 v;
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = gelu_fast2(v[j]);
-                    }
-                    *reinterpret_cast<f32x4*>(&stg[ml * STGLD + nl]) = v;
+                            for (int j = 0; j < 4; ++j) v[j] = alpha * acc[ni][mi][4 * q + j] + sbias[nl + j];
+                            if (p.act && !p.geglu) {
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) v[j] = gelu_fast2(v[j]);
+                            }
+                            *reinterpret_cast<f32x4*>(&stg[ml * STGLD + nl]) = v;
+                        }
                 }
             }
             __syncthreads();
             const int NT = p.geglu ? 64 : 128;
             const int nout0 = p.geglu ? nq / 2 : nq;
             const int cpr = NT / 8;
-            for (int c = tid; c < 128 * cpr; c += 512) {
+            for (int c = tid; c < 128 * cpr; c += 1024) {
                 const int row = c / cpr, cc = c - row * cpr;
                 const int m = mq + row, n = nout0 + cc * 8;
                 if (m >= p.M || n >= Nout) continue;
@@ -368,7 +304,7 @@ int launch256(const MudgGemmDesc& d, int vflags, const h16* zp, hipStream_t s) {
     const int tiles = ((d.M + 255) / 256) * ((d.N + 255) / 256);
     static int ablate = -1;
     if (ablate < 0) { const char* e = getenv("MUDG_ABLATE"); ablate = e ? atoi(e) : 0; }
-    hipLaunchKernelGGL(gemm256_kernel<MODE>, dim3(tiles, 1, d.batch), dim3(512), SMEM_BYTES, s, d, vflags, zp, ablate);
+    hipLaunchKernelGGL(gemm256_kernel<MODE>, dim3(tiles, 1, d.batch), dim3(1024), SMEM_BYTES, s, d, vflags, zp, ablate);
     return mudg_check_launch("mudg_gemm[256]");
 }
 
