@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--no-profile", action="store_true", help="skip hipEvent bracketing of kernel families")
     ap.add_argument("--no-graph", action="store_true", help="issue every kernel from Python instead of replaying a hipGraph")
     ap.add_argument("--profile-steps", type=int, default=2, help="eager steps re-run with hipEvents for the roofline")
+    ap.add_argument("--no-decode", action="store_true", help="skip the (untimed) 16-frame VAE decode used for clips/min")
     ap.add_argument("--operand", default=os.environ.get("MUDG_OPERAND", "bf16"), choices=["bf16", "fp16"],
                     help="16-bit MFMA operand type (bf16 is the BASELINE dtype; fp16 = the reference's autocast dtype)")
     return ap.parse_args()
@@ -147,6 +148,20 @@ def main():
     elapsed = parallel.max_over_ranks(elapsed, dist, device)
     finite = bool(torch.isfinite(x).all().item())
 
+    # One clip = 50 such steps + one AutoencoderKL decode of its 16 frames (outside the timed region; reported so that
+    # clips/min is a measured figure, not steps/s divided by 50).
+    decode_ms = None
+    if not args.no_decode:
+        z = x[:1].contiguous()
+        model.decode_first_stage(z)                      # warm-up: weight packing, allocator
+        torch.cuda.synchronize()
+        td = time.perf_counter()
+        frames = model.decode_first_stage(z)
+        torch.cuda.synchronize()
+        decode_ms = 1000.0 * (time.perf_counter() - td)
+        finite = finite and bool(torch.isfinite(frames).all().item())
+        del frames
+
     fams, prof_steps = [], args.steps
     if profile and use_graph:
         # a hipGraph replay cannot carry per-kernel events: re-run a few of the same steps eagerly (identical launches,
@@ -183,7 +198,8 @@ def main():
         "algorithmic_tflop_per_step": step_tflop,
         "achieved_tflops_per_gpu": round(step_tflop * args.batch * args.steps / elapsed, 2),
         "frac_of_bf16_mfma_peak": round(step_tflop * args.batch * args.steps / elapsed / PEAK_TFLOPS_BF16, 4),
-        "clips_per_min": round(60.0 * steps_per_s / 50.0, 4),
+        "clips_per_min": round(60.0 * world * args.batch / (50.0 * elapsed / args.steps + (decode_ms or 0.0) / 1000.0), 4),
+        "vae_decode_ms_per_clip": None if decode_ms is None else round(decode_ms, 2),
         "output_finite": finite,
     }
     if fams:

@@ -11,6 +11,8 @@
 //   reads in that same order.  V arrives already transposed (the projection GEMM writes V^T), so both LDS tiles
 //   are filled with plain 16-byte row copies.
 //   K/V tiles (64 keys) are staged global -> registers -> LDS with two LDS buffers and one barrier per tile.
+//   (Tried: running the K stream one tile ahead so the score MFMAs of tile t+1 could overlap the softmax of tile t —
+//   763 -> 634 TFLOP/s at N = 9216: +26 VGPRs and 32 extra register moves per tile, no interleave by hipcc.)
 //   Workgroups are numbered so that the query tiles of one (frame, head) run on one XCD and share its L2.
 //
 // mudg_temporal_attention: T <= 32 keys per pixel — a bandwidth problem.  One wave per (pixel, head), fp32 VALU
@@ -132,8 +134,11 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const MudgAttnDesc p, cons
 #pragma unroll
         for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+        // The running maximum only moves during the first few tiles; when no row of this wave raised it, alpha is
+        // exactly 1 and the 32-register rescale of O (and its exp) is skipped — bit-identical, not a threshold trick.
+        const bool grew = !__all(mx <= m_run);
+        const float m_new = grew ? fmaxf(m_run, mx) : m_run;
+        const float alpha = grew ? __builtin_amdgcn_exp2f((m_run - m_new) * c) : 1.0f;
         const float mc = m_new * c;
         m_run = m_new;
         float ps = 0.f;
@@ -142,13 +147,15 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const MudgAttnDesc p, cons
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float e = __builtin_amdgcn_exp2f(s[sub][r] * c - mc);
+                const float e = __builtin_amdgcn_exp2f(fmaf(s[sub][r], c, -mc));   // explicit: contraction is off globally
                 ps += e;
                 pk[sub][r >> 3][r & 7] = (h16)e;
             }
         l_run = l_run * alpha + ps;
+        if (grew) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+            for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+        }
 
         // ---- O^T += V^T P^T ; contraction slots follow the key order the score MFMA left in registers
 #pragma unroll
