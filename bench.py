@@ -107,7 +107,9 @@ def main():
     dist = parallel.init_from_env("nccl")[3]
 
     from mudg_amd import build as mbuild, configs, factory, hip
-    mbuild.build(verbose=False)
+    if rank == 0:
+        mbuild.build(verbose=False)          # no-op when the in-tree .so files are current; one rank only (no races)
+    parallel.barrier(dist)
     hip.set_operand(args.operand)
     hip.lib()
     from lvdm.models.samplers.ddim import DDIMSampler

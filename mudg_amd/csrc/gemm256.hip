@@ -46,11 +46,6 @@ __device__ __forceinline__ float gelu_fast2(float x) {
     return 0.5f * x * (1.0f + copysignf(e, x));
 }
 
-#define WAIT_VM4() asm volatile("s_waitcnt vmcnt(4)" ::: "memory")
-#define WAIT_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-#define WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-// raw barrier (no vmcnt drain, unlike __syncthreads) fenced against compiler motion of LDS accesses on both sides
-#define BARRIER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
 
 template <int MODE>
 __global__ __launch_bounds__(1024, 4) void gemm256_kernel(const MudgGemmDesc p, const int vflags, const h16* __restrict__ zpage, const int ablate) {
