@@ -45,7 +45,19 @@ __device__ __forceinline__ float gelu_fast(float x) {
     return 0.5f * x * (1.0f + copysignf(e, x));
 }
 
-template <int MODE>
+// voffset of a lane whose source row / tap does not exist: at num_records, so the buffer load returns 0 into the LDS.
+constexpr unsigned OOB = 0x80000000u;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const h16* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<h16*>(base), 0, (int)0x80000000u, 0x00020000);
+}
+
+// FAST (host-checked: K, Cin, csplit multiples of 64, no upsample, block-relative offsets < 2 GiB): operand tiles are
+// fetched with buffer_load_dwordx4 ... lds through block-relative buffer descriptors — the per-lane byte offset
+// (row * ld + swizzled chunk) is loop-invariant, the K / tap advance is one SGPR offset, and a missing row or tap is
+// an out-of-range offset that the hardware zero-fills.  The generic path (any K % 8 == 0, upsample, straddling
+// sources) computes 64-bit addresses per lane per K-tile and fetches padding from a zero page.
+template <int MODE, bool FAST>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const MudgGemmDesc p, const int vflags, const h16* __restrict__ zpage) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     h16* Xs = reinterpret_cast<h16*>(smem);
@@ -99,7 +111,81 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const MudgGemmDesc p, cons
     }
     const bool tap_uniform = MODE != 0 && (p.Cin & 63) == 0;     // a 64-wide K tile never straddles two taps
 
+    // FAST path state: descriptors based at the block's first source row, invariant lane offsets, tap validity bits.
+    __amdgpu_buffer_rsrc_t rX, rX2, rW;
+    unsigned vx[4], vx2[4], vw[4], vmask[4];
+    int tap_s = 0, c_s = 0;                                      // tap / channel of the next K-tile to issue
+    if constexpr (FAST) {
+        int64_t pix0 = m0;                                       // source pixel (row of X) of output row m0, before the tap shift
+        if (MODE == 1) {
+            const int hw = p.Hout * p.Wout;
+            const int f = m0 / hw, r = m0 - f * hw;
+            const int oy = r / p.Wout, ox = r - oy * p.Wout;
+            pix0 = ((int64_t)f * p.Hin + oy * p.stride) * p.Win + ox * p.stride;
+        }
+        const int64_t shift = MODE == 1 ? -(int64_t)(p.pad * p.Win + p.pad) : (MODE == 2 ? -(int64_t)p.HW : 0);
+        rX = make_rsrc(X + (pix0 + shift) * p.ldx);
+        rX2 = X2 ? make_rsrc(X2 + (pix0 + shift) * p.ldx2) : rX;
+        rW = make_rsrc(W + (int64_t)n0 * p.ldw);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int rl = 32 * wave + 8 * i + rsub;
+            int rel = rl;
+            unsigned mask = rv[i] ? 1u : 0u;
+            if (MODE == 1) {
+                rel = (int)((int64_t)(ra[i] + (rb[i] + p.pad) * p.Win + rc[i] + p.pad) - pix0);
+                mask = 0;
+                if (rv[i]) {
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) {
+                        const int iy = rb[i] + t / 3, ix = rc[i] + t % 3;
+                        if (iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win) mask |= 1u << t;
+                    }
+                }
+            } else if (MODE == 2) {
+                mask = 0;
+                if (rv[i]) {
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        const int it = rb[i] + t - 1;
+                        if (it >= 0 && it < p.T) mask |= 1u << t;
+                    }
+                }
+            }
+            vmask[i] = mask;
+            const unsigned cb = (unsigned)ch[i] * 16u;
+            vx[i] = (MODE == 0 && !rv[i]) ? OOB : (unsigned)rel * (unsigned)p.ldx * 2u + cb;
+            vx2[i] = (MODE == 0 && !rv[i]) ? OOB : (unsigned)rel * (unsigned)(X2 ? p.ldx2 : p.ldx) * 2u + cb;
+            vw[i] = (n0 + rl < p.N) ? (unsigned)rl * (unsigned)p.ldw * 2u + cb : OOB;
+        }
+    }
+
+    auto issue_fast = [&](int kt, int buf) {
+        const bool s2 = c_s >= p.csplit;
+        const int cc = s2 ? c_s - p.csplit : c_s;
+        const int ld = s2 ? p.ldx2 : p.ldx;
+        int soff;
+        if (MODE == 0) soff = cc * 2;
+        else if (MODE == 1) { const int dy = tap_s / 3, dx = tap_s - 3 * dy; soff = ((dy * p.Win + dx) * ld + cc) * 2; }
+        else soff = (tap_s * p.HW * ld + cc) * 2;
+        const int soffw = kt * (BK * 2);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            unsigned v = s2 ? vx2[i] : vx[i];
+            if (MODE != 0) v = ((vmask[i] >> tap_s) & 1u) ? v : OOB;
+            lptr_t lx = (lptr_t)(Xs + buf * TILE + (32 * wave + 8 * i) * LDSLD);
+            if (s2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rX2, lx, 16, (int)v, soff, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, lx, 16, (int)v, soff, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(Ws + buf * TILE + (32 * wave + 8 * i) * LDSLD), 16,
+                                                     (int)vw[i], soffw, 0, 0);
+        }
+        if (MODE == 0) c_s += BK;
+        else if (MODE == 1 && p.korder) { if (++tap_s == 9) { tap_s = 0; c_s += BK; } }
+        else { c_s += BK; if (c_s == p.Cin) { c_s = 0; ++tap_s; } }
+    };
+
     auto issue_tiles = [&](int kt, int buf) {
+        if constexpr (FAST) { issue_fast(kt, buf); return; }
         const int k0 = kt * BK;
         int tap_u = 0, c_u = 0;
         if (MODE != 0 && tap_uniform) {
@@ -300,20 +386,20 @@ const h16* zero_page() {
     return page;
 }
 
-template <int MODE>
+template <int MODE, bool FAST>
 int launch(const MudgGemmDesc& d, int vflags, hipStream_t s) {
     static bool attr_set = false;
     const h16* zp = zero_page();
     if (!zp) MUDG_FAIL(MUDG_ELAUNCH, "gemm: could not allocate the zero page");
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<MODE>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<MODE, FAST>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
         if (e != hipSuccess) MUDG_FAIL(MUDG_ELAUNCH, "gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
     const int tiles = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
     dim3 grid(tiles, 1, d.batch);
-    hipLaunchKernelGGL(gemm_kernel<MODE>, grid, dim3(256), SMEM_BYTES, s, d, vflags, zp);
+    hipLaunchKernelGGL((gemm_kernel<MODE, FAST>), grid, dim3(256), SMEM_BYTES, s, d, vflags, zp);
     return mudg_check_launch("mudg_gemm");
 }
 
@@ -337,6 +423,30 @@ bool use_gemm256(const MudgGemmDesc& d) {
 }
 
 }  // namespace
+
+// Whether the buffer-descriptor (FAST) kernels can run this problem; also used by gemm256.hip.  MUDG_GEMM_FAST=0
+// forces the generic address path (for A/B measurements and tests of both paths).
+bool mudg_gemm_fast_ok(const MudgGemmDesc& d) {
+    static int en = -1;
+    if (en < 0) {
+        const char* e = getenv("MUDG_GEMM_FAST");
+        en = e ? atoi(e) : 1;
+    }
+    if (!en) return false;
+    const int cin = d.mode == 0 ? d.K : d.Cin;
+    if ((d.K & 63) || (cin & 63) || (d.csplit & 63)) return false;
+    if (d.mode == 1 && d.upsample) return false;
+    const int64_t ld = d.X2 && d.ldx2 > d.ldx ? d.ldx2 : d.ldx;
+    int64_t rel = 255, soff = (int64_t)cin * 2;
+    if (d.mode == 1) {
+        rel = (int64_t)(255 / (d.Hout * d.Wout) + 2) * d.Hin * d.Win;
+        soff += (int64_t)(2 * d.Win + 2) * ld * 2;
+    } else if (d.mode == 2) {
+        soff += (int64_t)2 * d.HW * ld * 2;
+    }
+    const int64_t lim = (int64_t)1 << 31;
+    return rel * ld * 2 + 128 + soff + 16 < lim && (int64_t)255 * d.ldw * 2 + (int64_t)d.K * 2 + 144 < lim;
+}
 
 int mudg_gemm256_dispatch(const MudgGemmDesc& d, int vflags, const h16* zpage, hipStream_t s);
 
@@ -386,9 +496,11 @@ extern "C" int mudg_gemm(const MudgGemmDesc* dp, void* stream) {
         const h16* zp = zero_page();
         if (!zp) MUDG_FAIL(MUDG_ELAUNCH, "gemm: could not allocate the zero page");
         rc = mudg_gemm256_dispatch(d, vflags, zp, s);
-    } else if (d.mode == 0) rc = launch<0>(d, vflags, s);
-    else if (d.mode == 1) rc = launch<1>(d, vflags, s);
-    else rc = launch<2>(d, vflags, s);
+    } else if (mudg_gemm_fast_ok(d)) {
+        rc = d.mode == 0 ? launch<0, true>(d, vflags, s) : (d.mode == 1 ? launch<1, true>(d, vflags, s) : launch<2, true>(d, vflags, s));
+    } else {
+        rc = d.mode == 0 ? launch<0, false>(d, vflags, s) : (d.mode == 1 ? launch<1, false>(d, vflags, s) : launch<2, false>(d, vflags, s));
+    }
     const double flops = 2.0 * d.M * (double)d.N * d.K * d.batch;
     const double bytes = ((double)d.M * cin + (double)d.N * d.K + (double)d.M * (d.geglu ? d.N / 2 : d.N)) * 2.0 * d.batch;
     mudg_prof_end(slot, s, flops, bytes);

@@ -47,7 +47,13 @@ __device__ __forceinline__ float gelu_fast2(float x) {
 }
 
 
-template <int MODE>
+constexpr unsigned OOB = 0x80000000u;          // see gemm.hip: out-of-range voffset -> the buffer load zero-fills
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const h16* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<h16*>(base), 0, (int)0x80000000u, 0x00020000);
+}
+
+template <int MODE, bool FAST>
 __global__ __launch_bounds__(1024, 4) void gemm256_kernel(const MudgGemmDesc p, const int vflags, const h16* __restrict__ zpage, const int ablate) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     h16* L = reinterpret_cast<h16*>(smem);
@@ -98,7 +104,81 @@ __global__ __launch_bounds__(1024, 4) void gemm256_kernel(const MudgGemmDesc p, 
     }
     const bool tap_uniform = MODE != 0 && (p.Cin & 63) == 0;
 
+    // FAST path (same scheme as gemm.hip): block-relative buffer descriptors, invariant lane offsets, tap bits.
+    __amdgpu_buffer_rsrc_t rX, rX2, rW;
+    unsigned vx[2], vx2[2], vw[2], vmask[2];
+    int tap_s = 0, c_s = 0;
+    if constexpr (FAST) {
+        int64_t pix0 = m0;
+        if (MODE == 1) {
+            const int hw = p.Hout * p.Wout;
+            const int f = m0 / hw, r = m0 - f * hw;
+            const int oy = r / p.Wout, ox = r - oy * p.Wout;
+            pix0 = ((int64_t)f * p.Hin + oy * p.stride) * p.Win + ox * p.stride;
+        }
+        const int64_t shift = MODE == 1 ? -(int64_t)(p.pad * p.Win + p.pad) : (MODE == 2 ? -(int64_t)p.HW : 0);
+        rX = make_rsrc(X + (pix0 + shift) * p.ldx);
+        rX2 = X2 ? make_rsrc(X2 + (pix0 + shift) * p.ldx2) : rX;
+        rW = make_rsrc(W + (int64_t)n0 * p.ldw);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int rel = rl[i];
+            unsigned mask = rv[i] ? 1u : 0u;
+            if (MODE == 1) {
+                rel = (int)((int64_t)(ra[i] + (rb[i] + p.pad) * p.Win + rc[i] + p.pad) - pix0);
+                mask = 0;
+                if (rv[i]) {
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) {
+                        const int iy = rb[i] + t / 3, ix = rc[i] + t % 3;
+                        if (iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win) mask |= 1u << t;
+                    }
+                }
+            } else if (MODE == 2) {
+                mask = 0;
+                if (rv[i]) {
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        const int it = rb[i] + t - 1;
+                        if (it >= 0 && it < p.T) mask |= 1u << t;
+                    }
+                }
+            }
+            vmask[i] = mask;
+            const unsigned cb = (unsigned)ch[i] * 16u;
+            vx[i] = (MODE == 0 && !rv[i]) ? OOB : (unsigned)rel * (unsigned)p.ldx * 2u + cb;
+            vx2[i] = (MODE == 0 && !rv[i]) ? OOB : (unsigned)rel * (unsigned)(X2 ? p.ldx2 : p.ldx) * 2u + cb;
+            vw[i] = (n0 + rl[i] < p.N) ? (unsigned)rl[i] * (unsigned)p.ldw * 2u + cb : OOB;
+        }
+    }
+
+    auto issue_fast = [&](int kt) {
+        const bool s2 = c_s >= p.csplit;
+        const int cc = s2 ? c_s - p.csplit : c_s;
+        const int ld = s2 ? p.ldx2 : p.ldx;
+        int soff;
+        if (MODE == 0) soff = cc * 2;
+        else if (MODE == 1) { const int dy = tap_s / 3, dx = tap_s - 3 * dy; soff = ((dy * p.Win + dx) * ld + cc) * 2; }
+        else soff = (tap_s * p.HW * ld + cc) * 2;
+        const int soffw = kt * (BK * 2);
+        h16* xdst = L + (kt & 1) * KBUF;
+        h16* wdst = xdst + OTILE;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            unsigned v = s2 ? vx2[i] : vx[i];
+            if (MODE != 0) v = ((vmask[i] >> tap_s) & 1u) ? v : OOB;
+            lptr_t lx = (lptr_t)(xdst + (16 * wave + 8 * i) * 64);
+            if (s2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rX2, lx, 16, (int)v, soff, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, lx, 16, (int)v, soff, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(wdst + (16 * wave + 8 * i) * 64), 16, (int)vw[i], soffw, 0, 0);
+        }
+        if (MODE == 0) c_s += BK;
+        else if (MODE == 1 && p.korder) { if (++tap_s == 9) { tap_s = 0; c_s += BK; } }
+        else { c_s += BK; if (c_s == p.Cin) { c_s = 0; ++tap_s; } }
+    };
+
     auto issue_tiles = [&](int kt) {
+        if constexpr (FAST) { issue_fast(kt); return; }
         const int k0 = kt * BK;
         int tap_u = 0, c_u = 0;
         if (MODE != 0 && tap_uniform) {
@@ -287,11 +367,11 @@ __global__ __launch_bounds__(1024, 4) void gemm256_kernel(const MudgGemmDesc p, 
         }
 }
 
-template <int MODE>
+template <int MODE, bool FAST>
 int launch256(const MudgGemmDesc& d, int vflags, const h16* zp, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<MODE>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<MODE, FAST>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
         if (e != hipSuccess) MUDG_FAIL(MUDG_ELAUNCH, "gemm256: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
@@ -299,15 +379,22 @@ int launch256(const MudgGemmDesc& d, int vflags, const h16* zp, hipStream_t s) {
     const int tiles = ((d.M + 255) / 256) * ((d.N + 255) / 256);
     static int ablate = -1;
     if (ablate < 0) { const char* e = getenv("MUDG_ABLATE"); ablate = e ? atoi(e) : 0; }
-    hipLaunchKernelGGL(gemm256_kernel<MODE>, dim3(tiles, 1, d.batch), dim3(1024), SMEM_BYTES, s, d, vflags, zp, ablate);
+    hipLaunchKernelGGL((gemm256_kernel<MODE, FAST>), dim3(tiles, 1, d.batch), dim3(1024), SMEM_BYTES, s, d, vflags, zp, ablate);
     return mudg_check_launch("mudg_gemm[256]");
 }
 
 }  // namespace
 
 // Called by mudg_gemm (gemm.hip) once the descriptor is validated and the large-tile path is selected.
+bool mudg_gemm_fast_ok(const MudgGemmDesc& d);      // gemm.hip
+
 int mudg_gemm256_dispatch(const MudgGemmDesc& d, int vflags, const h16* zpage, hipStream_t s) {
-    if (d.mode == 0) return launch256<0>(d, vflags, zpage, s);
-    if (d.mode == 1) return launch256<1>(d, vflags, zpage, s);
-    return launch256<2>(d, vflags, zpage, s);
+    if (mudg_gemm_fast_ok(d)) {
+        if (d.mode == 0) return launch256<0, true>(d, vflags, zpage, s);
+        if (d.mode == 1) return launch256<1, true>(d, vflags, zpage, s);
+        return launch256<2, true>(d, vflags, zpage, s);
+    }
+    if (d.mode == 0) return launch256<0, false>(d, vflags, zpage, s);
+    if (d.mode == 1) return launch256<1, false>(d, vflags, zpage, s);
+    return launch256<2, false>(d, vflags, zpage, s);
 }

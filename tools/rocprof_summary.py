@@ -40,9 +40,32 @@ def pmc(path, scale=1.0, top=25):
         print(f"| `{short(name)}` | {ctr} | {n} | {tot:.4g} | {tot / max(n, 1):.4g} |")
 
 
+def pmc_dispatches(path, flt=""):
+    """One row per dispatch with every collected counter as a column (for single-kernel experiments)."""
+    con = sqlite3.connect(path)
+    cur = con.cursor()
+    cols = [r[1] for r in cur.execute("pragma table_info(counters_collection)").fetchall()]
+    did = "dispatch_id" if "dispatch_id" in cols else cols[0]
+    rows = cur.execute(f"select {did}, kernel_name, counter_name, sum(value) from counters_collection "
+                       f"group by {did}, kernel_name, counter_name order by {did}").fetchall()
+    table, names = {}, []
+    for d, k, c, v in rows:
+        if flt and flt not in k:
+            continue
+        table.setdefault((d, k), {})[c] = v
+        if c not in names:
+            names.append(c)
+    print("| dispatch | kernel | " + " | ".join(names) + " |")
+    print("|---|---|" + "---:|" * len(names))
+    for (d, k), vals in table.items():
+        print(f"| {d} | `{short(k, 40)}` | " + " | ".join(f"{vals.get(c, 0):.4g}" for c in names) + " |")
+
+
 if __name__ == "__main__":
     mode, path = sys.argv[1], sys.argv[2]
     if mode == "trace":
         trace(path)
+    elif mode == "pmcd":
+        pmc_dispatches(path, sys.argv[3] if len(sys.argv) > 3 else "")
     else:
         pmc(path, float(sys.argv[3]) if len(sys.argv) > 3 else 1.0)
