@@ -26,6 +26,9 @@ constexpr int TILE = BM * LDSLD;                // elements per operand per buff
 constexpr int SMEM_MAIN = 4 * TILE * 2;         // X[2] + W[2], bytes
 constexpr int SMEM_STG = BM * STGLD * 4 + BN * 4;
 constexpr int SMEM_BYTES = SMEM_MAIN > SMEM_STG ? SMEM_MAIN : SMEM_STG;
+// Single-buffer variant (short K): one K-tile buffer, the epilogue staged in two 64-row passes -> 4 workgroups per CU.
+constexpr int SMEM_STG_SB = (BM / 2) * STGLD * 4 + BN * 4;
+constexpr int SMEM_BYTES_SB = 2 * TILE * 2 > SMEM_STG_SB ? 2 * TILE * 2 : SMEM_STG_SB;
 
 constexpr int VF_Y = 1, VF_R = 2;               // 16-byte access allowed on Y / R
 
@@ -57,11 +60,15 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const h16* base) {
 // (row * ld + swizzled chunk) is loop-invariant, the K / tap advance is one SGPR offset, and a missing row or tap is
 // an out-of-range offset that the hardware zero-fills.  The generic path (any K % 8 == 0, upsample, straddling
 // sources) computes 64-bit addresses per lane per K-tile and fetches padding from a zero page.
-template <int MODE, bool FAST>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const MudgGemmDesc p, const int vflags, const h16* __restrict__ zpage) {
+// SB (short-K plain GEMMs, K <= 640): with 5-10 K-tiles per output tile the fixed cost of a tile (first fetch, epilogue)
+// is as long as its K loop, and only other resident workgroups can hide it.  One K-tile buffer instead of two and a
+// two-pass epilogue bring the LDS footprint to 34 KiB, so four workgroups share a CU (16 waves, 4 per SIMD) and overlap
+// each other's fetch / multiply / store phases; inside a workgroup fetch and multiply then alternate.
+template <int MODE, bool FAST, bool SB>
+__global__ __launch_bounds__(256, SB ? 4 : 2) void gemm_kernel(const MudgGemmDesc p, const int vflags, const h16* __restrict__ zpage) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     h16* Xs = reinterpret_cast<h16*>(smem);
-    h16* Ws = Xs + 2 * TILE;
+    h16* Ws = Xs + (SB ? 1 : 2) * TILE;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -236,13 +243,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const MudgGemmDesc p, cons
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     const int nk = (p.K + BK - 1) / BK;
-    issue_tiles(0, 0);
-    __syncthreads();                     // drains the DMA (vmcnt(0)) before anyone reads the tile
-
     const int sw = (l31 >> 1) & 7;       // read-side swizzle: the row bases are multiples of 32, so only lane bits count
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) issue_tiles(kt + 1, cur ^ 1);
+    auto multiply = [&](int cur) {
         const h16* xs = Xs + cur * TILE + (wm * 64 + l31) * LDSLD;
         const h16* ws = Ws + cur * TILE + (wn * 64 + l31) * LDSLD;
 #pragma unroll
@@ -259,19 +261,45 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const MudgGemmDesc p, cons
                 for (int mi = 0; mi < 2; ++mi)
                     acc[ni][mi] = MFMA_32x32x16(wf[ni], xf[mi], acc[ni][mi]);
         }
-        __syncthreads();
+    };
+    if constexpr (SB) {
+        for (int kt = 0; kt < nk; ++kt) {
+            issue_tiles(kt, 0);
+            __syncthreads();                 // vmcnt(0) + barrier: the tile has landed
+            multiply(0);
+            __syncthreads();                 // every wave is done reading before the next fetch overwrites the buffer
+        }
+    } else {
+        issue_tiles(0, 0);
+        __syncthreads();                     // drains the DMA (vmcnt(0)) before anyone reads the tile
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < nk) issue_tiles(kt + 1, cur ^ 1);
+            multiply(cur);
+            __syncthreads();
+        }
     }
 
     // ------------------------------------------------------------------ epilogue
     float* stg = reinterpret_cast<float*>(smem);
-    float* sbias = stg + BM * STGLD;
+    constexpr int NPASS = SB ? 2 : 1, PROWS = BM / NPASS;      // SB stages the tile in two 64-row passes (wave rows wm = pass)
+    float* sbias = stg + PROWS * STGLD;
     if (tid < BN) sbias[tid] = (p.bias && n0 + tid < p.N) ? p.bias[n0 + tid] : 0.f;
     __syncthreads();
 
     const float alpha = p.alpha;
+    const int NT = p.geglu ? BN / 2 : BN;
+    const int Nout = p.geglu ? p.N / 2 : p.N;
+    const int nout0 = p.geglu ? n0 / 2 : n0;
+    const int cpr = NT / 8;
+    const h16* R = (p.R && !p.res_fp32) ? reinterpret_cast<const h16*>(p.R) + bz * p.sR : nullptr;
+    const float* Rf = (p.R && p.res_fp32) ? reinterpret_cast<const float*>(p.R) + bz * p.sR : nullptr;
+#pragma unroll
+    for (int pass = 0; pass < NPASS; ++pass) {
+    if (NPASS == 1 || wm == pass) {
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
-        const int ml = wm * 64 + mi * 32 + l31;
+        const int ml = (NPASS == 1 ? wm * 64 : 0) + mi * 32 + l31;
         if (!p.geglu) {
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni)
@@ -302,17 +330,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const MudgGemmDesc p, cons
             }
         }
     }
+    }
     __syncthreads();
 
-    const int NT = p.geglu ? BN / 2 : BN;
-    const int Nout = p.geglu ? p.N / 2 : p.N;
-    const int nout0 = p.geglu ? n0 / 2 : n0;
-    const int cpr = NT / 8;
-    const h16* R = (p.R && !p.res_fp32) ? reinterpret_cast<const h16*>(p.R) + bz * p.sR : nullptr;
-    const float* Rf = (p.R && p.res_fp32) ? reinterpret_cast<const float*>(p.R) + bz * p.sR : nullptr;
-    for (int c = tid; c < BM * cpr; c += 256) {
+    for (int c = tid; c < PROWS * cpr; c += 256) {
         const int row = c / cpr, cc = c - row * cpr;
-        const int m = m0 + row, n = nout0 + cc * 8;
+        const int m = m0 + pass * PROWS + row, n = nout0 + cc * 8;
         if (m >= p.M || n >= Nout) continue;
         const int nvalid = (Nout - n) < 8 ? (Nout - n) : 8;
         float v[8];
@@ -374,6 +397,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const MudgGemmDesc p, cons
             }
         }
     }
+    if (NPASS > 1) __syncthreads();
+    }
 }
 
 const h16* zero_page() {
@@ -386,26 +411,28 @@ const h16* zero_page() {
     return page;
 }
 
-template <int MODE, bool FAST>
+template <int MODE, bool FAST, bool SB = false>
 int launch(const MudgGemmDesc& d, int vflags, hipStream_t s) {
     static bool attr_set = false;
     const h16* zp = zero_page();
     if (!zp) MUDG_FAIL(MUDG_ELAUNCH, "gemm: could not allocate the zero page");
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<MODE, FAST>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<MODE, FAST, SB>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, SB ? SMEM_BYTES_SB : SMEM_BYTES);
         if (e != hipSuccess) MUDG_FAIL(MUDG_ELAUNCH, "gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
     const int tiles = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
     dim3 grid(tiles, 1, d.batch);
-    hipLaunchKernelGGL((gemm_kernel<MODE, FAST>), grid, dim3(256), SMEM_BYTES, s, d, vflags, zp);
+    hipLaunchKernelGGL((gemm_kernel<MODE, FAST, SB>), grid, dim3(256), SB ? SMEM_BYTES_SB : SMEM_BYTES, s, d, vflags, zp);
     return mudg_check_launch("mudg_gemm");
 }
 
-// Large-tile path (gemm256.hip): 256x256 tiles stage half the bytes per FLOP, which pays when the K loop is long
-// and the column padding of the last tile is small; short-K / narrow-N shapes stay on the 128x128 kernel (measured
-// per shape family on MI355X, tools/kernel_bench.py).  MUDG_GEMM256=0 disables it, =1 forces it whenever M, N >= 256.
+// Large-tile path (gemm256.hip / gemm256p.hip): 256x256 tiles stage half the bytes per FLOP.  Measured per shape
+// family on MI355X (tools/exp_tiles.py) against the 128x128 kernels: it wins on the 3x3 convs with long K loops (K >= 5760:
+// +10...+30 %, even at N = 320 where 37 % of the second tile column is padding, because padded rows cost no DMA) and
+// marginally on the K >= 1024 GEGLU GEMMs; everywhere else four (or two) 128x128 workgroups per CU are as fast or faster.
+// MUDG_GEMM256=0 disables it, =1 forces it whenever M, N >= 256.
 bool use_gemm256(const MudgGemmDesc& d) {
     static int mode = -1;
     if (mode < 0) {
@@ -417,9 +444,25 @@ bool use_gemm256(const MudgGemmDesc& d) {
     const int64_t tn = (d.N + 255) / 256, tiles = ((d.M + 255) / 256) * tn * d.batch;
     const double waste = (double)(tn * 256 - d.N) / (double)(tn * 256);
     if (tiles < 128) return false;
-    if (d.mode == 1) return d.N >= 512 && waste <= 0.2;                     // 3x3 convs: K = 9 Cin is always long
-    if (d.mode == 2) return d.N >= 1024 && waste <= 0.13;
-    return d.N >= 1024 && waste <= 0.13 && (d.K >= 2048 || (d.geglu && d.K >= 1024));
+    if (d.mode == 1) return (d.N >= 512 && waste <= 0.2) || d.K >= 5760;
+    if (d.mode == 2) return false;
+    return d.geglu && d.N >= 1024 && waste <= 0.13 && d.K >= 1024;
+}
+
+// Plain GEMMs and temporal convs with at least three tiles per CU go to the single-buffer / 4-workgroups-per-CU variant
+// (see gemm_kernel): measured faster at every K (MDM1024 shapes: +6...+20 %); with few tiles the double-buffered
+// 2-per-CU kernel wins, and the 3x3 convs (tap-strided fetches, longer latency) keep their in-workgroup prefetch.
+// MUDG_GEMM_SB=0 disables it, =2 forces it for every FAST problem.
+bool use_single_buffer(const MudgGemmDesc& d) {
+    static int mode = -1;
+    if (mode < 0) {
+        const char* e = getenv("MUDG_GEMM_SB");
+        mode = e ? atoi(e) : 1;
+    }
+    if (mode == 0) return false;
+    if (mode == 2) return true;
+    const int64_t tiles = (int64_t)((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN) * d.batch;
+    return d.mode != 1 && tiles >= 768;
 }
 
 }  // namespace
@@ -497,7 +540,10 @@ extern "C" int mudg_gemm(const MudgGemmDesc* dp, void* stream) {
         if (!zp) MUDG_FAIL(MUDG_ELAUNCH, "gemm: could not allocate the zero page");
         rc = mudg_gemm256_dispatch(d, vflags, zp, s);
     } else if (mudg_gemm_fast_ok(d)) {
-        rc = d.mode == 0 ? launch<0, true>(d, vflags, s) : (d.mode == 1 ? launch<1, true>(d, vflags, s) : launch<2, true>(d, vflags, s));
+        if (use_single_buffer(d))
+            rc = d.mode == 0 ? launch<0, true, true>(d, vflags, s) : (d.mode == 1 ? launch<1, true, true>(d, vflags, s) : launch<2, true, true>(d, vflags, s));
+        else
+            rc = d.mode == 0 ? launch<0, true, false>(d, vflags, s) : (d.mode == 1 ? launch<1, true, false>(d, vflags, s) : launch<2, true, false>(d, vflags, s));
     } else {
         rc = d.mode == 0 ? launch<0, false>(d, vflags, s) : (d.mode == 1 ? launch<1, false>(d, vflags, s) : launch<2, false>(d, vflags, s));
     }

@@ -387,9 +387,16 @@ int launch256(const MudgGemmDesc& d, int vflags, const h16* zp, hipStream_t s) {
 
 // Called by mudg_gemm (gemm.hip) once the descriptor is validated and the large-tile path is selected.
 bool mudg_gemm_fast_ok(const MudgGemmDesc& d);      // gemm.hip
+int mudg_gemm256p_dispatch(const MudgGemmDesc& d, int vflags, hipStream_t s);      // gemm256p.hip
 
 int mudg_gemm256_dispatch(const MudgGemmDesc& d, int vflags, const h16* zpage, hipStream_t s) {
+    // The ping-pong kernel (gemm256p.hip) wins on long K loops without a GEGLU epilogue (3x3 convs at ds2 / ds4:
+    // +8...+12 %) and loses on K <= 3840 and on GEGLU tiles (one workgroup per CU: nothing hides its longer epilogue).
+    // MUDG_GEMM256P=0 keeps the 16-wave kernel everywhere, =2 uses the ping-pong kernel for every FAST problem.
+    static int pingpong = -1;
+    if (pingpong < 0) { const char* e = getenv("MUDG_GEMM256P"); pingpong = e ? atoi(e) : 1; }
     if (mudg_gemm_fast_ok(d)) {
+        if (pingpong == 2 || (pingpong == 1 && d.K >= 5120 && !d.geglu)) return mudg_gemm256p_dispatch(d, vflags, s);
         if (d.mode == 0) return launch256<0, true>(d, vflags, zpage, s);
         if (d.mode == 1) return launch256<1, true>(d, vflags, zpage, s);
         return launch256<2, true>(d, vflags, zpage, s);

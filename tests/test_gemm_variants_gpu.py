@@ -1,0 +1,31 @@
+"""Every contraction-kernel variant through the same kernel parity tests, in child processes (the variant switches are
+read once per process): the 16-wave and the ping-pong 256x256 kernels forced on every shape with M, N >= 256, the generic
+64-bit-address path of all kernels with the buffer-descriptor (FAST) path disabled, and the single-buffer short-K kernel
+forced on every FAST plain GEMM."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SELECT = "gemm or conv or tconv or resblock or transformer or geglu"
+
+
+@pytest.mark.parametrize("env", [
+    {"MUDG_GEMM256": "1", "MUDG_GEMM256P": "2"},
+    {"MUDG_GEMM256": "1", "MUDG_GEMM256P": "0"},
+    {"MUDG_GEMM256": "0"},
+    {"MUDG_GEMM_FAST": "0"},
+    {"MUDG_GEMM_FAST": "0", "MUDG_GEMM256": "1"},
+    {"MUDG_GEMM_SB": "2", "MUDG_GEMM256": "0"},
+], ids=lambda e: ",".join(f"{k[5:]}={v}" for k, v in e.items()))
+def test_kernel_parity_under_variant(cuda, env):
+    if any(k in os.environ for k in ("MUDG_GEMM256", "MUDG_GEMM256P", "MUDG_GEMM_FAST", "MUDG_GEMM_SB")):
+        pytest.skip("already running under a variant switch")
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_kernels_gpu.py", "tests/test_unet_gpu.py", "-m", "gpu",
+                        "-q", "-k", SELECT, "-p", "no:cacheprovider"],
+                       cwd=ROOT, env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+    print("\n".join(l for l in r.stdout.splitlines() if "passed" in l or "failed" in l))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
