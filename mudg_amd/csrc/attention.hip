@@ -12,7 +12,11 @@
 //   are filled with plain 16-byte row copies.
 //   K/V tiles (64 keys) are staged global -> registers -> LDS with two LDS buffers and one barrier per tile.
 //   (Tried: running the K stream one tile ahead so the score MFMAs of tile t+1 could overlap the softmax of tile t —
-//   763 -> 634 TFLOP/s at N = 9216: +26 VGPRs and 32 extra register moves per tile, no interleave by hipcc.)
+//   763 -> 634 TFLOP/s at N = 9216: +26 VGPRs and 32 extra register moves per tile, no interleave by hipcc.
+//   Also measured, same box, N = 9216, all within +-0.5 % of the baseline or worse: row sums through the matrix pipe
+//   (ones x P, -3.5 %), a constant zero accumulator instead of the per-tile zero fill, v_max3_f32 for the row max, and an
+//   8-byte stagger of V^T rows 16-31 that removes the 2-way bank conflict of the ds_read_b64 fragment reads: the kernel
+//   is bound by the S -> softmax -> PV dependency chain of each wave, not by VALU or LDS issue.)
 //   Workgroups are numbered so that the query tiles of one (frame, head) run on one XCD and share its L2.
 //
 // mudg_temporal_attention: T <= 32 keys per pixel — a bandwidth problem.  One wave per (pixel, head), fp32 VALU

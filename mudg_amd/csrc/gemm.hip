@@ -244,7 +244,11 @@ __global__ __launch_bounds__(256, SB ? 4 : 2) void gemm_kernel(const MudgGemmDes
 
     const int nk = (p.K + BK - 1) / BK;
     const int sw = (l31 >> 1) & 7;       // read-side swizzle: the row bases are multiples of 32, so only lane bits count
+    // A wave whose 64 output columns (or rows) all lie beyond N (M) has nothing to multiply: it still stages its share
+    // of the operand tiles but leaves its SIMD's MFMA pipe to the other resident workgroups (N = 320: 1/6 of the waves).
+    const bool wave_live = (n0 + wn * 64 < p.N) && (m0 + wm * 64 < p.M);
     auto multiply = [&](int cur) {
+        if (!wave_live) return;
         const h16* xs = Xs + cur * TILE + (wm * 64 + l31) * LDSLD;
         const h16* ws = Ws + cur * TILE + (wn * 64 + l31) * LDSLD;
 #pragma unroll

@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ X, 
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             float y = fmaf(xv[e], sc[c0 + e], sh[c0 + e]);
-            if (silu) y = silu_f(y);
+            if (silu) y = y * __builtin_amdgcn_rcpf(1.0f + __expf(-y));      // 1-ulp reciprocal: the result is rounded to h16
             o[e] = (h16)y;
         }
         st16(Y + (srow + r) * ldy + c0, as_u32x4(o));
