@@ -80,7 +80,17 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const MudgGemmDesc p, 
         const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
         tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
     }
-    const int tm = tile / ntn, tn = tile - tm * ntn;
+    // Tile order inside the XCD's range: groups of 8 tile rows, column by column, so that the ~64 tiles an XCD runs at
+    // once form an 8 x 8 patch (16 operand panels through its L2) instead of one 1 x 64 strip (65 panels) when N is wide.
+    int tm, tn;
+    {
+        const int ntm = (p.M + 256 - 1) / 256;
+        const int per = 8 * ntn, g = tile / per, first = g * 8;
+        const int gsz = (ntm - first) < 8 ? (ntm - first) : 8;
+        const int r = tile - g * per;
+        tn = r / gsz;
+        tm = first + (r - tn * gsz);
+    }
     const int m0 = tm * 256, n0 = tn * 256;
     const int64_t bz = blockIdx.z;
     const h16* X = reinterpret_cast<const h16*>(p.X) + bz * p.sX;

@@ -1,5 +1,5 @@
-cd /tmp && export TMPDIR=/tmp
-cd $GRAFT_REPO_ROOT
-python tools/exp_gn.py 2>&1 | grep -v amdgpu.ids
-rocprofv3 --kernel-trace --stats -d /tmp/p1 -- python tools/exp_gn.py > /tmp/p1.log 2>&1
-python tools/rocprof_summary.py trace $(find /tmp/p1 -name "*.db" | head -1) | grep "gn_\|ln_" | cut -c1-60,100-170
+TAG=auto python tools/exp_tiles.py 2>&1 | grep -v amdgpu.ids | grep gemm
+MUDG_GEMM256=0 python tools/exp_sq.py 2>&1 | grep -v amdgpu.ids
+MUDG_GEMM256=1 python tools/exp_sq.py 2>&1 | grep -v amdgpu.ids
+MUDG_GEMM256=1 MUDG_GEMM256P=2 python tools/exp_sq.py 2>&1 | grep -v amdgpu.ids
+python -m pytest tests/test_kernels_gpu.py -x -q -m gpu 2>&1 | tail -2
