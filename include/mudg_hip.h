@@ -88,6 +88,10 @@ typedef struct MudgGemmDesc {
                              hit L2 instead of coming back after a whole sweep over Cin */
     /* mode 2 */
     int T, HW;
+    float* stats;         /* NULL, or fp32 [ceil(M/128)][Nout][2]: the epilogue also writes, per 128-row block and output
+                             channel, the sum and the sum of squares of the values it stored (as stored: after rounding to
+                             bf16 when Y is bf16) — the first pass of the GroupNorm that consumes Y
+                             (mudg_groupnorm_fused).  Needs batch == 1 and no GEGLU. */
 } MudgGemmDesc;
 int mudg_gemm(const MudgGemmDesc* d, void* stream);
 
@@ -131,6 +135,13 @@ int mudg_groupnorm(const void* X, const void* X2, int csplit, int ldx, int ldx2,
                    int samples, int rows, int C, int groups, float eps, int silu,
                    float* ws, void* stream);
 /* x_fp32: X (and X2) hold fp32 instead of bf16; Y is always bf16 (it feeds an MFMA GEMM). */
+/* Same normalisation with the statistics pass replaced by the per-(128-row block, channel) partial sums the producing
+ * GEMM / conv wrote (MudgGemmDesc.stats): P1 covers X's csplit channels, P2 (NULL without X2) X2's C - csplit.
+ * Needs rows % 128 == 0 (a row block never straddles two samples).  ws: fp32 scratch of 2 * samples * groups floats. */
+int mudg_groupnorm_fused(const void* X, const void* X2, int csplit, int ldx, int ldx2, int x_fp32,
+                         const float* gamma, const float* beta, void* Y, int ldy,
+                         int samples, int rows, int C, int groups, float eps, int silu,
+                         const float* P1, const float* P2, float* ws, void* stream);
 
 /* LayerNorm over the last dim (attention.py:363-365, eps 1e-5). */
 int mudg_layernorm(const void* X, int ldx, int x_fp32, const float* gamma, const float* beta,

@@ -196,9 +196,15 @@ __global__ __launch_bounds__(256, SB ? 4 : 2) void gemm_kernel(const MudgGemmDes
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(Ws + buf * TILE + (32 * wave + 8 * i) * LDSLD), 16,
                                                      (int)vw[i], soffw, 0, 0);
         }
-        if (MODE == 0) c_s += BK;
-        else if (MODE == 1 && p.korder) { if (++tap_s == 9) { tap_s = 0; c_s += BK; } }
-        else { c_s += BK; if (c_s == p.Cin) { c_s = 0; ++tap_s; } }
+        if (MODE == 0) {
+            c_s += BK;
+        } else {                                   // select form: the branchy update sent tap_s / c_s to scratch memory
+            const int t1 = tap_s + 1, c1 = c_s + BK;
+            const bool slab = MODE == 1 && p.korder;
+            const bool wrap = slab ? (t1 == 9) : (c1 == p.Cin);
+            tap_s = slab ? (wrap ? 0 : t1) : (wrap ? t1 : tap_s);
+            c_s = slab ? (wrap ? c1 : c_s) : (wrap ? 0 : c1);
+        }
     };
 
     auto issue_tiles = [&](int kt, int buf) {
@@ -308,6 +314,9 @@ __global__ __launch_bounds__(256, SB ? 4 : 2) void gemm_kernel(const MudgGemmDes
     const int cpr = NT / 8;
     const h16* R = (p.R && !p.res_fp32) ? reinterpret_cast<const h16*>(p.R) + bz * p.sR : nullptr;
     const float* Rf = (p.R && p.res_fp32) ? reinterpret_cast<const float*>(p.R) + bz * p.sR : nullptr;
+    float gs[8], gq[8];            // GroupNorm partials of this thread's 8 output channels (p.stats)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { gs[j] = 0.f; gq[j] = 0.f; }
 #pragma unroll
     for (int pass = 0; pass < NPASS; ++pass) {
     if (NPASS == 1 || wm == pass) {
@@ -386,6 +395,13 @@ __global__ __launch_bounds__(256, SB ? 4 : 2) void gemm_kernel(const MudgGemmDes
                 for (int j = 0; j < 8; ++j) if (j < nvalid) v[j] += rp[j];
             }
         }
+        if (p.stats) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float t = (j < nvalid) ? (p.out_fp32 ? v[j] : (float)(h16)v[j]) : 0.f;
+                gs[j] += t; gq[j] = fmaf(t, t, gq[j]);
+            }
+        }
         if (p.out_fp32) {
             float* yp = reinterpret_cast<float*>(p.Y) + bz * p.sY + (int64_t)m * p.ldy + n;
             if (nvalid == 8 && (vflags & VF_Y)) {
@@ -412,6 +428,21 @@ __global__ __launch_bounds__(256, SB ? 4 : 2) void gemm_kernel(const MudgGemmDes
         }
     }
     if (NPASS > 1) __syncthreads();
+    }
+    if (p.stats) {
+        // thread t always handled channel chunk t % cpr: fold the 256 / cpr threads of a chunk in a fixed order
+        if (NPASS == 1) __syncthreads();
+        float* red = stg;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { red[tid * 17 + j] = gs[j]; red[tid * 17 + 8 + j] = gq[j]; }
+        __syncthreads();
+        if (tid < cpr * 16) {
+            const int cc = tid >> 4, j = tid & 15;
+            float t = 0.f;
+            for (int k = cc; k < 256; k += cpr) t += red[k * 17 + j];
+            const int n = nout0 + cc * 8 + (j & 7);
+            if (n < Nout) p.stats[((int64_t)(m0 / BM) * Nout + n) * 2 + (j >> 3)] = t;
+        }
     }
 }
 
@@ -538,6 +569,7 @@ extern "C" int mudg_gemm(const MudgGemmDesc* dp, void* stream) {
     }
     if (d.geglu) MUDG_REQUIRE((d.N & 63) == 0, "mudg_gemm: geglu needs N %% 64 == 0");
     if (d.gbias) MUDG_REQUIRE(d.rows_per_group > 0 && d.batch == 1, "mudg_gemm: gbias needs rows_per_group");
+    if (d.stats) MUDG_REQUIRE(d.batch == 1 && !d.geglu, "mudg_gemm: stats needs batch == 1 and no GEGLU");
     if (d.alpha == 0.f) d.alpha = 1.f;
     int vflags = 0;
     const int ybytes = d.out_fp32 ? 4 : 2;
@@ -549,17 +581,23 @@ extern "C" int mudg_gemm(const MudgGemmDesc* dp, void* stream) {
     const int fam = d.mode == 0 ? MUDG_FAM_GEMM : (d.mode == 1 ? MUDG_FAM_CONV : MUDG_FAM_TCONV);
     const int slot = mudg_prof_begin(fam, s);
     int rc;
+    // GroupNorm partials (d.stats) are written by the 128x128 kernels and the ping-pong kernel; the 16-wave 256x256
+    // kernel has no registers left for them (1024 threads -> 128 VGPRs) and declines such problems (returns 1).
+    rc = 1;
     if (use_gemm256(d)) {
         const h16* zp = zero_page();
         if (!zp) MUDG_FAIL(MUDG_ELAUNCH, "gemm: could not allocate the zero page");
         rc = mudg_gemm256_dispatch(d, vflags, zp, s);
-    } else if (mudg_gemm_fast_ok(d)) {
-        if (use_single_buffer(d))
-            rc = d.mode == 0 ? launch<0, true, true>(d, vflags, s) : (d.mode == 1 ? launch<1, true, true>(d, vflags, s) : launch<2, true, true>(d, vflags, s));
-        else
-            rc = d.mode == 0 ? launch<0, true, false>(d, vflags, s) : (d.mode == 1 ? launch<1, true, false>(d, vflags, s) : launch<2, true, false>(d, vflags, s));
-    } else {
-        rc = d.mode == 0 ? launch<0, false>(d, vflags, s) : (d.mode == 1 ? launch<1, false>(d, vflags, s) : launch<2, false>(d, vflags, s));
+    }
+    if (rc == 1) {
+        if (mudg_gemm_fast_ok(d)) {
+            if (use_single_buffer(d))
+                rc = d.mode == 0 ? launch<0, true, true>(d, vflags, s) : (d.mode == 1 ? launch<1, true, true>(d, vflags, s) : launch<2, true, true>(d, vflags, s));
+            else
+                rc = d.mode == 0 ? launch<0, true, false>(d, vflags, s) : (d.mode == 1 ? launch<1, true, false>(d, vflags, s) : launch<2, true, false>(d, vflags, s));
+        } else {
+            rc = d.mode == 0 ? launch<0, false>(d, vflags, s) : (d.mode == 1 ? launch<1, false>(d, vflags, s) : launch<2, false>(d, vflags, s));
+        }
     }
     const double flops = 2.0 * d.M * (double)d.N * d.K * d.batch;
     const double bytes = ((double)d.M * cin + (double)d.N * d.K + (double)d.M * (d.geglu ? d.N / 2 : d.N)) * 2.0 * d.batch;

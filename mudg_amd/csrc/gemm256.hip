@@ -182,9 +182,15 @@ __global__ __launch_bounds__(1024, 4) void gemm256_kernel(const MudgGemmDesc p, 
             else __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, lx, 16, (int)v, soff, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(wdst + (16 * wave + 8 * i) * 64), 16, (int)vw[i], soffw, 0, 0);
         }
-        if (MODE == 0) c_s += BK;
-        else if (MODE == 1 && p.korder) { if (++tap_s == 9) { tap_s = 0; c_s += BK; } }
-        else { c_s += BK; if (c_s == p.Cin) { c_s = 0; ++tap_s; } }
+        if (MODE == 0) {
+            c_s += BK;
+        } else {                                   // select form: the branchy update sent tap_s / c_s to scratch memory
+            const int t1 = tap_s + 1, c1 = c_s + BK;
+            const bool slab = MODE == 1 && p.korder;
+            const bool wrap = slab ? (t1 == 9) : (c1 == p.Cin);
+            tap_s = slab ? (wrap ? 0 : t1) : (wrap ? t1 : tap_s);
+            c_s = slab ? (wrap ? c1 : c_s) : (wrap ? 0 : c1);
+        }
     };
 
     auto issue_tiles = [&](int kt) {
@@ -407,6 +413,9 @@ int mudg_gemm256_dispatch(const MudgGemmDesc& d, int vflags, const h16* zpage, h
     if (pingpong < 0) { const char* e = getenv("MUDG_GEMM256P"); pingpong = e ? atoi(e) : 1; }
     if (mudg_gemm_fast_ok(d)) {
         if (pingpong == 2 || (pingpong == 1 && d.K >= 5120 && !d.geglu)) return mudg_gemm256p_dispatch(d, vflags, s);
+    }
+    if (d.stats) return 1;                   // declined: the 16-wave kernel does not write GroupNorm partials (see mudg_gemm)
+    if (mudg_gemm_fast_ok(d)) {
         if (d.mode == 0) return launch256<0, true>(d, vflags, zpage, s);
         if (d.mode == 1) return launch256<1, true>(d, vflags, zpage, s);
         return launch256<2, true>(d, vflags, zpage, s);

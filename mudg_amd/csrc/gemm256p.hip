@@ -331,6 +331,9 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const MudgGemmDesc p, 
             const int NT = p.geglu ? 64 : 128;
             const int nout0 = p.geglu ? nq / 2 : nq;
             const int cpr = NT / 8;
+            float gs[8], gq[8];        // GroupNorm partials of this thread's 8 output channels (p.stats)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { gs[j] = 0.f; gq[j] = 0.f; }
             for (int c = tid; c < 128 * cpr; c += 512) {
                 const int row = c / cpr, cc = c - row * cpr;
                 const int m = mq + row, n = nout0 + cc * 8;
@@ -376,6 +379,13 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const MudgGemmDesc p, 
                         for (int j = 0; j < 8; ++j) if (j < nvalid) v[j] += rp[j];
                     }
                 }
+                if (p.stats) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float t = (j < nvalid) ? (p.out_fp32 ? v[j] : (float)(h16)v[j]) : 0.f;
+                        gs[j] += t; gq[j] = fmaf(t, t, gq[j]);
+                    }
+                }
                 if (p.out_fp32) {
                     float* yp = reinterpret_cast<float*>(p.Y) + bz * p.sY + (int64_t)m * p.ldy + n;
                     if (nvalid == 8 && (vflags & VF_Y)) {
@@ -402,6 +412,20 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const MudgGemmDesc p, 
                 }
             }
             __syncthreads();
+            if (p.stats) {         // fold the 512 / cpr threads of each channel chunk in a fixed order (staging tile is free)
+                float* red = stg;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { red[tid * 17 + j] = gs[j]; red[tid * 17 + 8 + j] = gq[j]; }
+                __syncthreads();
+                if (tid < cpr * 16) {
+                    const int cc = tid >> 4, j = tid & 15;
+                    float t = 0.f;
+                    for (int k = cc; k < 512; k += cpr) t += red[k * 17 + j];
+                    const int n = nout0 + cc * 8 + (j & 7);
+                    if (n < Nout && mq < p.M) p.stats[((int64_t)(mq / 128) * Nout + n) * 2 + (j >> 3)] = t;
+                }
+                __syncthreads();
+            }
         }
 }
 

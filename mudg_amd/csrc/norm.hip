@@ -109,6 +109,35 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
     }
 }
 
+// Pass 2': the same fold over the per-(128-row block, channel) partials a producing GEMM / conv epilogue wrote
+// (MudgGemmDesc.stats): one wave per (sample, group), lanes stride over the sample's row blocks, every lane walks the
+// group's channels (which may straddle the two sources), fp64, fixed butterfly.
+__global__ __launch_bounds__(256) void gn_finalize_ch_kernel(const float* __restrict__ P1, const float* __restrict__ P2,
+                                                              int csplit, int C, float* __restrict__ stat, int samples,
+                                                              int groups, int blocks_per_sample, double count, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= samples * groups) return;
+    const int smp = i / groups, g = i - smp * groups;
+    const int cpg = C / groups, c0 = g * cpg;
+    double a = 0.0, b = 0.0;
+    for (int rb = lane; rb < blocks_per_sample; rb += 64) {
+        const int64_t blk = (int64_t)smp * blocks_per_sample + rb;
+        for (int c = c0; c < c0 + cpg; ++c) {
+            const float* q = (c < csplit) ? P1 + (blk * csplit + c) * 2 : P2 + (blk * (C - csplit) + (c - csplit)) * 2;
+            a += (double)q[0]; b += (double)q[1];
+        }
+    }
+    a = wave_sum_d(a); b = wave_sum_d(b);
+    if (lane == 0) {
+        const double mean = a / count;
+        double var = b / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        stat[i * 2] = (float)mean;
+        stat[i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+
 // Pass 3: y = (x - mean) * rstd * gamma + beta, optional SiLU.
 template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ X, const T* __restrict__ X2,
@@ -270,6 +299,36 @@ extern "C" int mudg_groupnorm(const void* X, const void* X2, int csplit, int ldx
                            csplit, ldx, ldx2, gamma, beta, (h16*)Y, ldy, rows, C, groups, nblk, silu, stat);
     const int rc = mudg_check_launch("mudg_groupnorm");
     mudg_prof_end(slot, s, 0.0, (double)samples * rows * C * (x_fp32 ? 10.0 : 6.0));
+    return rc;
+}
+
+extern "C" int mudg_groupnorm_fused(const void* X, const void* X2, int csplit, int ldx, int ldx2, int x_fp32,
+                                    const float* gamma, const float* beta, void* Y, int ldy, int samples, int rows, int C,
+                                    int groups, float eps, int silu, const float* P1, const float* P2, float* ws, void* stream) {
+    MUDG_REQUIRE(X && Y && gamma && beta && ws && P1, "mudg_groupnorm_fused: null pointer");
+    MUDG_REQUIRE(samples > 0 && rows > 0 && C > 0 && groups > 0, "mudg_groupnorm_fused: empty problem");
+    MUDG_REQUIRE(C % groups == 0 && (C & 7) == 0 && C <= GN_CMAX && groups <= 256, "mudg_groupnorm_fused: C=%d groups=%d unsupported", C, groups);
+    MUDG_REQUIRE(rows % 128 == 0, "mudg_groupnorm_fused: rows=%d per sample must be a multiple of the 128-row partial blocks", rows);
+    const int xq = x_fp32 ? 3 : 7;
+    MUDG_REQUIRE((ldx & xq) == 0 && (ldy & 7) == 0 && aligned16(X) && aligned16(Y), "mudg_groupnorm_fused: alignment");
+    MUDG_REQUIRE(samples <= 65535, "mudg_groupnorm_fused: too many samples");
+    if (!X2) { csplit = C; ldx2 = ldx; P2 = P1; }
+    else MUDG_REQUIRE(P2 && csplit > 0 && csplit < C && (csplit & 7) == 0 && (ldx2 & xq) == 0 && aligned16(X2), "mudg_groupnorm_fused: X2/csplit/P2");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    float* stat = ws;
+    const int slot = mudg_prof_begin(MUDG_FAM_GNORM, s);
+    const int ng = samples * groups;
+    hipLaunchKernelGGL(gn_finalize_ch_kernel, dim3((ng + 3) / 4), dim3(256), 0, s, P1, P2, csplit, C, stat, samples, groups,
+                       rows / 128, (double)rows * (C / groups), eps);
+    const int nblk = gn_chunks(samples, rows);
+    if (x_fp32)
+        hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(nblk, samples), dim3(256), 0, s, (const float*)X, (const float*)X2,
+                           csplit, ldx, ldx2, gamma, beta, (h16*)Y, ldy, rows, C, groups, nblk, silu, stat);
+    else
+        hipLaunchKernelGGL(gn_apply_kernel<h16>, dim3(nblk, samples), dim3(256), 0, s, (const h16*)X, (const h16*)X2,
+                           csplit, ldx, ldx2, gamma, beta, (h16*)Y, ldy, rows, C, groups, nblk, silu, stat);
+    const int rc = mudg_check_launch("mudg_groupnorm_fused");
+    mudg_prof_end(slot, s, 0.0, (double)samples * rows * C * (x_fp32 ? 6.0 : 4.0));
     return rc;
 }
 

@@ -39,17 +39,19 @@ def _ln(mod, x):
     return ops.layernorm(x, pk.f32(mod, "weight"), pk.f32(mod, "bias"), eps=mod.eps)
 
 
-def _linear(mod, x, residual=None, x2=None, stream=False):
-    """stream=True: the result is a residual-stream tensor and is written in fp32 (see module docstring)."""
-    return ops.gemm(x, pk.linear(mod), bias=pk.f32(mod, "bias"), residual=residual, x2=x2, out_fp32=stream)
+def _linear(mod, x, residual=None, x2=None, stream=False, stats=False):
+    """stream=True: the result is a residual-stream tensor and is written in fp32 (see module docstring).
+    stats=True: the result feeds a GroupNorm next — the epilogue also writes that norm's partial sums."""
+    return ops.gemm(x, pk.linear(mod), bias=pk.f32(mod, "bias"), residual=residual, x2=x2, out_fp32=stream, stats=stats)
 
 
 def _conv3x3(mod, x, frames, h, w, *, stride=1, upsample=False, gbias=None, rows_per_group=0, residual=None, x2=None,
-             stream=False):
+             stream=False, stats=True):
+    """Every 3x3 conv of the UNet is followed by a GroupNorm (the next block's, or out_layers'): stats defaults on."""
     wmat, cpad, korder = pk.conv3x3(mod)
     return ops.conv3x3(x, wmat, frames=frames, hin=h, win=w, cin=cpad, stride=stride, upsample=upsample,
                        bias=pk.f32(mod, "bias"), gbias=gbias, rows_per_group=rows_per_group, residual=residual, x2=x2,
-                       out_fp32=stream, korder=korder)
+                       out_fp32=stream, korder=korder, stats=stats)
 
 
 def _vt_projection(mod, src_rows, batches, n_per_batch):
@@ -78,7 +80,7 @@ def temporal_conv_block(mod, x, ctx, hw):
         y = _gn(norm, y, None, ctx.B, ctx.T * hw, True)
         last = i == len(stages) - 1
         y = ops.tconv3(y, pk.tconv(conv), clips=ctx.B, t=ctx.T, hw=hw, cin=conv.weight.shape[1],
-                       bias=pk.f32(conv, "bias"), residual=x if last else None, out_fp32=last)
+                       bias=pk.f32(conv, "bias"), residual=x if last else None, out_fp32=last, stats=True)
     return y
 
 
@@ -150,7 +152,7 @@ def spatial_transformer(mod, x, h, w, ctx):
     n = len(mod.transformer_blocks)
     for i, blk in enumerate(mod.transformer_blocks):
         cur = spatial_block(blk, cur, frames, hw, ctx, i == n - 1)
-    return _linear(mod.proj_out, cur, residual=x, stream=True)
+    return _linear(mod.proj_out, cur, residual=x, stream=True, stats=True)
 
 
 def temporal_block(blk, hcur, hw, ctx, last):
@@ -169,7 +171,7 @@ def temporal_transformer(mod, x, h, w, ctx):
     n = len(mod.transformer_blocks)
     for i, blk in enumerate(mod.transformer_blocks):
         cur = temporal_block(blk, cur, hw, ctx, i == n - 1)
-    return _linear(mod.proj_out, cur, residual=x, stream=True)
+    return _linear(mod.proj_out, cur, residual=x, stream=True, stats=True)
 
 
 def run_stage(seq, x, x2, h, w, ctx):
@@ -187,7 +189,8 @@ def run_stage(seq, x, x2, h, w, ctx):
             x = _conv3x3(m.op, ops.cast_bf16(x), frames, h, w, stride=2, stream=True)
             h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1
         elif name == "Upsample":
-            x = _conv3x3(m.conv, ops.cast_bf16(x), frames, h, w, upsample=True, stream=True)
+            # nearest-2x convs run on the 16-wave 256x256 kernel, which does not emit GroupNorm partials
+            x = _conv3x3(m.conv, ops.cast_bf16(x), frames, h, w, upsample=True, stream=True, stats=False)
             h, w = 2 * h, 2 * w
         elif isinstance(m, nn.Conv2d):                      # the stem (possibly swapped in by training-time surgery)
             x = _conv3x3(m, x, frames, h, w, stream=True)

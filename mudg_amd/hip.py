@@ -58,6 +58,7 @@ class GemmDesc(C.Structure):
         ("Hin", C.c_int), ("Win", C.c_int), ("Hout", C.c_int), ("Wout", C.c_int),
         ("Cin", C.c_int), ("stride", C.c_int), ("upsample", C.c_int), ("pad", C.c_int), ("korder", C.c_int),
         ("T", C.c_int), ("HW", C.c_int),
+        ("stats", C.c_void_p),
     ]
 
 
@@ -81,6 +82,7 @@ SIGNATURES = {
     "mudg_temporal_attention": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _F, _P]),
     "mudg_groupnorm_ws_floats": (_L, [_I, _I, _I]),
     "mudg_groupnorm": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P, _P]),
+    "mudg_groupnorm_fused": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P, _P, _P, _P]),
     "mudg_layernorm": (_I, [_P, _I, _I, _P, _P, _P, _I, _I, _I, _F, _P]),
     "mudg_softmax_rows": (_I, [_P, _I, _P, _I, _I, _I, _P]),
     "mudg_timestep_embedding": (_I, [_P, _P, _P, _I, _I, _P]),

@@ -43,8 +43,19 @@ def empty_rows(rows: int, cols: int, dtype=None, device=None) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------------------------------------ GEMM family
+GN_ATTR = "_mudg_gn_partials"      # python attribute a producer leaves on its output: fp32 [ceil(M/128)][N][2] partial sums
+
+
+def _attach_stats(d, out, M, nout):
+    """Ask the epilogue for GroupNorm partials of `out` (MudgGemmDesc.stats) and hang them on the tensor."""
+    ws = torch.empty(((M + 127) // 128, nout, 2), dtype=torch.float32, device=out.device)
+    d.stats = ws.data_ptr()
+    setattr(out, GN_ATTR, ws)
+
+
 def gemm(x, w, *, out=None, bias=None, gbias=None, rows_per_group=0, residual=None, x2=None, geglu=False,
-         out_fp32=False, alpha=1.0, batch=1, sx=0, sw=0, sy=0, sr=0, M=None, N=None, K=None, ldy=None, gelu=False):
+         out_fp32=False, alpha=1.0, batch=1, sx=0, sw=0, sy=0, sr=0, M=None, N=None, K=None, ldy=None, gelu=False,
+         stats=False):
     """out[m, n] = epilogue(alpha * sum_k x[m, k] w[n, k]); see MudgGemmDesc."""
     _rows(x); _rows(w)
     if M is None:
@@ -69,12 +80,14 @@ def gemm(x, w, *, out=None, bias=None, gbias=None, rows_per_group=0, residual=No
     d.rows_per_group, d.out_fp32, d.geglu, d.alpha, d.mode = rows_per_group, int(out_fp32), int(geglu), alpha, 0
     d.res_fp32 = int(residual is not None and residual.dtype == torch.float32)
     d.act = int(gelu)
+    if stats:
+        _attach_stats(d, out, M, nout)
     hip.check(hip.lib().mudg_gemm(C.byref(d), _stream()), "mudg_gemm")
     return out
 
 
 def conv3x3(x, w, *, frames, hin, win, cin, stride=1, upsample=False, out=None, bias=None, gbias=None,
-            rows_per_group=0, residual=None, x2=None, out_fp32=False, korder=0, pad=1):
+            rows_per_group=0, residual=None, x2=None, out_fp32=False, korder=0, pad=1, stats=False):
     """3x3 / pad 1 convolution on channels-last rows; w is packed [Cout][9*cin], K axis tap-major (korder 0) or
     64-channel-slab-major (korder 1, see MudgGemmDesc.korder)."""
     _rows(x); _rows(w)
@@ -100,11 +113,13 @@ def conv3x3(x, w, *, frames, hin, win, cin, stride=1, upsample=False, out=None, 
     d.batch, d.rows_per_group, d.alpha, d.mode = 1, rows_per_group, 1.0, 1
     d.Hin, d.Win, d.Hout, d.Wout, d.Cin, d.stride, d.upsample = hin, win, hout, wout, cin, stride, int(upsample)
     d.korder, d.pad = korder, pad
+    if stats:
+        _attach_stats(d, out, M, N)
     hip.check(hip.lib().mudg_gemm(C.byref(d), _stream()), "mudg_gemm[conv3x3]")
     return out
 
 
-def tconv3(x, w, *, clips, t, hw, cin, out=None, bias=None, residual=None, out_fp32=False):
+def tconv3(x, w, *, clips, t, hw, cin, out=None, bias=None, residual=None, out_fp32=False, stats=False):
     """(3,1,1) temporal convolution, pad (1,0,0), on rows ordered ((b t) hw); w packed [Cout][3*cin]."""
     _rows(x); _rows(w)
     M, N = clips * t * hw, w.shape[0]
@@ -120,6 +135,8 @@ def tconv3(x, w, *, clips, t, hw, cin, out=None, bias=None, residual=None, out_f
     d.ldr = residual.stride(0) if residual is not None else 0
     d.csplit, d.batch, d.alpha, d.mode = cin, 1, 1.0, 2
     d.Cin, d.T, d.HW = cin, t, hw
+    if stats:
+        _attach_stats(d, out, M, N)
     hip.check(hip.lib().mudg_gemm(C.byref(d), _stream()), "mudg_gemm[tconv3]")
     return out
 
@@ -149,13 +166,28 @@ def _rows_any(t):
     return t
 
 
-def groupnorm(x, gamma, beta, *, samples, rows, eps, silu, groups=32, x2=None, out=None):
+def groupnorm(x, gamma, beta, *, samples, rows, eps, silu, groups=32, x2=None, out=None, fused=True):
+    """GroupNorm(+SiLU).  When every source tensor still carries the partial sums its producing GEMM / conv wrote
+    (stats=True there) and a sample is a whole number of 128-row blocks, the statistics pass over x is skipped."""
     _rows_any(x)
     if x2 is not None and x2.dtype != x.dtype:
         raise hip.MudgError("groupnorm: both channel sources must share a dtype")
     c = x.shape[1] + (x2.shape[1] if x2 is not None else 0)
     if out is None:
         out = empty_rows(samples * rows, c, H16(), x.device)
+    p1 = getattr(x, GN_ATTR, None) if fused else None
+    p2 = getattr(x2, GN_ATTR, None) if (fused and x2 is not None) else None
+    ok = p1 is not None and rows % 128 == 0 and p1.shape[1] == x.shape[1] and p1.shape[0] * 128 >= samples * rows
+    if ok and x2 is not None:
+        ok = p2 is not None and p2.shape[1] == x2.shape[1] and p2.shape[0] == p1.shape[0]
+    if ok:
+        ws = torch.empty(2 * samples * groups, dtype=torch.float32, device=x.device)
+        hip.check(hip.lib().mudg_groupnorm_fused(x.data_ptr(), _ptr(x2), x.shape[1], x.stride(0),
+                                                 x2.stride(0) if x2 is not None else 0, int(x.dtype == torch.float32),
+                                                 gamma.data_ptr(), beta.data_ptr(),
+                                                 out.data_ptr(), out.stride(0), samples, rows, c, groups, eps, int(silu),
+                                                 p1.data_ptr(), _ptr(p2), ws.data_ptr(), _stream()), "mudg_groupnorm_fused")
+        return out
     n = hip.lib().mudg_groupnorm_ws_floats(samples, groups, rows)
     ws = torch.empty(n, dtype=torch.float32, device=x.device)
     hip.check(hip.lib().mudg_groupnorm(x.data_ptr(), _ptr(x2), x.shape[1], x.stride(0),

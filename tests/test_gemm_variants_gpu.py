@@ -10,7 +10,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SELECT = "gemm or conv or tconv or resblock or transformer or geglu"
+SELECT = "gemm or conv or tconv or resblock or transformer or geglu or fused"
 
 
 @pytest.mark.parametrize("env", [

@@ -468,3 +468,48 @@ def test_ddim_step_three_way_guidance(cuda):
     got_xp, got_x0 = ops.ddim_step(x.to(cuda), ec.to(cuda), eu.to(cuda), nz.to(cuda),
                                    [cfg, phi, sac, s1m, resc, sap, dirc, sig, cimg], e_m=em.to(cuda))
     assert rel_l2(got_x0, x0) < TOL_F32 and rel_l2(got_xp, xp) < TOL_F32
+
+
+# ---- GroupNorm statistics fused into the producing epilogue (MudgGemmDesc.stats -> mudg_groupnorm_fused)
+@pytest.mark.parametrize("out_fp32", [False, True])
+def test_groupnorm_fused_partials_match_the_two_pass_norm(cuda, out_fp32):
+    from mudg_amd import ops
+    g = torch.Generator().manual_seed(11)
+    frames, h, w, cin, c1, c2 = 6, 16, 16, 64, 320, 64               # rows per frame = 256 = 2 partial blocks
+    x = rnd(frames * h * w, cin, seed=1)
+    w1, w2 = rnd(c1, 9 * cin, seed=2, scale=0.05), rnd(c2, cin, seed=3, scale=0.1)
+    res = torch.randn(frames * h * w, c1, generator=g)
+    a = ops.conv3x3(x.to(cuda), w1.to(cuda), frames=frames, hin=h, win=w, cin=cin, residual=res.to(cuda) if out_fp32 else None,
+                    out_fp32=out_fp32, stats=True)
+    b = ops.gemm(x.to(cuda), w2.to(cuda), out_fp32=out_fp32, stats=True)
+    assert getattr(a, ops.GN_ATTR).shape == (frames * 2, c1, 2) and getattr(b, ops.GN_ATTR).shape == (frames * 2, c2, 2)
+    gam = (1 + 0.1 * torch.randn(c1 + c2, generator=g)).to(cuda)
+    bet = (0.1 * torch.randn(c1 + c2, generator=g)).to(cuda)
+    for samples, rows in ((frames, h * w), (2, 3 * h * w)):          # per-frame and per-clip statistics from the same partials
+        fused = ops.groupnorm(a, gam, bet, samples=samples, rows=rows, eps=1e-5, silu=True, x2=b)
+        plain = ops.groupnorm(a, gam, bet, samples=samples, rows=rows, eps=1e-5, silu=True, x2=b, fused=False)
+        ref = F.silu(F.group_norm(torch.cat([a, b], 1).float().cpu().reshape(samples, rows, -1).transpose(1, 2), 32,
+                                  gam.cpu(), bet.cpu(), 1e-5)).transpose(1, 2).reshape(-1, c1 + c2)
+        assert rel_l2(fused, plain.float().cpu()) < 5e-4                   # bf16 outputs of (nearly) the same statistics
+        assert rel_l2(fused, ref) < TOL_BF16
+    one = ops.groupnorm(a, gam[:c1].contiguous(), bet[:c1].contiguous(), samples=frames, rows=h * w, eps=1e-6, silu=False)
+    one_ref = F.group_norm(a.float().cpu().reshape(frames, h * w, c1).transpose(1, 2), 32, gam[:c1].cpu(), bet[:c1].cpu(), 1e-6)
+    assert rel_l2(one, one_ref.transpose(1, 2).reshape(-1, c1)) < TOL_BF16
+
+
+def test_groupnorm_fused_from_tconv_and_large_tiles(cuda):
+    from mudg_amd import ops
+    clips, t, hw, c = 2, 8, 1024, 256                                   # M = 16384, N = 768: the 256-wide kernels when forced
+    x = rnd(clips * t * hw, c, seed=1)
+    wp = rnd(3 * c, 3 * c, seed=2, scale=0.03)
+    y = ops.tconv3(x.to(cuda), wp.to(cuda), clips=clips, t=t, hw=hw, cin=c, stats=True)
+    gam, bet = torch.ones(3 * c, device=cuda), torch.zeros(3 * c, device=cuda)
+    fused = ops.groupnorm(y, gam, bet, samples=clips, rows=t * hw, eps=1e-5, silu=True)
+    plain = ops.groupnorm(y, gam, bet, samples=clips, rows=t * hw, eps=1e-5, silu=True, fused=False)
+    assert rel_l2(fused, plain.float().cpu()) < 5e-4
+    # a sample that is not a whole number of 128-row blocks takes the two-pass path (rows = 1000 here)
+    part = y[:16000]
+    setattr(part, ops.GN_ATTR, getattr(y, ops.GN_ATTR))
+    odd = ops.groupnorm(part, gam, bet, samples=16, rows=1000, eps=1e-5, silu=False)
+    odd_ref = F.group_norm(part.float().cpu().reshape(16, 1000, 3 * c).transpose(1, 2), 32, None, None, 1e-5)
+    assert rel_l2(odd, odd_ref.transpose(1, 2).reshape(-1, 3 * c)) < TOL_BF16
