@@ -17,6 +17,8 @@
 #include "common.h"
 #include <cstdlib>
 
+bool mudg_gemm_fast_ok(const MudgGemmDesc& d);
+
 namespace {
 
 constexpr int BM = 128, BN = 128, BK = 64;
@@ -474,10 +476,11 @@ int launch(const MudgGemmDesc& d, int vflags, hipStream_t s) {
 }
 
 // Large-tile path (gemm256.hip / gemm256p.hip): 256x256 tiles stage half the bytes per FLOP.  Measured per shape
-// family on MI355X (tools/exp_tiles.py) against the 128x128 kernels: it wins on the 3x3 convs with long K loops (K >= 5760:
-// +10...+30 %, even at N = 320 where 37 % of the second tile column is padding, because padded rows cost no DMA) and
-// marginally on the K >= 1024 GEGLU GEMMs; everywhere else four (or two) 128x128 workgroups per CU are as fast or faster.
-// MUDG_GEMM256=0 disables it, =1 forces it whenever M, N >= 256.
+// family on MI355X (tools/exp_tiles.py) against the 128x128 kernels: once the conv loaders kept their tap state in
+// registers, two or four resident 128x128 workgroups per CU beat both 256x256 kernels on every FAST 3x3 conv of the
+// UNet (1050-1120 vs 920-1070 TFLOP/s) and on the temporal convs; the large tiles remain for the nearest-2x upsample
+// convs (generic address path) and, marginally, the K >= 1024 GEGLU GEMMs.
+// MUDG_GEMM256=0 disables it, =1 forces it whenever M, N >= 256 (MUDG_GEMM256P then picks the kernel, see gemm256.hip).
 bool use_gemm256(const MudgGemmDesc& d) {
     static int mode = -1;
     if (mode < 0) {
@@ -489,14 +492,14 @@ bool use_gemm256(const MudgGemmDesc& d) {
     const int64_t tn = (d.N + 255) / 256, tiles = ((d.M + 255) / 256) * tn * d.batch;
     const double waste = (double)(tn * 256 - d.N) / (double)(tn * 256);
     if (tiles < 128) return false;
-    if (d.mode == 1) return (d.N >= 512 && waste <= 0.2) || d.K >= 5760;
+    if (d.mode == 1) return !mudg_gemm_fast_ok(d) && d.N >= 512 && waste <= 0.2;
     if (d.mode == 2) return false;
     return d.geglu && d.N >= 1024 && waste <= 0.13 && d.K >= 1024;
 }
 
-// Plain GEMMs and temporal convs with at least three tiles per CU go to the single-buffer / 4-workgroups-per-CU variant
-// (see gemm_kernel): measured faster at every K (MDM1024 shapes: +6...+20 %); with few tiles the double-buffered
-// 2-per-CU kernel wins, and the 3x3 convs (tap-strided fetches, longer latency) keep their in-workgroup prefetch.
+// Problems with at least three tiles per CU (eight for the 3x3 convs) go to the single-buffer / 4-workgroups-per-CU
+// variant (see gemm_kernel): measured faster at every K (MDM1024 shapes: +3...+20 %); with fewer tiles the
+// double-buffered 2-per-CU kernel wins.
 // MUDG_GEMM_SB=0 disables it, =2 forces it for every FAST problem.
 bool use_single_buffer(const MudgGemmDesc& d) {
     static int mode = -1;
@@ -507,7 +510,7 @@ bool use_single_buffer(const MudgGemmDesc& d) {
     if (mode == 0) return false;
     if (mode == 2) return true;
     const int64_t tiles = (int64_t)((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN) * d.batch;
-    return d.mode != 1 && tiles >= 768;
+    return tiles >= (d.mode == 1 ? 2048 : 768);
 }
 
 }  // namespace

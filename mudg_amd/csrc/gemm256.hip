@@ -406,9 +406,11 @@ bool mudg_gemm_fast_ok(const MudgGemmDesc& d);      // gemm.hip
 int mudg_gemm256p_dispatch(const MudgGemmDesc& d, int vflags, hipStream_t s);      // gemm256p.hip
 
 int mudg_gemm256_dispatch(const MudgGemmDesc& d, int vflags, const h16* zpage, hipStream_t s) {
-    // The ping-pong kernel (gemm256p.hip) wins on long K loops without a GEGLU epilogue (3x3 convs at ds2 / ds4:
-    // +8...+12 %) and loses on K <= 3840 and on GEGLU tiles (one workgroup per CU: nothing hides its longer epilogue).
-    // MUDG_GEMM256P=0 keeps the 16-wave kernel everywhere, =2 uses the ping-pong kernel for every FAST problem.
+    // The ping-pong kernel (gemm256p.hip) beats the 16-wave kernel on long K loops without a GEGLU epilogue (+8...+12 %
+    // at K >= 5120) and loses on K <= 3840 and on GEGLU tiles (one workgroup per CU: nothing hides its longer epilogue).
+    // With the default selection (mudg_gemm) only GEGLU GEMMs and generic-path convs reach this dispatcher, so the
+    // ping-pong kernel runs when forced: MUDG_GEMM256=1 sends every M, N >= 256 problem here, MUDG_GEMM256P=2 then uses
+    // it for every FAST problem, =0 never.
     static int pingpong = -1;
     if (pingpong < 0) { const char* e = getenv("MUDG_GEMM256P"); pingpong = e ? atoi(e) : 1; }
     if (mudg_gemm_fast_ok(d)) {
