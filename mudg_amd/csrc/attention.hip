@@ -16,7 +16,9 @@
 //   Also measured, same box, N = 9216, all within +-0.5 % of the baseline or worse: row sums through the matrix pipe
 //   (ones x P, -3.5 %), a constant zero accumulator instead of the per-tile zero fill, v_max3_f32 for the row max, and an
 //   8-byte stagger of V^T rows 16-31 that removes the 2-way bank conflict of the ds_read_b64 fragment reads: the kernel
-//   is bound by the S -> softmax -> PV dependency chain of each wave, not by VALU or LDS issue.)
+//   is bound by the S -> softmax -> PV dependency chain of each wave, not by VALU or LDS issue.  Splitting a staged tile
+//   into two 32-key online-softmax steps (so the second half's score MFMAs could run under the first half's softmax)
+//   measured -3 %: hipcc keeps the MFMA and VALU groups apart.)
 //   Workgroups are numbered so that the query tiles of one (frame, head) run on one XCD and share its L2.
 //
 // mudg_temporal_attention: T <= 32 keys per pixel — a bandwidth problem.  One wave per (pixel, head), fp32 VALU
