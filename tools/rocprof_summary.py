@@ -3,6 +3,7 @@
 into the small markdown tables committed under profiles/.
 
   python tools/rocprof_summary.py trace  <results.db>            per-kernel calls / total / avg / min / max / share
+  python tools/rocprof_summary.py mfma   <results.db>            MFMA utilisation per kernel from SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE
   python tools/rocprof_summary.py pmc    <results.db> [scale]    per-kernel sum and per-launch mean of each collected counter
                                                                   (scale multiplies the values, e.g. 2 for FETCH_SIZE on gfx950)
 """
@@ -40,6 +41,27 @@ def pmc(path, scale=1.0, top=25):
         print(f"| `{short(name)}` | {ctr} | {n} | {tot:.4g} | {tot / max(n, 1):.4g} |")
 
 
+def mfma(path, top=16):
+    """MFMA utilisation per kernel = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs): the busy counter
+    sums cycles over all SIMDs, GRBM_GUI_ACTIVE sums the active cycles of the 8 XCDs."""
+    cur = sqlite3.connect(path).cursor()
+    rows = cur.execute("select kernel_name, counter_name, count(*), sum(value) from counters_collection "
+                       "group by kernel_name, counter_name").fetchall()
+    per = {}
+    for name, ctr, n, tot in rows:
+        per.setdefault(name, {})[ctr] = (n, tot or 0.0)
+    print(f"# MFMA utilisation per kernel ({path.split('/')[-1]}): SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs)\n")
+    print("| kernel | launches | MFMA busy cycles (sum) | GRBM_GUI_ACTIVE (sum) | MFMA utilisation |")
+    print("|---|---:|---:|---:|---:|")
+    items = sorted(per.items(), key=lambda kv: -kv[1].get("SQ_VALU_MFMA_BUSY_CYCLES", (0, 0))[1])
+    for name, c in items[:top]:
+        busy = c.get("SQ_VALU_MFMA_BUSY_CYCLES", (0, 0.0))[1]
+        n, act = c.get("GRBM_GUI_ACTIVE", (0, 0.0))
+        if not act:
+            continue
+        print(f"| `{short(name, 60)}` | {n} | {busy:.4g} | {act:.4g} | {100.0 * busy / (act / 8.0 * 1024.0):.1f} % |")
+
+
 def pmc_dispatches(path, flt=""):
     """One row per dispatch with every collected counter as a column (for single-kernel experiments)."""
     con = sqlite3.connect(path)
@@ -65,6 +87,8 @@ if __name__ == "__main__":
     mode, path = sys.argv[1], sys.argv[2]
     if mode == "trace":
         trace(path)
+    elif mode == "mfma":
+        mfma(path)
     elif mode == "pmcd":
         pmc_dispatches(path, sys.argv[3] if len(sys.argv) > 3 else "")
     else:

@@ -15,6 +15,11 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float seed) {
             else if (OP == 1) a[i] = fmaf(a[i], 1.0001f, 0.5f);
             else if (OP == 2) a[i] = fmaxf(fmaxf(a[i], a[(i + 1) & 7]), seed);
             else if (OP == 3) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(*(double*)&a[i & 6]) : "v"(*(double*)&a[(i + 2) & 6]));
+            else if (OP == 4) asm volatile("v_dot2_f32_bf16 %0, %1, %2, %0" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(a[(i + 2) & 7]));
+            else if (OP == 5) asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(a[(i + 2) & 7]));
+            else if (OP == 6) asm volatile("v_dot2_f32_f16 %0, %1, %2, %0" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(a[(i + 2) & 7]));
+            else if (OP == 7) asm volatile("v_rcp_f32 %0, %0" : "+v"(a[i]));
+            else if (OP == 8) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "+v"(a[i]) : "v"(a[(i + 1) & 7]), "v"(a[(i + 2) & 7]));
         }
     }
     float s = 0;
@@ -42,5 +47,7 @@ void run(const char* name, float* out) {
 int main() {
     float* out; hipMalloc(&out, 256 * 8 * 256 * 4);
     run<0>("v_exp_f32", out); run<1>("v_fma_f32", out); run<2>("v_max3_f32", out); run<3>("v_pk_fma_f32", out);
+    run<4>("v_dot2_f32_bf16", out); run<5>("v_dot2c_f32_bf16", out); run<6>("v_dot2_f32_f16", out); run<7>("v_rcp_f32", out);
+    run<8>("v_cvt_pk_bf16_f32", out);
     return 0;
 }
