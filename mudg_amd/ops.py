@@ -51,6 +51,7 @@ def _attach_stats(d, out, M, nout):
     ws = torch.empty(((M + 127) // 128, nout, 2), dtype=torch.float32, device=out.device)
     d.stats = ws.data_ptr()
     setattr(out, GN_ATTR, ws)
+    setattr(out, GN_ATTR + "_version", out._version)      # a later torch in-place op on `out` invalidates the partials
 
 
 def gemm(x, w, *, out=None, bias=None, gbias=None, rows_per_group=0, residual=None, x2=None, geglu=False,
@@ -175,8 +176,12 @@ def groupnorm(x, gamma, beta, *, samples, rows, eps, silu, groups=32, x2=None, o
     c = x.shape[1] + (x2.shape[1] if x2 is not None else 0)
     if out is None:
         out = empty_rows(samples * rows, c, H16(), x.device)
-    p1 = getattr(x, GN_ATTR, None) if fused else None
-    p2 = getattr(x2, GN_ATTR, None) if (fused and x2 is not None) else None
+    def partials(t):
+        ws = getattr(t, GN_ATTR, None)
+        return ws if ws is not None and getattr(t, GN_ATTR + "_version", -1) == t._version else None
+
+    p1 = partials(x) if fused else None
+    p2 = partials(x2) if (fused and x2 is not None) else None
     ok = p1 is not None and rows % 128 == 0 and p1.shape[1] == x.shape[1] and p1.shape[0] * 128 >= samples * rows
     if ok and x2 is not None:
         ok = p2 is not None and p2.shape[1] == x2.shape[1] and p2.shape[0] == p1.shape[0]

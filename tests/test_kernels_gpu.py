@@ -510,6 +510,12 @@ def test_groupnorm_fused_from_tconv_and_large_tiles(cuda):
     # a sample that is not a whole number of 128-row blocks takes the two-pass path (rows = 1000 here)
     part = y[:16000]
     setattr(part, ops.GN_ATTR, getattr(y, ops.GN_ATTR))
+    setattr(part, ops.GN_ATTR + "_version", part._version)
     odd = ops.groupnorm(part, gam, bet, samples=16, rows=1000, eps=1e-5, silu=False)
     odd_ref = F.group_norm(part.float().cpu().reshape(16, 1000, 3 * c).transpose(1, 2), 32, None, None, 1e-5)
     assert rel_l2(odd, odd_ref.transpose(1, 2).reshape(-1, 3 * c)) < TOL_BF16
+    # a torch in-place update after production invalidates the partials: the norm must see the new values
+    y[::2].mul_(3.0)              # every other row: not a per-group affine map, so stale statistics would show
+    upd = ops.groupnorm(y, gam, bet, samples=clips, rows=t * hw, eps=1e-5, silu=False)
+    upd_ref = F.group_norm(y.float().cpu().reshape(clips, t * hw, 3 * c).transpose(1, 2), 32, None, None, 1e-5)
+    assert rel_l2(upd, upd_ref.transpose(1, 2).reshape(-1, 3 * c)) < TOL_BF16
