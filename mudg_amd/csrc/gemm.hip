@@ -16,6 +16,7 @@
 // Workgroups are numbered so that each XCD gets a contiguous run of tiles (neighbouring tiles share operand panels).
 #include "common.h"
 #include <cstdlib>
+#include <cmath>
 
 bool mudg_gemm_fast_ok(const MudgGemmDesc& d);
 
@@ -66,11 +67,33 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const h16* base) {
 // is as long as its K loop, and only other resident workgroups can hide it.  One K-tile buffer instead of two and a
 // two-pass epilogue bring the LDS footprint to 34 KiB, so four workgroups share a CU (16 waves, 4 per SIMD) and overlap
 // each other's fetch / multiply / store phases; inside a workgroup fetch and multiply then alternate.
+// GEGLU's gate: gelu(x) = x Phi(x) with Phi linearly interpolated from a 1025-entry table over [-8, 8] held in LDS
+// (|error| <= h^2/8 max|Phi''| = 7.4e-6 at h = 1/64 — below the h16 rounding of the result by two orders): ten VALU
+// instructions and one ds_read2 instead of the ~21 issue slots of the erf polynomial + v_exp + v_rcp, which made the
+// K = 320 GEGLU tiles VALU-bound (GELU was 21 % of their time).
+constexpr int PHI_N = 1024;
+constexpr int PHI_BYTES = (PHI_N + 4) * 4;
+__device__ __forceinline__ float gelu_lut(float x, const float* __restrict__ T) {
+    float u = fmaf(x, 64.0f, 512.0f);
+    u = __builtin_amdgcn_fmed3f(u, 0.0f, 1023.99f);
+    const int i = (int)u;
+    const float f = u - (float)i;
+    const float a = T[i], b = T[i + 1];
+    return x * fmaf(f, b - a, a);
+}
+
 template <int MODE, bool FAST, bool SB>
-__global__ __launch_bounds__(256, SB ? 4 : 2) void gemm_kernel(const MudgGemmDesc p, const int vflags, const h16* __restrict__ zpage) {
+__global__ __launch_bounds__(256, SB ? 4 : 2) void gemm_kernel(const MudgGemmDesc p, const int vflags, const h16* __restrict__ zpage,
+                                                                const float* __restrict__ phi) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     h16* Xs = reinterpret_cast<h16*>(smem);
     h16* Ws = Xs + (SB ? 1 : 2) * TILE;
+    float* phis = reinterpret_cast<float*>(smem + (SB ? SMEM_BYTES_SB : SMEM_BYTES));     // beyond every other LDS use
+    if (p.geglu && phi) {            // visible after the K loop's barriers
+        const int t4 = threadIdx.x * 4;
+        *reinterpret_cast<f32x4*>(&phis[t4]) = *reinterpret_cast<const f32x4*>(&phi[t4]);
+        if (threadIdx.x == 0) phis[PHI_N] = phi[PHI_N];
+    }
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -349,7 +372,7 @@ __global__ __launch_bounds__(256, SB ? 4 : 2) void gemm_kernel(const MudgGemmDes
                 for (int j = 0; j < 4; ++j) {
                     const float val = alpha * acc[0][mi][4 * g + j] + sbias[nl + j];
                     const float gate = alpha * acc[1][mi][4 * g + j] + sbias[nl + 32 + j];
-                    v[j] = val * gelu_fast(gate);
+                    v[j] = val * (phi ? gelu_lut(gate, phis) : gelu_fast(gate));
                 }
                 *reinterpret_cast<f32x4*>(&stg[ml * STGLD + wn * 32 + 8 * g + 4 * hi]) = v;
             }
@@ -458,6 +481,27 @@ const h16* zero_page() {
     return page;
 }
 
+// Phi(x) = 0.5 erfc(-x / sqrt 2) at x = -8 + i / 64, i = 0..1024, built once on the host in double precision.
+// MUDG_GELU_LUT=0 keeps the erf polynomial (A/B measurements).
+const float* phi_table() {
+    static float* tab = nullptr;
+    static int mode = -1;
+    if (mode < 0) { const char* e = getenv("MUDG_GELU_LUT"); mode = e ? atoi(e) : 1; }
+    if (!mode) return nullptr;
+    if (!tab) {
+        float host[PHI_N + 4];
+        for (int i = 0; i < PHI_N + 4; ++i) {
+            const double x = -8.0 + (double)(i < PHI_N ? i : PHI_N) / 64.0;
+            host[i] = (float)(0.5 * erfc(-x * 0.70710678118654752440));
+        }
+        void* ptr = nullptr;
+        if (hipMalloc(&ptr, sizeof(host)) != hipSuccess || hipMemcpy(ptr, host, sizeof(host), hipMemcpyHostToDevice) != hipSuccess)
+            return nullptr;
+        tab = static_cast<float*>(ptr);
+    }
+    return tab;
+}
+
 template <int MODE, bool FAST, bool SB = false>
 int launch(const MudgGemmDesc& d, int vflags, hipStream_t s) {
     static bool attr_set = false;
@@ -465,21 +509,22 @@ int launch(const MudgGemmDesc& d, int vflags, hipStream_t s) {
     if (!zp) MUDG_FAIL(MUDG_ELAUNCH, "gemm: could not allocate the zero page");
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<MODE, FAST, SB>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, SB ? SMEM_BYTES_SB : SMEM_BYTES);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (SB ? SMEM_BYTES_SB : SMEM_BYTES) + PHI_BYTES);
         if (e != hipSuccess) MUDG_FAIL(MUDG_ELAUNCH, "gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
     const int tiles = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
     dim3 grid(tiles, 1, d.batch);
-    hipLaunchKernelGGL((gemm_kernel<MODE, FAST, SB>), grid, dim3(256), SB ? SMEM_BYTES_SB : SMEM_BYTES, s, d, vflags, zp);
+    const float* phi = d.geglu ? phi_table() : nullptr;
+    hipLaunchKernelGGL((gemm_kernel<MODE, FAST, SB>), grid, dim3(256), (SB ? SMEM_BYTES_SB : SMEM_BYTES) + (phi ? PHI_BYTES : 0), s, d, vflags, zp, phi);
     return mudg_check_launch("mudg_gemm");
 }
 
 // Large-tile path (gemm256.hip / gemm256p.hip): 256x256 tiles stage half the bytes per FLOP.  Measured per shape
 // family on MI355X (tools/exp_tiles.py) against the 128x128 kernels: once the conv loaders kept their tap state in
 // registers, two or four resident 128x128 workgroups per CU beat both 256x256 kernels on every FAST 3x3 conv of the
-// UNet (1050-1120 vs 920-1070 TFLOP/s) and on the temporal convs; the large tiles remain for the nearest-2x upsample
-// convs (generic address path) and, marginally, the K >= 1024 GEGLU GEMMs.
+// UNet (1050-1120 vs 920-1070 TFLOP/s), on the temporal convs and on the plain / GEGLU GEMMs; the large tiles remain for
+// the nearest-2x upsample convs (generic address path).
 // MUDG_GEMM256=0 disables it, =1 forces it whenever M, N >= 256 (MUDG_GEMM256P then picks the kernel, see gemm256.hip).
 bool use_gemm256(const MudgGemmDesc& d) {
     static int mode = -1;
@@ -494,7 +539,7 @@ bool use_gemm256(const MudgGemmDesc& d) {
     if (tiles < 128) return false;
     if (d.mode == 1) return !mudg_gemm_fast_ok(d) && d.N >= 512 && waste <= 0.2;
     if (d.mode == 2) return false;
-    return d.geglu && d.N >= 1024 && waste <= 0.13 && d.K >= 1024;
+    return false;          // plain / GEGLU GEMMs: the 128x128 kernels win everywhere since the table GELU (744 vs 780 TFLOP/s at ds4)
 }
 
 // Problems with at least three tiles per CU (eight for the 3x3 convs) go to the single-buffer / 4-workgroups-per-CU
