@@ -213,8 +213,14 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const MudgAttnDesc p, cons
 
 // ------------------------------------------------------------------------------------------------ temporal
 // TP = padded sequence length (16 or 32); DP = 64 / TP lanes share one query row, each owning DW = 64 / DP dims.
+// A wave walks TATTN_ITEMS consecutive (pixel, head) items and fetches the next item's q / k / v rows before it computes
+// the current one: with one item per wave the ~3 loads per lane were issued, waited for and only then followed by ~800
+// VALU instructions, so most resident waves were computing and too few bytes were in flight (3.1 TB/s).
+// K and V of an item live in a per-wave LDS region: LDS operations of one wave execute in order, so no workgroup barrier.
+constexpr int TATTN_ITEMS = 4;
+
 template <int TP>
-__global__ __launch_bounds__(256) void tattn_kernel(const h16* __restrict__ QKV, h16* __restrict__ O,
+__global__ __launch_bounds__(256, TP == 16 ? 3 : 1) void tattn_kernel(const h16* __restrict__ QKV, h16* __restrict__ O,
                                                      int B, int T, int HW, int heads, int ldqkv, int ldo,
                                                      float scale, int total) {
     constexpr int DP = 64 / TP, DW = 64 / DP;
@@ -223,73 +229,90 @@ __global__ __launch_bounds__(256) void tattn_kernel(const h16* __restrict__ QKV,
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tq = lane / DP, dp = lane % DP;
-    const int w = blockIdx.x * 4 + wave;
-    const bool wok = w < total;
-    const int bp = wok ? w / heads : 0, h = wok ? w - bp * heads : 0;
-    const int b = bp / HW, px = bp - b * HW;
     const int C = heads * 64;
-    const bool rok = wok && tq < T;
+    const int w0 = (blockIdx.x * 4 + wave) * TATTN_ITEMS;
 
-    const int64_t row = ((int64_t)(b * T + tq) * HW + px);
-    const h16* src = QKV + row * ldqkv + h * 64 + dp * DW;
-
-    float qv[DW];
-#pragma unroll
-    for (int i = 0; i < DW / 8; ++i) {
-        const h16x8 t = as_h16x8(rok ? ld16(src + i * 8) : zero16());
-#pragma unroll
-        for (int e = 0; e < 8; ++e) qv[i * 8 + e] = (float)t[e];
-    }
-#pragma unroll
-    for (int i = 0; i < DW / 8; ++i) {
-        st16(&Ks[wave][tq * 64 + dp * DW + i * 8], rok ? ld16(src + C + i * 8) : zero16());
-        st16(&Vs[wave][tq * 64 + dp * DW + i * 8], rok ? ld16(src + 2 * C + i * 8) : zero16());
-    }
-    __syncthreads();
-
-    float sc[TP];
-    float mx = -INFINITY;
-#pragma unroll
-    for (int j = 0; j < TP; ++j) {
-        float a = 0.f;
+    u32x4 qn[DW / 8], kn[DW / 8], vn[DW / 8];        // the item being fetched
+    int64_t rown = 0; int hn = 0; bool okn = false;
+    auto fetch = [&](int w) {
+        okn = w < total && tq < T;
+        const int bp = w < total ? w / heads : 0;
+        hn = w < total ? w - bp * heads : 0;
+        const int b = bp / HW, px = bp - b * HW;
+        rown = ((int64_t)(b * T + tq) * HW + px);
+        const h16* src = QKV + rown * ldqkv + hn * 64 + dp * DW;
 #pragma unroll
         for (int i = 0; i < DW / 8; ++i) {
-            const h16x8 kk = *reinterpret_cast<const h16x8*>(&Ks[wave][j * 64 + dp * DW + i * 8]);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) a = fmaf(qv[i * 8 + e], (float)kk[e], a);
+            qn[i] = okn ? ld16(src + i * 8) : zero16();
+            kn[i] = okn ? ld16(src + C + i * 8) : zero16();
+            vn[i] = okn ? ld16(src + 2 * C + i * 8) : zero16();
         }
-#pragma unroll
-        for (int o = 1; o < DP; o <<= 1) a += __shfl_xor(a, o, 64);
-        a = (j < T) ? a * scale : -INFINITY;
-        sc[j] = a;
-        mx = fmaxf(mx, a);
-    }
-    float sum = 0.f;
-#pragma unroll
-    for (int j = 0; j < TP; ++j) { sc[j] = __expf(sc[j] - mx); sum += sc[j]; }
-    const float inv = 1.f / sum;
+    };
+    fetch(w0);
 
-    float ov[DW];
-#pragma unroll
-    for (int d = 0; d < DW; ++d) ov[d] = 0.f;
-#pragma unroll
-    for (int j = 0; j < TP; ++j) {
-        const float pj = sc[j] * inv;
+    for (int it = 0; it < TATTN_ITEMS; ++it) {
+        if (w0 + it >= total) break;                 // wave-uniform
+        // q stays packed: the score dot products run on v_dot2c_f32_{bf16,f16} (two exact products + fp32 accumulate
+        // per instruction, no widening converts)
+        h16x8 qv[DW / 8];
+        const int64_t row = rown; const int h = hn; const bool rok = okn;
+        __builtin_amdgcn_wave_barrier();             // the previous item's LDS reads are issued before these writes
 #pragma unroll
         for (int i = 0; i < DW / 8; ++i) {
-            const h16x8 vv = *reinterpret_cast<const h16x8*>(&Vs[wave][j * 64 + dp * DW + i * 8]);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) ov[i * 8 + e] = fmaf(pj, (float)vv[e], ov[i * 8 + e]);
+            qv[i] = as_h16x8(qn[i]);
+            st16(&Ks[wave][tq * 64 + dp * DW + i * 8], kn[i]);
+            st16(&Vs[wave][tq * 64 + dp * DW + i * 8], vn[i]);
         }
-    }
-    if (rok) {
-        h16* dst = O + row * ldo + h * 64 + dp * DW;
+        __builtin_amdgcn_wave_barrier();
+        if (it + 1 < TATTN_ITEMS) fetch(w0 + it + 1);
+
+        float sc[TP];
+        float mx = -INFINITY;
 #pragma unroll
-        for (int i = 0; i < DW / 8; ++i) {
-            h16x8 t;
+        for (int j = 0; j < TP; ++j) {
+            float a = 0.f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) t[e] = (h16)ov[i * 8 + e];
-            st16(dst + i * 8, as_u32x4(t));
+            for (int i = 0; i < DW / 8; ++i) {
+                const h16x8 kk = *reinterpret_cast<const h16x8*>(&Ks[wave][j * 64 + dp * DW + i * 8]);
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                    const h16x2 qp = {qv[i][e], qv[i][e + 1]}, kp = {kk[e], kk[e + 1]};
+                    a = DOT2_H16(qp, kp, a);
+                }
+            }
+#pragma unroll
+            for (int o = 1; o < DP; o <<= 1) a += __shfl_xor(a, o, 64);
+            a = (j < T) ? a * scale : -INFINITY;
+            sc[j] = a;
+            mx = fmaxf(mx, a);
+        }
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < TP; ++j) { sc[j] = __expf(sc[j] - mx); sum += sc[j]; }
+        const float inv = 1.f / sum;
+
+        float ov[DW];
+#pragma unroll
+        for (int d = 0; d < DW; ++d) ov[d] = 0.f;
+#pragma unroll
+        for (int j = 0; j < TP; ++j) {
+            const float pj = sc[j] * inv;
+#pragma unroll
+            for (int i = 0; i < DW / 8; ++i) {
+                const h16x8 vv = *reinterpret_cast<const h16x8*>(&Vs[wave][j * 64 + dp * DW + i * 8]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ov[i * 8 + e] = fmaf(pj, (float)vv[e], ov[i * 8 + e]);
+            }
+        }
+        if (rok) {
+            h16* dst = O + row * ldo + h * 64 + dp * DW;
+#pragma unroll
+            for (int i = 0; i < DW / 8; ++i) {
+                h16x8 t;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) t[e] = (h16)ov[i * 8 + e];
+                st16(dst + i * 8, as_u32x4(t));
+            }
         }
     }
 }
@@ -330,7 +353,7 @@ extern "C" int mudg_temporal_attention(const void* QKV, void* O, int B, int T, i
     MUDG_REQUIRE(total < (1ll << 31), "mudg_temporal_attention: grid too large");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int slot = mudg_prof_begin(MUDG_FAM_TATTN, s);
-    const unsigned grid = (unsigned)((total + 3) / 4);
+    const unsigned grid = (unsigned)((total + 4 * TATTN_ITEMS - 1) / (4 * TATTN_ITEMS));
     if (T <= 16)
         hipLaunchKernelGGL(tattn_kernel<16>, dim3(grid), dim3(256), 0, s, (const h16*)QKV, (h16*)O, B, T, HW, heads,
                            ldqkv, ldo, scale, (int)total);

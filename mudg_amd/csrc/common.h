@@ -10,10 +10,12 @@
 #ifdef MUDG_OPERAND_FP16
 typedef _Float16 h16;
 #define MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#define DOT2_H16(a, b, c) __builtin_amdgcn_fdot2(a, b, c, false)               /* v_dot2c_f32_f16: c + a.x b.x + a.y b.y */
 #define MUDG_OPERAND_CODE 1
 #else
 typedef __bf16 h16;
 #define MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#define DOT2_H16(a, b, c) __builtin_amdgcn_fdot2_f32_bf16(a, b, c, false)      /* v_dot2c_f32_bf16 */
 #define MUDG_OPERAND_CODE 0
 #endif
 typedef __attribute__((ext_vector_type(8))) h16 h16x8;
