@@ -110,26 +110,35 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
 }
 
 // Pass 2': the same fold over the per-(128-row block, channel) partials a producing GEMM / conv epilogue wrote
-// (MudgGemmDesc.stats): one wave per (sample, group), lanes stride over the sample's row blocks, every lane walks the
-// group's channels (which may straddle the two sources), fp64, fixed butterfly.
+// (MudgGemmDesc.stats): one 256-thread workgroup per (sample, group); thread t takes row blocks t, t + 256, ... and walks
+// the group's channels (8-byte loads; the channels may straddle the two sources); fp64 partials are combined by a fixed
+// wave butterfly and a fixed 4-term sum, so the result does not depend on scheduling.
 __global__ __launch_bounds__(256) void gn_finalize_ch_kernel(const float* __restrict__ P1, const float* __restrict__ P2,
                                                               int csplit, int C, float* __restrict__ stat, int samples,
                                                               int groups, int blocks_per_sample, double count, float eps) {
-    const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= samples * groups) return;
+    __shared__ double red[4][2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = blockIdx.x;
     const int smp = i / groups, g = i - smp * groups;
     const int cpg = C / groups, c0 = g * cpg;
     double a = 0.0, b = 0.0;
-    for (int rb = lane; rb < blocks_per_sample; rb += 64) {
+    for (int rb = tid; rb < blocks_per_sample; rb += 256) {
         const int64_t blk = (int64_t)smp * blocks_per_sample + rb;
+        float sa = 0.f, sb = 0.f;                 // <= 80 channels of one block: fp32 is exact enough before the fp64 fold
+#pragma unroll 4
         for (int c = c0; c < c0 + cpg; ++c) {
-            const float* q = (c < csplit) ? P1 + (blk * csplit + c) * 2 : P2 + (blk * (C - csplit) + (c - csplit)) * 2;
-            a += (double)q[0]; b += (double)q[1];
+            const f32x2 q = *reinterpret_cast<const f32x2*>((c < csplit) ? P1 + (blk * csplit + c) * 2
+                                                                         : P2 + (blk * (C - csplit) + (c - csplit)) * 2);
+            sa += q[0]; sb += q[1];
         }
+        a += (double)sa; b += (double)sb;
     }
     a = wave_sum_d(a); b = wave_sum_d(b);
-    if (lane == 0) {
+    if (lane == 0) { red[wave][0] = a; red[wave][1] = b; }
+    __syncthreads();
+    if (tid == 0) {
+        a = ((red[0][0] + red[1][0]) + red[2][0]) + red[3][0];
+        b = ((red[0][1] + red[1][1]) + red[2][1]) + red[3][1];
         const double mean = a / count;
         double var = b / count - mean * mean;
         if (var < 0.0) var = 0.0;
@@ -318,7 +327,7 @@ extern "C" int mudg_groupnorm_fused(const void* X, const void* X2, int csplit, i
     float* stat = ws;
     const int slot = mudg_prof_begin(MUDG_FAM_GNORM, s);
     const int ng = samples * groups;
-    hipLaunchKernelGGL(gn_finalize_ch_kernel, dim3((ng + 3) / 4), dim3(256), 0, s, P1, P2, csplit, C, stat, samples, groups,
+    hipLaunchKernelGGL(gn_finalize_ch_kernel, dim3(ng), dim3(256), 0, s, P1, P2, csplit, C, stat, samples, groups,
                        rows / 128, (double)rows * (C / groups), eps);
     const int nblk = gn_chunks(samples, rows);
     if (x_fp32)
