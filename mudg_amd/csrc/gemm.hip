@@ -218,8 +218,10 @@ __global__ __launch_bounds__(256, SB ? 4 : 2) void gemm_kernel(const MudgGemmDes
             lptr_t lx = (lptr_t)(Xs + buf * TILE + (32 * wave + 8 * i) * LDSLD);
             if (s2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rX2, lx, 16, (int)v, soff, 0, 0);
             else __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, lx, 16, (int)v, soff, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(Ws + buf * TILE + (32 * wave + 8 * i) * LDSLD), 16,
-                                                     (int)vw[i], soffw, 0, 0);
+            // W rows beyond N are never multiplied (their waves are idle, see wave_live): skip the zero-fill pieces
+            if (n0 + 32 * wave + 8 * i < p.N || (32 * wave + 8 * i) < 64)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(Ws + buf * TILE + (32 * wave + 8 * i) * LDSLD), 16,
+                                                         (int)vw[i], soffw, 0, 0);
         }
         if (MODE == 0) {
             c_s += BK;
