@@ -23,7 +23,8 @@
 //     group A, one full slot after group B's P1 reads; the DMA that overwrites X(kt) is issued in P0/P1 of kt+1;
 //   * K-tile kt+1 is complete once X rows 128-255 (issued in P1 of kt) landed: P3 waits vmcnt(4) — the four pieces
 //     issued after it (W halves of kt+2) may stay in flight — and both groups pass >= 1 barrier before P0 of kt+1.
-// Rejected before this one: an 8-wave kernel with a single barrier per K-tile (MFMA, ds_read and DMA streams did not
+// Two schedules: the four-phase one tabulated above and (default) a two-phase one with 16 MFMAs per section (see
+// phase2 below; +1...5 %).  Rejected before this one: an 8-wave kernel with a single barrier per K-tile (MFMA, ds_read and DMA streams did not
 // overlap: 660 TFLOP/s) — see gemm256.hip for the 16-wave kernel that is used when this one does not apply.
 #include "common.h"
 #include <cstdlib>
@@ -63,7 +64,7 @@ __device__ __forceinline__ float gelu_fast3(float x) {
         __builtin_amdgcn_sched_barrier(0);     \
     } while (0)
 
-template <int MODE>
+template <int MODE, bool PH2>
 __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const MudgGemmDesc p, const int vflags, const int ablate) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const MudgGemmDesc p, 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     h16x8 wf[2][4];         // [ni][ks], live across the four phases of a K-tile
-    h16x8 xf[2][2];         // [mi local][ks local], reloaded every phase
+    h16x8 xf[2][PH2 ? 4 : 2];   // [mi local][ks local], reloaded every phase
 
     // ---- prologue: K-tile 0 whole, W of K-tile 1 (what P2 / P3 of a K-tile "-1" would have issued)
     issue_x(0, 0);
@@ -284,12 +285,66 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const MudgGemmDesc p, 
     using I2 = std::integral_constant<int, 2>;
     using I3 = std::integral_constant<int, 3>;
 
+    // Two-phase variant (PH2): a phase = one M half x all four k-steps = 16 MFMAs per section, half as many barriers.
+    //   P0: ds_read W[n 0,1][k 0-3] X[m 0,1][k 0-3]; DMA X rows 0-255 of kt+1 -> kb^1 (X(kt-1) was last read in P1 of kt-1)
+    //   P1: ds_read X[m 2,3][k 0-3];                 DMA W rows 0-255 of kt+2 -> kb   (W(kt) was last read in P0 of kt);
+    //       then vmcnt(4): everything older than those four pieces — X(kt+1), W(kt+1) — has landed.
+    auto phase2 = [&](auto Pc, auto KBc, int kt) {
+        constexpr int P = decltype(Pc)::value, KB = decltype(KBc)::value;
+        constexpr int M0 = P * 2;
+        if (P == 0) {
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    wf[ni][k] = *reinterpret_cast<const h16x8*>(smem + aw[k] + KB * KB_BYTES + ni * 4096);
+        }
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                xf[mi][k] = *reinterpret_cast<const h16x8*>(smem + ax[k] + KB * KB_BYTES + (M0 + mi) * 4096);
+        const bool dma = !(ablate & 1);
+        if (P == 0) {
+            if (kt + 1 < nk && dma) { issue_x(0, KB ^ 1); issue_x(1, KB ^ 1); }
+        } else {
+            if (kt + 2 < nk && dma) {
+                issue_w(0, KB, kt + 2); issue_w(1, KB, kt + 2);
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        SECTION_BARRIER();
+        __builtin_amdgcn_s_setprio(1);
+        if (!(ablate & 4)) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+                        acc[ni][M0 + mi] = MFMA_32x32x16(wf[ni][k], xf[mi][k], acc[ni][M0 + mi]);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        SECTION_BARRIER();
+    };
+
     int kt = 0;
+    if constexpr (PH2) {
+        for (; kt + 1 < nk; kt += 2) {
+            phase2(I0{}, I0{}, kt); phase2(I1{}, I0{}, kt);
+            phase2(I0{}, I1{}, kt + 1); phase2(I1{}, I1{}, kt + 1);
+        }
+        if (kt < nk) { phase2(I0{}, I0{}, kt); phase2(I1{}, I0{}, kt); }
+    } else {
     for (; kt + 1 < nk; kt += 2) {
         phase(I0{}, I0{}, kt); phase(I1{}, I0{}, kt); phase(I2{}, I0{}, kt); phase(I3{}, I0{}, kt);
         phase(I0{}, I1{}, kt + 1); phase(I1{}, I1{}, kt + 1); phase(I2{}, I1{}, kt + 1); phase(I3{}, I1{}, kt + 1);
     }
     if (kt < nk) { phase(I0{}, I0{}, kt); phase(I1{}, I0{}, kt); phase(I2{}, I0{}, kt); phase(I3{}, I0{}, kt); }
+    }
     if (wr == 0) SECTION_BARRIER();            // group A waits for group B's last section
     __syncthreads();
 
@@ -429,17 +484,17 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const MudgGemmDesc p, 
         }
 }
 
-template <int MODE>
+template <int MODE, bool PH2>
 int launch256p(const MudgGemmDesc& d, int vflags, int ablate, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256p_kernel<MODE>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256p_kernel<MODE, PH2>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_MAIN);
         if (e != hipSuccess) MUDG_FAIL(MUDG_ELAUNCH, "gemm256p: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
     const int tiles = ((d.M + 255) / 256) * ((d.N + 255) / 256);
-    hipLaunchKernelGGL(gemm256p_kernel<MODE>, dim3(tiles, 1, d.batch), dim3(512), SMEM_MAIN, s, d, vflags, ablate);
+    hipLaunchKernelGGL((gemm256p_kernel<MODE, PH2>), dim3(tiles, 1, d.batch), dim3(512), SMEM_MAIN, s, d, vflags, ablate);
     return mudg_check_launch("mudg_gemm[256p]");
 }
 
@@ -449,7 +504,14 @@ int launch256p(const MudgGemmDesc& d, int vflags, int ablate, hipStream_t s) {
 int mudg_gemm256p_dispatch(const MudgGemmDesc& d, int vflags, hipStream_t s) {
     static int ablate = -1;                  // MUDG_ABLATE bit 0: no DMA in the K loop, bit 2: no MFMA (timing experiments only)
     if (ablate < 0) { const char* e = getenv("MUDG_ABLATE"); ablate = e ? atoi(e) : 0; }
-    if (d.mode == 0) return launch256p<0>(d, vflags, ablate, s);
-    if (d.mode == 1) return launch256p<1>(d, vflags, ablate, s);
-    return launch256p<2>(d, vflags, ablate, s);
+    static int ph2 = -1;                     // MUDG_PP_PHASES=4 selects the four-phase schedule (A/B measurements)
+    if (ph2 < 0) { const char* e = getenv("MUDG_PP_PHASES"); ph2 = (e && atoi(e) == 4) ? 0 : 1; }
+    if (ph2) {
+        if (d.mode == 0) return launch256p<0, true>(d, vflags, ablate, s);
+        if (d.mode == 1) return launch256p<1, true>(d, vflags, ablate, s);
+        return launch256p<2, true>(d, vflags, ablate, s);
+    }
+    if (d.mode == 0) return launch256p<0, false>(d, vflags, ablate, s);
+    if (d.mode == 1) return launch256p<1, false>(d, vflags, ablate, s);
+    return launch256p<2, false>(d, vflags, ablate, s);
 }
