@@ -24,6 +24,7 @@
 // mudg_temporal_attention: T <= 32 keys per pixel — a bandwidth problem.  One wave per (pixel, head), fp32 VALU
 //   dot products with K/V of that pixel in LDS; no MFMA.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -211,6 +212,195 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const MudgAttnDesc p, cons
     }
 }
 
+// Variant with 64 query rows per wave (two 32-row blocks): every K / V^T fragment read from LDS feeds two MFMAs instead
+// of one — half the LDS traffic per FLOP — and the two blocks' softmax chains are independent.  Workgroup = 256 queries.
+__global__ __launch_bounds__(256, 2) void attn64q_kernel(const MudgAttnDesc p, const int nqt, const int total) {
+    __shared__ __attribute__((aligned(16))) h16 Ks[2 * ATILE];
+    __shared__ __attribute__((aligned(16))) h16 Vs[2 * ATILE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    int w;
+    {
+        const int q8 = total >> 3, r8 = total & 7;
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        w = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    }
+    const int pair = w / nqt, qt = w - pair * nqt;
+    const int f = pair / p.heads, h = pair - f * p.heads;
+    const int kvb = f / p.kv_div;
+
+    const h16* Qp = reinterpret_cast<const h16*>(p.Q) + (int64_t)f * p.Nq * p.ldq + h * 64;
+    const h16* Kp = reinterpret_cast<const h16*>(p.K) + (int64_t)kvb * p.Nk * p.ldk + h * 64;
+    const h16* Vp = reinterpret_cast<const h16*>(p.Vt) + (int64_t)kvb * p.svt + (int64_t)(h * 64) * p.ldvt;
+    h16* Op = reinterpret_cast<h16*>(p.O) + (int64_t)f * p.Nq * p.ldo + h * 64;
+
+    int qrow[2];
+    bool qok[2];
+    h16x8 qf[2][4];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        qrow[qb] = qt * 256 + wave * 64 + qb * 32 + l31;
+        qok[qb] = qrow[qb] < p.Nq;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            qf[qb][ks] = as_h16x8(qok[qb] ? ld16(Qp + (int64_t)qrow[qb] * p.ldq + ks * 16 + hi * 8) : zero16());
+    }
+
+    const int lrow = tid >> 3, kc = tid & 7;
+    u32x4 kr[2], vr[2];
+    auto load_tiles = [&](int kt) {
+        const int j0 = kt * KB;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = lrow + 32 * i;
+            const int j = j0 + row;
+            kr[i] = (j < p.Nk) ? ld16(Kp + (int64_t)j * p.ldk + kc * 8) : zero16();
+            const int jc = j0 + kc * 8;
+            u32x4 v = zero16();
+            if (jc < p.Nk) {
+                v = ld16(Vp + (int64_t)row * p.ldvt + jc);
+                if (jc + 8 > p.Nk) {
+                    h16x8 hv = as_h16x8(v);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) if (jc + e >= p.Nk) hv[e] = (h16)0.f;
+                    v = as_u32x4(hv);
+                }
+            }
+            vr[i] = v;
+        }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            st16(&Ks[buf * ATILE + (lrow + 32 * i) * ALD + kc * 8], kr[i]);
+            st16(&Vs[buf * ATILE + (lrow + 32 * i) * ALD + kc * 8], vr[i]);
+        }
+    };
+
+    f32x16 o[2][2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o[qb][0][r] = 0.f; o[qb][1][r] = 0.f; }
+    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+    const float c = p.scale * 1.4426950408889634f;
+
+    const int nkt = (p.Nk + KB - 1) / KB;
+    load_tiles(0);
+    stage(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        const bool more = kt + 1 < nkt;
+        if (more) load_tiles(kt + 1);
+
+        f32x16 s[2][2];        // [qb][sub]
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[qb][sub][r] = 0.f;
+            const h16* kp = Ks + cur * ATILE + (sub * 32 + l31) * ALD + hi * 8;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const h16x8 kf = *reinterpret_cast<const h16x8*>(kp + ks * 16);
+                s[0][sub] = MFMA_32x32x16(kf, qf[0][ks], s[0][sub]);
+                s[1][sub] = MFMA_32x32x16(kf, qf[1][ks], s[1][sub]);
+            }
+        }
+        if (kt * KB + KB > p.Nk) {
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int j = kt * KB + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (j >= p.Nk) { s[0][sub][r] = -INFINITY; s[1][sub][r] = -INFINITY; }
+                }
+        }
+
+        h16x8 pk[2][2][2];     // [qb][sub][jj]
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            float mx = s[qb][0][0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[qb][0][r]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[qb][1][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const bool grew = !__all(mx <= m_run[qb]);
+            const float m_new = grew ? fmaxf(m_run[qb], mx) : m_run[qb];
+            const float alpha = grew ? __builtin_amdgcn_exp2f((m_run[qb] - m_new) * c) : 1.0f;
+            const float mc = m_new * c;
+            m_run[qb] = m_new;
+            float ps = 0.f;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float e = __builtin_amdgcn_exp2f(fmaf(s[qb][sub][r], c, -mc));
+                    ps += e;
+                    pk[qb][sub][r >> 3][r & 7] = (h16)e;
+                }
+            l_run[qb] = l_run[qb] * alpha + ps;
+            if (grew) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { o[qb][0][r] *= alpha; o[qb][1][r] *= alpha; }
+            }
+        }
+
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            const h16* vp = Vs + cur * ATILE + (dt * 32 + l31) * ALD + 4 * hi;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int kk = sub * 32 + jj * 16;
+                    const h16x4 lo = *reinterpret_cast<const h16x4*>(vp + kk);
+                    const h16x4 up = *reinterpret_cast<const h16x4*>(vp + kk + 8);
+                    h16x8 vf;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { vf[e] = lo[e]; vf[4 + e] = up[e]; }
+                    o[0][dt] = MFMA_32x32x16(vf, pk[0][sub][jj], o[0][dt]);
+                    o[1][dt] = MFMA_32x32x16(vf, pk[1][sub][jj], o[1][dt]);
+                }
+        }
+
+        if (more) stage(cur ^ 1);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
+        const float inv = 1.f / l_tot;
+        if (qok[qb]) {
+            h16* orow = Op + (int64_t)qrow[qb] * p.ldo;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    h16* dst = orow + dt * 32 + 8 * g + 4 * hi;
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = o[qb][dt][4 * g + j] * inv;
+                    if (p.accumulate) {
+                        Pack8 old; old.u = *reinterpret_cast<const u32x2*>(dst);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] += (float)old.h[j];
+                    }
+                    Pack8 nw;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) nw.h[j] = (h16)v[j];
+                    *reinterpret_cast<u32x2*>(dst) = nw.u;
+                }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ temporal
 // TP = padded sequence length (16 or 32); DP = 64 / TP lanes share one query row, each owning DW = 64 / DP dims.
 // A wave walks TATTN_ITEMS consecutive (pixel, head) items and fetches the next item's q / k / v rows before it computes
@@ -334,7 +524,18 @@ extern "C" int mudg_attention(const MudgAttnDesc* dp, void* stream) {
     MUDG_REQUIRE(total < (1ll << 31), "mudg_attention: grid too large");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int slot = mudg_prof_begin(MUDG_FAM_ATTN, s);
-    hipLaunchKernelGGL(attn_kernel, dim3((unsigned)total), dim3(256), 0, s, d, nqt, (int)total);
+    // Long self-attention runs 64 queries per wave (attn64q_kernel: +4.7 % at N = 9216); short key sequences (the text /
+    // image cross-attention) and small query counts keep the 32-query kernel.  MUDG_ATTN_Q=32 / 64 forces one of them.
+    static int var = -1;
+    if (var < 0) { const char* e = getenv("MUDG_ATTN_Q"); var = e ? atoi(e) : 0; }
+    const bool wide = var == 64 ? d.Nq >= 256 : (var == 32 ? false : (d.Nq >= 512 && d.Nk >= 256));
+    if (wide) {
+        const int nqt2 = (d.Nq + 255) / 256;
+        const int64_t total2 = (int64_t)nqt2 * d.F * d.heads;
+        hipLaunchKernelGGL(attn64q_kernel, dim3((unsigned)total2), dim3(256), 0, s, d, nqt2, (int)total2);
+    } else {
+        hipLaunchKernelGGL(attn_kernel, dim3((unsigned)total), dim3(256), 0, s, d, nqt, (int)total);
+    }
     const int rc = mudg_check_launch("mudg_attention");
     const double bh = (double)d.F * d.heads;
     mudg_prof_end(slot, s, 4.0 * bh * d.Nq * (double)d.Nk * 64.0,

@@ -1,7 +1,7 @@
 """Every contraction-kernel variant through the same kernel parity tests, in child processes (the variant switches are
 read once per process): the 16-wave and the ping-pong 256x256 kernels forced on every shape with M, N >= 256, the generic
 64-bit-address path of all kernels with the buffer-descriptor (FAST) path disabled, and the single-buffer short-K kernel
-forced on every FAST plain GEMM."""
+forced on every FAST plain GEMM; both flash-attention kernels (32 / 64 queries per wave) forced."""
 import os
 import subprocess
 import sys
@@ -10,7 +10,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SELECT = "gemm or conv or tconv or resblock or transformer or geglu or fused"
+SELECT = "gemm or conv or tconv or resblock or transformer or geglu or fused or attention or attn"
 
 
 @pytest.mark.parametrize("env", [
@@ -20,9 +20,11 @@ SELECT = "gemm or conv or tconv or resblock or transformer or geglu or fused"
     {"MUDG_GEMM_FAST": "0"},
     {"MUDG_GEMM_FAST": "0", "MUDG_GEMM256": "1"},
     {"MUDG_GEMM_SB": "2", "MUDG_GEMM256": "0"},
+    {"MUDG_ATTN_Q": "32"},
+    {"MUDG_ATTN_Q": "64"},
 ], ids=lambda e: ",".join(f"{k[5:]}={v}" for k, v in e.items()))
 def test_kernel_parity_under_variant(cuda, env):
-    if any(k in os.environ for k in ("MUDG_GEMM256", "MUDG_GEMM256P", "MUDG_GEMM_FAST", "MUDG_GEMM_SB")):
+    if any(k in os.environ for k in ("MUDG_GEMM256", "MUDG_GEMM256P", "MUDG_GEMM_FAST", "MUDG_GEMM_SB", "MUDG_ATTN_Q")):
         pytest.skip("already running under a variant switch")
     r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_kernels_gpu.py", "tests/test_unet_gpu.py", "-m", "gpu",
                         "-q", "-k", SELECT, "-p", "no:cacheprovider"],
