@@ -270,11 +270,16 @@ __global__ __launch_bounds__(256, 2) void attn64q_kernel(const MudgAttnDesc p, c
             vr[i] = v;
         }
     };
+    // V^T columns are stored permuted inside each group of 16 keys — [0-3, 8-11, 4-7, 12-15] — which is the order the score
+    // MFMA leaves a lane's keys in: a lane's 8 contraction slots of a PV MFMA are then one 16-byte LDS read, not two of 8.
+    const int vlo = (kc >> 1) * 16 + ((kc & 1) ? 4 : 0), vhi = (kc >> 1) * 16 + ((kc & 1) ? 12 : 8);
     auto stage = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             st16(&Ks[buf * ATILE + (lrow + 32 * i) * ALD + kc * 8], kr[i]);
-            st16(&Vs[buf * ATILE + (lrow + 32 * i) * ALD + kc * 8], vr[i]);
+            h16* vrow = &Vs[buf * ATILE + (lrow + 32 * i) * ALD];
+            *reinterpret_cast<u32x2*>(vrow + vlo) = u32x2{vr[i][0], vr[i][1]};
+            *reinterpret_cast<u32x2*>(vrow + vhi) = u32x2{vr[i][2], vr[i][3]};
         }
     };
 
@@ -353,17 +358,12 @@ __global__ __launch_bounds__(256, 2) void attn64q_kernel(const MudgAttnDesc p, c
 
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
-            const h16* vp = Vs + cur * ATILE + (dt * 32 + l31) * ALD + 4 * hi;
+            const h16* vp = Vs + cur * ATILE + (dt * 32 + l31) * ALD + 8 * hi;
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
                 for (int jj = 0; jj < 2; ++jj) {
-                    const int kk = sub * 32 + jj * 16;
-                    const h16x4 lo = *reinterpret_cast<const h16x4*>(vp + kk);
-                    const h16x4 up = *reinterpret_cast<const h16x4*>(vp + kk + 8);
-                    h16x8 vf;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { vf[e] = lo[e]; vf[4 + e] = up[e]; }
+                    const h16x8 vf = *reinterpret_cast<const h16x8*>(vp + sub * 32 + jj * 16);
                     o[0][dt] = MFMA_32x32x16(vf, pk[0][sub][jj], o[0][dt]);
                     o[1][dt] = MFMA_32x32x16(vf, pk[1][sub][jj], o[1][dt]);
                 }
