@@ -1,19 +1,24 @@
-// gemm.hip — the one MFMA contraction kernel of the path (plain GEMM, 3x3 conv and temporal 3-tap conv as
+// gemm.hip — the workhorse MFMA contraction kernel of the path (plain GEMM, 3x3 conv and temporal 3-tap conv as
 // implicit GEMMs on channels-last activations).  See include/mudg_hip.h (MudgGemmDesc) for semantics.
 //
 // Tiling (gfx950, wave64): 128x128 output tile per 256-thread workgroup, BK = 64, four waves as 2(M) x 2(N),
 // each wave owns 64x64 = 2x2 v_mfma_f32_32x32x16_bf16 tiles (64 fp32 accumulators per lane).
 // The MFMA is issued "transposed" (A operand = weight rows, B operand = activation rows) so that each lane ends
 // up with 4 consecutive output channels of one pixel — the epilogue then moves 16-byte pieces.
-// Staging: HBM/L2 -> LDS directly with global_load_lds_dwordx4 (no VGPR round trip, no ds_write pass: the first
-// version staged through registers and was LDS-write-bound at ~600 TFLOP/s).  The DMA writes lane-linear 1-KiB
-// pieces (8 rows x 128 B), so the LDS tile is unpadded [128][64] h16 and bank conflicts are removed by an XOR
-// swizzle applied on the SOURCE side (which 16-byte chunk of the row a lane fetches) and mirrored on the fragment
-// reads: chunk c of row r lives in slot c ^ ((r >> 1) & 7); with that, every 16-lane ds_read_b128 group touches 16
-// distinct 16-byte slots of the 256-byte bank row.  Out-of-range rows / taps / K tail fetch from a 16-byte zero page.
-// Two LDS buffers, one barrier per K-tile: the DMA of tile k+1 flies under the MFMAs of tile k.
-// Epilogue: accumulators (+bias, GEGLU) -> fp32 LDS tile -> coalesced 16-B rows (+group bias, +residual) -> HBM.
-// Workgroups are numbered so that each XCD gets a contiguous run of tiles (neighbouring tiles share operand panels).
+// Staging: HBM/L2 -> LDS directly by LDS-DMA (no VGPR round trip, no ds_write pass: the first version staged through
+// registers and was LDS-write-bound at ~600 TFLOP/s).  The DMA writes lane-linear 1-KiB pieces (8 rows x 128 B), so the
+// LDS tile is unpadded [128][64] h16 and bank conflicts are removed by an XOR swizzle applied on the SOURCE side (which
+// 16-byte chunk of the row a lane fetches) and mirrored on the fragment reads: chunk c of row r lives in slot
+// c ^ ((r >> 1) & 7); with that, every 16-lane ds_read_b128 group touches 16 distinct 16-byte slots of the 256-byte bank row.
+// Two address paths (template FAST): buffer_load ... lds through block-relative buffer descriptors with loop-invariant lane
+// offsets and hardware zero-fill for padding (every K / Cin % 64 == 0 problem without upsampling), or global_load_lds with
+// per-lane 64-bit addresses and a zero page (everything else).
+// Two occupancy variants (template SB): one K-tile buffer + two-pass epilogue = 4 workgroups per CU that overlap each
+// other's fetch / multiply / store phases, or two K-tile buffers (the DMA of tile k+1 flies under the MFMAs of tile k) at 2
+// workgroups per CU; use_single_buffer() picks by tile count.
+// Epilogue: accumulators (+bias, GEGLU through an LDS Phi table) -> fp32 LDS tile -> coalesced 16-B rows (+group bias,
+// +residual, optional GroupNorm partial sums of what was stored) -> HBM.
+// Workgroups are numbered so that each XCD gets a contiguous run of tiles, walked in 8-row groups (8 x 8 tile patches).
 #include "common.h"
 #include <cstdlib>
 #include <cmath>

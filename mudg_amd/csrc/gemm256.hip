@@ -1,9 +1,9 @@
-// gemm256.hip — the large-tile variant of the contraction kernel (same MudgGemmDesc semantics as gemm.hip) for
-// shapes with enough 256x256 tiles to fill the chip.
+// gemm256.hip — the 16-wave large-tile variant of the contraction kernel (same MudgGemmDesc semantics as gemm.hip) for
+// shapes with enough 256x256 tiles to fill the chip; in the default selection it serves the nearest-2x upsample convs
+// (mudg_gemm, use_gemm256), everything else having moved back to the 128x128 kernels once those were tuned.
 //
-// Why: ablations on MI355X show the 128x128 kernel is bound by the L2 -> LDS DMA stream (it saturates at ~8.5-12 TB/s;
-// at 64 FLOP per staged byte that is ~600-750 TFLOP/s, which is where that kernel sits).  A 256x256x64 block tile
-// stages half the bytes per FLOP.  Sixteen waves (1024 threads, one workgroup per CU, 4 waves per SIMD) form a 4 x 4
+// Why it exists: a 256x256x64 block tile stages half the bytes per FLOP of the 128x128 tile (whose first version was
+// bound by the L2 -> LDS DMA stream at ~600-750 TFLOP/s).  Sixteen waves (1024 threads, one workgroup per CU, 4 waves per SIMD) form a 4 x 4
 // grid and each keeps the 64x64 wave tile of gemm.hip (2x2 v_mfma_f32_32x32x16, 64 accumulators, ~125 VGPRs), so the
 // per-wave instruction stream is unchanged while each K-tile's 64 KiB arrive with four 1-KiB global_load_lds
 // instructions per wave.  Two K-tile buffers (2 x 64 KiB, XOR-swizzled [256][64] tiles as in gemm.hip), one barrier
