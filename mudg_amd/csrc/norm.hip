@@ -24,10 +24,21 @@ template <> struct Load8<float> {
     }
 };
 
+// Row chunks per sample of the statistics pass.  A function of `rows` only: the partition decides the order of the
+// fp32 partial sums, and a sample's result must not depend on how many other samples share the launch (clip-level data
+// parallelism relies on bit-identical per-clip results, tests/test_fullsize_gpu.py).
 __host__ __device__ inline int gn_chunks(int samples, int rows) {
+    (void)samples;
+    int want = rows / 64;
+    if (want > 1024) want = 1024;
+    return want < 1 ? 1 : want;
+}
+
+// Workgroups per sample of the apply pass (no effect on the arithmetic): enough of them to fill the chip.
+__host__ __device__ inline int gn_apply_blocks(int samples, int rows) {
     int want = 2048 / (samples > 0 ? samples : 1);
     if (want < 1) want = 1;
-    int most = (rows + 15) / 16;
+    const int most = (rows + 15) / 16;
     if (want > most) want = most;
     if (want > 1024) want = 1024;
     return want < 1 ? 1 : want;
@@ -299,7 +310,7 @@ extern "C" int mudg_groupnorm(const void* X, const void* X2, int csplit, int ldx
     const int ng = samples * groups;
     hipLaunchKernelGGL(gn_finalize_kernel, dim3((ng + 3) / 4), dim3(256), 0, s, part, stat, samples, groups, nchunks,
                        (double)rows * (C / groups), eps);
-    const int nblk = nchunks;
+    const int nblk = gn_apply_blocks(samples, rows);
     if (x_fp32)
         hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(nblk, samples), dim3(256), 0, s, (const float*)X, (const float*)X2,
                            csplit, ldx, ldx2, gamma, beta, (h16*)Y, ldy, rows, C, groups, nblk, silu, stat);
@@ -329,7 +340,7 @@ extern "C" int mudg_groupnorm_fused(const void* X, const void* X2, int csplit, i
     const int ng = samples * groups;
     hipLaunchKernelGGL(gn_finalize_ch_kernel, dim3(ng), dim3(256), 0, s, P1, P2, csplit, C, stat, samples, groups,
                        rows / 128, (double)rows * (C / groups), eps);
-    const int nblk = gn_chunks(samples, rows);
+    const int nblk = gn_apply_blocks(samples, rows);
     if (x_fp32)
         hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(nblk, samples), dim3(256), 0, s, (const float*)X, (const float*)X2,
                            csplit, ldx, ldx2, gamma, beta, (h16*)Y, ldy, rows, C, groups, nblk, silu, stat);
