@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_parity_suite_in_fp16_operand_mode(cuda):
     env = dict(os.environ, MUDG_OPERAND="fp16")
     r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_kernels_gpu.py", "tests/test_unet_gpu.py",
-                        "tests/test_pipeline_gpu.py", "-m", "gpu", "-q", "-s", "-p", "no:cacheprovider"],
+                        "tests/test_pipeline_gpu.py", "tests/test_fullsize_gpu.py", "-m", "gpu", "-q", "-s", "-p", "no:cacheprovider"],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     tail = "\n".join(l for l in r.stdout.splitlines() if "rel-L2" in l or "passed" in l or "failed" in l)
     print(tail)
