@@ -199,7 +199,8 @@ def make_vt(v, heads):
 
 
 @pytest.mark.parametrize("frames,heads,nq,nk,kv_div", [(2, 2, 200, 200, 1), (1, 5, 384, 384, 1), (4, 2, 150, 77, 2),
-                                                       (3, 1, 70, 16, 1), (1, 1, 128, 64, 1)])
+                                                       (3, 1, 70, 16, 1), (1, 1, 128, 64, 1),
+                                                       (2, 3, 700, 333, 1), (2, 2, 1024, 1100, 2)])     # 64-queries-per-wave kernel, ragged
 def test_attention(cuda, frames, heads, nq, nk, kv_div):
     from mudg_amd import ops
     c = heads * 64
