@@ -84,3 +84,55 @@ def test_vae_decode_is_per_frame_at_576x1024(big):
     assert pair.shape == (1, 3, 2, 576, 1024) and torch.isfinite(pair).all()
     for got, want in ((pair[:, :, :1], f0), (pair[:, :, 1:], f1)):
         assert ((got - want).float().norm() / want.float().norm()).item() < 1e-6
+
+
+def test_three_modality_batch_at_mdm512_matches_single_clips(big):
+    """The reference's own batch shape (colour / depth / semantic, virtual_pose_render.py:90-100) at MDM512 (40 x 64
+    latents: other tile counts, other kernel variants than MDM1024): every stream equals its single-clip run."""
+    from mudg_amd import factory
+    model, _ = big
+    inp = factory.synthetic_inputs(model, "512", 3, model.betas.device if hasattr(model, "betas") else "cuda", seed=5)
+    both = _forward(model, inp, slice(0, 3), t=333)
+    assert both.shape == (3, 4, 16, 40, 64) and torch.isfinite(both).all()
+    for i in range(3):
+        one = _forward(model, inp, slice(i, i + 1), t=333)
+        rel = ((both[i:i + 1] - one).float().norm() / one.float().norm()).item()
+        assert rel < 1e-6, (i, rel)
+
+
+def test_guided_ddim_steps_are_clip_independent_at_mdm1024(big):
+    """Two guided DDIM steps (CFG 7.5, rescale 0.7, eta 1 with injected noise) on a batch of two clips against the same
+    steps on each clip alone: the per-sample statistics of the fused update (std over C, T, H, W) and everything
+    upstream of them must not mix clips."""
+    from lvdm.models.samplers.ddim import DDIMSampler
+    model, inp = big
+    sampler = DDIMSampler(model)
+    sampler.make_schedule(50, ddim_discretize="uniform_trailing", ddim_eta=1.0, verbose=False)
+    dev = inp["x_T"].device
+    g = torch.Generator(device=dev).manual_seed(17)
+    noises = [torch.randn(inp["x_T"].shape, generator=g, device=dev) for _ in range(2)]
+
+    def run(sl):
+        x = inp["x_T"][sl].clone()
+        pick = lambda d: {"c_crossattn": [d["c_crossattn"][0][sl]], "c_concat": [d["c_concat"][0][sl]]}
+        cond, uc = pick(inp["cond"]), pick(inp["uc"])
+        for step, index in enumerate((49, 48)):
+            ts = torch.full((x.shape[0],), int(sampler.ddim_timesteps[index]), device=dev, dtype=torch.long)
+            import lvdm.models.samplers.ddim as ddim_mod
+            orig = ddim_mod.noise_like
+            ddim_mod.noise_like = lambda shape, device, repeat=False, n=noises[step][sl]: n
+            try:
+                with torch.no_grad():
+                    x = sampler.p_sample_ddim(x, cond, ts, index=index, unconditional_guidance_scale=7.5,
+                                              unconditional_conditioning=uc, guidance_rescale=0.7, fs=inp["fs"][sl],
+                                              class_label=inp["class_label"][sl])[0]
+            finally:
+                ddim_mod.noise_like = orig
+        return x
+
+    both = run(slice(0, 2))
+    assert torch.isfinite(both).all()
+    for i in range(2):
+        one = run(slice(i, i + 1))
+        rel = ((both[i:i + 1] - one).float().norm() / one.float().norm()).item()
+        assert rel < 1e-6, (i, rel)
