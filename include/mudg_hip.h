@@ -202,6 +202,16 @@ int mudg_ddim_step(const float* x, const float* e_c, const float* e_u, const flo
 int mudg_gaussian_sample(const float* moments, const float* noise, float* out, int N, int C, int HW, float scale,
                          void* stream);
 
+/* ------------------------------------------------------------------ post-processing of decoded frames
+ * (virtual_render/eval_tools.py: byte / integer work, results bit-equal to the reference's)
+ * frames_to_u8:     out[b][t][p][c] = (uint8) trunc((clamp(v[b][c][t][p], -1, 1) + 1) / 2 * 255)      eval_tools.py:22-27
+ * depth_from_u8:    depth[i] = ((r + g + b) / 3) / 255 over `pixels` (.., 3)-interleaved uint8 pixels   eval_tools.py:71
+ * semantic_nearest: planar (3, hw) uint8 image -> label of the nearest of the 19 palette colours (Euclidean distance,
+ *                   first minimum wins) and the image recoloured with the palette                       eval_tools.py:309-347 */
+int mudg_frames_to_u8(const float* video, uint8_t* out, int B, int C, int T, int64_t HW, void* stream);
+int mudg_depth_from_u8(const uint8_t* frames, float* depth, int64_t pixels, void* stream);
+int mudg_semantic_nearest(const uint8_t* img, uint8_t* vis, int64_t* labels, int64_t hw, void* stream);
+
 /* ------------------------------------------------------------------ event profiler (bench.py roofline)
  * When enabled, every launch of kernel family `fam` is bracketed by hipEvents on its own stream. */
 enum { MUDG_FAM_GEMM = 0, MUDG_FAM_CONV = 1, MUDG_FAM_TCONV = 2, MUDG_FAM_ATTN = 3, MUDG_FAM_TATTN = 4,

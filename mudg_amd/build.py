@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libmudg_hip.so")
 OUT_FP16 = os.path.join(HERE, "libmudg_hip_fp16.so")
-SOURCES = ["capi.hip", "gemm.hip", "gemm256.hip", "gemm256p.hip", "attention.hip", "norm.hip", "misc.hip"]
+SOURCES = ["capi.hip", "gemm.hip", "gemm256.hip", "gemm256p.hip", "attention.hip", "norm.hip", "misc.hip", "post.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-ffp-contract=off"]
 

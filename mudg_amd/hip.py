@@ -95,6 +95,9 @@ SIGNATURES = {
     "mudg_axpy_f32": (_I, [_P, _P, _L, _F, _P]),
     "mudg_lincomb": (_I, [_P, _P, _P, _P, _P, _I, _L, _P]),
     "mudg_ddim_ws_doubles": (_L, [_I]),
+    "mudg_frames_to_u8": (_I, [_P, _P, _I, _I, _I, _L, _P]),
+    "mudg_depth_from_u8": (_I, [_P, _P, _L, _P]),
+    "mudg_semantic_nearest": (_I, [_P, _P, _P, _L, _P]),
     "mudg_ddim_step": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _L, C.POINTER(C.c_float), _P, _P]),
     "mudg_gaussian_sample": (_I, [_P, _P, _P, _I, _I, _I, _F, _P]),
     "mudg_prof_enable": (_I, [_I]),

@@ -367,3 +367,38 @@ def ddim_step(x, e_c, e_u, noise, coef, e_m=None):
     hip.check(hip.lib().mudg_ddim_step(x.data_ptr(), e_c.data_ptr(), _ptr(e_u), _ptr(e_m), _ptr(noise), x_prev.data_ptr(),
                                        pred_x0.data_ptr(), b, n, arr, ws.data_ptr(), _stream()), "mudg_ddim_step")
     return x_prev, pred_x0
+
+
+# ------------------------------------------------------------------------------------------------ post-processing
+def frames_to_uint8(video):
+    """(b, c, t, h, w) float -> (b, t, h, w, c) uint8: clamp to [-1, 1], (x + 1) / 2 * 255, truncate (eval_tools.py:22-27)."""
+    if video.dim() != 5 or not video.is_cuda:
+        raise hip.MudgError(f"frames_to_uint8: expected a cuda (b, c, t, h, w) tensor, got {tuple(video.shape)} on {video.device}")
+    v = video.to(torch.float32).contiguous()
+    b, c, t, h, w = v.shape
+    out = torch.empty((b, t, h, w, c), dtype=torch.uint8, device=v.device)
+    hip.check(hip.lib().mudg_frames_to_u8(v.data_ptr(), out.data_ptr(), b, c, t, h * w, _stream()), "mudg_frames_to_u8")
+    return out
+
+
+def depth_from_uint8(frames):
+    """(..., h, w, 3) uint8 -> (..., 1, h, w) float32 in [0, 1]: channel mean / 255 (eval_tools.py:71)."""
+    if frames.dtype != torch.uint8 or frames.shape[-1] != 3 or not frames.is_cuda:
+        raise hip.MudgError("depth_from_uint8: expected a cuda (..., h, w, 3) uint8 tensor")
+    f = frames.contiguous()
+    out = torch.empty(f.shape[:-3] + (1,) + f.shape[-3:-1], dtype=torch.float32, device=f.device)
+    hip.check(hip.lib().mudg_depth_from_u8(f.data_ptr(), out.data_ptr(), f.numel() // 3, _stream()), "mudg_depth_from_u8")
+    return out
+
+
+def semantic_nearest(img):
+    """(3, h, w) uint8 -> ((3, h, w) uint8 recoloured, (h, w) int64 labels): nearest of 19 palette colours
+    (eval_tools.py:309-347)."""
+    if img.dtype != torch.uint8 or img.dim() != 3 or img.shape[0] != 3 or not img.is_cuda:
+        raise hip.MudgError("semantic_nearest: expected a cuda (3, h, w) uint8 tensor")
+    x = img.contiguous()
+    vis = torch.empty_like(x)
+    lab = torch.empty(x.shape[1:], dtype=torch.int64, device=x.device)
+    hip.check(hip.lib().mudg_semantic_nearest(x.data_ptr(), vis.data_ptr(), lab.data_ptr(), x.shape[1] * x.shape[2], _stream()),
+              "mudg_semantic_nearest")
+    return vis, lab

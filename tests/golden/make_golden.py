@@ -271,7 +271,40 @@ def golden_resampler():
                           "out": net(x).clone()})
 
 
+def golden_postprocess():
+    """Per-modality post-processing of decoded frames (eval_tools.py:20-27 uint8 conversion, 71-72 depth = channel mean,
+    309-347 visualize_semantic = nearest of 19 palette colours): integer / byte work, captured from the reference's own
+    function (visualize_semantic) and its own inline expressions."""
+    tvio = types.ModuleType("torchvision.io")
+    sys.modules["torchvision"].io = tvio
+    sys.modules["torchvision.io"] = tvio
+    import PIL.Image                                                          # eval_tools.py uses PIL.Image after a bare `import PIL`
+    spec = importlib.util.spec_from_file_location("ref_eval_tools", os.path.join(REF, "virtual_render", "eval_tools.py"))
+    et = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(et)
+    g = torch.Generator().manual_seed(cfgs.SEED + 9)
+    video = torch.randn(2, 3, 3, 24, 32, generator=g) * 0.9                  # (b, c, t, h, w); values beyond [-1, 1] included
+    video[0, :, 0, 0, :4] = torch.tensor([[-1.0, 1.0, 0.0, 0.999999], [-1.5, 1.5, -0.0, 0.003921568], [1.0, -1.0, 0.5, -0.5]])
+    clamped = torch.clamp(video.float(), -1., 1.)                           # eval_tools.py:23
+    grids = [((clamped[i] + 1.0) / 2.0 * 255).to(torch.uint8).permute(1, 2, 3, 0) for i in range(2)]   # eval_tools.py:26-27, thwc
+    u8 = torch.stack(grids)                                                 # (b, t, h, w, c)
+    depth = torch.stack([torch.stack([torch.mean(gr[t].permute(2, 0, 1).float(), dim=0, keepdim=True) / 255
+                                      for t in range(gr.shape[0])]) for gr in grids])            # eval_tools.py:71
+    pal = torch.tensor([[255, 120, 50], [255, 192, 203], [255, 255, 0], [0, 150, 245], [0, 255, 255], [255, 127, 0], [255, 0, 0],
+                        [255, 240, 150], [135, 60, 0], [160, 32, 240], [255, 0, 255], [139, 137, 137], [75, 0, 75], [150, 240, 80],
+                        [230, 230, 250], [0, 175, 0], [0, 255, 127], [222, 155, 161], [140, 62, 69]], dtype=torch.uint8)
+    img = torch.randint(0, 256, (3, 24, 32), generator=g, dtype=torch.uint8)
+    img[:, 0, :19] = pal.t()                                                # every palette colour exactly
+    img[:, 1, 0] = torch.tensor([255, 123, 25], dtype=torch.uint8)          # equidistant from entries 0 and 5 -> first wins?
+    vis, lab = et.visualize_semantic(img, return_pt=True)
+    save("postprocess.pt", {"video": video, "u8": u8, "depth": depth, "semantic_in": img, "semantic_vis": vis.clone(),
+                            "semantic_labels": lab.clone()})
+
+
 if __name__ == "__main__":
+    if "--only-post" in sys.argv:
+        golden_postprocess()
+        sys.exit(0)
     if "--only-encode" in sys.argv:
         golden_encode()
         sys.exit(0)
@@ -284,3 +317,4 @@ if __name__ == "__main__":
     golden_pipeline()
     golden_encode()
     golden_resampler()
+    golden_postprocess()

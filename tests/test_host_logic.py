@@ -145,3 +145,34 @@ def test_instantiate_from_config_contract():
     assert instantiate_from_config("__is_first_stage__") is None
     with pytest.raises(KeyError):
         instantiate_from_config({"params": {}})
+
+
+def test_window_loop_refeeds_the_colour_stream_like_the_reference(monkeypatch):
+    """synthesize_windows (virtual_pose_render.py:222-355 on tensors): windows advance by half, the colour stream's first
+    half of the sparse frames is the previous window's last generated half, frame 0 comes from the dense frames, depth and
+    semantic streams are not re-fed."""
+    import types
+    import virtual_render.virtual_pose_render as vpr
+    seen = []
+
+    def fake_synthesis(model, prompts, sparse_x, sparse_depth, class_label, noise_shape, **kw):
+        seen.append(sparse_x.clone())
+        k = len(seen)
+        return torch.full((3, 1, 3, 16, 4, 4), 0.1 * k) + torch.arange(16).view(1, 1, 1, 16, 1, 1) * 0.01 + 5.0 * (k == 2)
+
+    monkeypatch.setattr(vpr, "image_guided_synthesis", fake_synthesis)
+    model = types.SimpleNamespace(device=torch.device("cpu"))
+    g = torch.Generator().manual_seed(0)
+    wins = [{"sparse": torch.randn(3, 3, 16, 4, 4, generator=g), "dense": torch.randn(3, 3, 16, 4, 4, generator=g),
+             "sparse_depth": torch.randn(3, 3, 16, 4, 4, generator=g), "class_label": torch.tensor([[0], [500], [1]])}
+            for _ in range(3)]
+    outs = vpr.synthesize_windows(model, wins, [3, 4, 16, 1, 1], video_length=16)
+    assert len(outs) == 3 and all(o.shape == (3, 1, 3, 16, 4, 4) for o in outs)
+    assert float(outs[1].max()) <= 1.0                                     # clamped like batch_samples (:243)
+    assert torch.equal(seen[0], wins[0]["sparse"])                         # first window untouched
+    for w in (1, 2):
+        prev = outs[w - 1]
+        assert torch.equal(seen[w][0, :, 1:8], prev[0, 0, :, 9:16])        # last half generated -> first half sparse
+        assert torch.equal(seen[w][0, :, 0], wins[w]["dense"][0, :, 0])    # frame 0 from the dense frames (:275)
+        assert torch.equal(seen[w][0, :, 8:], wins[w]["sparse"][0, :, 8:])
+        assert torch.equal(seen[w][1:], wins[w]["sparse"][1:])             # depth / semantic streams are not re-fed

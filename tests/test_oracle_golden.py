@@ -126,3 +126,18 @@ def test_resampler_matches_reference():
     x = seeding.seeded_input("clip_tokens", (3, 257, g["cfg"]["embedding_dim"]), g["seed"])
     out = o_res.forward(sd, x, g["cfg"]["heads"], g["cfg"]["depth"])
     assert out.shape == g["out"].shape and rel_l2(out, g["out"]) < 1e-5
+
+
+def test_postprocess_oracle_matches_reference_bit_for_bit():
+    """uint8 conversion, depth = channel mean and the 19-colour semantic lookup (eval_tools.py) are byte / integer work:
+    the numpy restatement must reproduce the reference's outputs exactly."""
+    import numpy as np
+    from oracle import postprocess as pp
+    g = golden("postprocess.pt")
+    u8 = pp.frames_to_uint8(g["video"].numpy())
+    assert u8.dtype == np.uint8 and np.array_equal(u8, g["u8"].numpy())
+    depth = pp.depth_from_uint8(g["u8"].numpy())
+    assert np.array_equal(depth, g["depth"].numpy())
+    vis, lab = pp.visualize_semantic(g["semantic_in"].numpy())
+    assert np.array_equal(lab, g["semantic_labels"].numpy()) and np.array_equal(vis, g["semantic_vis"].numpy())
+    assert lab[0, :19].tolist() == list(range(19))          # every palette colour maps to itself

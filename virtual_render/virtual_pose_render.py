@@ -1,7 +1,9 @@
 """The tensor-level part of MuDG's inference driver (reference: virtual_render/virtual_pose_render.py —
 get_latent_z 54-59, image_guided_synthesis 62-147), with the same argument order, cond / uc dict layout and return
 value, on the MI355X path.  The reference file also holds the Waymo frame loaders, PNG/NPY writers and the CLI; those
-are host I/O outside the denoising path (SURVEY.md §8(f) rank 3 covers only this call sequence).
+are host I/O outside the denoising path (SURVEY.md §8(f) rank 3 covers this call sequence, the sliding-window loop with its
+autoregressive colour re-feed — `synthesize_windows` below, fed with tensors by the caller — and the per-modality
+post-processing in `virtual_render/eval_tools.py`).
 
 Conditioning encoders: `model.embedder` (CLIP image tower) and `model.cond_stage_model` (CLIP text tower) are whatever
 modules the config instantiated — they are third-party and not part of this path; `model.image_proj_model` (the
@@ -69,3 +71,32 @@ def image_guided_synthesis(model, prompts, sparse_x, sparse_depth, class_label, 
                                     **kwargs)
         variants.append(model.decode_first_stage(samples))
     return torch.stack(variants).permute(1, 0, 2, 3, 4, 5)    # (batch, variants, c, t, h, w)
+
+
+def synthesize_windows(model, windows, noise_shape, video_length=16, **synthesis_kwargs):
+    """The sliding-window loop of run_inference_multi (virtual_pose_render.py:222-355) on tensors.
+
+    `windows` yields, per window, a dict with the three modality streams in the reference's order (colour, depth,
+    semantic): "sparse" (3, c, t, h, w), "dense" (3, c, t, h, w), "sparse_depth" (3, c, t, h, w), "class_label" (3, 1) —
+    what get_color_frames / get_depth_frames / get_semantic_frames / get_sparse_depth load from disk there.  Consecutive
+    windows overlap by half (the index advances by video_length // 2, :247); before a window is synthesised, the colour
+    stream's first video_length // 2 sparse frames are replaced by the last video_length // 2 frames generated for the
+    previous window (:269-274) and its frame 0 by the dense frame 0 (:275).  Returns the list of clamped samples
+    (3, n_samples, c, t, h, w) per window, as batch_samples after :243."""
+    half = video_length // 2
+    carry = None
+    results = []
+    for win in windows:
+        sparse = win["sparse"].clone()
+        if carry is not None:
+            sparse[0, :, 0:half] = carry[:, 0:half]
+            sparse[0, :, 0] = win["dense"][0, :, 0]
+        dev = model.device
+        samples = image_guided_synthesis(model, [""] * sparse.shape[0], sparse.to(dev), win["sparse_depth"].to(dev),
+                                         win["class_label"].to(dev), noise_shape, **synthesis_kwargs)
+        samples = torch.clamp(samples.float(), -1., 1.)
+        results.append(samples)
+        for nn in range(samples.shape[0]):
+            if int(win["class_label"][nn, 0]) == 0:                        # the colour stream re-feeds itself
+                carry = samples[nn, 0, :, half:video_length].to(sparse.device)      # (c, half, h, w)
+    return results
