@@ -49,6 +49,7 @@ def parse():
 
 PEAK_TFLOPS_BF16 = 2500.0     # dense MFMA bf16, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
+MEASURED_MFMA_PEAK_TFLOPS = 1747.5    # tools/ubench/mfma_peak.hip: v_mfma_f32_32x32x16_bf16, random operands, best of 1-8 waves/SIMD (zeros: 2393.8)
 MFMA_FAMS = ("gemm", "conv3x3", "tconv3", "attention")
 
 
@@ -252,6 +253,11 @@ def main():
                                        f"hipEvents on the launch stream over {prof_steps} eager steps re-run right after "
                                        "the timed region (the timed region replays the same launches as a hipGraph)")
         out["roofline"].update(pmc_traffic(dom["family"], args))
+        if dom["bound"] == "mfma":
+            # next to the nominal peak, the rate this chip sustains on register-resident MFMAs with random
+            # bf16 operands (tools/ubench/mfma_peak.hip, measured on the same pool: the chip clocks to its power budget)
+            out["roofline"]["measured_mfma_peak"] = MEASURED_MFMA_PEAK_TFLOPS
+            out["roofline"]["frac_of_measured_peak"] = round(dom["achieved"] / MEASURED_MFMA_PEAK_TFLOPS, 4)
         out["kernels"] = kernels
         out["kernel_time_ms_per_step"] = round(total_ms / prof_steps, 3)
     if world == 1 and not args.no_cpu_baseline:
