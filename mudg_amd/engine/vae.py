@@ -21,10 +21,11 @@ def _gn(mod, x, frames, hw, swish):
 
 
 def _conv3x3(mod, x, frames, h, w, upsample=False, residual=None, stream=False, stride=1, pad=1):
-    """stream=True: the output is a residual-stream tensor, kept in fp32 (same policy as the UNet executor)."""
+    """stream=True: the output is a residual-stream tensor, kept in fp32 (same policy as the UNet executor).  Every conv
+    here except the nearest-2x ones (16-wave kernel) also writes the partial sums of the GroupNorm that follows it."""
     wmat, cpad, korder = pk.conv3x3(mod)
     return ops.conv3x3(x, wmat, frames=frames, hin=h, win=w, cin=cpad, upsample=upsample, bias=pk.f32(mod, "bias"),
-                       residual=residual, out_fp32=stream, korder=korder, stride=stride, pad=pad)
+                       residual=residual, out_fp32=stream, korder=korder, stride=stride, pad=pad, stats=not upsample)
 
 
 def resnet_block(mod, x, frames, h, w):
