@@ -42,8 +42,10 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="issue every kernel from Python instead of replaying a hipGraph")
     ap.add_argument("--profile-steps", type=int, default=2, help="eager steps re-run with hipEvents for the roofline")
     ap.add_argument("--no-decode", action="store_true", help="skip the (untimed) 16-frame VAE decode used for clips/min")
-    ap.add_argument("--operand", default=os.environ.get("MUDG_OPERAND", "bf16"), choices=["bf16", "fp16"],
-                    help="16-bit MFMA operand type (bf16 is the BASELINE dtype; fp16 = the reference's autocast dtype)")
+    ap.add_argument("--operand", default=os.environ.get("MUDG_OPERAND", "bf16"), choices=["bf16", "fp16", "bf16x3", "bf16x6"],
+                    help="MFMA operand type: bf16 (the BASELINE dtype), fp16 (the reference's autocast dtype), or the "
+                         "split-operand precision modes bf16x3 / bf16x6 (2 / 3 bf16 pieces per value, 3 / 6 MFMAs per product "
+                         "tile: the modes that meet the 1e-3 decoded-frame tolerance; their cost is what this flag measures)")
     return ap.parse_args()
 
 

@@ -35,8 +35,14 @@ extern "C" {
 
 /* ABI version; bumped whenever a struct below changes. */
 int mudg_version(void);
-/* 16-bit MFMA operand type of this build: 0 = bfloat16 (libmudg_hip.so), 1 = IEEE fp16 (libmudg_hip_fp16.so).
- * Wherever this header says "bf16" for an operand buffer, the fp16 build expects fp16 in its place. */
+/* MFMA operand type of this build: 0 = bfloat16 (libmudg_hip.so), 1 = IEEE fp16 (libmudg_hip_fp16.so),
+ * 2 = split bf16 x 2 planes (libmudg_hip_x3.so: 16 significand bits, 3 MFMAs per product tile),
+ * 3 = split bf16 x 3 planes (libmudg_hip_x6.so: 24 significand bits, 6 MFMAs per product tile: fp32-class).
+ * Wherever this header says "bf16" for an operand buffer, the fp16 build expects fp16 in its place, and the split builds
+ * expect PLANES bf16 pieces per value: piece p of element (r, c) of a rows matrix with row stride ld lives at
+ * r * ld + p * (ld / PLANES) + c, value = sum of the pieces, piece 0 = bf16(value), piece 1 = bf16(value - piece 0), ...
+ * (so an operand matrix of width C needs ld >= PLANES * C, and ld a multiple of 8 * PLANES).  fp32 buffers (residual
+ * stream, biases, statistics) are the same in every build. */
 int mudg_operand_dtype(void);
 /* Text for the most recent non-zero return on this thread. */
 const char* mudg_last_error(void);
@@ -176,8 +182,15 @@ int mudg_axpy_f32(float* y, const float* x, int64_t n, float alpha, void* stream
  * predict_eps_from_z_and_v (ddpm3d.py:239-251) with ca, cb gathered per sample (device fp32 [B]). */
 int mudg_lincomb(float* out, const float* x, const float* y, const float* ca, const float* cb, int B, int64_t n,
                  void* stream);
-/* fp32 -> bf16 cast of n contiguous elements (a fp32 stream tensor entering an MFMA GEMM as an operand). */
+/* fp32 -> bf16 cast of n contiguous elements (a fp32 stream tensor entering an MFMA GEMM as an operand).
+ * 16-bit-operand builds only (a flat cast has no plane layout); mudg_cast_rows serves every build. */
 int mudg_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream);
+/* dst[r][c] = src[r][c] for rows x cols elements between rows matrices of either kind, any direction: operand
+ * (*_fp32 = 0: h16, or PLANES pieces per value in the split builds) or fp32 (*_fp32 = 1).  Row strides in elements.
+ * This is how fp32 tensors (context tokens ddpm3d.py:1320-1322, skip-conv inputs) become MFMA operands and how an
+ * operand matrix is read back as fp32. */
+int mudg_cast_rows(const void* src, int src_fp32, int64_t lds, void* dst, int dst_fp32, int64_t ldd, int64_t rows,
+                   int64_t cols, void* stream);
 /* Zero the channel range [c0, c1) of a rows buffer (padding lanes of the stem input). */
 int mudg_zero_channels(void* dst, int rows, int ld, int c0, int c1, void* stream);
 

@@ -148,7 +148,9 @@ class DDIMSampler(object):
             e_u = self.model.apply_model(x, t, unconditional_conditioning, **kwargs) if guided else None
         coef = self.step_coefficients(index, unconditional_guidance_scale if guided else 1.0,
                                       guidance_rescale if guided else 0.0, temperature)
-        noise = noise_like(x.shape, x.device, repeat_noise) if coef[7] != 0.0 else None
+        # always drawn, as the reference does (ddim.py:272: sigma_t * noise_like(...)): with eta = 0 the term is 0 * noise, but
+        # the device generator advances identically, so later draws under the same seed (n_samples > 1) match
+        noise = noise_like(x.shape, x.device, repeat_noise)
         return ops.ddim_step(x.float().contiguous(), e_c.float().contiguous(),
                              None if e_u is None else e_u.float().contiguous(), noise, coef)
 

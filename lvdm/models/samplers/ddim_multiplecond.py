@@ -38,5 +38,7 @@ class DDIMSampler(_TwoWaySampler):
                 e_m = self.model.apply_model(x, t, uc_img, **kwargs)
         coef = self.step_coefficients(index, unconditional_guidance_scale if guided else 1.0,
                                       guidance_rescale if guided else 0.0, temperature) + [float(cfg_img)]
-        noise = noise_like(x.shape, x.device, repeat_noise) if coef[7] != 0.0 else None
+        # always drawn, as the reference does (ddim.py:272: sigma_t * noise_like(...)): with eta = 0 the term is 0 * noise, but
+        # the device generator advances identically, so later draws under the same seed (n_samples > 1) match
+        noise = noise_like(x.shape, x.device, repeat_noise)
         return ops.ddim_step(x, e_c, e_u, noise, coef, e_m=e_m)

@@ -1,4 +1,4 @@
-"""Build libmudg_hip.so (gfx950) and the oracle's optional native pieces, in-tree.
+"""Build the gfx950 kernel libraries (libmudg_hip*.so), in-tree.
 
 `python -m mudg_amd.build` compiles every .hip under mudg_amd/csrc with hipcc for gfx950 and links one shared
 library next to the sources.  hipcc cross-compiles without a GPU, so this runs in the CPU-only build container;
@@ -17,6 +17,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libmudg_hip.so")
 OUT_FP16 = os.path.join(HERE, "libmudg_hip_fp16.so")
+OUT_X3 = os.path.join(HERE, "libmudg_hip_x3.so")
+OUT_X6 = os.path.join(HERE, "libmudg_hip_x6.so")
 SOURCES = ["capi.hip", "gemm.hip", "gemm256.hip", "gemm256p.hip", "attention.hip", "norm.hip", "misc.hip", "post.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-ffp-contract=off"]
@@ -71,8 +73,11 @@ def _build_one(out: str, extra, tag: str, force: bool, verbose: bool) -> str:
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
-    """Both operand-type builds of the same sources: bf16 (default) and fp16 (-DMUDG_OPERAND_FP16)."""
+    """Every operand-type build of the same sources: bf16 (default), fp16 (-DMUDG_OPERAND_FP16) and the split-operand
+    precision modes bf16x3 / bf16x6 (-DMUDG_PLANES=2 / 3; csrc/common.h)."""
     _build_one(OUT_FP16, ["-DMUDG_OPERAND_FP16"], "fp16", force, verbose)
+    _build_one(OUT_X3, ["-DMUDG_PLANES=2"], "x3", force, verbose)
+    _build_one(OUT_X6, ["-DMUDG_PLANES=3"], "x6", force, verbose)
     return _build_one(OUT, [], "bf16", force, verbose)
 
 

@@ -507,6 +507,266 @@ __global__ __launch_bounds__(256, TP == 16 ? 3 : 1) void tattn_kernel(const h16*
     }
 }
 
+
+#if MUDG_PLANES > 1
+// ------------------------------------------------------------------------------------------------ split-operand builds
+// attn_kernel with every operand carried as PLANES bf16 pieces (common.h): Q / K / V^T pieces come from planes of the
+// input matrices, the probabilities are split in registers, and both contractions accumulate the kept (piece, piece)
+// partial products — NSEG MFMAs where the 16-bit kernel issues one.  Exponentials and the output normalisation are the
+// same fp32 arithmetic.  One K / V^T tile per piece in LDS; precision first: 32 queries per wave, no 64-query variant.
+__global__ __launch_bounds__(256, 1) void attn_split_kernel(const MudgAttnDesc p, const int nqt, const int total) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    h16* Ks = reinterpret_cast<h16*>(smem_raw);                   // [2 buffers][PLANES][ATILE]
+    h16* Vs = Ks + 2 * PLANES * ATILE;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    int w;
+    {
+        const int q8 = total >> 3, r8 = total & 7;
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        w = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    }
+    const int pair = w / nqt, qt = w - pair * nqt;
+    const int f = pair / p.heads, h = pair - f * p.heads;
+    const int kvb = f / p.kv_div;
+    const int psq = p.ldq / PLANES, psk = p.ldk / PLANES, psv = p.ldvt / PLANES, pso = p.ldo / PLANES;
+
+    const h16* Qp = reinterpret_cast<const h16*>(p.Q) + (int64_t)f * p.Nq * p.ldq + h * 64;
+    const h16* Kp = reinterpret_cast<const h16*>(p.K) + (int64_t)kvb * p.Nk * p.ldk + h * 64;
+    const h16* Vp = reinterpret_cast<const h16*>(p.Vt) + (int64_t)kvb * p.svt + (int64_t)(h * 64) * p.ldvt;
+    h16* Op = reinterpret_cast<h16*>(p.O) + (int64_t)f * p.Nq * p.ldo + h * 64;
+
+    const int q = qt * QB + wave * 32 + l31;
+    const bool qok = q < p.Nq;
+    h16x8 qf[PLANES][4];
+#pragma unroll
+    for (int pl = 0; pl < PLANES; ++pl)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            qf[pl][ks] = as_h16x8(qok ? ld16(Qp + (int64_t)q * p.ldq + pl * psq + ks * 16 + hi * 8) : zero16());
+
+    const int lrow = tid >> 3, kc = tid & 7;
+    u32x4 kr[PLANES][2], vr[PLANES][2];
+    auto load_tiles = [&](int kt) {
+        const int j0 = kt * KB;
+#pragma unroll
+        for (int pl = 0; pl < PLANES; ++pl)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = lrow + 32 * i;
+                const int j = j0 + row;
+                kr[pl][i] = (j < p.Nk) ? ld16(Kp + (int64_t)j * p.ldk + pl * psk + kc * 8) : zero16();
+                const int jc = j0 + kc * 8;
+                u32x4 v = zero16();
+                if (jc < p.Nk) {
+                    v = ld16(Vp + (int64_t)row * p.ldvt + pl * psv + jc);
+                    if (jc + 8 > p.Nk) {
+                        h16x8 hv = as_h16x8(v);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) if (jc + e >= p.Nk) hv[e] = (h16)0.f;
+                        v = as_u32x4(hv);
+                    }
+                }
+                vr[pl][i] = v;
+            }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int pl = 0; pl < PLANES; ++pl)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                st16(&Ks[(buf * PLANES + pl) * ATILE + (lrow + 32 * i) * ALD + kc * 8], kr[pl][i]);
+                st16(&Vs[(buf * PLANES + pl) * ATILE + (lrow + 32 * i) * ALD + kc * 8], vr[pl][i]);
+            }
+    };
+
+    f32x16 o[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;
+    const float c = p.scale * 1.4426950408889634f;
+
+    const int nkt = (p.Nk + KB - 1) / KB;
+    load_tiles(0);
+    stage(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        const bool more = kt + 1 < nkt;
+        if (more) load_tiles(kt + 1);
+
+        f32x16 s[2];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[sub][r] = 0.f;
+#pragma unroll
+            for (int sg = 0; sg < NSEG; ++sg) {
+                const h16* kp = Ks + (cur * PLANES + seg_xp(sg)) * ATILE + (sub * 32 + l31) * ALD + hi * 8;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const h16x8 kf = *reinterpret_cast<const h16x8*>(kp + ks * 16);
+                    s[sub] = MFMA_32x32x16(kf, qf[seg_wp(sg)][ks], s[sub]);
+                }
+            }
+        }
+        if (kt * KB + KB > p.Nk) {
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int j = kt * KB + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (j >= p.Nk) s[sub][r] = -INFINITY;
+                }
+        }
+
+        float mx = s[0][0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = exp2f((m_run - m_new) * c);
+        const float mc = m_new * c;
+        m_run = m_new;
+        float ps = 0.f;
+        h16x8 pk[PLANES][2][2];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = exp2f(fmaf(s[sub][r], c, -mc));
+                ps += e;
+                h16 piece[PLANES];
+                split_operand(e, piece);
+#pragma unroll
+                for (int pl = 0; pl < PLANES; ++pl) pk[pl][sub][r >> 3][r & 7] = piece[pl];
+            }
+        l_run = l_run * alpha + ps;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int sg = 0; sg < NSEG; ++sg) {
+                const h16* vp = Vs + (cur * PLANES + seg_xp(sg)) * ATILE + (dt * 32 + l31) * ALD + 4 * hi;
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        const int kk = sub * 32 + jj * 16;
+                        const h16x4 lo = *reinterpret_cast<const h16x4*>(vp + kk);
+                        const h16x4 up = *reinterpret_cast<const h16x4*>(vp + kk + 8);
+                        h16x8 vf;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { vf[e] = lo[e]; vf[4 + e] = up[e]; }
+                        o[dt] = MFMA_32x32x16(vf, pk[seg_wp(sg)][sub][jj], o[dt]);
+                    }
+            }
+
+        if (more) stage(cur ^ 1);
+        __syncthreads();
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    if (qok) {
+        h16* orow = Op + (int64_t)q * p.ldo;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                h16* dst = orow + dt * 32 + 8 * g + 4 * hi;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v = o[dt][4 * g + j] / l_tot;
+                    if (p.accumulate) v += load1_operand(dst + j, pso);
+                    store1_operand(dst + j, pso, v);
+                }
+            }
+    }
+}
+
+// Temporal attention of the split builds: q / k / v pieces are summed to fp32 on load and the T x T problem runs on
+// fp32 FMAs (this kernel is bandwidth-bound in every build).  One wave per (pixel, head), K / V of the item in LDS.
+template <int TP>
+__global__ __launch_bounds__(256, 1) void tattn_split_kernel(const h16* __restrict__ QKV, h16* __restrict__ O, int B, int T, int HW,
+                                                              int heads, int ldqkv, int ldo, float scale, int total) {
+    constexpr int DP = 64 / TP, DW = 64 / DP;
+    __shared__ float Ks[4][TP * 64];
+    __shared__ float Vs[4][TP * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tq = lane / DP, dp = lane % DP;
+    const int C = heads * 64;
+    const int w = blockIdx.x * 4 + wave;
+    if (w >= total) return;
+    const int bp = w / heads, h = w - bp * heads;
+    const int b = bp / HW, px = bp - b * HW;
+    const bool ok = tq < T;
+    const int64_t row = ((int64_t)(b * T + tq) * HW + px);
+    const h16* src = QKV + row * ldqkv + h * 64 + dp * DW;
+    const int64_t ps = ldqkv / PLANES;
+    float qv[DW];
+#pragma unroll
+    for (int i = 0; i < DW / 8; ++i) {
+        float q8[8], k8[8], v8[8];
+        if (ok) {
+            load8_operand(src + i * 8, ps, q8);
+            load8_operand(src + C + i * 8, ps, k8);
+            load8_operand(src + 2 * C + i * 8, ps, v8);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { q8[e] = 0.f; k8[e] = 0.f; v8[e] = 0.f; }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            qv[i * 8 + e] = q8[e];
+            Ks[wave][tq * 64 + dp * DW + i * 8 + e] = k8[e];
+            Vs[wave][tq * 64 + dp * DW + i * 8 + e] = v8[e];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    float sc[TP];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < TP; ++j) {
+        float a = 0.f;
+#pragma unroll
+        for (int d = 0; d < DW; ++d) a = fmaf(qv[d], Ks[wave][j * 64 + dp * DW + d], a);
+#pragma unroll
+        for (int o = 1; o < DP; o <<= 1) a += __shfl_xor(a, o, 64);
+        a = (j < T) ? a * scale : -INFINITY;
+        sc[j] = a;
+        mx = fmaxf(mx, a);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < TP; ++j) { sc[j] = expf(sc[j] - mx); sum += sc[j]; }
+    float ov[DW];
+#pragma unroll
+    for (int d = 0; d < DW; ++d) ov[d] = 0.f;
+#pragma unroll
+    for (int j = 0; j < TP; ++j) {
+        const float pj = sc[j] / sum;
+#pragma unroll
+        for (int d = 0; d < DW; ++d) ov[d] = fmaf(pj, Vs[wave][j * 64 + dp * DW + d], ov[d]);
+    }
+    if (ok) {
+        h16* dst = O + row * ldo + h * 64 + dp * DW;
+#pragma unroll
+        for (int i = 0; i < DW / 8; ++i) {
+            float o8[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o8[e] = ov[i * 8 + e];
+            store8_operand(dst + i * 8, ldo / PLANES, o8);
+        }
+    }
+}
+#endif  // MUDG_PLANES > 1
+
 }  // namespace
 
 extern "C" int mudg_attention(const MudgAttnDesc* dp, void* stream) {
@@ -515,9 +775,11 @@ extern "C" int mudg_attention(const MudgAttnDesc* dp, void* stream) {
     MUDG_REQUIRE(d.Q && d.K && d.Vt && d.O, "mudg_attention: null pointer");
     MUDG_REQUIRE(d.F > 0 && d.heads > 0 && d.Nq > 0 && d.Nk > 0, "mudg_attention: empty problem");
     MUDG_REQUIRE(d.kv_div >= 1 && d.F % d.kv_div == 0, "mudg_attention: kv_div=%d F=%d", d.kv_div, d.F);
-    MUDG_REQUIRE((d.ldq & 7) == 0 && (d.ldk & 7) == 0 && (d.ldvt & 7) == 0 && (d.ldo & 3) == 0 && (d.svt & 7) == 0,
-                 "mudg_attention: row strides must be multiples of 8 (ldo of 4)");
-    MUDG_REQUIRE(d.ldvt >= d.Nk, "mudg_attention: ldvt=%d < Nk=%d", d.ldvt, d.Nk);
+    MUDG_REQUIRE(d.ldq % (8 * PLANES) == 0 && d.ldk % (8 * PLANES) == 0 && d.ldvt % (8 * PLANES) == 0 && d.ldo % (4 * PLANES) == 0 &&
+                 (d.svt & 7) == 0, "mudg_attention: row strides must be multiples of %d (ldo of %d)", 8 * PLANES, 4 * PLANES);
+    MUDG_REQUIRE(d.ldvt / PLANES >= d.Nk, "mudg_attention: ldvt=%d < %d x Nk=%d", d.ldvt, PLANES, d.Nk);
+    MUDG_REQUIRE(d.ldq / PLANES >= d.heads * 64 && d.ldk / PLANES >= d.heads * 64 && d.ldo / PLANES >= d.heads * 64,
+                 "mudg_attention: row strides too small for %d heads", d.heads);
     MUDG_REQUIRE(aligned16(d.Q) && aligned16(d.K) && aligned16(d.Vt) && aligned16(d.O), "mudg_attention: alignment");
     const int nqt = (d.Nq + QB - 1) / QB;
     const int64_t total = (int64_t)nqt * d.F * d.heads;
@@ -529,6 +791,21 @@ extern "C" int mudg_attention(const MudgAttnDesc* dp, void* stream) {
     static int var = -1;
     if (var < 0) { const char* e = getenv("MUDG_ATTN_Q"); var = e ? atoi(e) : 0; }
     const bool wide = var == 64 ? d.Nq >= 256 : (var == 32 ? false : (d.Nq >= 512 && d.Nk >= 256));
+#if MUDG_PLANES > 1
+    {
+        constexpr int smem = 4 * PLANES * ATILE * (int)sizeof(h16);
+        static bool attr_done[64] = {};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) MUDG_FAIL(MUDG_ELAUNCH, "mudg_attention: hipGetDevice");
+        if (!attr_done[dev]) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            if (e != hipSuccess) MUDG_FAIL(MUDG_ELAUNCH, "mudg_attention: hipFuncSetAttribute: %s", hipGetErrorString(e));
+            attr_done[dev] = true;
+        }
+        (void)wide;
+        hipLaunchKernelGGL(attn_split_kernel, dim3((unsigned)total), dim3(256), smem, s, d, nqt, (int)total);
+    }
+#else
     if (wide) {
         const int nqt2 = (d.Nq + 255) / 256;
         const int64_t total2 = (int64_t)nqt2 * d.F * d.heads;
@@ -536,6 +813,7 @@ extern "C" int mudg_attention(const MudgAttnDesc* dp, void* stream) {
     } else {
         hipLaunchKernelGGL(attn_kernel, dim3((unsigned)total), dim3(256), 0, s, d, nqt, (int)total);
     }
+#endif
     const int rc = mudg_check_launch("mudg_attention");
     const double bh = (double)d.F * d.heads;
     mudg_prof_end(slot, s, 4.0 * bh * d.Nq * (double)d.Nk * 64.0,
@@ -548,12 +826,21 @@ extern "C" int mudg_temporal_attention(const void* QKV, void* O, int B, int T, i
     MUDG_REQUIRE(QKV && O, "mudg_temporal_attention: null pointer");
     MUDG_REQUIRE(B > 0 && HW > 0 && heads > 0, "mudg_temporal_attention: empty problem");
     MUDG_REQUIRE(T >= 1 && T <= 32, "mudg_temporal_attention: T=%d outside [1,32]", T);
-    MUDG_REQUIRE((ldqkv & 7) == 0 && (ldo & 7) == 0 && aligned16(QKV) && aligned16(O), "mudg_temporal_attention: alignment");
-    MUDG_REQUIRE(ldqkv >= 3 * heads * 64 && ldo >= heads * 64, "mudg_temporal_attention: row strides too small");
+    MUDG_REQUIRE(ldqkv % (8 * PLANES) == 0 && ldo % (8 * PLANES) == 0 && aligned16(QKV) && aligned16(O), "mudg_temporal_attention: alignment");
+    MUDG_REQUIRE(ldqkv / PLANES >= 3 * heads * 64 && ldo / PLANES >= heads * 64, "mudg_temporal_attention: row strides too small");
     const int64_t total = (int64_t)B * HW * heads;
     MUDG_REQUIRE(total < (1ll << 31), "mudg_temporal_attention: grid too large");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int slot = mudg_prof_begin(MUDG_FAM_TATTN, s);
+#if MUDG_PLANES > 1
+    const unsigned grid = (unsigned)((total + 3) / 4);
+    if (T <= 16)
+        hipLaunchKernelGGL(tattn_split_kernel<16>, dim3(grid), dim3(256), 0, s, (const h16*)QKV, (h16*)O, B, T, HW, heads,
+                           ldqkv, ldo, scale, (int)total);
+    else
+        hipLaunchKernelGGL(tattn_split_kernel<32>, dim3(grid), dim3(256), 0, s, (const h16*)QKV, (h16*)O, B, T, HW, heads,
+                           ldqkv, ldo, scale, (int)total);
+#else
     const unsigned grid = (unsigned)((total + 4 * TATTN_ITEMS - 1) / (4 * TATTN_ITEMS));
     if (T <= 16)
         hipLaunchKernelGGL(tattn_kernel<16>, dim3(grid), dim3(256), 0, s, (const h16*)QKV, (h16*)O, B, T, HW, heads,
@@ -561,6 +848,7 @@ extern "C" int mudg_temporal_attention(const void* QKV, void* O, int B, int T, i
     else
         hipLaunchKernelGGL(tattn_kernel<32>, dim3(grid), dim3(256), 0, s, (const h16*)QKV, (h16*)O, B, T, HW, heads,
                            ldqkv, ldo, scale, (int)total);
+#endif
     const int rc = mudg_check_launch("mudg_temporal_attention");
     mudg_prof_end(slot, s, 4.0 * total * (double)T * T * 64.0, (double)total * T * 64.0 * 2.0 * 4.0);
     return rc;

@@ -46,7 +46,7 @@ void mudg_prof_end(int slot, hipStream_t s, double flops, double bytes) {
 
 extern "C" {
 
-int mudg_version(void) { return 1; }
+int mudg_version(void) { return 2; }
 int mudg_operand_dtype(void) { return MUDG_OPERAND_CODE; }
 const char* mudg_last_error(void) { return g_err; }
 

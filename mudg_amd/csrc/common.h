@@ -7,7 +7,22 @@
 // h16 = the 16-bit MFMA operand type of this build: bfloat16 by default (libmudg_hip.so), IEEE half when compiled
 // with -DMUDG_OPERAND_FP16 (libmudg_hip_fp16.so).  Same MFMA rate, same bytes; fp16 has three more mantissa bits
 // (operand rounding 2^-12 instead of 2^-9) and is what the reference itself computes in under torch.autocast.
+//
+// Split-operand precision modes (-DMUDG_PLANES=2 -> libmudg_hip_x3.so, =3 -> libmudg_hip_x6.so): an operand value x is
+// carried as PLANES bf16 numbers x = x0 + x1 (+ x2) with x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1)
+// (16 / 24 significand bits), and a product sum_k x_k w_k is accumulated from the bf16 x bf16 partial products whose
+// magnitude is above the representation error: x0 w0 + x0 w1 + x1 w0 (3 MFMAs per tile, PLANES = 2) or additionally
+// x0 w2 + x2 w0 + x1 w1 (6 MFMAs, PLANES = 3: fp32-class).  In memory, an operand matrix [rows][C] with row stride ld
+// holds plane p of element (r, c) at r * ld + p * (ld / PLANES) + c: allocations are PLANES times as wide and any column
+// slice of one keeps the same plane distance.  The contraction kernels run the ordinary K loop once per kept (x plane,
+// w plane) pair with shifted column offsets — the MFMA code itself is the same as in the 16-bit builds.
+#ifndef MUDG_PLANES
+#define MUDG_PLANES 1
+#endif
 #ifdef MUDG_OPERAND_FP16
+#if MUDG_PLANES != 1
+#error "split operands are bf16"
+#endif
 typedef _Float16 h16;
 #define MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
 #define DOT2_H16(a, b, c) __builtin_amdgcn_fdot2(a, b, c, false)               /* v_dot2c_f32_f16: c + a.x b.x + a.y b.y */
@@ -16,8 +31,14 @@ typedef _Float16 h16;
 typedef __bf16 h16;
 #define MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
 #define DOT2_H16(a, b, c) __builtin_amdgcn_fdot2_f32_bf16(a, b, c, false)      /* v_dot2c_f32_bf16 */
-#define MUDG_OPERAND_CODE 0
+#define MUDG_OPERAND_CODE (MUDG_PLANES == 1 ? 0 : MUDG_PLANES)
 #endif
+constexpr int PLANES = MUDG_PLANES;
+// (x plane, w plane) pairs of the kept partial products, smallest terms first so they are not absorbed by the large one.
+constexpr int NSEG = PLANES == 1 ? 1 : (PLANES == 2 ? 3 : 6);
+__host__ __device__ constexpr int seg_xp(int s) { return PLANES == 1 ? 0 : (PLANES == 2 ? (s == 0 ? 1 : 0) : (s == 0 ? 2 : (s == 1 ? 0 : (s == 2 ? 1 : (s == 3 ? 1 : 0))))); }
+__host__ __device__ constexpr int seg_wp(int s) { return PLANES == 1 ? 0 : (PLANES == 2 ? (s == 1 ? 1 : 0) : (s == 0 ? 0 : (s == 1 ? 2 : (s == 2 ? 1 : (s == 4 ? 1 : 0))))); }
+// PLANES = 2: (1,0) (0,1) (0,0);  PLANES = 3: (2,0) (0,2) (1,1) (1,0) (0,1) (0,0)
 typedef __attribute__((ext_vector_type(8))) h16 h16x8;
 typedef __attribute__((ext_vector_type(4))) h16 h16x4;
 typedef __attribute__((ext_vector_type(2))) h16 h16x2;
@@ -38,6 +59,54 @@ union Pack8 { u32x2 u; h16x4 h; };
 
 __device__ __forceinline__ h16x8 as_h16x8(u32x4 v) { Pack16 p; p.u = v; return p.h; }
 __device__ __forceinline__ u32x4 as_u32x4(h16x8 v) { Pack16 p; p.h = v; return p.u; }
+
+// ---- operand element I/O: one logical value = PLANES h16 numbers `ps` elements apart (ps = row stride / PLANES) ----
+// Eight consecutive channels: 16-byte accesses per plane.
+__device__ __forceinline__ void store8_operand(h16* dst, int64_t ps, const float (&v)[8]) {
+    float r[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = v[e];
+#pragma unroll
+    for (int p = 0; p < PLANES; ++p) {
+        h16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { o[e] = (h16)r[e]; r[e] -= (float)o[e]; }
+        st16(dst + p * ps, as_u32x4(o));
+    }
+}
+__device__ __forceinline__ void load8_operand(const h16* src, int64_t ps, float (&v)[8]) {
+    const h16x8 t0 = as_h16x8(ld16(src));
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (float)t0[e];
+#pragma unroll
+    for (int p = 1; p < PLANES; ++p) {
+        const h16x8 t = as_h16x8(ld16(src + p * ps));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += (float)t[e];
+    }
+}
+__device__ __forceinline__ void store1_operand(h16* dst, int64_t ps, float v) {
+#pragma unroll
+    for (int p = 0; p < PLANES; ++p) { const h16 o = (h16)v; dst[p * ps] = o; v -= (float)o; }
+}
+__device__ __forceinline__ float load1_operand(const h16* src, int64_t ps) {
+    float v = (float)src[0];
+#pragma unroll
+    for (int p = 1; p < PLANES; ++p) v += (float)src[p * ps];
+    return v;
+}
+// One value -> its PLANES pieces in registers (P of the attention kernels).
+__device__ __forceinline__ void split_operand(float v, h16 (&o)[PLANES]) {
+#pragma unroll
+    for (int p = 0; p < PLANES; ++p) { o[p] = (h16)v; v -= (float)o[p]; }
+}
+// The value an operand store will represent (GroupNorm partial sums are taken over what was stored).
+__device__ __forceinline__ float operand_round(float v) {
+    float r = v, acc = 0.f;
+#pragma unroll
+    for (int p = 0; p < PLANES; ++p) { const h16 o = (h16)r; acc += (float)o; r -= (float)o; }
+    return acc;
+}
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }

@@ -162,6 +162,8 @@ __global__ __launch_bounds__(256, SB ? 4 : 2) void gemm_kernel(const MudgGemmDes
     __amdgpu_buffer_rsrc_t rX, rX2, rW;
     unsigned vx[4], vx2[4], vw[4], vmask[4];
     int tap_s = 0, c_s = 0;                                      // tap / channel of the next K-tile to issue
+    int seg_s = 0, kt_s = 0;                                     // split operands: (x plane, w plane) pass and K-tile inside it
+    const int nk = (p.K + BK - 1) / BK;
     if constexpr (FAST) {
         int64_t pix0 = m0;                                       // source pixel (row of X) of output row m0, before the tap shift
         if (MODE == 1) {
@@ -215,7 +217,11 @@ __global__ __launch_bounds__(256, SB ? 4 : 2) void gemm_kernel(const MudgGemmDes
         if (MODE == 0) soff = cc * 2;
         else if (MODE == 1) { const int dy = tap_s / 3, dx = tap_s - 3 * dy; soff = ((dy * p.Win + dx) * ld + cc) * 2; }
         else soff = (tap_s * p.HW * ld + cc) * 2;
-        const int soffw = kt * (BK * 2);
+        int soffw = (PLANES > 1 ? kt_s : kt) * (BK * 2);
+        if constexpr (PLANES > 1) {                  // this pass's operand planes: column offsets of ld / PLANES elements
+            soff += seg_xp(seg_s) * (ld / PLANES) * 2;
+            soffw += seg_wp(seg_s) * (p.ldw / PLANES) * 2;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             unsigned v = s2 ? vx2[i] : vx[i];
@@ -237,10 +243,20 @@ __global__ __launch_bounds__(256, SB ? 4 : 2) void gemm_kernel(const MudgGemmDes
             tap_s = slab ? (wrap ? 0 : t1) : (wrap ? t1 : tap_s);
             c_s = slab ? (wrap ? c1 : c_s) : (wrap ? 0 : c1);
         }
+        if constexpr (PLANES > 1) {                  // end of a pass over K: next plane pair, K walk restarts (select form)
+            const bool last = kt_s + 1 == nk;
+            kt_s = last ? 0 : kt_s + 1;
+            seg_s = last ? seg_s + 1 : seg_s;
+            tap_s = last ? 0 : tap_s;
+            c_s = last ? 0 : c_s;
+        }
     };
 
     auto issue_tiles = [&](int kt, int buf) {
         if constexpr (FAST) { issue_fast(kt, buf); return; }
+        const int seg = PLANES > 1 ? kt / nk : 0;
+        kt -= seg * nk;
+        const int xo1 = seg_xp(seg) * (p.ldx / PLANES), xo2 = seg_xp(seg) * (p.ldx2 / PLANES), wo = seg_wp(seg) * (p.ldw / PLANES);
         const int k0 = kt * BK;
         int tap_u = 0, c_u = 0;
         if (MODE != 0 && tap_uniform) {
@@ -254,13 +270,13 @@ __global__ __launch_bounds__(256, SB ? 4 : 2) void gemm_kernel(const MudgGemmDes
             const h16* src = zpage;
             if (MODE == 0) {
                 if (rv[i] && kv)
-                    src = (k < p.csplit) ? X + (int64_t)rm[i] * p.ldx + k : X2 + (int64_t)rm[i] * p.ldx2 + (k - p.csplit);
+                    src = (k < p.csplit) ? X + (int64_t)rm[i] * p.ldx + k + xo1 : X2 + (int64_t)rm[i] * p.ldx2 + (k - p.csplit) + xo2;
             } else {
                 int tap, c;
                 if (tap_uniform) { tap = tap_u; c = c_u + ch[i] * 8; }
                 else { tap = k / p.Cin; c = k - tap * p.Cin; }
-                const h16* base = X; int cc = c, ld = p.ldx;
-                if (c >= p.csplit) { base = X2; cc = c - p.csplit; ld = p.ldx2; }
+                const h16* base = X; int cc = c + xo1, ld = p.ldx;
+                if (c >= p.csplit) { base = X2; cc = c - p.csplit + xo2; ld = p.ldx2; }
                 if (MODE == 1) {
                     const int dy = tap / 3, dx = tap - dy * 3;
                     const int hlim = p.upsample ? 2 * p.Hin : p.Hin;
@@ -277,7 +293,7 @@ __global__ __launch_bounds__(256, SB ? 4 : 2) void gemm_kernel(const MudgGemmDes
             }
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Xs + buf * TILE + (32 * wave + 8 * i) * LDSLD), 16, 0, 0);
             const int n = n0 + 32 * wave + 8 * i + rsub;
-            const h16* wsrc = (n < p.N && kv) ? W + (int64_t)n * p.ldw + k : zpage;
+            const h16* wsrc = (n < p.N && kv) ? W + (int64_t)n * p.ldw + k + wo : zpage;
             __builtin_amdgcn_global_load_lds((gptr_t)wsrc, (lptr_t)(Ws + buf * TILE + (32 * wave + 8 * i) * LDSLD), 16, 0, 0);
         }
     };
@@ -290,7 +306,7 @@ __global__ __launch_bounds__(256, SB ? 4 : 2) void gemm_kernel(const MudgGemmDes
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    const int nk = (p.K + BK - 1) / BK;
+    const int nkt = nk * NSEG;           // K-tiles over all (x plane, w plane) passes
     const int sw = (l31 >> 1) & 7;       // read-side swizzle: the row bases are multiples of 32, so only lane bits count
     // A wave whose 64 output columns (or rows) all lie beyond N (M) has nothing to multiply: it still stages its share
     // of the operand tiles but leaves its SIMD's MFMA pipe to the other resident workgroups (N = 320: 1/6 of the waves).
@@ -315,7 +331,7 @@ __global__ __launch_bounds__(256, SB ? 4 : 2) void gemm_kernel(const MudgGemmDes
         }
     };
     if constexpr (SB) {
-        for (int kt = 0; kt < nk; ++kt) {
+        for (int kt = 0; kt < nkt; ++kt) {
             issue_tiles(kt, 0);
             __syncthreads();                 // vmcnt(0) + barrier: the tile has landed
             multiply(0);
@@ -324,9 +340,9 @@ __global__ __launch_bounds__(256, SB ? 4 : 2) void gemm_kernel(const MudgGemmDes
     } else {
         issue_tiles(0, 0);
         __syncthreads();                     // drains the DMA (vmcnt(0)) before anyone reads the tile
-        for (int kt = 0; kt < nk; ++kt) {
+        for (int kt = 0; kt < nkt; ++kt) {
             const int cur = kt & 1;
-            if (kt + 1 < nk) issue_tiles(kt + 1, cur ^ 1);
+            if (kt + 1 < nkt) issue_tiles(kt + 1, cur ^ 1);
             multiply(cur);
             __syncthreads();
         }
@@ -366,7 +382,7 @@ __global__ __launch_bounds__(256, SB ? 4 : 2) void gemm_kernel(const MudgGemmDes
                     for (int j = 0; j < 4; ++j) v[j] = alpha * acc[ni][mi][4 * g + j] + sbias[nl + j];
                     if (p.act) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = gelu_fast(v[j]);
+                        for (int j = 0; j < 4; ++j) v[j] = PLANES > 1 ? gelu_erf_f(v[j]) : gelu_fast(v[j]);
                     }
                     *reinterpret_cast<f32x4*>(&stg[ml * STGLD + nl]) = v;
                 }
@@ -379,7 +395,7 @@ __global__ __launch_bounds__(256, SB ? 4 : 2) void gemm_kernel(const MudgGemmDes
                 for (int j = 0; j < 4; ++j) {
                     const float val = alpha * acc[0][mi][4 * g + j] + sbias[nl + j];
                     const float gate = alpha * acc[1][mi][4 * g + j] + sbias[nl + 32 + j];
-                    v[j] = val * (phi ? gelu_lut(gate, phis) : gelu_fast(gate));
+                    v[j] = val * (PLANES > 1 ? gelu_erf_f(gate) : (phi ? gelu_lut(gate, phis) : gelu_fast(gate)));
                 }
                 *reinterpret_cast<f32x4*>(&stg[ml * STGLD + wn * 32 + 8 * g + 4 * hi]) = v;
             }
@@ -408,12 +424,13 @@ __global__ __launch_bounds__(256, SB ? 4 : 2) void gemm_kernel(const MudgGemmDes
         if (R) {
             const h16* rp = R + (int64_t)m * p.ldr + n;
             if (nvalid == 8 && (vflags & VF_R)) {
-                const h16x8 rr = as_h16x8(ld16(rp));
+                float rr[8];
+                load8_operand(rp, p.ldr / PLANES, rr);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] += (float)rr[j];
+                for (int j = 0; j < 8; ++j) v[j] += rr[j];
             } else {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) if (j < nvalid) v[j] += (float)rp[j];
+                for (int j = 0; j < 8; ++j) if (j < nvalid) v[j] += load1_operand(rp + j, p.ldr / PLANES);
             }
         }
         if (Rf) {
@@ -430,7 +447,7 @@ __global__ __launch_bounds__(256, SB ? 4 : 2) void gemm_kernel(const MudgGemmDes
         if (p.stats) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float t = (j < nvalid) ? (p.out_fp32 ? v[j] : (float)(h16)v[j]) : 0.f;
+                const float t = (j < nvalid) ? (p.out_fp32 ? v[j] : operand_round(v[j])) : 0.f;
                 gs[j] += t; gq[j] = fmaf(t, t, gq[j]);
             }
         }
@@ -449,13 +466,10 @@ __global__ __launch_bounds__(256, SB ? 4 : 2) void gemm_kernel(const MudgGemmDes
         } else {
             h16* yp = reinterpret_cast<h16*>(p.Y) + bz * p.sY + (int64_t)m * p.ldy + n;
             if (nvalid == 8 && (vflags & VF_Y)) {
-                h16x8 o;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = (h16)v[j];
-                st16(yp, as_u32x4(o));
+                store8_operand(yp, p.ldy / PLANES, v);
             } else {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) if (j < nvalid) yp[j] = (h16)v[j];
+                for (int j = 0; j < 8; ++j) if (j < nvalid) store1_operand(yp + j, p.ldy / PLANES, v[j]);
             }
         }
     }
@@ -478,23 +492,37 @@ __global__ __launch_bounds__(256, SB ? 4 : 2) void gemm_kernel(const MudgGemmDes
     }
 }
 
+// Lazily created per-device state (a zero page, the Phi table, the kernels' LDS opt-in): keyed by the current device so
+// that one process may drive several GPUs.
+constexpr int MAX_DEVICES = 64;
+int current_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return -1;
+    return dev;
+}
+
 const h16* zero_page() {
-    static h16* page = nullptr;
-    if (!page) {
+    static h16* page[MAX_DEVICES] = {};
+    const int dev = current_device();
+    if (dev < 0) return nullptr;
+    if (!page[dev]) {
         void* ptr = nullptr;
         if (hipMalloc(&ptr, 256) != hipSuccess || hipMemset(ptr, 0, 256) != hipSuccess) return nullptr;
-        page = static_cast<h16*>(ptr);
+        page[dev] = static_cast<h16*>(ptr);
     }
-    return page;
+    return page[dev];
 }
 
 // Phi(x) = 0.5 erfc(-x / sqrt 2) at x = -8 + i / 64, i = 0..1024, built once on the host in double precision.
 // MUDG_GELU_LUT=0 keeps the erf polynomial (A/B measurements).
 const float* phi_table() {
-    static float* tab = nullptr;
+    static float* tabs[MAX_DEVICES] = {};
     static int mode = -1;
     if (mode < 0) { const char* e = getenv("MUDG_GELU_LUT"); mode = e ? atoi(e) : 1; }
-    if (!mode) return nullptr;
+    if (!mode || PLANES > 1) return nullptr;          // the split-operand builds evaluate erf exactly
+    const int dev = current_device();
+    if (dev < 0) return nullptr;
+    float*& tab = tabs[dev];
     if (!tab) {
         float host[PHI_N + 4];
         for (int i = 0; i < PHI_N + 4; ++i) {
@@ -511,9 +539,10 @@ const float* phi_table() {
 
 template <int MODE, bool FAST, bool SB = false>
 int launch(const MudgGemmDesc& d, int vflags, hipStream_t s) {
-    static bool attr_set = false;
+    static bool attr_done[MAX_DEVICES] = {};
     const h16* zp = zero_page();
     if (!zp) MUDG_FAIL(MUDG_ELAUNCH, "gemm: could not allocate the zero page");
+    bool& attr_set = attr_done[current_device()];
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<MODE, FAST, SB>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (SB ? SMEM_BYTES_SB : SMEM_BYTES) + PHI_BYTES);
@@ -539,7 +568,7 @@ bool use_gemm256(const MudgGemmDesc& d) {
         const char* e = getenv("MUDG_GEMM256");
         mode = e ? atoi(e) : 2;
     }
-    if (mode == 0 || d.M < 256 || d.N < 256) return false;
+    if (mode == 0 || PLANES > 1 || d.M < 256 || d.N < 256) return false;      // the 256x256 kernels are 16-bit-operand only
     if (mode == 1) return true;
     const int64_t tn = (d.N + 255) / 256, tiles = ((d.M + 255) / 256) * tn * d.batch;
     const double waste = (double)(tn * 256 - d.N) / (double)(tn * 256);
@@ -580,7 +609,7 @@ bool mudg_gemm_fast_ok(const MudgGemmDesc& d) {
     if ((d.K & 63) || (cin & 63) || (d.csplit & 63)) return false;
     if (d.mode == 1 && d.upsample) return false;
     const int64_t ld = d.X2 && d.ldx2 > d.ldx ? d.ldx2 : d.ldx;
-    int64_t rel = 255, soff = (int64_t)cin * 2;
+    int64_t rel = 255, soff = (int64_t)cin * 2 + (PLANES > 1 ? ld * 2 : 0);
     if (d.mode == 1) {
         rel = (int64_t)(255 / (d.Hout * d.Wout) + 2) * d.Hin * d.Win;
         soff += (int64_t)(2 * d.Win + 2) * ld * 2;
@@ -588,7 +617,7 @@ bool mudg_gemm_fast_ok(const MudgGemmDesc& d) {
         soff += (int64_t)2 * d.HW * ld * 2;
     }
     const int64_t lim = (int64_t)1 << 31;
-    return rel * ld * 2 + 128 + soff + 16 < lim && (int64_t)255 * d.ldw * 2 + (int64_t)d.K * 2 + 144 < lim;
+    return rel * ld * 2 + 128 + soff + 16 < lim && (int64_t)(255 + (PLANES > 1)) * d.ldw * 2 + (int64_t)d.K * 2 + 144 < lim;
 }
 
 int mudg_gemm256_dispatch(const MudgGemmDesc& d, int vflags, const h16* zpage, hipStream_t s);
@@ -600,15 +629,21 @@ extern "C" int mudg_gemm(const MudgGemmDesc* dp, void* stream) {
     MUDG_REQUIRE(d.M > 0 && d.N > 0 && d.K > 0, "mudg_gemm: empty problem M=%d N=%d K=%d", d.M, d.N, d.K);
     MUDG_REQUIRE(d.mode >= 0 && d.mode <= 2, "mudg_gemm: mode %d", d.mode);
     MUDG_REQUIRE((d.K & 7) == 0, "mudg_gemm: K=%d must be a multiple of 8", d.K);
-    MUDG_REQUIRE((d.ldx & 7) == 0 && (d.ldw & 7) == 0, "mudg_gemm: ldx=%d ldw=%d must be multiples of 8", d.ldx, d.ldw);
+    MUDG_REQUIRE(d.ldx % (8 * PLANES) == 0 && d.ldw % (8 * PLANES) == 0, "mudg_gemm: ldx=%d ldw=%d must be multiples of %d", d.ldx, d.ldw, 8 * PLANES);
     MUDG_REQUIRE(aligned16(d.X) && aligned16(d.W), "mudg_gemm: X/W must be 16-byte aligned");
     MUDG_REQUIRE((d.sX & 7) == 0 && (d.sW & 7) == 0, "mudg_gemm: batch strides must be multiples of 8");
     if (d.batch < 1) d.batch = 1;
     const int cin = d.mode == 0 ? d.K : d.Cin;
     if (!d.X2) d.csplit = cin;
     else {
-        MUDG_REQUIRE(aligned16(d.X2) && (d.ldx2 & 7) == 0, "mudg_gemm: X2 alignment");
+        MUDG_REQUIRE(aligned16(d.X2) && d.ldx2 % (8 * PLANES) == 0, "mudg_gemm: X2 alignment");
         MUDG_REQUIRE(d.csplit > 0 && d.csplit < cin && (d.csplit & 7) == 0, "mudg_gemm: csplit=%d", d.csplit);
+    }
+    if (PLANES > 1) {      // plane p of an operand row sits p * (ld / PLANES) elements further: the planes must not overlap
+        MUDG_REQUIRE(d.ldx / PLANES >= d.csplit && d.ldw / PLANES >= d.K && (!d.X2 || d.ldx2 / PLANES >= cin - d.csplit),
+                     "mudg_gemm: split operands need ld / %d >= the logical width (ldx=%d ldx2=%d ldw=%d)", PLANES, d.ldx, d.ldx2, d.ldw);
+        MUDG_REQUIRE(d.out_fp32 || d.ldy % PLANES == 0, "mudg_gemm: ldy=%d must be a multiple of %d", d.ldy, PLANES);
+        MUDG_REQUIRE(!d.R || d.res_fp32 || d.ldr % PLANES == 0, "mudg_gemm: ldr=%d must be a multiple of %d", d.ldr, PLANES);
     }
     if (d.mode == 1) {
         MUDG_REQUIRE(d.Cin > 0 && (d.Cin & 7) == 0 && d.K == 9 * d.Cin, "mudg_gemm: conv K=%d Cin=%d", d.K, d.Cin);
@@ -628,9 +663,9 @@ extern "C" int mudg_gemm(const MudgGemmDesc* dp, void* stream) {
     if (d.alpha == 0.f) d.alpha = 1.f;
     int vflags = 0;
     const int ybytes = d.out_fp32 ? 4 : 2;
-    if (aligned16(d.Y) && ((int64_t)d.ldy * ybytes) % 16 == 0 && ((int64_t)d.sY * ybytes) % 16 == 0) vflags |= VF_Y;
+    if (aligned16(d.Y) && ((int64_t)d.ldy * ybytes) % (d.out_fp32 ? 16 : 16 * PLANES) == 0 && ((int64_t)d.sY * ybytes) % 16 == 0) vflags |= VF_Y;
     const int rbytes = d.res_fp32 ? 4 : 2;
-    if (d.R && aligned16(d.R) && ((int64_t)d.ldr * rbytes) % 16 == 0 && ((int64_t)d.sR * rbytes) % 16 == 0) vflags |= VF_R;
+    if (d.R && aligned16(d.R) && ((int64_t)d.ldr * rbytes) % (d.res_fp32 ? 16 : 16 * PLANES) == 0 && ((int64_t)d.sR * rbytes) % 16 == 0) vflags |= VF_R;
 
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int fam = d.mode == 0 ? MUDG_FAM_GEMM : (d.mode == 1 ? MUDG_FAM_CONV : MUDG_FAM_TCONV);
@@ -654,7 +689,7 @@ extern "C" int mudg_gemm(const MudgGemmDesc* dp, void* stream) {
             rc = d.mode == 0 ? launch<0, false>(d, vflags, s) : (d.mode == 1 ? launch<1, false>(d, vflags, s) : launch<2, false>(d, vflags, s));
         }
     }
-    const double flops = 2.0 * d.M * (double)d.N * d.K * d.batch;
+    const double flops = 2.0 * d.M * (double)d.N * d.K * d.batch;          // algorithmic (the split builds issue NSEG times as many)
     const double bytes = ((double)d.M * cin + (double)d.N * d.K + (double)d.M * (d.geglu ? d.N / 2 : d.N)) * 2.0 * d.batch;
     mudg_prof_end(slot, s, flops, bytes);
     return rc;

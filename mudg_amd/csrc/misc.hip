@@ -53,8 +53,12 @@ __global__ void ncthw_to_rows_kernel(const ST* __restrict__ src, h16* __restrict
     const int64_t bt = i / HW;
     const int t = (int)(bt % T), b = (int)(bt / T);
     for (int c = 0; c < C; ++c)
-        dst[i * ld + coff + c] = (h16)(float)src[(((int64_t)b * C + c) * Ttot + t0 + t) * HW + p];
+        store1_operand(dst + i * ld + coff + c, ld / PLANES, (float)src[(((int64_t)b * C + c) * Ttot + t0 + t) * HW + p]);
 }
+
+// A rows-matrix element as fp32: operand storage (PLANES pieces) or plain fp32.
+__device__ __forceinline__ float row_value(const h16* p, int ld) { return load1_operand(p, ld / PLANES); }
+__device__ __forceinline__ float row_value(const float* p, int) { return *p; }
 
 template <typename ST, typename DT>
 __global__ void rows_to_ncthw_kernel(const ST* __restrict__ src, int ld, int coff, DT* __restrict__ dst, int B, int C,
@@ -66,14 +70,15 @@ __global__ void rows_to_ncthw_kernel(const ST* __restrict__ src, int ld, int cof
     const int64_t bt = i / HW;
     const int t = (int)(bt % T), b = (int)(bt / T);
     for (int c = 0; c < C; ++c)
-        dst[(((int64_t)b * C + c) * Ttot + t0 + t) * HW + p] = (DT)((float)src[i * ld + coff + c] * scale);
+        dst[(((int64_t)b * C + c) * Ttot + t0 + t) * HW + p] = (DT)(row_value(src + i * ld + coff + c, ld) * scale);
 }
 
 __global__ void zero_channels_kernel(h16* __restrict__ dst, int64_t rows, int ld, int c0, int c1) {
     const int w = c1 - c0;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows * w) return;
-    dst[(i / w) * ld + c0 + (int)(i % w)] = (h16)0.f;
+#pragma unroll
+    for (int p = 0; p < PLANES; ++p) dst[(i / w) * ld + p * (ld / PLANES) + c0 + (int)(i % w)] = (h16)0.f;
 }
 
 __global__ void copy_rows_kernel(const h16* __restrict__ src, int64_t lds, h16* __restrict__ dst, int64_t ldd, int64_t rows,
@@ -83,12 +88,28 @@ __global__ void copy_rows_kernel(const h16* __restrict__ src, int64_t lds, h16* 
         const int64_t cv = cols >> 3;
         if (i >= rows * cv) return;
         const int64_t r = i / cv, c = (i - r * cv) << 3;
-        st16(dst + r * ldd + c, ld16(src + r * lds + c));
+#pragma unroll
+        for (int p = 0; p < PLANES; ++p) st16(dst + r * ldd + p * (ldd / PLANES) + c, ld16(src + r * lds + p * (lds / PLANES) + c));
     } else {
         if (i >= rows * cols) return;
         const int64_t r = i / cols, c = i - r * cols;
-        dst[r * ldd + c] = src[r * lds + c];
+#pragma unroll
+        for (int p = 0; p < PLANES; ++p) dst[r * ldd + p * (ldd / PLANES) + c] = src[r * lds + p * (lds / PLANES) + c];
     }
+}
+
+// dst[r][c] = src[r][c] between operand (h16 planes) and fp32 rows matrices, any direction.
+template <typename ST, typename DT>
+__global__ void cast_rows_kernel(const ST* __restrict__ src, int64_t lds, DT* __restrict__ dst, int64_t ldd, int64_t rows,
+                                 int64_t cols) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cols) return;
+    const int64_t r = i / cols, c = i - r * cols;
+    float v;
+    if constexpr (sizeof(ST) == 2) v = load1_operand(reinterpret_cast<const h16*>(src) + r * lds + c, lds / PLANES);
+    else v = src[r * lds + c];
+    if constexpr (sizeof(DT) == 2) store1_operand(reinterpret_cast<h16*>(dst) + r * ldd + c, ldd / PLANES, v);
+    else dst[r * ldd + c] = v;
 }
 
 __global__ void cast_kernel(const float* __restrict__ src, h16* __restrict__ dst, int64_t n8, int64_t n) {
@@ -235,7 +256,7 @@ extern "C" int mudg_small_linear(const float* x, const void* W, int w_is_bf16, c
 
 extern "C" int mudg_ncthw_to_rows(const void* src, int src_is_fp32, void* dst, int B, int C, int T, int HW, int ld, int coff,
                                   int Ttot, int t0, void* stream) {
-    MUDG_REQUIRE(src && dst && B > 0 && C > 0 && T > 0 && HW > 0 && coff >= 0 && coff + C <= ld, "mudg_ncthw_to_rows: bad arguments");
+    MUDG_REQUIRE(src && dst && B > 0 && C > 0 && T > 0 && HW > 0 && coff >= 0 && ld % PLANES == 0 && coff + C <= ld / PLANES, "mudg_ncthw_to_rows: bad arguments");
     if (Ttot <= 0) { Ttot = T; t0 = 0; }
     MUDG_REQUIRE(t0 >= 0 && t0 + T <= Ttot, "mudg_ncthw_to_rows: frame window [%d, %d) outside %d", t0, t0 + T, Ttot);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -248,7 +269,8 @@ extern "C" int mudg_ncthw_to_rows(const void* src, int src_is_fp32, void* dst, i
 
 extern "C" int mudg_rows_to_ncthw(const void* src, int src_is_fp32, int ld, int coff, void* dst, int dst_is_fp32, int B, int C,
                                   int T, int HW, float scale, int Ttot, int t0, void* stream) {
-    MUDG_REQUIRE(src && dst && B > 0 && C > 0 && T > 0 && HW > 0 && coff >= 0 && coff + C <= ld, "mudg_rows_to_ncthw: bad arguments");
+    MUDG_REQUIRE(src && dst && B > 0 && C > 0 && T > 0 && HW > 0 && coff >= 0 && (src_is_fp32 ? coff + C <= ld : (ld % PLANES == 0 && coff + C <= ld / PLANES)),
+                 "mudg_rows_to_ncthw: bad arguments");
     if (Ttot <= 0) { Ttot = T; t0 = 0; }
     MUDG_REQUIRE(t0 >= 0 && t0 + T <= Ttot, "mudg_rows_to_ncthw: frame window [%d, %d) outside %d", t0, t0 + T, Ttot);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -265,17 +287,32 @@ extern "C" int mudg_rows_to_ncthw(const void* src, int src_is_fp32, int ld, int 
 }
 
 extern "C" int mudg_zero_channels(void* dst, int rows, int ld, int c0, int c1, void* stream) {
-    MUDG_REQUIRE(dst && rows > 0 && c0 >= 0 && c1 > c0 && c1 <= ld, "mudg_zero_channels: bad arguments");
+    MUDG_REQUIRE(dst && rows > 0 && c0 >= 0 && c1 > c0 && ld % PLANES == 0 && c1 <= ld / PLANES, "mudg_zero_channels: bad arguments");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int64_t n = (int64_t)rows * (c1 - c0);
     hipLaunchKernelGGL(zero_channels_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (h16*)dst, (int64_t)rows, ld, c0, c1);
     return mudg_check_launch("mudg_zero_channels");
 }
 
-extern "C" int mudg_copy_rows(const void* src, int64_t lds, void* dst, int64_t ldd, int64_t rows, int64_t cols, void* stream) {
-    MUDG_REQUIRE(src && dst && rows > 0 && cols > 0 && lds >= cols && ldd >= cols, "mudg_copy_rows: bad arguments");
+extern "C" int mudg_cast_rows(const void* src, int src_fp32, int64_t lds, void* dst, int dst_fp32, int64_t ldd, int64_t rows,
+                              int64_t cols, void* stream) {
+    MUDG_REQUIRE(src && dst && rows > 0 && cols > 0, "mudg_cast_rows: bad arguments");
+    MUDG_REQUIRE(src_fp32 ? lds >= cols : (lds % PLANES == 0 && lds / PLANES >= cols), "mudg_cast_rows: lds=%lld", (long long)lds);
+    MUDG_REQUIRE(dst_fp32 ? ldd >= cols : (ldd % PLANES == 0 && ldd / PLANES >= cols), "mudg_cast_rows: ldd=%lld", (long long)ldd);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const int vec = aligned16(src) && aligned16(dst) && !(lds & 7) && !(ldd & 7) && !(cols & 7);
+    const dim3 grid((unsigned)((rows * cols + 255) / 256));
+    if (src_fp32 && dst_fp32) hipLaunchKernelGGL((cast_rows_kernel<float, float>), grid, dim3(256), 0, s, (const float*)src, lds, (float*)dst, ldd, rows, cols);
+    else if (src_fp32) hipLaunchKernelGGL((cast_rows_kernel<float, h16>), grid, dim3(256), 0, s, (const float*)src, lds, (h16*)dst, ldd, rows, cols);
+    else if (dst_fp32) hipLaunchKernelGGL((cast_rows_kernel<h16, float>), grid, dim3(256), 0, s, (const h16*)src, lds, (float*)dst, ldd, rows, cols);
+    else hipLaunchKernelGGL((cast_rows_kernel<h16, h16>), grid, dim3(256), 0, s, (const h16*)src, lds, (h16*)dst, ldd, rows, cols);
+    return mudg_check_launch("mudg_cast_rows");
+}
+
+extern "C" int mudg_copy_rows(const void* src, int64_t lds, void* dst, int64_t ldd, int64_t rows, int64_t cols, void* stream) {
+    MUDG_REQUIRE(src && dst && rows > 0 && cols > 0 && lds % PLANES == 0 && ldd % PLANES == 0 && lds / PLANES >= cols &&
+                 ldd / PLANES >= cols, "mudg_copy_rows: bad arguments");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int vec = aligned16(src) && aligned16(dst) && lds % (8 * PLANES) == 0 && ldd % (8 * PLANES) == 0 && !(cols & 7);
     const int64_t n = vec ? rows * (cols >> 3) : rows * cols;
     hipLaunchKernelGGL(copy_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const h16*)src, lds, (h16*)dst,
                        ldd, rows, cols, vec);
@@ -284,6 +321,7 @@ extern "C" int mudg_copy_rows(const void* src, int64_t lds, void* dst, int64_t l
 
 extern "C" int mudg_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream) {
     MUDG_REQUIRE(src && dst && n > 0 && aligned16(src) && aligned16(dst), "mudg_cast_f32_bf16: bad arguments");
+    if (PLANES > 1) MUDG_FAIL(MUDG_EUNSUPPORTED, "mudg_cast_f32_bf16: a flat cast has no plane layout in the split-operand builds; use mudg_cast_rows");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int64_t n8 = n >> 3;
     hipLaunchKernelGGL(cast_kernel, dim3((unsigned)((n8 + 1 + 255) / 256)), dim3(256), 0, s, src, (h16*)dst, n8, n);

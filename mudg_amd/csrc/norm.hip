@@ -7,17 +7,13 @@ namespace {
 
 constexpr int GN_CMAX = 4096;
 
-// Eight consecutive channels of one pixel as fp32, from h16 (16 B) or fp32 (32 B) storage.
+// Eight consecutive channels of one pixel as fp32, from operand (h16, PLANES pieces `ld / PLANES` apart) or fp32 storage.
 template <typename T> struct Load8;
 template <> struct Load8<h16> {
-    static __device__ __forceinline__ void get(const h16* p, float (&x)[8]) {
-        const h16x8 t = as_h16x8(ld16(p));
-#pragma unroll
-        for (int e = 0; e < 8; ++e) x[e] = (float)t[e];
-    }
+    static __device__ __forceinline__ void get(const h16* p, int ld, float (&x)[8]) { load8_operand(p, ld / PLANES, x); }
 };
 template <> struct Load8<float> {
-    static __device__ __forceinline__ void get(const float* p, float (&x)[8]) {
+    static __device__ __forceinline__ void get(const float* p, int, float (&x)[8]) {
         const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) { x[e] = a[e]; x[4 + e] = b[e]; }
@@ -69,7 +65,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ X, 
             if (c0 >= csplit) { base = X2; cc = c0 - csplit; ld = ldx2; }
             for (int r = r0 + wave; r < r1; r += 4) {
                 float xv[8];
-                Load8<T>::get(base + (srow + r) * ld + cc, xv);
+                Load8<T>::get(base + (srow + r) * ld + cc, ld, xv);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { s[e] += xv[e]; q[e] = fmaf(xv[e], xv[e], q[e]); }
             }
@@ -188,15 +184,16 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ X, 
         const T* base = X; int cc = c0, ld = ldx;
         if (c0 >= csplit) { base = X2; cc = c0 - csplit; ld = ldx2; }
         float xv[8];
-        Load8<T>::get(base + (srow + r) * ld + cc, xv);
-        h16x8 o;
+        Load8<T>::get(base + (srow + r) * ld + cc, ld, xv);
+        float o[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             float y = fmaf(xv[e], sc[c0 + e], sh[c0 + e]);
-            if (silu) y = y * __builtin_amdgcn_rcpf(1.0f + __expf(-y));      // 1-ulp reciprocal: the result is rounded to h16
-            o[e] = (h16)y;
+            if (silu) y = PLANES > 1 ? y / (1.0f + expf(-y))                   // split builds: IEEE division, full-precision exp
+                                     : y * __builtin_amdgcn_rcpf(1.0f + __expf(-y));      // 1-ulp reciprocal: the result is rounded to h16
+            o[e] = y;
         }
-        st16(Y + (srow + r) * ldy + c0, as_u32x4(o));
+        store8_operand(Y + (srow + r) * ldy + c0, ldy / PLANES, o);
     }
 }
 
@@ -215,7 +212,7 @@ __global__ __launch_bounds__(256) void ln_kernel(const T* __restrict__ X, int ld
     for (int i = 0; i < VMAX; ++i) {
         const int v = lane + 64 * i;
         if (v < nvec) {
-            Load8<T>::get(X + row * ldx + v * 8, x[i]);
+            Load8<T>::get(X + row * ldx + v * 8, ldx, x[i]);
 #pragma unroll
             for (int e = 0; e < 8; ++e) s += x[i][e];
         } else {
@@ -242,13 +239,13 @@ __global__ __launch_bounds__(256) void ln_kernel(const T* __restrict__ X, int ld
             const f32x4 g1 = *reinterpret_cast<const f32x4*>(gamma + v * 8 + 4);
             const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + v * 8);
             const f32x4 b1 = *reinterpret_cast<const f32x4*>(beta + v * 8 + 4);
-            h16x8 o;
+            float o[8];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                o[e] = (h16)fmaf((x[i][e] - mean) * rstd, g0[e], b0[e]);
-                o[4 + e] = (h16)fmaf((x[i][4 + e] - mean) * rstd, g1[e], b1[e]);
+                o[e] = fmaf((x[i][e] - mean) * rstd, g0[e], b0[e]);
+                o[4 + e] = fmaf((x[i][4 + e] - mean) * rstd, g1[e], b1[e]);
             }
-            st16(Y + row * ldy + v * 8, as_u32x4(o));
+            store8_operand(Y + row * ldy + v * 8, ldy / PLANES, o);
         }
     }
 }
@@ -268,13 +265,13 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
     mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     __syncthreads();
     float sum = 0.f;
-    for (int c = tid; c < cols; c += 256) sum += __expf(s[c] - mx);
+    for (int c = tid; c < cols; c += 256) sum += PLANES > 1 ? expf(s[c] - mx) : __expf(s[c] - mx);
     sum = wave_sum(sum);
     if (lane == 0) red[wave] = sum;
     __syncthreads();
     sum = ((red[0] + red[1]) + red[2]) + red[3];
     const float inv = 1.f / sum;
-    for (int c = tid; c < cols; c += 256) p[c] = (h16)(__expf(s[c] - mx) * inv);
+    for (int c = tid; c < cols; c += 256) store1_operand(p + c, ldp / PLANES, (PLANES > 1 ? expf(s[c] - mx) : __expf(s[c] - mx)) * inv);
 }
 
 }  // namespace
@@ -291,11 +288,12 @@ extern "C" int mudg_groupnorm(const void* X, const void* X2, int csplit, int ldx
     MUDG_REQUIRE(samples > 0 && rows > 0 && C > 0 && groups > 0, "mudg_groupnorm: empty problem");
     MUDG_REQUIRE(C % groups == 0 && (C & 7) == 0 && C <= GN_CMAX, "mudg_groupnorm: C=%d groups=%d unsupported", C, groups);
     MUDG_REQUIRE(groups <= 256, "mudg_groupnorm: groups=%d > 256", groups);
-    const int xq = x_fp32 ? 3 : 7;      // row stride granule so that every 8-channel vector is 16-byte aligned
-    MUDG_REQUIRE((ldx & xq) == 0 && (ldy & 7) == 0 && aligned16(X) && aligned16(Y), "mudg_groupnorm: alignment");
+    const int xq = x_fp32 ? 4 : 8 * PLANES;      // row stride granule so that every 8-channel vector (of every plane) is 16-byte aligned
+    MUDG_REQUIRE(ldx % xq == 0 && ldy % (8 * PLANES) == 0 && aligned16(X) && aligned16(Y), "mudg_groupnorm: alignment");
+    MUDG_REQUIRE(ldy / PLANES >= C, "mudg_groupnorm: ldy=%d too small for %d plane(s) of %d channels", ldy, PLANES, C);
     MUDG_REQUIRE(samples <= 65535, "mudg_groupnorm: too many samples");
     if (!X2) { csplit = C; ldx2 = ldx; }
-    else MUDG_REQUIRE(csplit > 0 && csplit < C && (csplit & 7) == 0 && (ldx2 & xq) == 0 && aligned16(X2), "mudg_groupnorm: X2/csplit");
+    else MUDG_REQUIRE(csplit > 0 && csplit < C && (csplit & 7) == 0 && ldx2 % xq == 0 && aligned16(X2), "mudg_groupnorm: X2/csplit");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int nchunks = gn_chunks(samples, rows);
     float* part = ws;
@@ -329,11 +327,12 @@ extern "C" int mudg_groupnorm_fused(const void* X, const void* X2, int csplit, i
     MUDG_REQUIRE(samples > 0 && rows > 0 && C > 0 && groups > 0, "mudg_groupnorm_fused: empty problem");
     MUDG_REQUIRE(C % groups == 0 && (C & 7) == 0 && C <= GN_CMAX && groups <= 256, "mudg_groupnorm_fused: C=%d groups=%d unsupported", C, groups);
     MUDG_REQUIRE(rows % 128 == 0, "mudg_groupnorm_fused: rows=%d per sample must be a multiple of the 128-row partial blocks", rows);
-    const int xq = x_fp32 ? 3 : 7;
-    MUDG_REQUIRE((ldx & xq) == 0 && (ldy & 7) == 0 && aligned16(X) && aligned16(Y), "mudg_groupnorm_fused: alignment");
+    const int xq = x_fp32 ? 4 : 8 * PLANES;
+    MUDG_REQUIRE(ldx % xq == 0 && ldy % (8 * PLANES) == 0 && aligned16(X) && aligned16(Y), "mudg_groupnorm_fused: alignment");
+    MUDG_REQUIRE(ldy / PLANES >= C, "mudg_groupnorm_fused: ldy=%d too small for %d plane(s) of %d channels", ldy, PLANES, C);
     MUDG_REQUIRE(samples <= 65535, "mudg_groupnorm_fused: too many samples");
     if (!X2) { csplit = C; ldx2 = ldx; P2 = P1; }
-    else MUDG_REQUIRE(P2 && csplit > 0 && csplit < C && (csplit & 7) == 0 && (ldx2 & xq) == 0 && aligned16(X2), "mudg_groupnorm_fused: X2/csplit/P2");
+    else MUDG_REQUIRE(P2 && csplit > 0 && csplit < C && (csplit & 7) == 0 && ldx2 % xq == 0 && aligned16(X2), "mudg_groupnorm_fused: X2/csplit/P2");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     float* stat = ws;
     const int slot = mudg_prof_begin(MUDG_FAM_GNORM, s);
@@ -356,8 +355,9 @@ extern "C" int mudg_layernorm(const void* X, int ldx, int x_fp32, const float* g
                               int rows, int C, float eps, void* stream) {
     MUDG_REQUIRE(X && Y && gamma && beta, "mudg_layernorm: null pointer");
     MUDG_REQUIRE(rows > 0 && C > 0 && (C & 7) == 0 && C <= 4096, "mudg_layernorm: rows=%d C=%d unsupported", rows, C);
-    MUDG_REQUIRE((ldx & (x_fp32 ? 3 : 7)) == 0 && (ldy & 7) == 0 && aligned16(X) && aligned16(Y) && aligned16(gamma) &&
+    MUDG_REQUIRE(ldx % (x_fp32 ? 4 : 8 * PLANES) == 0 && ldy % (8 * PLANES) == 0 && aligned16(X) && aligned16(Y) && aligned16(gamma) &&
                  aligned16(beta), "mudg_layernorm: alignment");
+    MUDG_REQUIRE(ldy / PLANES >= C, "mudg_layernorm: ldy=%d too small for %d plane(s) of %d channels", ldy, PLANES, C);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int slot = mudg_prof_begin(MUDG_FAM_LNORM, s);
     const dim3 grid((rows + 3) / 4);
@@ -375,7 +375,7 @@ extern "C" int mudg_layernorm(const void* X, int ldx, int x_fp32, const float* g
 }
 
 extern "C" int mudg_softmax_rows(const float* S, int lds, void* P, int ldp, int rows, int cols, void* stream) {
-    MUDG_REQUIRE(S && P && rows > 0 && cols > 0, "mudg_softmax_rows: bad arguments");
+    MUDG_REQUIRE(S && P && rows > 0 && cols > 0 && ldp % PLANES == 0 && ldp / PLANES >= cols, "mudg_softmax_rows: bad arguments");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int slot = mudg_prof_begin(MUDG_FAM_MISC, s);
     hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, s, S, lds, (h16*)P, ldp, cols);

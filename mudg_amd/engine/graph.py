@@ -13,12 +13,13 @@ copies it points at would be stale otherwise.
 import torch
 
 from . import unet as U
+from .packing import _version
 
 
 def _params_signature(model):
     sig = 0
     for p in model.parameters():
-        sig = (sig * 1000003 + p._version + (p.data_ptr() & 0xFFFFF)) & 0xFFFFFFFFFFFF
+        sig = (sig * 1000003 + _version(p) + (p.data_ptr() & 0xFFFFF)) & 0xFFFFFFFFFFFF
     return sig
 
 

@@ -11,8 +11,15 @@ from .. import hip
 
 
 
+def _version(p):
+    try:
+        return p._version
+    except RuntimeError:            # tensors created under torch.inference_mode() do not track versions
+        return 0
+
+
 def _key(params):
-    return tuple((p.data_ptr(), p._version, p.dtype, tuple(p.shape)) for p in params)
+    return tuple((p.data_ptr(), _version(p), p.dtype, tuple(p.shape)) for p in params)
 
 
 def cached(module, name, params, build):
@@ -44,11 +51,28 @@ def f32(module, name):
     return cached(module, "f32:" + name, (p,), lambda: p.detach().float().contiguous())
 
 
+def operand(t2d):
+    """fp32 [N, K] -> the MFMA operand matrix the kernels read: a 16-bit cast, or in the split-operand builds the
+    pieces hi = bf16(w), mid = bf16(w - hi), ... side by side ([N, planes * K] storage, returned as the [N, K] view of
+    piece 0; see ops.empty_rows).  One-off layout work on the device, redone only when the parameter changes."""
+    planes, dt = hip.planes(), hip.operand_dtype()
+    t2d = t2d.detach()
+    if planes == 1:
+        return t2d.to(dt).contiguous()
+    rest = t2d.float()
+    pieces = []
+    for _ in range(planes):
+        piece = rest.to(dt)
+        pieces.append(piece)
+        rest = rest - piece.float()
+    return torch.cat(pieces, dim=1).contiguous()[:, :t2d.shape[1]]
+
+
 def linear(mod):
     """[N, K] bf16 from nn.Linear / 1x1 Conv2d / k=1 Conv1d weights."""
     w = mod.weight
     _need_cuda(w, type(mod).__name__)
-    return cached(mod, "w", (w,), lambda: w.detach().reshape(w.shape[0], -1).to(hip.operand_dtype()).contiguous())
+    return cached(mod, "w", (w,), lambda: operand(w.detach().reshape(w.shape[0], -1)))
 
 
 def linear_cat(owner, name, mods):
@@ -56,7 +80,7 @@ def linear_cat(owner, name, mods):
     ws = tuple(m.weight for m in mods)
     for w in ws:
         _need_cuda(w, name)
-    return cached(owner, name, ws, lambda: torch.cat([w.detach().to(hip.operand_dtype()) for w in ws], 0).contiguous())
+    return cached(owner, name, ws, lambda: operand(torch.cat([w.detach().float() for w in ws], 0)))
 
 
 def conv3x3(mod):
@@ -75,7 +99,7 @@ def conv3x3(mod):
             t = t.reshape(cout, 9, cin // 64, 64).permute(0, 2, 1, 3)
         elif cpad != cin:
             t = torch.nn.functional.pad(t, (0, cpad - cin))
-        return t.reshape(cout, 9 * cpad).to(hip.operand_dtype()).contiguous()
+        return operand(t.reshape(cout, 9 * cpad))
 
     return cached(mod, "w3x3", (w,), build), cpad, korder
 
@@ -84,8 +108,7 @@ def tconv(mod):
     """(Cout, Cin, 3, 1, 1) -> [Cout][tap][Cin] bf16."""
     w = mod.weight
     _need_cuda(w, type(mod).__name__)
-    return cached(mod, "wt", (w,), lambda: w.detach()[:, :, :, 0, 0].permute(0, 2, 1).reshape(w.shape[0], -1)
-                  .to(hip.operand_dtype()).contiguous())
+    return cached(mod, "wt", (w,), lambda: operand(w.detach()[:, :, :, 0, 0].permute(0, 2, 1).reshape(w.shape[0], -1)))
 
 
 def geglu(mod):
@@ -100,6 +123,6 @@ def geglu(mod):
     def build():
         idx = torch.arange(inner, device=w.device).reshape(-1, 32)
         order = torch.cat([idx, idx + inner], dim=1).reshape(-1)
-        return (w.detach()[order].to(hip.operand_dtype()).contiguous(), b.detach()[order].float().contiguous())
+        return (operand(w.detach()[order]), b.detach()[order].float().contiguous())
 
     return cached(mod, "geglu", (w, b), build)

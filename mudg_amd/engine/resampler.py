@@ -13,8 +13,8 @@ from . import packing as pk
 def _kv_weights(attn):
     w = attn.to_kv.weight
     inner = w.shape[0] // 2
-    wk = pk.cached(attn, "wk", (w,), lambda: w.detach()[:inner].to(ops.H16()).contiguous())
-    wv = pk.cached(attn, "wv", (w,), lambda: w.detach()[inner:].to(ops.H16()).contiguous())
+    wk = pk.cached(attn, "wk", (w,), lambda: pk.operand(w.detach()[:inner]))
+    wv = pk.cached(attn, "wv", (w,), lambda: pk.operand(w.detach()[inner:]))
     return wk, wv, inner
 
 
@@ -26,7 +26,7 @@ def forward(mod, x):
     dev = x.device
     lat_p = mod.latents
     n2, dim = lat_p.shape[1], lat_p.shape[2]
-    xin = ops.cast_bf16(x.reshape(b * n1, e).float().contiguous())
+    xin = ops.cast_bf16(x.reshape(b * n1, e).float().contiguous())      # fp32 tokens -> MFMA operand rows
     xs = ops.gemm(xin, pk.linear(mod.proj_in), bias=pk.f32(mod.proj_in, "bias"))            # (b*n1, dim) operand rows
     # fp32 latent stream: the learned queries replicated per batch entry (resampler.py:134; a copy, no arithmetic)
     lat = lat_p.detach().float().repeat(b, 1, 1).reshape(b * n2, dim).contiguous()
@@ -47,9 +47,9 @@ def forward(mod, x):
         k = ops.gemm(kv_in, wk)
         ldv = (nk + 7) // 8 * 8
         vt = ops.empty_rows(b * inner, ldv, None, dev)
-        ops.gemm(wv, kv_in, out=vt, batch=b, sx=0, sw=nk * dim, sy=inner * ldv, M=inner, N=nk, K=dim, ldy=ldv)
+        ops.gemm(wv, kv_in, out=vt, batch=b, sx=0, sw=nk * kv_in.stride(0), sy=inner * vt.stride(0), M=inner, N=nk, K=dim)
         att = ops.empty_rows(b * n2, inner, None, dev)
-        ops.attention(q, k, vt, att, frames=b, heads=heads, nq=n2, nk=nk, ldvt=ldv, svt=inner * ldv, scale=attn.scale)
+        ops.attention(q, k, vt, att, frames=b, heads=heads, nq=n2, nk=nk, scale=attn.scale)
         lat = ops.gemm(att, pk.linear(attn.to_out), residual=lat, out_fp32=True)
         hid = ops.gemm(ops.layernorm(lat, pk.f32(ff[0], "weight"), pk.f32(ff[0], "bias"), eps=ff[0].eps),
                        pk.linear(ff[1]), gelu=True)

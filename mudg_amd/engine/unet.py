@@ -60,9 +60,9 @@ def _vt_projection(mod, src_rows, batches, n_per_batch):
     c, k = w.shape
     ld = (n_per_batch + 7) // 8 * 8
     out = ops.empty_rows(batches * c, ld, ops.H16(), src_rows.device)
-    ops.gemm(w, src_rows, out=out, batch=batches, sx=0, sw=n_per_batch * src_rows.stride(0), sy=c * ld,
-             M=c, N=n_per_batch, K=k, ldy=ld)
-    return out, ld
+    ops.gemm(w, src_rows, out=out, batch=batches, sx=0, sw=n_per_batch * src_rows.stride(0), sy=c * out.stride(0),
+             M=c, N=n_per_batch, K=k)
+    return out, out.stride(0)
 
 
 def _feed_forward(ff, x_norm, residual, stream=True):
@@ -227,20 +227,19 @@ def make_context(model, ctx, context, t_len, device):
     if L <= 77:
         raise ValueError("context needs more than the 77 text tokens (image tokens follow them)")
     flat = context.contiguous()
-    if flat.dtype not in (torch.float32, ops.H16()):
+    if flat.dtype != torch.float32:
         flat = flat.float()
-    rows = ops.cast_bf16(flat.reshape(ctx.B * L, D))
     ctx.n_text = 77
     # openaimodel3d.py:581-587: per-frame image tokens when L == 77 + 16 T, otherwise the whole context per frame
     if L == 77 + 16 * t_len:
         ctx.n_img, ctx.img_div = 16, 1
     else:
         ctx.n_img, ctx.img_div = L - 77, t_len
-    rows3 = rows.reshape(ctx.B, L, D)
     text = ops.empty_rows(ctx.B * 77, D, ops.H16(), device)
     img = ops.empty_rows(ctx.B * (L - 77), D, ops.H16(), device)
-    ops.copy_rows(rows3[:, :77].reshape(ctx.B, 77 * D), text.reshape(ctx.B, 77 * D))
-    ops.copy_rows(rows3[:, 77:].reshape(ctx.B, (L - 77) * D), img.reshape(ctx.B, (L - 77) * D))
+    for b in range(ctx.B):       # fp32 tokens -> MFMA operand rows, text and image tokens into their own matrices
+        ops.cast_rows(flat[b, :77], text[b * 77:(b + 1) * 77])
+        ops.cast_rows(flat[b, 77:], img[b * (L - 77):(b + 1) * (L - 77)])
     ctx.text, ctx.img = text, img
 
 

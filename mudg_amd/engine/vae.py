@@ -45,15 +45,13 @@ def attn_block(mod, x, frames, hw):
         raise NotImplementedError(f"VAE attention needs h*w divisible by 8 (got {hw})")
     hn = _gn(mod.norm, x, frames, hw, False)
     wqk = pk.cached(mod, "qk", (mod.q.weight, mod.k.weight),
-                    lambda: torch.cat([mod.q.weight.detach().reshape(c, c), mod.k.weight.detach().reshape(c, c)], 0)
-                    .to(ops.H16()).contiguous())
+                    lambda: pk.operand(torch.cat([mod.q.weight.detach().reshape(c, c), mod.k.weight.detach().reshape(c, c)], 0)))
     bqk = pk.cached(mod, "bqk", (mod.q.bias, mod.k.bias),
                     lambda: torch.cat([mod.q.bias.detach(), mod.k.bias.detach()]).float().contiguous())
     qk = ops.gemm(hn, wqk, bias=bqk)                                   # [frames*hw, 2C]
     ldv = (hw + 7) // 8 * 8
     vt = ops.empty_rows(frames * c, ldv, ops.H16(), x.device)               # V^T per frame (bias added after P @ V)
-    ops.gemm(pk.linear(mod.v), hn, out=vt, batch=frames, sx=0, sw=hw * hn.stride(0), sy=c * ldv, M=c, N=hw, K=c,
-             ldy=ldv)
+    ops.gemm(pk.linear(mod.v), hn, out=vt, batch=frames, sx=0, sw=hw * hn.stride(0), sy=c * vt.stride(0), M=c, N=hw, K=c)
     att = ops.empty_rows(frames * hw, c, ops.H16(), x.device)
     per = max(1, min(frames, MAX_SCORE_BYTES // (hw * hw * 4)))
     scores = torch.empty((per * hw, hw), dtype=torch.float32, device=x.device)
@@ -65,8 +63,8 @@ def attn_block(mod, x, frames, hw):
         ops.gemm(q[rows], k[rows], out=scores, out_fp32=True, alpha=float(int(c) ** (-0.5)), batch=n,
                  sx=hw * qk.stride(0), sw=hw * qk.stride(0), sy=hw * hw, M=hw, N=hw, K=c, ldy=hw)
         ops.softmax_rows(scores[:n * hw], probs[:n * hw])
-        ops.gemm(probs, vt[f0 * c:(f0 + n) * c], out=att[rows], bias=pk.f32(mod.v, "bias"), batch=n, sx=hw * hw,
-                 sw=c * ldv, sy=hw * c, M=hw, N=c, K=hw, ldy=c)
+        ops.gemm(probs, vt[f0 * c:(f0 + n) * c], out=att[rows], bias=pk.f32(mod.v, "bias"), batch=n, sx=hw * probs.stride(0),
+                 sw=c * vt.stride(0), sy=hw * att.stride(0), M=hw, N=c, K=hw)
     return ops.gemm(att, pk.linear(mod.proj_out), bias=pk.f32(mod.proj_out, "bias"), residual=x, out_fp32=True)
 
 
@@ -148,9 +146,9 @@ def _decode_rows(ae, rows_z, frames, h, w, inv_scale):
     lat = ops.empty_rows(rows_z.shape[0], cpad, ops.H16(), rows_z.device)
     if cpad > zc:
         ops.zero_channels(lat, zc, cpad)
-    wpq = pk.cached(pq, "wpad", (pq.weight,), lambda: torch.nn.functional.pad(
-        pq.weight.detach().reshape(zc, -1), (0, rows_z.shape[1] - pq.weight.shape[1])).to(ops.H16()).contiguous())
-    ops.gemm(rows_z, wpq, out=lat, bias=pk.f32(pq, "bias"), alpha=inv_scale, N=zc, ldy=cpad)
+    wpq = pk.cached(pq, "wpad", (pq.weight,), lambda: pk.operand(torch.nn.functional.pad(
+        pq.weight.detach().reshape(zc, -1), (0, rows_z.shape[1] - pq.weight.shape[1]))))
+    ops.gemm(rows_z, wpq, out=lat, bias=pk.f32(pq, "bias"), alpha=inv_scale, N=zc)
     return decoder_rows(ae.decoder, lat, frames, h, w)
 
 

@@ -10,9 +10,14 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATHS = {"bf16": os.path.join(_HERE, "libmudg_hip.so"), "fp16": os.path.join(_HERE, "libmudg_hip_fp16.so")}
-# The 16-bit MFMA operand type is a property of the loaded library (one per process): bf16 unless MUDG_OPERAND=fp16
-# is set in the environment or set_operand("fp16") is called before the first kernel call.
+LIB_PATHS = {"bf16": os.path.join(_HERE, "libmudg_hip.so"), "fp16": os.path.join(_HERE, "libmudg_hip_fp16.so"),
+             "bf16x3": os.path.join(_HERE, "libmudg_hip_x3.so"), "bf16x6": os.path.join(_HERE, "libmudg_hip_x6.so")}
+# operand name -> (mudg_operand_dtype() code, bf16 pieces per operand value)
+_MODES = {"bf16": (0, 1), "fp16": (1, 1), "bf16x3": (2, 2), "bf16x6": (3, 3)}
+# The MFMA operand type is a property of the loaded library (one per process): bf16 unless MUDG_OPERAND=fp16 | bf16x3 |
+# bf16x6 is set in the environment or set_operand(...) is called before the first kernel call.  bf16x3 / bf16x6 are the
+# split-operand precision modes (csrc/common.h): every operand value is 2 / 3 bf16 pieces and every product tile takes
+# 3 / 6 MFMAs — 16 / 24 significand bits at roughly 1/3 / 1/6 of the contraction throughput.
 _operand = os.environ.get("MUDG_OPERAND", "bf16").lower()
 LIB_PATH = LIB_PATHS["bf16"]
 
@@ -21,7 +26,7 @@ def set_operand(name: str) -> None:
     global _operand
     name = name.lower()
     if name not in LIB_PATHS:
-        raise MudgError(f"unknown operand type {name!r} (bf16 | fp16)")
+        raise MudgError(f"unknown operand type {name!r} ({' | '.join(LIB_PATHS)})")
     if _lib is not None and name != _operand:
         raise MudgError("the operand type must be chosen before the first kernel call")
     _operand = name
@@ -34,6 +39,12 @@ def operand_name() -> str:
 def operand_dtype():
     import torch
     return torch.float16 if _operand == "fp16" else torch.bfloat16
+
+
+def planes() -> int:
+    """bf16 pieces per operand value: 1 in the 16-bit builds; 2 / 3 in bf16x3 / bf16x6, where an operand matrix of C
+    columns is allocated PLANES * C wide and piece p of a row starts at column offset p * (row stride / PLANES)."""
+    return _MODES[_operand][1] if _operand in _MODES else 1
 
 _lib = None
 
@@ -90,6 +101,7 @@ SIGNATURES = {
     "mudg_ncthw_to_rows": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "mudg_rows_to_ncthw": (_I, [_P, _I, _I, _I, _P, _I, _I, _I, _I, _I, _F, _I, _I, _P]),
     "mudg_cast_f32_bf16": (_I, [_P, _P, _L, _P]),
+    "mudg_cast_rows": (_I, [_P, _I, _L, _P, _I, _L, _L, _L, _P]),
     "mudg_zero_channels": (_I, [_P, _I, _I, _I, _I, _P]),
     "mudg_copy_rows": (_I, [_P, _L, _P, _L, _L, _L, _P]),
     "mudg_axpy_f32": (_I, [_P, _P, _L, _F, _P]),
@@ -116,7 +128,7 @@ def lib() -> C.CDLL:
         # contexts and streams we launch on), so make sure it is loaded before our library resolves the same SONAME.
         import torch  # noqa: F401
         if _operand not in LIB_PATHS:
-            raise MudgError(f"MUDG_OPERAND={_operand!r}: expected bf16 or fp16")
+            raise MudgError(f"MUDG_OPERAND={_operand!r}: expected one of {', '.join(LIB_PATHS)}")
         path = LIB_PATHS[_operand]
         if not os.path.exists(path):
             raise MudgError(
@@ -127,7 +139,7 @@ def lib() -> C.CDLL:
             fn = getattr(handle, name)      # AttributeError = symbol missing = broken build
             fn.restype = res
             fn.argtypes = args
-        if handle.mudg_operand_dtype() != (1 if _operand == "fp16" else 0):
+        if handle.mudg_operand_dtype() != _MODES[_operand][0]:
             raise MudgError(f"{path} was not built for {_operand} operands")
         _lib = handle
     return _lib

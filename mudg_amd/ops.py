@@ -38,7 +38,13 @@ def _rows(t: torch.Tensor, dtype=None) -> torch.Tensor:
 
 
 def empty_rows(rows: int, cols: int, dtype=None, device=None) -> torch.Tensor:
+    """A rows matrix.  Operand matrices of the split-operand builds (hip.planes() > 1) are allocated planes * cols wide
+    and returned as the [rows, cols] view of piece 0: piece p of a row starts stride(0) / planes elements further, which
+    every column slice of the view inherits (the kernels derive the plane distance from the row stride)."""
     dtype = dtype or H16()
+    planes = hip.planes() if dtype == H16() else 1
+    if planes > 1:
+        return torch.empty((rows, planes * cols), dtype=dtype, device=device or "cuda")[:, :cols]
     return torch.empty((rows, cols), dtype=dtype, device=device or "cuda")
 
 
@@ -46,12 +52,26 @@ def empty_rows(rows: int, cols: int, dtype=None, device=None) -> torch.Tensor:
 GN_ATTR = "_mudg_gn_partials"      # python attribute a producer leaves on its output: fp32 [ceil(M/128)][N][2] partial sums
 
 
+def _drop_stats(t):
+    """A kernel is about to write into `t` through its raw pointer (torch's version counter does not see that): partial
+    sums a previous producer hung on it would be stale."""
+    if t is not None and getattr(t, GN_ATTR, None) is not None:
+        setattr(t, GN_ATTR, None)
+
+
+def _version(t):
+    try:
+        return t._version
+    except RuntimeError:            # inference tensors do not track versions
+        return 0
+
+
 def _attach_stats(d, out, M, nout):
     """Ask the epilogue for GroupNorm partials of `out` (MudgGemmDesc.stats) and hang them on the tensor."""
     ws = torch.empty(((M + 127) // 128, nout, 2), dtype=torch.float32, device=out.device)
     d.stats = ws.data_ptr()
     setattr(out, GN_ATTR, ws)
-    setattr(out, GN_ATTR + "_version", out._version)      # a later torch in-place op on `out` invalidates the partials
+    setattr(out, GN_ATTR + "_version", _version(out))     # a later torch in-place op on `out` invalidates the partials
 
 
 def gemm(x, w, *, out=None, bias=None, gbias=None, rows_per_group=0, residual=None, x2=None, geglu=False,
@@ -68,6 +88,8 @@ def gemm(x, w, *, out=None, bias=None, gbias=None, rows_per_group=0, residual=No
     nout = N // 2 if geglu else N
     if out is None:
         out = empty_rows(M, nout, torch.float32 if out_fp32 else H16(), x.device)
+    else:
+        _drop_stats(out)
     d = hip.GemmDesc()
     d.X, d.X2, d.W, d.Y = x.data_ptr(), _ptr(x2), w.data_ptr(), out.data_ptr()
     d.bias, d.gbias, d.R = _ptr(bias), _ptr(gbias), _ptr(residual)
@@ -101,6 +123,8 @@ def conv3x3(x, w, *, frames, hin, win, cin, stride=1, upsample=False, out=None, 
     M, N = frames * hout * wout, w.shape[0]
     if out is None:
         out = empty_rows(M, N, torch.float32 if out_fp32 else H16(), x.device)
+    else:
+        _drop_stats(out)
     d = hip.GemmDesc()
     d.X, d.X2, d.W, d.Y = x.data_ptr(), _ptr(x2), w.data_ptr(), out.data_ptr()
     d.bias, d.gbias, d.R = _ptr(bias), _ptr(gbias), _ptr(residual)
@@ -126,6 +150,8 @@ def tconv3(x, w, *, clips, t, hw, cin, out=None, bias=None, residual=None, out_f
     M, N = clips * t * hw, w.shape[0]
     if out is None:
         out = empty_rows(M, N, torch.float32 if out_fp32 else H16(), x.device)
+    else:
+        _drop_stats(out)
     d = hip.GemmDesc()
     d.X, d.W, d.Y = x.data_ptr(), w.data_ptr(), out.data_ptr()
     d.bias, d.R = _ptr(bias), _ptr(residual)
@@ -143,7 +169,13 @@ def tconv3(x, w, *, clips, t, hw, cin, out=None, bias=None, residual=None, out_f
 
 
 # ------------------------------------------------------------------------------------------------ attention
-def attention(q, k, vt, out, *, frames, heads, nq, nk, ldvt, svt, kv_div=1, scale=0.125, accumulate=False):
+def attention(q, k, vt, out, *, frames, heads, nq, nk, ldvt=None, svt=None, kv_div=1, scale=0.125, accumulate=False):
+    """vt: V^T as [kv batches * heads * 64, keys] rows (row stride = ldvt, batch stride = heads * 64 rows by default)."""
+    if ldvt is None:
+        ldvt = vt.stride(0)
+    if svt is None:
+        svt = heads * 64 * ldvt
+    _drop_stats(out)
     d = hip.AttnDesc()
     d.Q, d.K, d.Vt, d.O = q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr()
     d.F, d.heads, d.Nq, d.Nk = frames, heads, nq, nk
@@ -178,7 +210,7 @@ def groupnorm(x, gamma, beta, *, samples, rows, eps, silu, groups=32, x2=None, o
         out = empty_rows(samples * rows, c, H16(), x.device)
     def partials(t):
         ws = getattr(t, GN_ATTR, None)
-        return ws if ws is not None and getattr(t, GN_ATTR + "_version", -1) == t._version else None
+        return ws if ws is not None and getattr(t, GN_ATTR + "_version", -1) == _version(t) else None
 
     p1 = partials(x) if fused else None
     p2 = partials(x2) if (fused and x2 is not None) else None
@@ -290,26 +322,33 @@ def zero_channels(dst, c0, c1):
     return dst
 
 
+def cast_rows(src, dst):
+    """dst[r, c] = src[r, c] between rows matrices of either kind (operand or fp32), any direction (mudg_cast_rows)."""
+    if src.dim() != 2 or dst.dim() != 2 or src.shape != dst.shape or src.stride(1) != 1 or dst.stride(1) != 1:
+        raise hip.MudgError(f"cast_rows: expected equal-shape rows matrices, got {tuple(src.shape)} -> {tuple(dst.shape)}")
+    for t in (src, dst):
+        if t.dtype not in (torch.float32, H16()) or not t.is_cuda:
+            raise hip.MudgError(f"cast_rows: expected cuda fp32 / operand tensors, got {t.dtype} on {t.device}")
+    hip.check(hip.lib().mudg_cast_rows(src.data_ptr(), int(src.dtype == torch.float32), src.stride(0), dst.data_ptr(),
+                                       int(dst.dtype == torch.float32), dst.stride(0), src.shape[0], src.shape[1], _stream()),
+              "mudg_cast_rows")
+    return dst
+
+
 def cast_bf16(src):
-    """fp32 tensor -> bf16 copy of the same shape (bf16 input is returned as is)."""
+    """fp32 rows matrix -> MFMA operand rows of the same shape (an operand matrix is returned as is)."""
     if src.dtype == H16():
         return src
-    if src.dtype != torch.float32 or not src.is_contiguous():
-        raise hip.MudgError("cast_bf16 expects a contiguous fp32 tensor")
-    out = torch.empty(src.shape, dtype=H16(), device=src.device)
-    hip.check(hip.lib().mudg_cast_f32_bf16(src.data_ptr(), out.data_ptr(), src.numel(), _stream()),
-              "mudg_cast_f32_bf16")
-    return out
+    if src.dtype != torch.float32 or src.dim() != 2 or src.stride(1) != 1:
+        raise hip.MudgError("cast_bf16 expects a 2-D fp32 rows matrix")
+    return cast_rows(src, empty_rows(src.shape[0], src.shape[1], H16(), src.device))
 
 
 def to_f32(src):
-    """16-bit operand tensor -> fp32 copy of the same shape (the layout kernel with one channel is a plain cast)."""
-    src = src.contiguous()
-    out = torch.empty(src.shape, dtype=torch.float32, device=src.device)
-    n = src.numel()
-    hip.check(hip.lib().mudg_rows_to_ncthw(src.data_ptr(), int(src.dtype == torch.float32), 1, 0, out.data_ptr(), 1,
-                                           1, 1, 1, n, 1.0, 1, 0, _stream()), "mudg_rows_to_ncthw[cast]")
-    return out
+    """Operand rows matrix -> fp32 copy of the same shape."""
+    if src.dim() != 2:
+        raise hip.MudgError("to_f32 expects a 2-D rows matrix")
+    return cast_rows(src, torch.empty(src.shape, dtype=torch.float32, device=src.device))
 
 
 def copy_rows(src, dst):
@@ -324,6 +363,7 @@ def add_(y, x, alpha=1.0):
     """y += alpha * x on contiguous fp32 tensors of equal size."""
     if y.dtype != torch.float32 or x.dtype != torch.float32 or not (y.is_contiguous() and x.is_contiguous()):
         raise hip.MudgError("add_ expects contiguous fp32 tensors")
+    _drop_stats(y)
     hip.check(hip.lib().mudg_axpy_f32(y.data_ptr(), x.data_ptr(), y.numel(), alpha, _stream()), "mudg_axpy_f32")
     return y
 

@@ -36,12 +36,17 @@ def step_coefficients(sched, dd, index):
     return out
 
 
-def p_sample_ddim(x, e_cond, e_uncond, noise, coef, cfg_scale, guidance_rescale):
-    """One update given the two UNet outputs (v-prediction).  Returns (x_prev, pred_x0)."""
+def p_sample_ddim(x, e_cond, e_uncond, noise, coef, cfg_scale, guidance_rescale, e_img=None, cfg_img=None):
+    """One update given the two UNet outputs (v-prediction).  Returns (x_prev, pred_x0).
+    With e_img (the pass conditioned on image tokens + empty prompt) the guidance is the three-way form of
+    lvdm/models/samplers/ddim_multiplecond.py:226-233: e_u + cfg_img (e_img - e_u) + s (e_c - e_img)."""
     if e_uncond is None or cfg_scale == 1.0:
         v = e_cond
     else:
-        v = e_uncond + cfg_scale * (e_cond - e_uncond)
+        if e_img is not None:
+            v = e_uncond + (cfg_scale if cfg_img is None else cfg_img) * (e_img - e_uncond) + cfg_scale * (e_cond - e_img)
+        else:
+            v = e_uncond + cfg_scale * (e_cond - e_uncond)
         if guidance_rescale > 0.0:
             v = rescale_noise_cfg(v, e_cond, guidance_rescale)
     e_t = coef["sqrt_ac"] * v + coef["sqrt_1mac"] * x            # predict_eps_from_z_and_v
@@ -54,8 +59,9 @@ def p_sample_ddim(x, e_cond, e_uncond, noise, coef, cfg_scale, guidance_rescale)
 
 @torch.no_grad()
 def ddim_sample(apply_model, sched, x_T, cond, uncond, steps, noises, eta=1.0, cfg_scale=7.5, guidance_rescale=0.7,
-                spacing="uniform_trailing", trace=None):
-    """ddim_sampling loop.  apply_model(x, t_long, cond) -> v.  noises[i] is the noise of loop iteration i."""
+                spacing="uniform_trailing", trace=None, uncond_img=None, cfg_img=None):
+    """ddim_sampling loop.  apply_model(x, t_long, cond) -> v.  noises[i] is the noise of loop iteration i.
+    uncond_img: the third conditioning of ddim_multiplecond (pass order there: cond, uncond, uncond_img)."""
     from .schedule import ddim_schedule
     dd = ddim_schedule(sched, steps, spacing, eta)
     x = x_T
@@ -65,8 +71,10 @@ def ddim_sample(apply_model, sched, x_T, cond, uncond, steps, noises, eta=1.0, c
         ts = torch.full((b,), int(step), dtype=torch.long)
         e_c = apply_model(x, ts, cond)
         e_u = apply_model(x, ts, uncond) if uncond is not None and cfg_scale != 1.0 else None
+        e_m = apply_model(x, ts, uncond_img) if (e_u is not None and uncond_img is not None) else None
         coef = step_coefficients(sched, dd, index)
-        x, x0 = p_sample_ddim(x, e_c, e_u, noises[i] if noises is not None else None, coef, cfg_scale, guidance_rescale)
+        x, x0 = p_sample_ddim(x, e_c, e_u, noises[i] if noises is not None else None, coef, cfg_scale, guidance_rescale,
+                              e_img=e_m, cfg_img=cfg_img)
         if trace is not None:
-            trace.append({"e_c": e_c, "e_u": e_u, "x_prev": x, "pred_x0": x0})
+            trace.append({"index": index, "e_c": e_c, "e_u": e_u, "e_m": e_m, "x_prev": x, "pred_x0": x0})
     return x

@@ -31,3 +31,12 @@ SEED = 123
 
 RESAMPLER = dict(dim=128, depth=2, dim_head=64, heads=2, num_queries=16, embedding_dim=96, output_dim=64,
                  ff_mult=4, video_length=4)
+
+# 50-step runs of the same pipeline (the reference's real step count, render.sh:25-31): eta 1 with recorded noise, and eta 0
+SAMPLER50 = dict(SAMPLER, steps=50)
+# three-way classifier-free guidance (ddim_multiplecond.py:213-236)
+THREEWAY = dict(SAMPLER, cfg_img=2.0)
+# image_guided_synthesis-shaped driver run (virtual_pose_render.py:62-147) with fake CLIP towers (towers.py)
+DRIVER = dict(pixels=64, clip_tokens=257, clip_dim=96, tower_seed_img=11, tower_seed_txt=12, cpu_seed=3, cfg_img=2.0,
+              resampler=dict(dim=128, depth=1, dim_head=64, heads=2, num_queries=16, embedding_dim=96, output_dim=64,
+                             ff_mult=2, video_length=4))

@@ -301,6 +301,186 @@ def golden_postprocess():
                             "semantic_labels": lab.clone()})
 
 
+# ---------------------------------------------------------------------------------------------- 8. 50-step runs
+def _pipeline_inputs(steps):
+    shp = cfgs.UNET_B_SHAPE
+    B, T, H, W = shp["B"], shp["T"], shp["H"], shp["W"]
+    seed = cfgs.SEED + 2
+    d = {"ctx_c": seeding.seeded_input("ctx_cond", (B, 77 + 16 * T, cfgs.UNET_B["context_dim"]), seed),
+         "ctx_u": seeding.seeded_input("ctx_uncond", (B, 77 + 16 * T, cfgs.UNET_B["context_dim"]), seed),
+         "concat": seeding.seeded_input("c_concat", (B, 8, T, H, W), seed, 0.18215 * 5),
+         "x_T": seeding.seeded_input("x_T", (B, 4, T, H, W), seed),
+         "noises": [seeding.seeded_input(f"noise{i}", (B, 4, T, H, W), seed) for i in range(steps)]}
+    return d, (B, T, H, W)
+
+
+def _seeded_diffusion():
+    model = build_diffusion(cfgs.UNET_B, cfgs.DIFFUSION)
+    unet_shapes, unet_cks = reseed(model.model.diffusion_model, cfgs.SEED)
+    vae_shapes, vae_cks = reseed(model.first_stage_model, cfgs.SEED + 1)
+    return model, {"unet_cfg": cfgs.UNET_B, "diffusion_cfg": cfgs.DIFFUSION, "vae_ddconfig": cfgs.VAE_DD,
+                   "shape": cfgs.UNET_B_SHAPE, "seed": cfgs.SEED, "unet_checksum": unet_cks, "vae_checksum": vae_cks,
+                   "unet_param_shapes": unet_shapes, "vae_param_shapes": vae_shapes}
+
+
+def golden_pipeline50():
+    """The 2-step pipeline golden at the reference's real step count: 50 DDIM steps, eta 1 with recorded noise, and an
+    eta = 0 run; every 5th x_prev is kept so error growth along the trajectory can be seen."""
+    s = cfgs.SAMPLER50
+    model, meta = _seeded_diffusion()
+    inp, (B, T, H, W) = _pipeline_inputs(s["steps"])
+    class_label = torch.tensor(s["class_labels"], dtype=torch.long)[:, None]
+    fs = torch.full((B,), s["fs"], dtype=torch.long)
+    cond = {"c_crossattn": [inp["ctx_c"]], "c_concat": [inp["concat"]]}
+    uc = {"c_crossattn": [inp["ctx_u"]], "c_concat": [inp["concat"]]}
+    runs = {}
+    for eta in (1.0, 0.0):
+        it = iter(inp["noises"])
+        ref_ddim.noise_like = lambda shape, device, repeat=False: next(it)
+        sampler = CPUSampler(model)
+        kept = []
+        orig_p = sampler.p_sample_ddim
+
+        def p_tapped(x, c, t, index, **kw):
+            xp, x0 = orig_p(x, c, t, index=index, **kw)
+            if index % 5 == 0:
+                kept.append({"index": index, "x_prev": xp.clone()})
+            return xp, x0
+
+        sampler.p_sample_ddim = p_tapped
+        samples, _ = sampler.sample(S=s["steps"], conditioning=cond, batch_size=B, shape=[4, T, H, W], verbose=False,
+                                    unconditional_guidance_scale=s["cfg_scale"], unconditional_conditioning=uc,
+                                    eta=eta, cfg_img=None, mask=None, x0=None, fs=fs, x_T=inp["x_T"],
+                                    timestep_spacing=s["spacing"], guidance_rescale=s["guidance_rescale"],
+                                    sparse_x=inp["concat"][:, :4], class_label=class_label,
+                                    unconditional_conditioning_img_nonetext=None)
+        runs[f"eta{eta:g}"] = {"eta": eta, "kept": kept, "samples": samples.clone(),
+                               "decoded": model.decode_first_stage(samples).clone(),
+                               "ddim_timesteps": torch.as_tensor(np.ascontiguousarray(sampler.ddim_timesteps))}
+    save("pipeline50.pt", dict(meta, sampler=s, runs=runs))
+
+
+# ---------------------------------------------------------------------------------------------- 9. three-way CFG
+def golden_threeway():
+    """ddim_multiplecond.DDIMSampler (p_sample_ddim 213-236): e_u + cfg_img (e_img - e_u) + s (e_c - e_img), 2 steps."""
+    from lvdm.models.samplers import ddim_multiplecond as ref_mc
+
+    class CPUSampler3(ref_mc.DDIMSampler):
+        def register_buffer(self, name, attr):
+            setattr(self, name, attr)
+
+    s = cfgs.THREEWAY
+    model, meta = _seeded_diffusion()
+    inp, (B, T, H, W) = _pipeline_inputs(s["steps"])
+    class_label = torch.tensor(s["class_labels"], dtype=torch.long)[:, None]
+    fs = torch.full((B,), s["fs"], dtype=torch.long)
+    n_img = 16 * T
+    cond = {"c_crossattn": [inp["ctx_c"]], "c_concat": [inp["concat"]]}
+    uc = {"c_crossattn": [inp["ctx_u"]], "c_concat": [inp["concat"]]}
+    # image tokens of the conditional context, text tokens of the unconditional one (virtual_pose_render.py:106-109)
+    uc2 = {"c_crossattn": [torch.cat([inp["ctx_u"][:, :77], inp["ctx_c"][:, 77:77 + n_img]], 1)], "c_concat": [inp["concat"]]}
+    it = iter(inp["noises"])
+    ref_mc.noise_like = lambda shape, device, repeat=False: next(it)
+    outs, trace = [], []
+    orig_apply = model.apply_model
+
+    def tapped(x, t, c, **kw):
+        y = orig_apply(x, t, c, **kw)
+        outs.append(y.clone())
+        return y
+
+    model.apply_model = tapped
+    sampler = CPUSampler3(model)
+    orig_p = sampler.p_sample_ddim
+
+    def p_tapped(x, c, t, index, **kw):
+        xp, x0 = orig_p(x, c, t, index=index, **kw)
+        trace.append({"index": index, "e_c": outs[-3], "e_u": outs[-2], "e_m": outs[-1], "x_prev": xp.clone(),
+                      "pred_x0": x0.clone()})
+        return xp, x0
+
+    sampler.p_sample_ddim = p_tapped
+    samples, _ = sampler.sample(S=s["steps"], conditioning=cond, batch_size=B, shape=[4, T, H, W], verbose=False,
+                                unconditional_guidance_scale=s["cfg_scale"], unconditional_conditioning=uc,
+                                eta=s["eta"], cfg_img=s["cfg_img"], mask=None, x0=None, fs=fs, x_T=inp["x_T"],
+                                timestep_spacing=s["spacing"], guidance_rescale=s["guidance_rescale"],
+                                sparse_x=inp["concat"][:, :4], class_label=class_label,
+                                unconditional_conditioning_img_nonetext=uc2)
+    save("threeway.pt", dict(meta, sampler=s, trace=trace, samples=samples.clone()))
+
+
+# ---------------------------------------------------------------------------------------------- 10. the driver function
+def golden_driver():
+    """The reference's own image_guided_synthesis (virtual_pose_render.py:62-147) run on the tiny model with the fake CLIP
+    towers of towers.py: Resampler, two VAE encodes (CPU-generator posterior noise), cond / uc / uc_2 assembly, two-way and
+    three-way guided sampling with x_T and the per-step noise injected, decode."""
+    towers = _load("towers")
+    for name in ("omegaconf", "megfile", "torchvision.transforms", "virtual_render.eval_tools", "virtual_render.data_tools"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["omegaconf"].OmegaConf = object
+    sys.modules["megfile"].smart_open = None
+    sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+    sys.modules["pytorch_lightning"].seed_everything = lambda *a, **k: None
+    for n in ("save_virtual_color_results", "save_virtual_depth_results", "save_virtual_semantic_results"):
+        setattr(sys.modules["virtual_render.eval_tools"], n, None)
+    for n in ("get_color_frames", "get_sparse_depth", "get_depth_frames", "get_semantic_frames"):
+        setattr(sys.modules["virtual_render.data_tools"], n, None)
+    spec = importlib.util.spec_from_file_location("ref_vpr", os.path.join(REF, "virtual_render", "virtual_pose_render.py"))
+    vpr = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(vpr)
+    from lvdm.models.samplers import ddim_multiplecond as ref_mc
+    from lvdm.modules.encoders.resampler import Resampler
+
+    class CPUSampler3(ref_mc.DDIMSampler):
+        def register_buffer(self, name, attr):
+            setattr(self, name, attr)
+
+    vpr.DDIMSampler, vpr.DDIMSampler_multicond = CPUSampler, CPUSampler3
+    d = cfgs.DRIVER
+    model, meta = _seeded_diffusion()
+    shp = cfgs.UNET_B_SHAPE
+    B, T, H, W = shp["B"], shp["T"], shp["H"], shp["W"]
+    model.image_proj_model = Resampler(**d["resampler"]).eval()
+    rs_shapes, rs_cks = reseed(model.image_proj_model, cfgs.SEED + 5)
+    model.embedder = towers.FakeImageTower(d["clip_tokens"], d["clip_dim"], d["tower_seed_img"])
+    model.cond_stage_model = towers.FakeTextTower(cfgs.UNET_B["context_dim"], d["tower_seed_txt"])
+    seed = cfgs.SEED + 6
+    px = d["pixels"]
+    sparse = seeding.seeded_input("drv_sparse", (B, 3, T, px, px), seed, 0.5).clamp(-1, 1)
+    depth = seeding.seeded_input("drv_depth", (B, 3, T, px, px), seed, 0.5).clamp(-1, 1)
+    x_T = seeding.seeded_input("drv_x_T", (B, 4, T, H, W), seed)
+    noises = [seeding.seeded_input(f"drv_noise{i}", (B, 4, T, H, W), seed) for i in range(2)]
+    labels = torch.tensor(cfgs.SAMPLER["class_labels"], dtype=torch.long)[:, None]
+    common = dict(ddim_steps=2, ddim_eta=1.0, unconditional_guidance_scale=cfgs.SAMPLER["cfg_scale"], fs=cfgs.SAMPLER["fs"],
+                  text_input=True, timestep_spacing=cfgs.SAMPLER["spacing"], guidance_rescale=cfgs.SAMPLER["guidance_rescale"])
+    outs = {}
+    for tag, extra in (("two_way", {}), ("three_way", {"multiple_cond_cfg": True, "cfg_img": d["cfg_img"]})):
+        it = iter(noises)
+        ref_ddim.noise_like = lambda shape, device, repeat=False: next(it)
+        ref_mc.noise_like = ref_ddim.noise_like
+        torch.manual_seed(d["cpu_seed"])
+        out = vpr.image_guided_synthesis(model, ["a street"] * B, sparse, depth, labels, [B, 4, T, H, W], x_T=x_T,
+                                         **common, **extra)
+        outs[tag] = out.clone()
+    save("driver.pt", dict(meta, driver=d, resampler_param_shapes=rs_shapes, resampler_checksum=rs_cks, outs=outs))
+
+
+# ---------------------------------------------------------------------------------------------- 11. the YAML configs
+def golden_yaml():
+    """model.params of the reference's two inference YAMLs as JSON: mudg_amd/configs.py is asserted equal to it, and every
+    `target:` in it must resolve against this repo's overlay (tests/test_host_logic.py)."""
+    import json
+    import yaml
+    out = {}
+    for tag, name in (("1024", "stage2-1024_mdm_waymo_infer.yaml"), ("512", "stage1-512_mdm_waymo_infer.yaml")):
+        with open(os.path.join(REF, "configs", name)) as f:
+            out[tag] = yaml.safe_load(f)["model"]
+    path = os.path.join(HERE, "mdm_yaml.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print(f"wrote {path}")
+
+
 if __name__ == "__main__":
     if "--only-post" in sys.argv:
         golden_postprocess()
@@ -311,6 +491,12 @@ if __name__ == "__main__":
     if "--only-resampler" in sys.argv:
         golden_resampler()
         sys.exit(0)
+    if "--only-round2" in sys.argv:
+        golden_pipeline50()
+        golden_threeway()
+        golden_driver()
+        golden_yaml()
+        sys.exit(0)
     golden_schedule()
     golden_unet("a", cfgs.UNET_A, cfgs.UNET_A_SHAPE)
     golden_unet("b", cfgs.UNET_B, cfgs.UNET_B_SHAPE)
@@ -318,3 +504,7 @@ if __name__ == "__main__":
     golden_encode()
     golden_resampler()
     golden_postprocess()
+    golden_pipeline50()
+    golden_threeway()
+    golden_driver()
+    golden_yaml()

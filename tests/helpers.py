@@ -42,9 +42,11 @@ def unet_inputs(cfg, shp, seed):
     return x, ctx
 
 
-def pipeline_inputs(g):
+def pipeline_inputs(g, steps=None):
     """Rebuild the tensors make_golden.golden_pipeline fed the reference."""
-    shp, s, seed = g["shape"], g["sampler"], g["seed"] + 2
+    shp, s, seed = g["shape"], dict(g["sampler"]), g["seed"] + 2
+    if steps is not None:
+        s["steps"] = steps
     B, T, H, W = shp["B"], shp["T"], shp["H"], shp["W"]
     cd = g["unet_cfg"]["context_dim"]
     return {

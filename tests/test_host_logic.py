@@ -20,10 +20,13 @@ def test_library_exports_every_declared_symbol():
     declared = set(re.findall(r"\b(mudg_[a-z0-9_]+)\s*\(", header))
     assert declared, "no declarations parsed"
     assert declared == set(hip.SIGNATURES), (declared ^ set(hip.SIGNATURES))
-    lib = ctypes.CDLL(hip.LIB_PATH)
-    for name in declared:
-        assert hasattr(lib, name), f"{name} not exported"
-    assert hip.lib().mudg_version() == 1
+    for mode, path in hip.LIB_PATHS.items():          # every operand-type build exports the whole ABI
+        lib = ctypes.CDLL(path)
+        for name in declared:
+            assert hasattr(lib, name), f"{name} not exported by {path}"
+        lib.mudg_operand_dtype.restype = ctypes.c_int
+        assert lib.mudg_operand_dtype() == hip._MODES[mode][0]
+    assert hip.lib().mudg_version() == 2
 
 
 def test_descriptor_structs_match_header_field_order():

@@ -1,0 +1,268 @@
+"""Kernel parity that holds in EVERY operand mode of the library (bf16, fp16, bf16x3, bf16x6).
+
+Inputs are fp32 values converted to MFMA operands by the library itself (mudg_cast_rows: one 16-bit number, or 2 / 3
+bf16 pieces per value in the split-operand builds), read back exactly with the same entry point, and the reference is
+computed in fp64 from those read-back values — so what is measured is the kernels' arithmetic, not the input rounding.
+Operand outputs carry one operand rounding (2^-9 bf16, 2^-12 fp16, ~2^-18 x3, ~2^-26 x6); fp32 outputs carry what the
+mode drops inside the contraction (nothing in the 16-bit modes, the x1*w1 partial product in x3).
+
+This file runs in the default mode directly, and once per other mode in a child process (test_precision_modes_gpu.py)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from mudg_amd import hip as _hip
+
+pytestmark = pytest.mark.gpu
+
+MODE = _hip.operand_name()
+# (operand-output tolerance, fp32-output tolerance) as rel-L2
+TOL_OP, TOL_F32 = {"bf16": (3e-3, 2e-5), "fp16": (4e-4, 2e-5), "bf16x3": (1.5e-5, 1.5e-5), "bf16x6": (1e-6, 1e-6)}[MODE]
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-300))
+
+
+def f32(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def operand(x, cuda):
+    """fp32 [rows, C] -> (operand rows on the GPU, the exact values they hold as fp64 on the CPU)."""
+    from mudg_amd import ops
+    t = ops.cast_bf16(x.to(cuda).float().contiguous())
+    return t, ops.to_f32(t).double().cpu()
+
+
+def value(t):
+    from mudg_amd import ops
+    return (ops.to_f32(t) if t.dtype != torch.float32 else t).double().cpu()
+
+
+def test_cast_round_trip_is_exact_to_the_modes_precision(cuda):
+    x = f32(300, 72, seed=1)
+    t, v = operand(x, cuda)
+    assert tuple(t.shape) == (300, 72) and t.stride(0) == 72 * _hip.planes()
+    eps = {"bf16": 2 ** -8, "fp16": 2 ** -11, "bf16x3": 2 ** -17, "bf16x6": 2 ** -24}[MODE]
+    assert float(((v - x.double()).abs() / x.double().abs().clamp_min(1e-30)).max()) <= eps
+    from mudg_amd import ops
+    again = ops.cast_rows(t, ops.empty_rows(300, 72, None, cuda))        # operand -> operand keeps every piece
+    assert torch.equal(value(again), v)
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (200, 96, 72), (1000, 320, 320), (77, 256, 1024), (300, 4, 320),
+                                   (129, 200, 8), (2000, 128, 640)])
+def test_gemm(cuda, M, N, K):
+    from mudg_amd import ops
+    x, xv = operand(f32(M, K, seed=1), cuda)
+    w, wv = operand(f32(N, K, seed=2, scale=0.05), cuda)
+    r, rv = operand(f32(M, N, seed=4), cuda)
+    b = f32(N, seed=3)
+    ref = xv @ wv.t() + b.double() + rv
+    y = ops.gemm(x, w, bias=b.to(cuda), residual=r)
+    assert tuple(y.shape) == (M, N) and rel(value(y), ref) < TOL_OP
+    r32 = f32(M, N, seed=5)
+    y32 = ops.gemm(x, w, bias=b.to(cuda), residual=r32.to(cuda), out_fp32=True, alpha=0.5)
+    assert y32.dtype == torch.float32 and rel(y32, 0.5 * (xv @ wv.t()) + b.double() + r32.double()) < TOL_F32
+
+
+def test_gemm_two_sources_group_bias_geglu_and_gelu(cuda):
+    from mudg_amd import ops
+    from test_kernels_gpu import pack_geglu
+    M, N, K1, K2 = 6 * 40, 96, 64, 128
+    x1, v1 = operand(f32(M, K1, seed=1), cuda)
+    x2, v2 = operand(f32(M, K2, seed=2), cuda)
+    w, wv = operand(f32(N, K1 + K2, seed=3, scale=0.05), cuda)
+    gb = f32(6, N, seed=4)
+    ref = torch.cat([v1, v2], 1) @ wv.t() + gb.double().repeat_interleave(40, 0)
+    y = ops.gemm(x1, w, x2=x2, gbias=gb.to(cuda), rows_per_group=40)
+    assert rel(value(y), ref) < TOL_OP
+    # GEGLU (value * gelu_erf(gate)) and the plain GELU epilogue
+    C = 64
+    x, xv = operand(f32(300, C, seed=5), cuda)
+    wf, bf = f32(8 * C, C, seed=6, scale=0.1), f32(8 * C, seed=7, scale=0.1)
+    wp, bp = pack_geglu(wf, bf)
+    wg, wgv = operand(wp, cuda)
+    h = xv @ wgv.t() + bp.double()                                   # packed order: blocks of [32 value | 32 gate]
+    h = h.reshape(300, -1, 2, 32)
+    ref = (h[:, :, 0] * F.gelu(h[:, :, 1])).reshape(300, -1)
+    y = ops.gemm(x, wg, bias=bp.to(cuda), geglu=True)
+    # the 16-bit builds evaluate the gate through a 1025-entry table (7e-6 absolute): inside their operand rounding
+    assert tuple(y.shape) == (300, 4 * C) and rel(value(y), ref) < TOL_OP
+    w2, w2v = operand(f32(96, C, seed=8, scale=0.1), cuda)
+    y = ops.gemm(x, w2, gelu=True, out_fp32=True)
+    assert rel(y, F.gelu(xv @ w2v.t())) < max(TOL_F32, 2e-6)
+
+
+def test_gemm_swapped_batched_writes_v_transposed(cuda):
+    from mudg_amd import ops
+    frames, hw, C = 3, 77, 128
+    x, xv = operand(f32(frames * hw, C, seed=1), cuda)
+    wv_t, wv = operand(f32(C, C, seed=2, scale=0.1), cuda)
+    ld = (hw + 7) // 8 * 8
+    out = ops.empty_rows(frames * C, ld, None, cuda)
+    ops.gemm(wv_t, x, out=out, batch=frames, sx=0, sw=hw * x.stride(0), sy=C * out.stride(0), M=C, N=hw, K=C)
+    want = (xv @ wv.t()).reshape(frames, hw, C).transpose(1, 2)
+    got = value(out).reshape(frames, C, ld)[:, :, :hw]
+    assert rel(got, want) < TOL_OP
+
+
+def _rows(x):            # (F, C, H, W) -> [F*H*W, C]
+    return x.permute(0, 2, 3, 1).reshape(-1, x.shape[1]).contiguous()
+
+
+def _unrows(v, f, h, w):
+    return v.reshape(f, h, w, -1).permute(0, 3, 1, 2)
+
+
+@pytest.mark.parametrize("cin,cout,h,w,stride,ups,slab", [(64, 96, 9, 16, 1, False, False), (64, 64, 10, 16, 2, False, True),
+                                                          (72, 40, 5, 7, 2, False, False), (64, 128, 5, 8, 1, True, False),
+                                                          (16, 320, 9, 16, 1, False, False), (128, 96, 10, 12, 1, False, True)])
+def test_conv3x3(cuda, cin, cout, h, w, stride, ups, slab):
+    from mudg_amd import ops
+    from test_kernels_gpu import pack_conv, pack_conv_slab
+    frames = 3
+    x, xv = operand(_rows(f32(frames, cin, h, w, seed=1)), cuda)
+    wt = f32(cout, cin, 3, 3, seed=2, scale=0.05)
+    wp, wpv = operand(pack_conv_slab(wt) if slab else pack_conv(wt), cuda)
+    b = f32(cout, seed=3)
+    # rebuild the (Cout, Cin, 3, 3) filter from the values the packed operand actually holds
+    if slab:
+        wq = wpv.reshape(cout, cin // 64, 9, 64).permute(0, 2, 1, 3).reshape(cout, 3, 3, cin).permute(0, 3, 1, 2)
+    else:
+        wq = wpv.reshape(cout, 3, 3, cin).permute(0, 3, 1, 2)
+    xin = _unrows(xv, frames, h, w)
+    if ups:
+        xin = F.interpolate(xin, scale_factor=2, mode="nearest")
+    ref = F.conv2d(xin, wq, b.double(), stride=stride, padding=1)
+    y = ops.conv3x3(x, wp, frames=frames, hin=h, win=w, cin=cin, stride=stride, upsample=ups, bias=b.to(cuda),
+                    korder=int(slab), stats=not ups)
+    assert rel(_unrows(value(y), frames, ref.shape[2], ref.shape[3]), ref) < TOL_OP
+    y32 = ops.conv3x3(x, wp, frames=frames, hin=h, win=w, cin=cin, stride=stride, upsample=ups, bias=b.to(cuda),
+                      korder=int(slab), out_fp32=True)
+    assert rel(_unrows(y32.double().cpu(), frames, ref.shape[2], ref.shape[3]), ref) < TOL_F32
+
+
+def test_tconv3(cuda):
+    from mudg_amd import ops
+    B, T, H, W, cin, cout = 2, 5, 6, 8, 64, 96
+    x5 = f32(B, cin, T, H, W, seed=1)
+    x, xv = operand(x5.permute(0, 2, 3, 4, 1).reshape(-1, cin).contiguous(), cuda)
+    wt = f32(cout, cin, 3, 1, 1, seed=2, scale=0.05)
+    wp, wpv = operand(wt[:, :, :, 0, 0].permute(0, 2, 1).reshape(cout, -1).contiguous(), cuda)
+    b = f32(cout, seed=3)
+    wq = wpv.reshape(cout, 3, cin).permute(0, 2, 1)[..., None, None]
+    xin = xv.reshape(B, T, H, W, cin).permute(0, 4, 1, 2, 3)
+    ref = F.conv3d(xin, wq, b.double(), padding=(1, 0, 0)).permute(0, 2, 3, 4, 1).reshape(-1, cout)
+    y = ops.tconv3(x, wp, clips=B, t=T, hw=H * W, cin=cin, bias=b.to(cuda), out_fp32=True)
+    assert rel(y, ref) < TOL_F32
+
+
+def _attention_ref(qv, kv, vv, frames, heads, nq, nk, scale, kv_div=1):
+    q = qv.reshape(frames, nq, heads, 64).permute(0, 2, 1, 3)
+    k = kv.reshape(frames // kv_div, nk, heads, 64).permute(0, 2, 1, 3).repeat_interleave(kv_div, 0)
+    v = vv.reshape(frames // kv_div, nk, heads, 64).permute(0, 2, 1, 3).repeat_interleave(kv_div, 0)
+    p = torch.softmax(q @ k.transpose(-1, -2) * scale, dim=-1)
+    return (p @ v).permute(0, 2, 1, 3).reshape(frames * nq, heads * 64)
+
+
+def _vt(vvals, batches, nk, c, cuda):
+    """V^T operand [batches * C, ld] from V values [batches * nk, C]."""
+    from mudg_amd import ops
+    ld = (nk + 7) // 8 * 8
+    out = ops.empty_rows(batches * c, ld, None, cuda)
+    src = torch.zeros(batches * c, ld)
+    src.reshape(batches, c, ld)[:, :, :nk] = vvals.float().reshape(batches, nk, c).transpose(1, 2)
+    ops.cast_rows(src.to(cuda), out)
+    return out
+
+
+@pytest.mark.parametrize("frames,heads,nq,nk,kv_div", [(2, 2, 200, 200, 1), (3, 1, 640, 640, 1), (4, 2, 96, 77, 2),
+                                                       (2, 3, 130, 16, 1)])
+def test_attention(cuda, frames, heads, nq, nk, kv_div):
+    from mudg_amd import ops
+    c = heads * 64
+    q, qv = operand(f32(frames * nq, c, seed=1), cuda)
+    k, kv = operand(f32(frames // kv_div * nk, c, seed=2), cuda)
+    vsrc, vv = operand(f32(frames // kv_div * nk, c, seed=3), cuda)
+    vt = _vt(vv, frames // kv_div, nk, c, cuda)
+    out = ops.empty_rows(frames * nq, c, None, cuda)
+    ops.attention(q, k, vt, out, frames=frames, heads=heads, nq=nq, nk=nk, kv_div=kv_div, scale=0.125)
+    ref = _attention_ref(qv, kv, vv, frames, heads, nq, nk, 0.125, kv_div)
+    # the probabilities enter the second MFMA as operands: one more operand rounding than a GEMM output
+    assert rel(value(out), ref) < 2 * TOL_OP
+    first = value(out)
+    ops.attention(q, k, vt, out, frames=frames, heads=heads, nq=nq, nk=nk, kv_div=kv_div, scale=0.125, accumulate=True)
+    assert rel(value(out), 2 * first) < 2 * TOL_OP
+
+
+@pytest.mark.parametrize("T", [16, 7, 32])
+def test_temporal_attention(cuda, T):
+    from mudg_amd import ops
+    B, HW, heads = 2, 37, 3
+    c = heads * 64
+    qkv, v = operand(f32(B * T * HW, 3 * c, seed=1), cuda)
+    out = ops.empty_rows(B * T * HW, c, None, cuda)
+    ops.temporal_attention(qkv, out, clips=B, t=T, hw=HW, heads=heads, scale=0.125)
+    x = v.reshape(B, T, HW, 3, heads, 64).permute(3, 0, 2, 4, 1, 5)           # (qkv, b, p, h, t, d)
+    p = torch.softmax(x[0] @ x[1].transpose(-1, -2) * 0.125, dim=-1)
+    ref = (p @ x[2]).permute(0, 3, 1, 2, 4).reshape(B * T * HW, c)
+    assert rel(value(out), ref) < 2 * TOL_OP
+
+
+@pytest.mark.parametrize("x_fp32", [True, False])
+def test_groupnorm_and_layernorm(cuda, x_fp32):
+    from mudg_amd import ops
+    samples, rows, C = 3, 200, 96
+    xs = f32(samples * rows, C, seed=1) * 2 + 0.5
+    if x_fp32:
+        x, xv = xs.to(cuda), xs.double()
+    else:
+        x, xv = operand(xs, cuda)
+    g, b = 1 + 0.1 * f32(C, seed=2), 0.1 * f32(C, seed=3)
+    for silu in (False, True):
+        y = ops.groupnorm(x, g.to(cuda), b.to(cuda), samples=samples, rows=rows, eps=1e-5, silu=silu)
+        ref = F.group_norm(xv.reshape(samples, rows, C).transpose(1, 2), 32, g.double(), b.double(), 1e-5).transpose(1, 2)
+        ref = ref.reshape(-1, C)
+        if silu:
+            ref = ref * torch.sigmoid(ref)
+        assert rel(value(y), ref) < TOL_OP
+    y = ops.layernorm(x, g.to(cuda), b.to(cuda), eps=1e-5)
+    assert rel(value(y), F.layer_norm(xv, (C,), g.double(), b.double(), 1e-5)) < TOL_OP
+
+
+def test_groupnorm_fused_statistics_from_the_producing_conv(cuda):
+    """A conv writes the next GroupNorm's partial sums (over the values it stored); the fused norm must agree with the
+    two-pass one on the same tensor."""
+    from mudg_amd import ops
+    from test_kernels_gpu import pack_conv_slab
+    frames, h, w, cin, cout = 2, 16, 16, 64, 64                      # 256 rows per frame: two 128-row blocks
+    x, _ = operand(_rows(f32(frames, cin, h, w, seed=1)), cuda)
+    wp, _ = operand(pack_conv_slab(f32(cout, cin, 3, 3, seed=2, scale=0.05)), cuda)
+    g, b = 1 + 0.1 * f32(cout, seed=3), 0.1 * f32(cout, seed=4)
+    for out_fp32 in (False, True):
+        y = ops.conv3x3(x, wp, frames=frames, hin=h, win=w, cin=cin, korder=1, stats=True, out_fp32=out_fp32)
+        fused = ops.groupnorm(y, g.to(cuda), b.to(cuda), samples=frames, rows=h * w, eps=1e-5, silu=True)
+        plain = ops.groupnorm(y, g.to(cuda), b.to(cuda), samples=frames, rows=h * w, eps=1e-5, silu=True, fused=False)
+        assert rel(value(fused), value(plain)) < max(TOL_OP, 1e-6)
+
+
+def test_softmax_rows_and_layout_kernels(cuda):
+    from mudg_amd import ops
+    s = f32(50, 333, seed=1) * 3
+    p = ops.softmax_rows(s.to(cuda))
+    assert rel(value(p), torch.softmax(s.double(), -1)) < TOL_OP
+    x = f32(2, 5, 3, 4, 6, seed=2)                                        # (b c t h w)
+    rows = ops.empty_rows(2 * 3 * 24, 8, None, cuda)
+    ops.ncthw_to_rows(x.to(cuda), rows, 0)
+    ops.zero_channels(rows, 5, 8)
+    v = value(rows)
+    want = x.permute(0, 2, 3, 4, 1).reshape(-1, 5).double()
+    assert rel(v[:, :5], want) < TOL_OP and float(v[:, 5:].abs().max()) == 0.0
+    back = ops.rows_to_ncthw(rows, (2, 5, 3, 4, 6))
+    assert rel(back, x) < TOL_OP
+    dst = ops.empty_rows(2 * 3 * 24, 8, None, cuda)
+    ops.copy_rows(rows, dst)
+    assert torch.equal(value(dst), v)

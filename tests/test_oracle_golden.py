@@ -104,6 +104,63 @@ def test_sampler_and_decode_match_reference():
     assert rel_l2(d2, g["decode_direct"]["out"]) < 1e-5
 
 
+def _oracle_pipeline(g, steps):
+    usd = seeded_sd(g["unet_param_shapes"], g["seed"], g["unet_checksum"])
+    vsd = seeded_sd(g["vae_param_shapes"], g["seed"] + 1, g["vae_checksum"])
+    inp, dc = pipeline_inputs(g, steps), g["diffusion_cfg"]
+    sched = o_sched.model_schedule(dc["timesteps"], dc["linear_start"], dc["linear_end"], dc["rescale_betas_zero_snr"],
+                                   dc["base_scale"])
+    lab = inp["class_label"][:, 0]
+
+    def apply_model(x, t, ctx):
+        return o_unet.unet_forward(usd, g["unet_cfg"], torch.cat([x, inp["concat"]], dim=1), t, lab, ctx, inp["fs"])
+
+    return usd, vsd, inp, sched, apply_model
+
+
+@pytest.mark.parametrize("eta", [1.0, 0.0])
+def test_fifty_step_sampler_and_decode_match_reference(eta):
+    """The reference's real step count (render.sh:25-31): 50 guided steps with the recorded noise (eta 1) and eta 0.
+    fp32 on both sides with different summation orders: the trajectory error is printed at every kept step."""
+    g = golden("pipeline50.pt")
+    s, run = g["sampler"], g["runs"][f"eta{eta:g}"]
+    usd, vsd, inp, sched, apply_model = _oracle_pipeline(g, s["steps"])
+    trace = []
+    samples = o_ddim.ddim_sample(apply_model, sched, inp["x_T"], inp["ctx_c"], inp["ctx_u"], s["steps"], inp["noises"],
+                                 eta, s["cfg_scale"], s["guidance_rescale"], s["spacing"], trace)
+    by_index = {t["index"]: t for t in trace}
+    errs = [(k["index"], rel_l2(by_index[k["index"]]["x_prev"], k["x_prev"])) for k in run["kept"]]
+    dec = o_vae.decode_first_stage(vsd, g["vae_ddconfig"], samples, g["diffusion_cfg"]["scale_factor"])
+    e_s, e_d = rel_l2(samples, run["samples"]), rel_l2(dec, run["decoded"])
+    print(f"oracle 50 steps eta {eta:g}: samples {e_s:.2e} decoded {e_d:.2e}; along the way " +
+          " ".join(f"{i}:{e:.1e}" for i, e in errs))
+    assert e_s < 1e-4 and e_d < 1e-4
+
+
+def test_three_way_guidance_matches_reference():
+    """ddim_multiplecond.DDIMSampler.p_sample_ddim (213-236) via the oracle: per-pass outputs, the update and the samples."""
+    g = golden("threeway.pt")
+    s = g["sampler"]
+    usd, vsd, inp, sched, apply_model = _oracle_pipeline(g, s["steps"])
+    uc2 = torch.cat([inp["ctx_u"][:, :77], inp["ctx_c"][:, 77:]], 1)
+    trace = []
+    samples = o_ddim.ddim_sample(apply_model, sched, inp["x_T"], inp["ctx_c"], inp["ctx_u"], s["steps"], inp["noises"],
+                                 s["eta"], s["cfg_scale"], s["guidance_rescale"], s["spacing"], trace, uncond_img=uc2,
+                                 cfg_img=s["cfg_img"])
+    for got, ref in zip(trace, g["trace"]):
+        for k in ("e_c", "e_u", "e_m", "pred_x0", "x_prev"):
+            assert rel_l2(got[k], ref[k]) < 1e-4, k
+    assert rel_l2(samples, g["samples"]) < 1e-4
+    dd = o_sched.ddim_schedule(sched, s["steps"], s["spacing"], s["eta"])
+    x = inp["x_T"]
+    for i, ref in enumerate(g["trace"]):       # the update alone on the reference's own three outputs
+        coef = o_ddim.step_coefficients(sched, dd, ref["index"])
+        xp, x0 = o_ddim.p_sample_ddim(x, ref["e_c"], ref["e_u"], inp["noises"][i], coef, s["cfg_scale"],
+                                      s["guidance_rescale"], e_img=ref["e_m"], cfg_img=s["cfg_img"])
+        assert rel_l2(x0, ref["pred_x0"]) < 2e-6 and rel_l2(xp, ref["x_prev"]) < 2e-6
+        x = ref["x_prev"]
+
+
 def test_vae_encode_matches_reference():
     from helpers import seeding
     g = golden("encode.pt")

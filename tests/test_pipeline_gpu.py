@@ -1,10 +1,13 @@
-"""End-to-end parity on the GPU against the vectors the reference produced for the image_guided_synthesis-shaped run
-(tests/golden/pipeline.pt): 3-modality batch, hybrid conditioning, CFG 7.5 + rescale 0.7, eta 1 with the recorded
-noise, 2 DDIM steps, then AutoencoderKL decode.  bf16-operand kernels vs the fp32 reference: classifier-free guidance
-multiplies the (independent) errors of the two UNet passes by ~7.5/6.5, so two guided steps land at ~4e-2 on the
-latents and the decoded frames (measured 3.8e-2 / 4.3e-2); the decoder alone is at 7e-3 - 1.2e-2.  Bounds asserted:
-6e-2 end to end, 2e-2 decode-only; achieved figures are printed.  (BASELINE's 1e-3 target needs fp32-class operands;
-see DESIGN.md "Precision".)"""
+"""End-to-end parity on the GPU against vectors the reference produced (tests/golden/make_golden.py): the
+image_guided_synthesis-shaped run (3-modality batch, hybrid conditioning, CFG 7.5 + rescale 0.7, recorded noise) at 2 steps
+(pipeline.pt) and at the reference's real 50 steps with eta 1 and eta 0 (pipeline50.pt), three-way guidance (threeway.pt),
+the VAE encoder, the Resampler, and the reference's own driver function with fake CLIP towers (driver.pt).
+
+THE CONTRACT (BASELINE.json north_star): decoded frames within 1e-3 rel-L2 of the reference.  It is asserted with the
+literal constant below in the operand modes built to meet it — the split-operand precision modes bf16x3 / bf16x6
+(MUDG_OPERAND=..., run in child processes by test_precision_modes_gpu.py).  The 16-bit operand modes cannot meet it:
+operand rounding (2^-9 bf16, 2^-12 fp16) is amplified ~10x by classifier-free guidance and compounds over the steps; for
+them the tests print the measured error and hold it to REGRESSION bounds that only guard against getting worse."""
 import pytest
 import torch
 
@@ -13,10 +16,13 @@ from helpers import golden, pipeline_inputs, rel_l2, seeded_sd
 from mudg_amd import hip as _hip
 
 pytestmark = pytest.mark.gpu
-# With fp16 operands (MUDG_OPERAND=fp16) the same checks measure 4.7e-3 / 5.2e-3 end to end, 9e-4 ... 1.5e-3 for the
-# decoder alone and 1.3e-3 / 7e-4 for the encoder.
-FP16 = _hip.operand_name() == "fp16"
-TOL_E2E, TOL_DEC, TOL_ENC = (1e-2, 3e-3, 3e-3) if FP16 else (6e-2, 2e-2, 2e-2)
+CONTRACT = 1e-3                       # north_star: decoded frames, per-pixel rel-L2
+MODE = _hip.operand_name()
+MEETS_CONTRACT = MODE in ("bf16x3", "bf16x6")
+# regression guards for the 16-bit modes (NOT the contract): 2 guided steps end to end / decode alone / encode alone
+TOL_E2E, TOL_DEC, TOL_ENC = {"bf16": (6e-2, 2e-2, 2e-2), "fp16": (1e-2, 3e-3, 3e-3),
+                             "bf16x3": (CONTRACT, CONTRACT, CONTRACT), "bf16x6": (CONTRACT, CONTRACT, CONTRACT)}[MODE]
+FP16 = MODE == "fp16"
 
 
 def build_model(g, dev):
@@ -138,51 +144,131 @@ def test_resampler_matches_reference(cuda):
     out = net(x.to(cuda))
     err = rel_l2(out, g["out"])
     print(f"resampler rel-L2 vs reference: {err:.3e}")
-    assert out.shape == g["out"].shape and err < (3e-3 if FP16 else 1.5e-2)
+    assert out.shape == g["out"].shape and err < {"bf16": 1.5e-2, "fp16": 3e-3, "bf16x3": 1e-4, "bf16x6": 1e-5}[MODE]
 
 
-class _FakeTower(torch.nn.Module):
-    """Stands in for the CLIP towers (outside the path): deterministic tensors of the right shapes."""
+def _sample(model, g, inp, s, cuda, monkeypatch, eta, sampler_mod=None, **extra):
+    """sampler.sample(...) with the recorded noise injected, as make_golden.py drove the reference."""
+    from lvdm.models.samplers import ddim as my_ddim
+    mod = sampler_mod or my_ddim
+    cond = {"c_crossattn": [inp["ctx_c"].to(cuda)], "c_concat": [inp["concat"].to(cuda)]}
+    uc = {"c_crossattn": [inp["ctx_u"].to(cuda)], "c_concat": [inp["concat"].to(cuda)]}
+    noises = iter(inp["noises"])
+    fake = lambda shape, device, repeat=False: next(noises).to(device)
+    monkeypatch.setattr(my_ddim, "noise_like", fake)
+    if mod is not my_ddim:
+        monkeypatch.setattr(mod, "noise_like", fake)
+    sampler = mod.DDIMSampler(model)
+    shp = g["shape"]
+    kw = dict(cfg_img=None, unconditional_conditioning_img_nonetext=None)
+    kw.update(extra)
+    samples, _ = sampler.sample(S=s["steps"], conditioning=cond, batch_size=shp["B"],
+                                shape=[4, shp["T"], shp["H"], shp["W"]], verbose=False,
+                                unconditional_guidance_scale=s["cfg_scale"], unconditional_conditioning=uc,
+                                eta=eta, mask=None, x0=None, fs=inp["fs"].to(cuda), x_T=inp["x_T"].to(cuda),
+                                timestep_spacing=s["spacing"], guidance_rescale=s["guidance_rescale"],
+                                sparse_x=inp["concat"][:, :4].to(cuda), class_label=inp["class_label"].to(cuda), **kw)
+    return sampler, samples
 
-    def __init__(self, tokens, dim, seed):
-        super().__init__()
-        self.tokens, self.dim, self.seed = tokens, dim, seed
 
-    def _make(self, n, salt, device):
-        g = torch.Generator().manual_seed(self.seed + salt)
-        return torch.randn(n, self.tokens, self.dim, generator=g).to(device)
+@pytest.mark.parametrize("eta", [1.0, 0.0])
+def test_fifty_step_run_decoded_frames_against_reference(cuda, monkeypatch, eta):
+    """The reference's real step count (render.sh:25-31): 50 guided steps + decode against pipeline50.pt."""
+    g = golden("pipeline50.pt")
+    model = build_model(g, cuda)
+    s, run = g["sampler"], g["runs"][f"eta{eta:g}"]
+    inp = pipeline_inputs(g)
+    sampler, samples = _sample(model, g, inp, s, cuda, monkeypatch, eta)
+    assert list(sampler.ddim_timesteps) == list(run["ddim_timesteps"].numpy())
+    decoded = model.decode_first_stage(samples)
+    err_s, err_d = rel_l2(samples, run["samples"]), rel_l2(decoded, run["decoded"])
+    print(f"[{MODE}] 50 steps eta {eta:g} rel-L2 vs reference: latents {err_s:.3e}  decoded frames {err_d:.3e}  "
+          f"(contract {CONTRACT:g}: {'MET' if err_d <= CONTRACT else 'not met'})")
+    assert torch.isfinite(decoded).all()
+    if MEETS_CONTRACT:
+        assert err_d <= 1e-3 and err_s <= 1e-3
 
-    def forward(self, img):
-        return self._make(img.shape[0], int(img.abs().sum().item() > 0), img.device)
 
-    def encode(self, prompts):
-        return self._make(len(prompts), sum(len(p) for p in prompts) > 0, self.dev)
-
-
-def test_driver_image_guided_synthesis_two_and_three_way(cuda):
-    """The reference driver's call sequence end to end on tensors: VAE encodes of the sparse RGB / depth clips,
-    Resampler, hybrid conditioning, guided sampling (two-way and three-way CFG), decode."""
-    from lvdm.modules.encoders.resampler import Resampler
-    from virtual_render.virtual_pose_render import image_guided_synthesis
+def test_two_step_run_decoded_frames_meet_the_contract_in_the_precision_modes(cuda, monkeypatch):
     g = golden("pipeline.pt")
     model = build_model(g, cuda)
+    s, inp = g["sampler"], pipeline_inputs(g)
+    _, samples = _sample(model, g, inp, s, cuda, monkeypatch, s["eta"])
+    err_d = rel_l2(model.decode_first_stage(samples), g["decoded"])
+    print(f"[{MODE}] 2 steps: decoded frames rel-L2 vs reference {err_d:.3e} (contract {CONTRACT:g})")
+    if MEETS_CONTRACT:
+        assert err_d <= 1e-3
+
+
+def test_three_way_guidance_matches_reference(cuda, monkeypatch):
+    """ddim_multiplecond (reference p_sample_ddim 213-236) against threeway.pt: the fused update alone on the reference's
+    own three UNet outputs is fp32-exact; the whole 2-step run is held to the mode's end-to-end bound."""
+    from lvdm.models.samplers import ddim_multiplecond as my_mc
+    from mudg_amd import ops
+    g = golden("threeway.pt")
+    model = build_model(g, cuda)
+    s, inp = g["sampler"], pipeline_inputs(g)
+    n_img = 16 * g["shape"]["T"]
+    uc2 = {"c_crossattn": [torch.cat([inp["ctx_u"][:, :77], inp["ctx_c"][:, 77:77 + n_img]], 1).to(cuda)],
+           "c_concat": [inp["concat"].to(cuda)]}
+    sampler, samples = _sample(model, g, inp, s, cuda, monkeypatch, s["eta"], sampler_mod=my_mc, cfg_img=s["cfg_img"],
+                               unconditional_conditioning_img_nonetext=uc2)
+    err = rel_l2(samples, g["samples"])
+    print(f"[{MODE}] three-way CFG, 2 steps: latents rel-L2 vs reference {err:.3e}")
+    assert err < TOL_E2E
+    x = inp["x_T"]
+    for i, ref in enumerate(g["trace"]):
+        coef = sampler.step_coefficients(ref["index"], s["cfg_scale"], s["guidance_rescale"]) + [float(s["cfg_img"])]
+        xp, x0 = ops.ddim_step(x.to(cuda), ref["e_c"].to(cuda), ref["e_u"].to(cuda), inp["noises"][i].to(cuda), coef,
+                               e_m=ref["e_m"].to(cuda))
+        assert rel_l2(x0, ref["pred_x0"]) < 2e-6 and rel_l2(xp, ref["x_prev"]) < 2e-6
+        x = ref["x_prev"]
+
+
+def test_driver_image_guided_synthesis_matches_the_reference_function(cuda, monkeypatch):
+    """This repo's virtual_render.image_guided_synthesis against the output of the REFERENCE's function of the same name
+    (virtual_pose_render.py:62-147) run with the same fake CLIP towers, seeded Resampler / UNet / VAE, CPU-generator
+    posterior noise, x_T and per-step noise (driver.pt): Resampler, two VAE encodes, cond / uc / uc_2 assembly, two-way
+    and three-way guided sampling, decode."""
+    from helpers import seeding, _load
+    from lvdm.models.samplers import ddim as my_ddim, ddim_multiplecond as my_mc
+    from lvdm.modules.encoders.resampler import Resampler
+    from virtual_render.virtual_pose_render import image_guided_synthesis
+    towers = _load("towers")
+    g = golden("driver.pt")
+    d = g["driver"]
+    model = build_model(g, cuda)
     shp = g["shape"]
-    T, D = shp["T"], g["unet_cfg"]["context_dim"]
-    model.image_proj_model = Resampler(dim=128, depth=1, dim_head=64, heads=2, num_queries=16, embedding_dim=96,
-                                       output_dim=D, ff_mult=2, video_length=T).to(cuda)
-    model.embedder = _FakeTower(257, 96, 1)
-    model.cond_stage_model = _FakeTower(77, D, 2)
-    model.cond_stage_model.dev = cuda
-    gen = torch.Generator().manual_seed(9)
-    sparse = (torch.rand(3, 3, T, 64, 64, generator=gen) * 2 - 1).to(cuda)
-    depth = (torch.rand(3, 3, T, 64, 64, generator=gen) * 2 - 1).to(cuda)
-    labels = torch.tensor([[0], [500], [1]], device=cuda)
-    common = dict(ddim_steps=2, ddim_eta=1.0, unconditional_guidance_scale=7.5, fs=10, text_input=True,
-                  timestep_spacing="uniform_trailing", guidance_rescale=0.7)
-    torch.manual_seed(3)
-    out2 = image_guided_synthesis(model, ["a street"] * 3, sparse, depth, labels, [3, 4, T, 8, 8], **common)
-    torch.manual_seed(3)
-    out3 = image_guided_synthesis(model, ["a street"] * 3, sparse, depth, labels, [3, 4, T, 8, 8],
-                                  multiple_cond_cfg=True, cfg_img=2.0, **common)
-    assert out2.shape == (3, 1, 3, T, 64, 64) and out3.shape == out2.shape
-    assert torch.isfinite(out2).all() and torch.isfinite(out3).all() and not torch.equal(out2, out3)
+    B, T, H, W = shp["B"], shp["T"], shp["H"], shp["W"]
+    model.image_proj_model = Resampler(**d["resampler"])
+    model.image_proj_model.load_state_dict(seeded_sd(g["resampler_param_shapes"], g["seed"] + 5, g["resampler_checksum"]), strict=True)
+    model.image_proj_model = model.image_proj_model.to(cuda).eval()
+    model.embedder = towers.FakeImageTower(d["clip_tokens"], d["clip_dim"], d["tower_seed_img"])
+    model.cond_stage_model = towers.FakeTextTower(g["unet_cfg"]["context_dim"], d["tower_seed_txt"], cuda)
+    seed, px = g["seed"] + 6, d["pixels"]
+    sparse = seeding.seeded_input("drv_sparse", (B, 3, T, px, px), seed, 0.5).clamp(-1, 1).to(cuda)
+    depth = seeding.seeded_input("drv_depth", (B, 3, T, px, px), seed, 0.5).clamp(-1, 1).to(cuda)
+    x_T = seeding.seeded_input("drv_x_T", (B, 4, T, H, W), seed).to(cuda)
+    noises = [seeding.seeded_input(f"drv_noise{i}", (B, 4, T, H, W), seed) for i in range(2)]
+    labels = torch.tensor(cfgs_sampler()["class_labels"], dtype=torch.long)[:, None].to(cuda)
+    sm = cfgs_sampler()
+    common = dict(ddim_steps=2, ddim_eta=1.0, unconditional_guidance_scale=sm["cfg_scale"], fs=sm["fs"], text_input=True,
+                  timestep_spacing=sm["spacing"], guidance_rescale=sm["guidance_rescale"])
+    for tag, extra in (("two_way", {}), ("three_way", {"multiple_cond_cfg": True, "cfg_img": d["cfg_img"]})):
+        it = iter(noises)
+        fake = lambda shape, device, repeat=False: next(it).to(device)
+        monkeypatch.setattr(my_ddim, "noise_like", fake)
+        monkeypatch.setattr(my_mc, "noise_like", fake)
+        torch.manual_seed(d["cpu_seed"])
+        out = image_guided_synthesis(model, ["a street"] * B, sparse, depth, labels, [B, 4, T, H, W], x_T=x_T, **common, **extra)
+        want = g["outs"][tag]
+        err = rel_l2(out, want)
+        print(f"[{MODE}] driver image_guided_synthesis {tag}: decoded frames rel-L2 vs the reference's function {err:.3e}")
+        assert out.shape == want.shape and err < TOL_E2E
+        if MEETS_CONTRACT:
+            assert err <= 1e-3
+
+
+def cfgs_sampler():
+    from helpers import cfgs
+    return cfgs.SAMPLER
