@@ -339,9 +339,15 @@ def cast_bf16(src):
     """fp32 rows matrix -> MFMA operand rows of the same shape (an operand matrix is returned as is)."""
     if src.dtype == H16():
         return src
-    if src.dtype != torch.float32 or src.dim() != 2 or src.stride(1) != 1:
-        raise hip.MudgError("cast_bf16 expects a 2-D fp32 rows matrix")
-    return cast_rows(src, empty_rows(src.shape[0], src.shape[1], H16(), src.device))
+    if src.dtype != torch.float32:
+        raise hip.MudgError("cast_bf16 expects fp32")
+    if src.dim() == 2 and src.stride(1) == 1:
+        return cast_rows(src, empty_rows(src.shape[0], src.shape[1], H16(), src.device))
+    if hip.planes() > 1 or not src.is_contiguous():
+        raise hip.MudgError("cast_bf16: only 2-D rows matrices have an operand layout in the split-operand builds")
+    out = torch.empty(src.shape, dtype=H16(), device=src.device)         # 16-bit builds: any contiguous shape, flat
+    hip.check(hip.lib().mudg_cast_f32_bf16(src.data_ptr(), out.data_ptr(), src.numel(), _stream()), "mudg_cast_f32_bf16")
+    return out
 
 
 def to_f32(src):

@@ -46,7 +46,7 @@ def test_cast_round_trip_is_exact_to_the_modes_precision(cuda):
     t, v = operand(x, cuda)
     assert tuple(t.shape) == (300, 72) and t.stride(0) == 72 * _hip.planes()
     eps = {"bf16": 2 ** -8, "fp16": 2 ** -11, "bf16x3": 2 ** -17, "bf16x6": 2 ** -24}[MODE]
-    assert float(((v - x.double()).abs() / x.double().abs().clamp_min(1e-30)).max()) <= eps
+    assert bool(((v - x.double()).abs() <= eps * x.double().abs() + 2.0 ** -25).all())      # + fp16's subnormal spacing
     from mudg_amd import ops
     again = ops.cast_rows(t, ops.empty_rows(300, 72, None, cuda))        # operand -> operand keeps every piece
     assert torch.equal(value(again), v)
