@@ -30,3 +30,63 @@ def checkpoint(func, inputs, params, flag):
     """Activation checkpointing only matters for backward; the HIP path is inference-only, so this is a call-through
     (the reference's driver forces use_checkpoint=False as well: virtual_pose_render.py:156)."""
     return func(*inputs)
+
+
+# ---- the remaining public helpers of the reference module (lvdm/common.py:8-78), so that MuDG modules which import
+# them from here (lvdm/modules/encoders/condition.py:7 `from lvdm.common import autocast`) keep working when this
+# package overlays the reference's.  They carry no hot-path arithmetic.
+def gather_data(data, return_np=True):
+    """all_gather of a tensor over the default process group (common.py:8-13)."""
+    import torch.distributed as dist
+    parts = [torch.zeros_like(data) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, data)
+    return [p.cpu().numpy() for p in parts] if return_np else parts
+
+
+def autocast(f):
+    """Decorator: run f under torch.cuda.amp.autocast with the ambient autocast dtype / cache settings (common.py:16-22).
+    The HIP kernels fix their own precision, so this only matters for third-party modules that use it (the CLIP towers)."""
+    import functools
+
+    @functools.wraps(f)
+    def wrapped(*args, **kwargs):
+        with torch.cuda.amp.autocast(enabled=True, dtype=torch.get_autocast_gpu_dtype(),
+                                     cache_enabled=torch.is_autocast_cache_enabled()):
+            return f(*args, **kwargs)
+    return wrapped
+
+
+def identity(*args, **kwargs):
+    return torch.nn.Identity()
+
+
+def uniq(arr):
+    return {el: True for el in arr}.keys()
+
+
+def mean_flat(tensor):
+    """Mean over all non-batch dimensions (common.py:51-55); host-side loss bookkeeping in the reference."""
+    return tensor.mean(dim=list(range(1, tensor.dim())))
+
+
+def ismap(x):
+    return isinstance(x, torch.Tensor) and x.dim() == 4 and x.shape[1] > 3
+
+
+def isimage(x):
+    return isinstance(x, torch.Tensor) and x.dim() == 4 and x.shape[1] in (1, 3)
+
+
+def max_neg_value(t):
+    return -torch.finfo(t.dtype).max
+
+
+def shape_to_str(x):
+    return "x".join(str(s) for s in x.shape)
+
+
+def init_(tensor):
+    import math
+    std = 1.0 / math.sqrt(tensor.shape[-1])
+    tensor.uniform_(-std, std)
+    return tensor

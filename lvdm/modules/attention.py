@@ -29,6 +29,9 @@ class CrossAttention(nn.Module):
         super().__init__()
         _unsupported(relative_position, "relative position attention")
         _unsupported(image_cross_attention_scale_learnable, "a learnable image cross-attention scale")
+        # the attention kernels are written for 64-wide heads (what every MuDG config uses: num_head_channels 64, and
+        # 8 x 64 in init_attn); any other width would build and then compute the wrong thing
+        _unsupported(dim_head != 64, f"attention head width {dim_head} (only 64)")
         inner = dim_head * heads
         context_dim = default(context_dim, query_dim)
         self.scale = dim_head ** -0.5

@@ -29,3 +29,8 @@ def count_params(model, verbose=False):
     if verbose:
         print(f"{model.__class__.__name__} has {total * 1.e-6:.2f} M params.")
     return total
+
+
+def check_istarget(name, para_list):
+    """True when `name` contains any entry of para_list (reference utils/utils.py:15-24: selects trainable parameters)."""
+    return any(para in name for para in para_list)
