@@ -78,8 +78,10 @@ typedef struct MudgGemmDesc {
     int batch;            /* blockIdx.z count (>=1) */
     int64_t sX, sW, sY, sR;         /* per-batch strides in elements */
     int rows_per_group;   /* for gbias; 0 = unused */
-    int out_fp32;         /* 1: Y is fp32 */
-    int res_fp32;         /* 1: R is fp32 (the residual stream is kept in fp32 between blocks) */
+    int out_fp32;         /* storage of Y: 0 = MFMA operand (bf16 ...), 1 = fp32, 2 = IEEE fp16 */
+    int res_fp32;         /* storage of R, same codes.  The residual stream (block outputs, the transformers' token stream,
+                             encoder skips: what later layers add onto) is kept as fp16 by the 16-bit builds' callers — the
+                             reference's own stream is fp16 under torch.autocast — and as fp32 by the split-operand builds' */
     int geglu;            /* 1: W rows are packed [32 value | 32 gate] blocks and
                              Y[m][j] = v_j * gelu_erf(g_j), Nout = N/2 (attention.py:579-586) */
     int act;              /* 1: Y = gelu_erf(.) applied after bias (Perceiver FeedForward, resampler.py:27-34); 0: none */
@@ -140,7 +142,9 @@ int mudg_groupnorm(const void* X, const void* X2, int csplit, int ldx, int ldx2,
                    const float* gamma, const float* beta, void* Y, int ldy,
                    int samples, int rows, int C, int groups, float eps, int silu,
                    float* ws, void* stream);
-/* x_fp32: X (and X2) hold fp32 instead of bf16; Y is always bf16 (it feeds an MFMA GEMM). */
+/* x_fp32: storage of X (and X2): 0 = operand (bf16 ...), 1 = fp32, 2 = IEEE fp16 (the residual stream of the 16-bit
+ * builds); Y is always an MFMA operand (it feeds a GEMM).  Same codes in mudg_layernorm, mudg_cast_rows (src_fp32 /
+ * dst_fp32) and mudg_rows_to_ncthw (src_is_fp32). */
 /* Same normalisation with the statistics pass replaced by the per-(128-row block, channel) partial sums the producing
  * GEMM / conv wrote (MudgGemmDesc.stats): P1 covers X's csplit channels, P2 (NULL without X2) X2's C - csplit.
  * Needs rows % 128 == 0 (a row block never straddles two samples).  ws: fp32 scratch of 2 * samples * groups floats. */
@@ -185,8 +189,8 @@ int mudg_lincomb(float* out, const float* x, const float* y, const float* ca, co
 /* fp32 -> bf16 cast of n contiguous elements (a fp32 stream tensor entering an MFMA GEMM as an operand).
  * 16-bit-operand builds only (a flat cast has no plane layout); mudg_cast_rows serves every build. */
 int mudg_cast_f32_bf16(const float* src, void* dst, int64_t n, void* stream);
-/* dst[r][c] = src[r][c] for rows x cols elements between rows matrices of either kind, any direction: operand
- * (*_fp32 = 0: h16, or PLANES pieces per value in the split builds) or fp32 (*_fp32 = 1).  Row strides in elements.
+/* dst[r][c] = src[r][c] for rows x cols elements between rows matrices of any kind, any direction: operand
+ * (*_fp32 = 0: h16, or PLANES pieces per value in the split builds), fp32 (1) or fp16 (2).  Row strides in elements.
  * This is how fp32 tensors (context tokens ddpm3d.py:1320-1322, skip-conv inputs) become MFMA operands and how an
  * operand matrix is read back as fp32. */
 int mudg_cast_rows(const void* src, int src_fp32, int64_t lds, void* dst, int dst_fp32, int64_t ldd, int64_t rows,

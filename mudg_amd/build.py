@@ -19,7 +19,7 @@ OUT = os.path.join(HERE, "libmudg_hip.so")
 OUT_FP16 = os.path.join(HERE, "libmudg_hip_fp16.so")
 OUT_X3 = os.path.join(HERE, "libmudg_hip_x3.so")
 OUT_X6 = os.path.join(HERE, "libmudg_hip_x6.so")
-SOURCES = ["capi.hip", "gemm.hip", "gemm256.hip", "gemm256p.hip", "attention.hip", "norm.hip", "misc.hip", "post.hip"]
+SOURCES = ["capi.hip", "gemm.hip", "gemm256.hip", "attention.hip", "norm.hip", "misc.hip", "post.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-ffp-contract=off"]
 

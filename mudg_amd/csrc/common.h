@@ -60,6 +60,24 @@ union Pack8 { u32x2 u; h16x4 h; };
 __device__ __forceinline__ h16x8 as_h16x8(u32x4 v) { Pack16 p; p.u = v; return p.h; }
 __device__ __forceinline__ u32x4 as_u32x4(h16x8 v) { Pack16 p; p.h = v; return p.u; }
 
+// ---- residual-stream / plain buffers: storage kind codes used by out_fp32 / res_fp32 / x_fp32 style arguments ----
+// 0 = MFMA operand (h16, PLANES pieces), 1 = fp32, 2 = IEEE fp16 "stream" storage: the tensors later layers add onto
+// (block outputs, the transformers' token stream, skips) are kept at 2 bytes per value in the 16-bit builds — the
+// reference's own stream is fp16 under torch.autocast — and at fp32 in the split-operand precision builds.
+enum { KIND_OPERAND = 0, KIND_F32 = 1, KIND_F16 = 2 };
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+__device__ __forceinline__ void load8_f16(const _Float16* p, float (&v)[8]) {
+    union { u32x4 u; f16x8 h; } t; t.u = ld16(p);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (float)t.h[e];
+}
+__device__ __forceinline__ void store8_f16(_Float16* p, const float (&v)[8]) {
+    union { u32x4 u; f16x8 h; } t;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t.h[e] = (_Float16)v[e];
+    st16(p, t.u);
+}
+
 // ---- operand element I/O: one logical value = PLANES h16 numbers `ps` elements apart (ps = row stride / PLANES) ----
 // Eight consecutive channels: 16-byte accesses per plane.
 __device__ __forceinline__ void store8_operand(h16* dst, int64_t ps, const float (&v)[8]) {

@@ -360,8 +360,9 @@ __global__ __launch_bounds__(256, SB ? 4 : 2) void gemm_kernel(const MudgGemmDes
     const int Nout = p.geglu ? p.N / 2 : p.N;
     const int nout0 = p.geglu ? n0 / 2 : n0;
     const int cpr = NT / 8;
-    const h16* R = (p.R && !p.res_fp32) ? reinterpret_cast<const h16*>(p.R) + bz * p.sR : nullptr;
-    const float* Rf = (p.R && p.res_fp32) ? reinterpret_cast<const float*>(p.R) + bz * p.sR : nullptr;
+    const h16* R = (p.R && p.res_fp32 == KIND_OPERAND) ? reinterpret_cast<const h16*>(p.R) + bz * p.sR : nullptr;
+    const float* Rf = (p.R && p.res_fp32 == KIND_F32) ? reinterpret_cast<const float*>(p.R) + bz * p.sR : nullptr;
+    const _Float16* Rh = (p.R && p.res_fp32 == KIND_F16) ? reinterpret_cast<const _Float16*>(p.R) + bz * p.sR : nullptr;
     float gs[8], gq[8];            // GroupNorm partials of this thread's 8 output channels (p.stats)
 #pragma unroll
     for (int j = 0; j < 8; ++j) { gs[j] = 0.f; gq[j] = 0.f; }
@@ -444,14 +445,34 @@ __global__ __launch_bounds__(256, SB ? 4 : 2) void gemm_kernel(const MudgGemmDes
                 for (int j = 0; j < 8; ++j) if (j < nvalid) v[j] += rp[j];
             }
         }
+        if (Rh) {
+            const _Float16* rp = Rh + (int64_t)m * p.ldr + n;
+            if (nvalid == 8 && (vflags & VF_R)) {
+                float rr[8];
+                load8_f16(rp, rr);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] += rr[j];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (j < nvalid) v[j] += (float)rp[j];
+            }
+        }
         if (p.stats) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float t = (j < nvalid) ? (p.out_fp32 ? v[j] : operand_round(v[j])) : 0.f;
+                const float t = (j < nvalid) ? (p.out_fp32 == KIND_F32 ? v[j] : (p.out_fp32 == KIND_F16 ? (float)(_Float16)v[j] : operand_round(v[j]))) : 0.f;
                 gs[j] += t; gq[j] = fmaf(t, t, gq[j]);
             }
         }
-        if (p.out_fp32) {
+        if (p.out_fp32 == KIND_F16) {
+            _Float16* yp = reinterpret_cast<_Float16*>(p.Y) + bz * p.sY + (int64_t)m * p.ldy + n;
+            if (nvalid == 8 && (vflags & VF_Y)) {
+                store8_f16(yp, v);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (j < nvalid) yp[j] = (_Float16)v[j];
+            }
+        } else if (p.out_fp32) {
             float* yp = reinterpret_cast<float*>(p.Y) + bz * p.sY + (int64_t)m * p.ldy + n;
             if (nvalid == 8 && (vflags & VF_Y)) {
                 f32x4 a, b;
@@ -556,12 +577,12 @@ int launch(const MudgGemmDesc& d, int vflags, hipStream_t s) {
     return mudg_check_launch("mudg_gemm");
 }
 
-// Large-tile path (gemm256.hip / gemm256p.hip): 256x256 tiles stage half the bytes per FLOP.  Measured per shape
+// Large-tile path (gemm256.hip): 256x256 tiles stage half the bytes per FLOP.  Measured per shape
 // family on MI355X (tools/exp_tiles.py) against the 128x128 kernels: once the conv loaders kept their tap state in
 // registers, two or four resident 128x128 workgroups per CU beat both 256x256 kernels on every FAST 3x3 conv of the
 // UNet (1050-1120 vs 920-1070 TFLOP/s), on the temporal convs and on the plain / GEGLU GEMMs; the large tiles remain for
 // the nearest-2x upsample convs (generic address path).
-// MUDG_GEMM256=0 disables it, =1 forces it whenever M, N >= 256 (MUDG_GEMM256P then picks the kernel, see gemm256.hip).
+// MUDG_GEMM256=0 disables it, =1 forces it whenever M, N >= 256.
 bool use_gemm256(const MudgGemmDesc& d) {
     static int mode = -1;
     if (mode < 0) {
@@ -662,16 +683,17 @@ extern "C" int mudg_gemm(const MudgGemmDesc* dp, void* stream) {
     if (d.stats) MUDG_REQUIRE(d.batch == 1 && !d.geglu, "mudg_gemm: stats needs batch == 1 and no GEGLU");
     if (d.alpha == 0.f) d.alpha = 1.f;
     int vflags = 0;
-    const int ybytes = d.out_fp32 ? 4 : 2;
+    MUDG_REQUIRE(d.out_fp32 >= 0 && d.out_fp32 <= 2 && d.res_fp32 >= 0 && d.res_fp32 <= 2, "mudg_gemm: out_fp32 / res_fp32 are 0 (operand), 1 (fp32) or 2 (fp16)");
+    const int ybytes = d.out_fp32 == KIND_F32 ? 4 : 2;
     if (aligned16(d.Y) && ((int64_t)d.ldy * ybytes) % (d.out_fp32 ? 16 : 16 * PLANES) == 0 && ((int64_t)d.sY * ybytes) % 16 == 0) vflags |= VF_Y;
-    const int rbytes = d.res_fp32 ? 4 : 2;
+    const int rbytes = d.res_fp32 == KIND_F32 ? 4 : 2;
     if (d.R && aligned16(d.R) && ((int64_t)d.ldr * rbytes) % (d.res_fp32 ? 16 : 16 * PLANES) == 0 && ((int64_t)d.sR * rbytes) % 16 == 0) vflags |= VF_R;
 
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int fam = d.mode == 0 ? MUDG_FAM_GEMM : (d.mode == 1 ? MUDG_FAM_CONV : MUDG_FAM_TCONV);
     const int slot = mudg_prof_begin(fam, s);
     int rc;
-    // GroupNorm partials (d.stats) are written by the 128x128 kernels and the ping-pong kernel; the 16-wave 256x256
+    // GroupNorm partials (d.stats) are written by the 128x128 kernels; the 16-wave 256x256
     // kernel has no registers left for them (1024 threads -> 128 VGPRs) and declines such problems (returns 1).
     rc = 1;
     if (use_gemm256(d)) {
@@ -690,7 +712,10 @@ extern "C" int mudg_gemm(const MudgGemmDesc* dp, void* stream) {
         }
     }
     const double flops = 2.0 * d.M * (double)d.N * d.K * d.batch;          // algorithmic (the split builds issue NSEG times as many)
-    const double bytes = ((double)d.M * cin + (double)d.N * d.K + (double)d.M * (d.geglu ? d.N / 2 : d.N)) * 2.0 * d.batch;
+    // algorithmic bytes at 16-bit storage: activations in (taps are re-reads of the same rows), weights, the result, and the
+    // residual the epilogue adds when there is one
+    const double nout = d.geglu ? d.N / 2 : d.N;
+    const double bytes = ((double)d.M * cin + (double)d.N * d.K + (double)d.M * nout * (d.R ? 2.0 : 1.0)) * 2.0 * d.batch;
     mudg_prof_end(slot, s, flops, bytes);
     return rc;
 }

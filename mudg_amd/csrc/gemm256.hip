@@ -276,8 +276,9 @@ __global__ __launch_bounds__(1024, 4) void gemm256_kernel(const MudgGemmDesc p, 
     float* sbias = stg + 128 * STGLD;
     const float alpha = p.alpha;
     const int Nout = p.geglu ? p.N / 2 : p.N;
-    const h16* R = (p.R && !p.res_fp32) ? reinterpret_cast<const h16*>(p.R) + bz * p.sR : nullptr;
-    const float* Rf = (p.R && p.res_fp32) ? reinterpret_cast<const float*>(p.R) + bz * p.sR : nullptr;
+    const h16* R = (p.R && p.res_fp32 == KIND_OPERAND) ? reinterpret_cast<const h16*>(p.R) + bz * p.sR : nullptr;
+    const float* Rf = (p.R && p.res_fp32 == KIND_F32) ? reinterpret_cast<const float*>(p.R) + bz * p.sR : nullptr;
+    const _Float16* Rh = (p.R && p.res_fp32 == KIND_F16) ? reinterpret_cast<const _Float16*>(p.R) + bz * p.sR : nullptr;
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
@@ -354,7 +355,27 @@ __global__ __launch_bounds__(1024, 4) void gemm256_kernel(const MudgGemmDesc p, 
                         for (int j = 0; j < 8; ++j) if (j < nvalid) v[j] += rp[j];
                     }
                 }
-                if (p.out_fp32) {
+                if (Rh) {
+                    const _Float16* rp = Rh + (int64_t)m * p.ldr + n;
+                    if (nvalid == 8 && (vflags & VF_R)) {
+                        float rr[8];
+                        load8_f16(rp, rr);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] += rr[j];
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) if (j < nvalid) v[j] += (float)rp[j];
+                    }
+                }
+                if (p.out_fp32 == KIND_F16) {
+                    _Float16* yp = reinterpret_cast<_Float16*>(p.Y) + bz * p.sY + (int64_t)m * p.ldy + n;
+                    if (nvalid == 8 && (vflags & VF_Y)) {
+                        store8_f16(yp, v);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) if (j < nvalid) yp[j] = (_Float16)v[j];
+                    }
+                } else if (p.out_fp32) {
                     float* yp = reinterpret_cast<float*>(p.Y) + bz * p.sY + (int64_t)m * p.ldy + n;
                     if (nvalid == 8 && (vflags & VF_Y)) {
                         f32x4 a, b;
@@ -403,19 +424,8 @@ int launch256(const MudgGemmDesc& d, int vflags, const h16* zp, hipStream_t s) {
 
 // Called by mudg_gemm (gemm.hip) once the descriptor is validated and the large-tile path is selected.
 bool mudg_gemm_fast_ok(const MudgGemmDesc& d);      // gemm.hip
-int mudg_gemm256p_dispatch(const MudgGemmDesc& d, int vflags, hipStream_t s);      // gemm256p.hip
 
 int mudg_gemm256_dispatch(const MudgGemmDesc& d, int vflags, const h16* zpage, hipStream_t s) {
-    // The ping-pong kernel (gemm256p.hip) beats the 16-wave kernel on long K loops without a GEGLU epilogue (+8...+12 %
-    // at K >= 5120) and loses on K <= 3840 and on GEGLU tiles (one workgroup per CU: nothing hides its longer epilogue).
-    // With the default selection (mudg_gemm) only GEGLU GEMMs and generic-path convs reach this dispatcher, so the
-    // ping-pong kernel runs when forced: MUDG_GEMM256=1 sends every M, N >= 256 problem here, MUDG_GEMM256P=2 then uses
-    // it for every FAST problem, =0 never.
-    static int pingpong = -1;
-    if (pingpong < 0) { const char* e = getenv("MUDG_GEMM256P"); pingpong = e ? atoi(e) : 1; }
-    if (mudg_gemm_fast_ok(d)) {
-        if (pingpong == 2 || (pingpong == 1 && d.K >= 5120 && !d.geglu)) return mudg_gemm256p_dispatch(d, vflags, s);
-    }
     if (d.stats) return 1;                   // declined: the 16-wave kernel does not write GroupNorm partials (see mudg_gemm)
     if (mudg_gemm_fast_ok(d)) {
         if (d.mode == 0) return launch256<0, true>(d, vflags, zpage, s);

@@ -59,6 +59,8 @@ __global__ void ncthw_to_rows_kernel(const ST* __restrict__ src, h16* __restrict
 // A rows-matrix element as fp32: operand storage (PLANES pieces) or plain fp32.
 __device__ __forceinline__ float row_value(const h16* p, int ld) { return load1_operand(p, ld / PLANES); }
 __device__ __forceinline__ float row_value(const float* p, int) { return *p; }
+struct StreamH { _Float16 v; };       // fp16 residual-stream storage (KIND_F16); a type of its own since h16 may be _Float16 too
+__device__ __forceinline__ float row_value(const StreamH* p, int) { return (float)p->v; }
 
 template <typename ST, typename DT>
 __global__ void rows_to_ncthw_kernel(const ST* __restrict__ src, int ld, int coff, DT* __restrict__ dst, int B, int C,
@@ -105,11 +107,10 @@ __global__ void cast_rows_kernel(const ST* __restrict__ src, int64_t lds, DT* __
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows * cols) return;
     const int64_t r = i / cols, c = i - r * cols;
-    float v;
-    if constexpr (sizeof(ST) == 2) v = load1_operand(reinterpret_cast<const h16*>(src) + r * lds + c, lds / PLANES);
-    else v = src[r * lds + c];
-    if constexpr (sizeof(DT) == 2) store1_operand(reinterpret_cast<h16*>(dst) + r * ldd + c, ldd / PLANES, v);
-    else dst[r * ldd + c] = v;
+    const float v = row_value(src + r * lds + c, (int)lds);
+    if constexpr (sizeof(DT) == 4) dst[r * ldd + c] = v;
+    else if constexpr (__is_same(DT, StreamH)) dst[r * ldd + c].v = (_Float16)v;
+    else store1_operand(dst + r * ldd + c, ldd / PLANES, v);
 }
 
 __global__ void cast_kernel(const float* __restrict__ src, h16* __restrict__ dst, int64_t n8, int64_t n) {
@@ -276,7 +277,10 @@ extern "C" int mudg_rows_to_ncthw(const void* src, int src_is_fp32, int ld, int 
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int64_t n = (int64_t)B * T * HW;
     const dim3 grid((unsigned)((n + 255) / 256));
-    if (src_is_fp32) {
+    if (src_is_fp32 == KIND_F16) {
+        if (dst_is_fp32) hipLaunchKernelGGL((rows_to_ncthw_kernel<StreamH, float>), grid, dim3(256), 0, s, (const StreamH*)src, ld, coff, (float*)dst, B, C, T, HW, scale, Ttot, t0);
+        else hipLaunchKernelGGL((rows_to_ncthw_kernel<StreamH, h16>), grid, dim3(256), 0, s, (const StreamH*)src, ld, coff, (h16*)dst, B, C, T, HW, scale, Ttot, t0);
+    } else if (src_is_fp32) {
         if (dst_is_fp32) hipLaunchKernelGGL((rows_to_ncthw_kernel<float, float>), grid, dim3(256), 0, s, (const float*)src, ld, coff, (float*)dst, B, C, T, HW, scale, Ttot, t0);
         else hipLaunchKernelGGL((rows_to_ncthw_kernel<float, h16>), grid, dim3(256), 0, s, (const float*)src, ld, coff, (h16*)dst, B, C, T, HW, scale, Ttot, t0);
     } else {
@@ -294,17 +298,24 @@ extern "C" int mudg_zero_channels(void* dst, int rows, int ld, int c0, int c1, v
     return mudg_check_launch("mudg_zero_channels");
 }
 
+template <typename ST>
+static void launch_cast_rows(const ST* src, int64_t lds, void* dst, int dst_kind, int64_t ldd, int64_t rows, int64_t cols, hipStream_t s) {
+    const dim3 grid((unsigned)((rows * cols + 255) / 256));
+    if (dst_kind == KIND_F32) hipLaunchKernelGGL((cast_rows_kernel<ST, float>), grid, dim3(256), 0, s, src, lds, (float*)dst, ldd, rows, cols);
+    else if (dst_kind == KIND_F16) hipLaunchKernelGGL((cast_rows_kernel<ST, StreamH>), grid, dim3(256), 0, s, src, lds, (StreamH*)dst, ldd, rows, cols);
+    else hipLaunchKernelGGL((cast_rows_kernel<ST, h16>), grid, dim3(256), 0, s, src, lds, (h16*)dst, ldd, rows, cols);
+}
+
 extern "C" int mudg_cast_rows(const void* src, int src_fp32, int64_t lds, void* dst, int dst_fp32, int64_t ldd, int64_t rows,
                               int64_t cols, void* stream) {
     MUDG_REQUIRE(src && dst && rows > 0 && cols > 0, "mudg_cast_rows: bad arguments");
+    MUDG_REQUIRE(src_fp32 >= 0 && src_fp32 <= 2 && dst_fp32 >= 0 && dst_fp32 <= 2, "mudg_cast_rows: kinds are 0 (operand), 1 (fp32), 2 (fp16)");
     MUDG_REQUIRE(src_fp32 ? lds >= cols : (lds % PLANES == 0 && lds / PLANES >= cols), "mudg_cast_rows: lds=%lld", (long long)lds);
     MUDG_REQUIRE(dst_fp32 ? ldd >= cols : (ldd % PLANES == 0 && ldd / PLANES >= cols), "mudg_cast_rows: ldd=%lld", (long long)ldd);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    const dim3 grid((unsigned)((rows * cols + 255) / 256));
-    if (src_fp32 && dst_fp32) hipLaunchKernelGGL((cast_rows_kernel<float, float>), grid, dim3(256), 0, s, (const float*)src, lds, (float*)dst, ldd, rows, cols);
-    else if (src_fp32) hipLaunchKernelGGL((cast_rows_kernel<float, h16>), grid, dim3(256), 0, s, (const float*)src, lds, (h16*)dst, ldd, rows, cols);
-    else if (dst_fp32) hipLaunchKernelGGL((cast_rows_kernel<h16, float>), grid, dim3(256), 0, s, (const h16*)src, lds, (float*)dst, ldd, rows, cols);
-    else hipLaunchKernelGGL((cast_rows_kernel<h16, h16>), grid, dim3(256), 0, s, (const h16*)src, lds, (h16*)dst, ldd, rows, cols);
+    if (src_fp32 == KIND_F32) launch_cast_rows((const float*)src, lds, dst, dst_fp32, ldd, rows, cols, s);
+    else if (src_fp32 == KIND_F16) launch_cast_rows((const StreamH*)src, lds, dst, dst_fp32, ldd, rows, cols, s);
+    else launch_cast_rows((const h16*)src, lds, dst, dst_fp32, ldd, rows, cols, s);
     return mudg_check_launch("mudg_cast_rows");
 }
 

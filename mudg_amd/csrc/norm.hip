@@ -12,6 +12,10 @@ template <typename T> struct Load8;
 template <> struct Load8<h16> {
     static __device__ __forceinline__ void get(const h16* p, int ld, float (&x)[8]) { load8_operand(p, ld / PLANES, x); }
 };
+struct StreamH { _Float16 v; };       // fp16 residual-stream storage (KIND_F16): a type of its own, h16 may be _Float16 too
+template <> struct Load8<StreamH> {
+    static __device__ __forceinline__ void get(const StreamH* p, int, float (&x)[8]) { load8_f16(reinterpret_cast<const _Float16*>(p), x); }
+};
 template <> struct Load8<float> {
     static __device__ __forceinline__ void get(const float* p, int, float (&x)[8]) {
         const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
@@ -288,7 +292,8 @@ extern "C" int mudg_groupnorm(const void* X, const void* X2, int csplit, int ldx
     MUDG_REQUIRE(samples > 0 && rows > 0 && C > 0 && groups > 0, "mudg_groupnorm: empty problem");
     MUDG_REQUIRE(C % groups == 0 && (C & 7) == 0 && C <= GN_CMAX, "mudg_groupnorm: C=%d groups=%d unsupported", C, groups);
     MUDG_REQUIRE(groups <= 256, "mudg_groupnorm: groups=%d > 256", groups);
-    const int xq = x_fp32 ? 4 : 8 * PLANES;      // row stride granule so that every 8-channel vector (of every plane) is 16-byte aligned
+    MUDG_REQUIRE(x_fp32 >= 0 && x_fp32 <= 2, "mudg_groupnorm: x_fp32 is 0 (operand), 1 (fp32) or 2 (fp16)");
+    const int xq = x_fp32 == KIND_F32 ? 4 : (x_fp32 == KIND_F16 ? 8 : 8 * PLANES);      // row stride granule so that every 8-channel vector (of every plane) is 16-byte aligned
     MUDG_REQUIRE(ldx % xq == 0 && ldy % (8 * PLANES) == 0 && aligned16(X) && aligned16(Y), "mudg_groupnorm: alignment");
     MUDG_REQUIRE(ldy / PLANES >= C, "mudg_groupnorm: ldy=%d too small for %d plane(s) of %d channels", ldy, PLANES, C);
     MUDG_REQUIRE(samples <= 65535, "mudg_groupnorm: too many samples");
@@ -299,7 +304,10 @@ extern "C" int mudg_groupnorm(const void* X, const void* X2, int csplit, int ldx
     float* part = ws;
     float* stat = ws + (int64_t)samples * nchunks * groups * 2;
     const int slot = mudg_prof_begin(MUDG_FAM_GNORM, s);
-    if (x_fp32)
+    if (x_fp32 == KIND_F16)
+        hipLaunchKernelGGL(gn_stats_kernel<StreamH>, dim3(nchunks, samples), dim3(256), 0, s, (const StreamH*)X, (const StreamH*)X2,
+                           csplit, ldx, ldx2, rows, C, groups, nchunks, part);
+    else if (x_fp32)
         hipLaunchKernelGGL(gn_stats_kernel<float>, dim3(nchunks, samples), dim3(256), 0, s, (const float*)X, (const float*)X2,
                            csplit, ldx, ldx2, rows, C, groups, nchunks, part);
     else
@@ -309,14 +317,17 @@ extern "C" int mudg_groupnorm(const void* X, const void* X2, int csplit, int ldx
     hipLaunchKernelGGL(gn_finalize_kernel, dim3((ng + 3) / 4), dim3(256), 0, s, part, stat, samples, groups, nchunks,
                        (double)rows * (C / groups), eps);
     const int nblk = gn_apply_blocks(samples, rows);
-    if (x_fp32)
+    if (x_fp32 == KIND_F16)
+        hipLaunchKernelGGL(gn_apply_kernel<StreamH>, dim3(nblk, samples), dim3(256), 0, s, (const StreamH*)X, (const StreamH*)X2,
+                           csplit, ldx, ldx2, gamma, beta, (h16*)Y, ldy, rows, C, groups, nblk, silu, stat);
+    else if (x_fp32)
         hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(nblk, samples), dim3(256), 0, s, (const float*)X, (const float*)X2,
                            csplit, ldx, ldx2, gamma, beta, (h16*)Y, ldy, rows, C, groups, nblk, silu, stat);
     else
         hipLaunchKernelGGL(gn_apply_kernel<h16>, dim3(nblk, samples), dim3(256), 0, s, (const h16*)X, (const h16*)X2,
                            csplit, ldx, ldx2, gamma, beta, (h16*)Y, ldy, rows, C, groups, nblk, silu, stat);
     const int rc = mudg_check_launch("mudg_groupnorm");
-    mudg_prof_end(slot, s, 0.0, (double)samples * rows * C * (x_fp32 ? 10.0 : 6.0));
+    mudg_prof_end(slot, s, 0.0, (double)samples * rows * C * (x_fp32 == KIND_F32 ? 10.0 : 6.0));
     return rc;
 }
 
@@ -327,7 +338,8 @@ extern "C" int mudg_groupnorm_fused(const void* X, const void* X2, int csplit, i
     MUDG_REQUIRE(samples > 0 && rows > 0 && C > 0 && groups > 0, "mudg_groupnorm_fused: empty problem");
     MUDG_REQUIRE(C % groups == 0 && (C & 7) == 0 && C <= GN_CMAX && groups <= 256, "mudg_groupnorm_fused: C=%d groups=%d unsupported", C, groups);
     MUDG_REQUIRE(rows % 128 == 0, "mudg_groupnorm_fused: rows=%d per sample must be a multiple of the 128-row partial blocks", rows);
-    const int xq = x_fp32 ? 4 : 8 * PLANES;
+    MUDG_REQUIRE(x_fp32 >= 0 && x_fp32 <= 2, "mudg_groupnorm_fused: x_fp32 is 0 (operand), 1 (fp32) or 2 (fp16)");
+    const int xq = x_fp32 == KIND_F32 ? 4 : (x_fp32 == KIND_F16 ? 8 : 8 * PLANES);
     MUDG_REQUIRE(ldx % xq == 0 && ldy % (8 * PLANES) == 0 && aligned16(X) && aligned16(Y), "mudg_groupnorm_fused: alignment");
     MUDG_REQUIRE(ldy / PLANES >= C, "mudg_groupnorm_fused: ldy=%d too small for %d plane(s) of %d channels", ldy, PLANES, C);
     MUDG_REQUIRE(samples <= 65535, "mudg_groupnorm_fused: too many samples");
@@ -340,14 +352,17 @@ extern "C" int mudg_groupnorm_fused(const void* X, const void* X2, int csplit, i
     hipLaunchKernelGGL(gn_finalize_ch_kernel, dim3(ng), dim3(256), 0, s, P1, P2, csplit, C, stat, samples, groups,
                        rows / 128, (double)rows * (C / groups), eps);
     const int nblk = gn_apply_blocks(samples, rows);
-    if (x_fp32)
+    if (x_fp32 == KIND_F16)
+        hipLaunchKernelGGL(gn_apply_kernel<StreamH>, dim3(nblk, samples), dim3(256), 0, s, (const StreamH*)X, (const StreamH*)X2,
+                           csplit, ldx, ldx2, gamma, beta, (h16*)Y, ldy, rows, C, groups, nblk, silu, stat);
+    else if (x_fp32)
         hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(nblk, samples), dim3(256), 0, s, (const float*)X, (const float*)X2,
                            csplit, ldx, ldx2, gamma, beta, (h16*)Y, ldy, rows, C, groups, nblk, silu, stat);
     else
         hipLaunchKernelGGL(gn_apply_kernel<h16>, dim3(nblk, samples), dim3(256), 0, s, (const h16*)X, (const h16*)X2,
                            csplit, ldx, ldx2, gamma, beta, (h16*)Y, ldy, rows, C, groups, nblk, silu, stat);
     const int rc = mudg_check_launch("mudg_groupnorm_fused");
-    mudg_prof_end(slot, s, 0.0, (double)samples * rows * C * (x_fp32 ? 6.0 : 4.0));
+    mudg_prof_end(slot, s, 0.0, (double)samples * rows * C * (x_fp32 == KIND_F32 ? 6.0 : 4.0));
     return rc;
 }
 
@@ -355,7 +370,8 @@ extern "C" int mudg_layernorm(const void* X, int ldx, int x_fp32, const float* g
                               int rows, int C, float eps, void* stream) {
     MUDG_REQUIRE(X && Y && gamma && beta, "mudg_layernorm: null pointer");
     MUDG_REQUIRE(rows > 0 && C > 0 && (C & 7) == 0 && C <= 4096, "mudg_layernorm: rows=%d C=%d unsupported", rows, C);
-    MUDG_REQUIRE(ldx % (x_fp32 ? 4 : 8 * PLANES) == 0 && ldy % (8 * PLANES) == 0 && aligned16(X) && aligned16(Y) && aligned16(gamma) &&
+    MUDG_REQUIRE(x_fp32 >= 0 && x_fp32 <= 2, "mudg_layernorm: x_fp32 is 0 (operand), 1 (fp32) or 2 (fp16)");
+    MUDG_REQUIRE(ldx % (x_fp32 == KIND_F32 ? 4 : (x_fp32 == KIND_F16 ? 8 : 8 * PLANES)) == 0 && ldy % (8 * PLANES) == 0 && aligned16(X) && aligned16(Y) && aligned16(gamma) &&
                  aligned16(beta), "mudg_layernorm: alignment");
     MUDG_REQUIRE(ldy / PLANES >= C, "mudg_layernorm: ldy=%d too small for %d plane(s) of %d channels", ldy, PLANES, C);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -363,14 +379,16 @@ extern "C" int mudg_layernorm(const void* X, int ldx, int x_fp32, const float* g
     const dim3 grid((rows + 3) / 4);
     const int nvec = C >> 3;
     if (nvec <= 64 * 3) {
-        if (x_fp32) hipLaunchKernelGGL((ln_kernel<3, float>), grid, dim3(256), 0, s, (const float*)X, ldx, gamma, beta, (h16*)Y, ldy, rows, C, eps);
+        if (x_fp32 == KIND_F16) hipLaunchKernelGGL((ln_kernel<3, StreamH>), grid, dim3(256), 0, s, (const StreamH*)X, ldx, gamma, beta, (h16*)Y, ldy, rows, C, eps);
+        else if (x_fp32) hipLaunchKernelGGL((ln_kernel<3, float>), grid, dim3(256), 0, s, (const float*)X, ldx, gamma, beta, (h16*)Y, ldy, rows, C, eps);
         else hipLaunchKernelGGL((ln_kernel<3, h16>), grid, dim3(256), 0, s, (const h16*)X, ldx, gamma, beta, (h16*)Y, ldy, rows, C, eps);
     } else {
-        if (x_fp32) hipLaunchKernelGGL((ln_kernel<8, float>), grid, dim3(256), 0, s, (const float*)X, ldx, gamma, beta, (h16*)Y, ldy, rows, C, eps);
+        if (x_fp32 == KIND_F16) hipLaunchKernelGGL((ln_kernel<8, StreamH>), grid, dim3(256), 0, s, (const StreamH*)X, ldx, gamma, beta, (h16*)Y, ldy, rows, C, eps);
+        else if (x_fp32) hipLaunchKernelGGL((ln_kernel<8, float>), grid, dim3(256), 0, s, (const float*)X, ldx, gamma, beta, (h16*)Y, ldy, rows, C, eps);
         else hipLaunchKernelGGL((ln_kernel<8, h16>), grid, dim3(256), 0, s, (const h16*)X, ldx, gamma, beta, (h16*)Y, ldy, rows, C, eps);
     }
     const int rc = mudg_check_launch("mudg_layernorm");
-    mudg_prof_end(slot, s, 0.0, (double)rows * C * (x_fp32 ? 6.0 : 4.0));
+    mudg_prof_end(slot, s, 0.0, (double)rows * C * (x_fp32 == KIND_F32 ? 6.0 : 4.0));
     return rc;
 }
 

@@ -13,8 +13,10 @@ skip-concat ride in the implicit-GEMM loader, V is produced already transposed f
 
 Precision: MFMA operands (normalised activations, weights) are bf16 with fp32 accumulation; the RESIDUAL STREAM —
 every tensor that a later block adds onto: block outputs, the transformers' inner token stream, the encoder skips —
-is kept in fp32, and GroupNorm / LayerNorm read it in fp32.  Rounding the stream to bf16 at each of the ~150
-residual adds was measured to dominate the end-to-end error (2.1e-2 rel-L2 per forward against the fp32 reference).
+is kept in ops.STREAM(): IEEE fp16 in the 16-bit operand builds (11 significand bits: three more than a bf16 operand, so
+the ~150 residual adds stay below the operand rounding — a bf16 stream was measured to dominate the end-to-end error,
+2.1e-2 against 1.6e-2 per forward — at half the HBM bytes of fp32; it is also what the reference's stream is under
+torch.autocast), fp32 in the split-operand precision builds.  GroupNorm / LayerNorm read it and compute in fp32.
 """
 import torch
 import torch.nn as nn
@@ -40,18 +42,18 @@ def _ln(mod, x):
 
 
 def _linear(mod, x, residual=None, x2=None, stream=False, stats=False):
-    """stream=True: the result is a residual-stream tensor and is written in fp32 (see module docstring).
+    """stream=True: the result is a residual-stream tensor and is written in ops.STREAM() (see module docstring).
     stats=True: the result feeds a GroupNorm next — the epilogue also writes that norm's partial sums."""
-    return ops.gemm(x, pk.linear(mod), bias=pk.f32(mod, "bias"), residual=residual, x2=x2, out_fp32=stream, stats=stats)
+    return ops.gemm(x, pk.linear(mod), bias=pk.f32(mod, "bias"), residual=residual, x2=x2, out_stream=stream, stats=stats)
 
 
 def _conv3x3(mod, x, frames, h, w, *, stride=1, upsample=False, gbias=None, rows_per_group=0, residual=None, x2=None,
-             stream=False, stats=True):
+             stream=False, stats=True, fp32=False):
     """Every 3x3 conv of the UNet is followed by a GroupNorm (the next block's, or out_layers'): stats defaults on."""
     wmat, cpad, korder = pk.conv3x3(mod)
     return ops.conv3x3(x, wmat, frames=frames, hin=h, win=w, cin=cpad, stride=stride, upsample=upsample,
                        bias=pk.f32(mod, "bias"), gbias=gbias, rows_per_group=rows_per_group, residual=residual, x2=x2,
-                       out_fp32=stream, korder=korder, stats=stats)
+                       out_stream=stream, out_fp32=fp32, korder=korder, stats=stats)
 
 
 def _vt_projection(mod, src_rows, batches, n_per_batch):
@@ -80,7 +82,7 @@ def temporal_conv_block(mod, x, ctx, hw):
         y = _gn(norm, y, None, ctx.B, ctx.T * hw, True)
         last = i == len(stages) - 1
         y = ops.tconv3(y, pk.tconv(conv), clips=ctx.B, t=ctx.T, hw=hw, cin=conv.weight.shape[1],
-                       bias=pk.f32(conv, "bias"), residual=x if last else None, out_fp32=last, stats=True)
+                       bias=pk.f32(conv, "bias"), residual=x if last else None, out_stream=last, stats=True)
     return y
 
 
@@ -322,7 +324,7 @@ def forward(model, x, timesteps, c_label=None, context=None, features_adapter=No
         cur, h, w = run_stage(stage, cur, skip, h, w, ctx)
     norm, conv = model.out[0], model.out[2]
     cur = _gn(norm, cur, None, B * T, h * w, True)
-    y = _conv3x3(conv, cur, B * T, h, w, stream=True)
+    y = _conv3x3(conv, cur, B * T, h, w, fp32=True, stats=False)          # the prediction itself leaves in fp32
     out_dtype = first.dtype if first.dtype in (torch.float32, ops.H16()) else torch.float32
     out = ops.rows_to_ncthw(y, (B, model.out_channels, T, h, w), dtype=out_dtype)
     return out if out.dtype == first.dtype else out.to(first.dtype)

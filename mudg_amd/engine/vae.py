@@ -20,12 +20,13 @@ def _gn(mod, x, frames, hw, swish):
                          silu=swish, groups=mod.num_groups)
 
 
-def _conv3x3(mod, x, frames, h, w, upsample=False, residual=None, stream=False, stride=1, pad=1):
-    """stream=True: the output is a residual-stream tensor, kept in fp32 (same policy as the UNet executor).  Every conv
+def _conv3x3(mod, x, frames, h, w, upsample=False, residual=None, stream=False, stride=1, pad=1, fp32=False):
+    """stream=True: the output is a residual-stream tensor, kept in ops.STREAM() (same policy as the UNet executor).  Every conv
     here except the nearest-2x ones (16-wave kernel) also writes the partial sums of the GroupNorm that follows it."""
     wmat, cpad, korder = pk.conv3x3(mod)
     return ops.conv3x3(x, wmat, frames=frames, hin=h, win=w, cin=cpad, upsample=upsample, bias=pk.f32(mod, "bias"),
-                       residual=residual, out_fp32=stream, korder=korder, stride=stride, pad=pad, stats=not upsample)
+                       residual=residual, out_stream=stream, out_fp32=fp32, korder=korder, stride=stride, pad=pad,
+                       stats=not (upsample or fp32))
 
 
 def resnet_block(mod, x, frames, h, w):
@@ -34,7 +35,7 @@ def resnet_block(mod, x, frames, h, w):
     skip = x
     if mod.in_channels != mod.out_channels:
         skip = ops.gemm(ops.cast_bf16(x), pk.linear(mod.nin_shortcut), bias=pk.f32(mod.nin_shortcut, "bias"),
-                        out_fp32=True)
+                        out_stream=True)
     return _conv3x3(mod.conv2, a, frames, h, w, residual=skip, stream=True)
 
 
@@ -65,7 +66,7 @@ def attn_block(mod, x, frames, hw):
         ops.softmax_rows(scores[:n * hw], probs[:n * hw])
         ops.gemm(probs, vt[f0 * c:(f0 + n) * c], out=att[rows], bias=pk.f32(mod.v, "bias"), batch=n, sx=hw * probs.stride(0),
                  sw=c * vt.stride(0), sy=hw * att.stride(0), M=hw, N=c, K=hw)
-    return ops.gemm(att, pk.linear(mod.proj_out), bias=pk.f32(mod.proj_out, "bias"), residual=x, out_fp32=True)
+    return ops.gemm(att, pk.linear(mod.proj_out), bias=pk.f32(mod.proj_out, "bias"), residual=x, out_stream=True)
 
 
 def decoder_rows(dec, x, frames, h, w):
@@ -85,7 +86,7 @@ def decoder_rows(dec, x, frames, h, w):
             x = _conv3x3(level.upsample.conv, ops.cast_bf16(x), frames, h, w, upsample=True, stream=True)
             h, w = 2 * h, 2 * w
     x = _gn(dec.norm_out, x, frames, h * w, True)
-    return _conv3x3(dec.conv_out, x, frames, h, w, stream=True), h, w
+    return _conv3x3(dec.conv_out, x, frames, h, w, fp32=True), h, w          # the decoded pixels leave in fp32
 
 
 def encoder_rows(enc, x, frames, h, w):

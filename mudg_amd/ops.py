@@ -21,6 +21,31 @@ def H16():
     return hip.operand_dtype()
 
 
+def STREAM():
+    """torch dtype of the residual stream — the tensors later layers add onto (block outputs, the transformers' token
+    stream, encoder skips): fp16 in the 16-bit operand builds (2 bytes per value through HBM; the reference's own stream
+    is fp16 under torch.autocast), fp32 in the split-operand precision builds.  MUDG_STREAM=fp32 forces fp32."""
+    import os
+    if hip.planes() > 1 or os.environ.get("MUDG_STREAM", "").lower() == "fp32":
+        return torch.float32
+    return torch.float16
+
+
+def kind(t) -> int:
+    """Storage code of a rows matrix for the C-ABI (out_fp32 / res_fp32 / x_fp32 ...): 0 operand, 1 fp32, 2 fp16."""
+    if t.dtype == torch.float32:
+        return 1
+    if t.dtype == H16():
+        return 0
+    if t.dtype == torch.float16:
+        return 2
+    raise hip.MudgError(f"no storage code for {t.dtype}")
+
+
+def _out_dtype(out_fp32, out_stream):
+    return torch.float32 if out_fp32 else (STREAM() if out_stream else H16())
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -76,8 +101,9 @@ def _attach_stats(d, out, M, nout):
 
 def gemm(x, w, *, out=None, bias=None, gbias=None, rows_per_group=0, residual=None, x2=None, geglu=False,
          out_fp32=False, alpha=1.0, batch=1, sx=0, sw=0, sy=0, sr=0, M=None, N=None, K=None, ldy=None, gelu=False,
-         stats=False):
-    """out[m, n] = epilogue(alpha * sum_k x[m, k] w[n, k]); see MudgGemmDesc."""
+         stats=False, out_stream=False):
+    """out[m, n] = epilogue(alpha * sum_k x[m, k] w[n, k]); see MudgGemmDesc.  The result is an MFMA operand matrix by
+    default, fp32 with out_fp32, the residual-stream dtype (STREAM()) with out_stream; `out=` decides by its dtype."""
     _rows(x); _rows(w)
     if M is None:
         M = x.shape[0]
@@ -87,7 +113,7 @@ def gemm(x, w, *, out=None, bias=None, gbias=None, rows_per_group=0, residual=No
         K = w.shape[1]
     nout = N // 2 if geglu else N
     if out is None:
-        out = empty_rows(M, nout, torch.float32 if out_fp32 else H16(), x.device)
+        out = empty_rows(M, nout, _out_dtype(out_fp32, out_stream), x.device)
     else:
         _drop_stats(out)
     d = hip.GemmDesc()
@@ -100,8 +126,8 @@ def gemm(x, w, *, out=None, bias=None, gbias=None, rows_per_group=0, residual=No
     d.ldr = residual.stride(0) if residual is not None else 0
     d.csplit = x.shape[1] if x2 is not None else K
     d.batch, d.sX, d.sW, d.sY, d.sR = batch, sx, sw, sy, sr
-    d.rows_per_group, d.out_fp32, d.geglu, d.alpha, d.mode = rows_per_group, int(out_fp32), int(geglu), alpha, 0
-    d.res_fp32 = int(residual is not None and residual.dtype == torch.float32)
+    d.rows_per_group, d.out_fp32, d.geglu, d.alpha, d.mode = rows_per_group, kind(out), int(geglu), alpha, 0
+    d.res_fp32 = kind(residual) if residual is not None else 0
     d.act = int(gelu)
     if stats:
         _attach_stats(d, out, M, nout)
@@ -110,7 +136,7 @@ def gemm(x, w, *, out=None, bias=None, gbias=None, rows_per_group=0, residual=No
 
 
 def conv3x3(x, w, *, frames, hin, win, cin, stride=1, upsample=False, out=None, bias=None, gbias=None,
-            rows_per_group=0, residual=None, x2=None, out_fp32=False, korder=0, pad=1, stats=False):
+            rows_per_group=0, residual=None, x2=None, out_fp32=False, korder=0, pad=1, stats=False, out_stream=False):
     """3x3 / pad 1 convolution on channels-last rows; w is packed [Cout][9*cin], K axis tap-major (korder 0) or
     64-channel-slab-major (korder 1, see MudgGemmDesc.korder)."""
     _rows(x); _rows(w)
@@ -122,14 +148,14 @@ def conv3x3(x, w, *, frames, hin, win, cin, stride=1, upsample=False, out=None, 
         hout, wout = (hin + 1 - 3) // stride + 1, (win + 1 - 3) // stride + 1
     M, N = frames * hout * wout, w.shape[0]
     if out is None:
-        out = empty_rows(M, N, torch.float32 if out_fp32 else H16(), x.device)
+        out = empty_rows(M, N, _out_dtype(out_fp32, out_stream), x.device)
     else:
         _drop_stats(out)
     d = hip.GemmDesc()
     d.X, d.X2, d.W, d.Y = x.data_ptr(), _ptr(x2), w.data_ptr(), out.data_ptr()
     d.bias, d.gbias, d.R = _ptr(bias), _ptr(gbias), _ptr(residual)
-    d.out_fp32 = int(out.dtype == torch.float32)
-    d.res_fp32 = int(residual is not None and residual.dtype == torch.float32)
+    d.out_fp32 = kind(out)
+    d.res_fp32 = kind(residual) if residual is not None else 0
     d.M, d.N, d.K = M, N, 9 * cin
     d.ldx, d.ldw, d.ldy = x.stride(0), w.stride(0), out.stride(0)
     d.ldx2 = x2.stride(0) if x2 is not None else 0
@@ -144,19 +170,19 @@ def conv3x3(x, w, *, frames, hin, win, cin, stride=1, upsample=False, out=None, 
     return out
 
 
-def tconv3(x, w, *, clips, t, hw, cin, out=None, bias=None, residual=None, out_fp32=False, stats=False):
+def tconv3(x, w, *, clips, t, hw, cin, out=None, bias=None, residual=None, out_fp32=False, stats=False, out_stream=False):
     """(3,1,1) temporal convolution, pad (1,0,0), on rows ordered ((b t) hw); w packed [Cout][3*cin]."""
     _rows(x); _rows(w)
     M, N = clips * t * hw, w.shape[0]
     if out is None:
-        out = empty_rows(M, N, torch.float32 if out_fp32 else H16(), x.device)
+        out = empty_rows(M, N, _out_dtype(out_fp32, out_stream), x.device)
     else:
         _drop_stats(out)
     d = hip.GemmDesc()
     d.X, d.W, d.Y = x.data_ptr(), w.data_ptr(), out.data_ptr()
     d.bias, d.R = _ptr(bias), _ptr(residual)
-    d.out_fp32 = int(out.dtype == torch.float32)
-    d.res_fp32 = int(residual is not None and residual.dtype == torch.float32)
+    d.out_fp32 = kind(out)
+    d.res_fp32 = kind(residual) if residual is not None else 0
     d.M, d.N, d.K = M, N, 3 * cin
     d.ldx, d.ldw, d.ldy = x.stride(0), w.stride(0), out.stride(0)
     d.ldr = residual.stride(0) if residual is not None else 0
@@ -194,8 +220,8 @@ def temporal_attention(qkv, out, *, clips, t, hw, heads, scale=0.125):
 
 # ------------------------------------------------------------------------------------------------ norms
 def _rows_any(t):
-    if t.dim() != 2 or t.stride(1) != 1 or t.dtype not in (H16(), torch.float32) or not t.is_cuda:
-        raise hip.MudgError(f"expected a cuda bf16/fp32 rows matrix, got {tuple(t.shape)} {t.dtype} on {t.device}")
+    if t.dim() != 2 or t.stride(1) != 1 or t.dtype not in (H16(), torch.float32, torch.float16) or not t.is_cuda:
+        raise hip.MudgError(f"expected a cuda operand / fp32 / fp16 rows matrix, got {tuple(t.shape)} {t.dtype} on {t.device}")
     return t
 
 
@@ -220,7 +246,7 @@ def groupnorm(x, gamma, beta, *, samples, rows, eps, silu, groups=32, x2=None, o
     if ok:
         ws = torch.empty(2 * samples * groups, dtype=torch.float32, device=x.device)
         hip.check(hip.lib().mudg_groupnorm_fused(x.data_ptr(), _ptr(x2), x.shape[1], x.stride(0),
-                                                 x2.stride(0) if x2 is not None else 0, int(x.dtype == torch.float32),
+                                                 x2.stride(0) if x2 is not None else 0, kind(x),
                                                  gamma.data_ptr(), beta.data_ptr(),
                                                  out.data_ptr(), out.stride(0), samples, rows, c, groups, eps, int(silu),
                                                  p1.data_ptr(), _ptr(p2), ws.data_ptr(), _stream()), "mudg_groupnorm_fused")
@@ -228,7 +254,7 @@ def groupnorm(x, gamma, beta, *, samples, rows, eps, silu, groups=32, x2=None, o
     n = hip.lib().mudg_groupnorm_ws_floats(samples, groups, rows)
     ws = torch.empty(n, dtype=torch.float32, device=x.device)
     hip.check(hip.lib().mudg_groupnorm(x.data_ptr(), _ptr(x2), x.shape[1], x.stride(0),
-                                       x2.stride(0) if x2 is not None else 0, int(x.dtype == torch.float32),
+                                       x2.stride(0) if x2 is not None else 0, kind(x),
                                        gamma.data_ptr(), beta.data_ptr(),
                                        out.data_ptr(), out.stride(0), samples, rows, c, groups, eps, int(silu),
                                        ws.data_ptr(), _stream()), "mudg_groupnorm")
@@ -239,7 +265,7 @@ def layernorm(x, gamma, beta, *, eps=1e-5, out=None):
     _rows_any(x)
     if out is None:
         out = empty_rows(x.shape[0], x.shape[1], H16(), x.device)
-    hip.check(hip.lib().mudg_layernorm(x.data_ptr(), x.stride(0), int(x.dtype == torch.float32), gamma.data_ptr(),
+    hip.check(hip.lib().mudg_layernorm(x.data_ptr(), x.stride(0), kind(x), gamma.data_ptr(),
                                        beta.data_ptr(), out.data_ptr(),
                                        out.stride(0), x.shape[0], x.shape[1], eps, _stream()), "mudg_layernorm")
     return out
@@ -309,7 +335,7 @@ def rows_to_ncthw(src, shape, coff=0, dtype=torch.float32, scale=1.0, out=None, 
     elif tuple(out.shape) != tuple(shape) or not out.is_contiguous():
         raise hip.MudgError("rows_to_ncthw: `out` must be a contiguous tensor of the stated shape")
     n = t if frames is None else frames
-    hip.check(hip.lib().mudg_rows_to_ncthw(src.data_ptr(), int(src.dtype == torch.float32), src.stride(0), coff,
+    hip.check(hip.lib().mudg_rows_to_ncthw(src.data_ptr(), kind(src), src.stride(0), coff,
                                            out.data_ptr(), int(out.dtype == torch.float32), b, c, n, h * w, scale,
                                            t, t0, _stream()),
               "mudg_rows_to_ncthw")
@@ -327,20 +353,22 @@ def cast_rows(src, dst):
     if src.dim() != 2 or dst.dim() != 2 or src.shape != dst.shape or src.stride(1) != 1 or dst.stride(1) != 1:
         raise hip.MudgError(f"cast_rows: expected equal-shape rows matrices, got {tuple(src.shape)} -> {tuple(dst.shape)}")
     for t in (src, dst):
-        if t.dtype not in (torch.float32, H16()) or not t.is_cuda:
-            raise hip.MudgError(f"cast_rows: expected cuda fp32 / operand tensors, got {t.dtype} on {t.device}")
-    hip.check(hip.lib().mudg_cast_rows(src.data_ptr(), int(src.dtype == torch.float32), src.stride(0), dst.data_ptr(),
-                                       int(dst.dtype == torch.float32), dst.stride(0), src.shape[0], src.shape[1], _stream()),
+        if not t.is_cuda:
+            raise hip.MudgError(f"cast_rows: expected cuda tensors, got {t.device}")
+    hip.check(hip.lib().mudg_cast_rows(src.data_ptr(), kind(src), src.stride(0), dst.data_ptr(),
+                                       kind(dst), dst.stride(0), src.shape[0], src.shape[1], _stream()),
               "mudg_cast_rows")
     return dst
 
 
 def cast_bf16(src):
-    """fp32 rows matrix -> MFMA operand rows of the same shape (an operand matrix is returned as is)."""
+    """fp32 / stream rows matrix -> MFMA operand rows of the same shape (an operand matrix is returned as is)."""
     if src.dtype == H16():
         return src
+    if src.dtype == torch.float16 and src.dim() == 2 and src.stride(1) == 1:        # fp16 stream -> bf16 operand
+        return cast_rows(src, empty_rows(src.shape[0], src.shape[1], H16(), src.device))
     if src.dtype != torch.float32:
-        raise hip.MudgError("cast_bf16 expects fp32")
+        raise hip.MudgError("cast_bf16 expects fp32 (or a 2-D stream matrix)")
     if src.dim() == 2 and src.stride(1) == 1:
         return cast_rows(src, empty_rows(src.shape[0], src.shape[1], H16(), src.device))
     if hip.planes() > 1 or not src.is_contiguous():

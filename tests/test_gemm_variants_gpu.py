@@ -1,5 +1,5 @@
 """Every contraction-kernel variant through the same kernel parity tests, in child processes (the variant switches are
-read once per process): the 16-wave and the ping-pong 256x256 kernels forced on every shape with M, N >= 256, the generic
+read once per process): the 16-wave 256x256 kernel forced on every shape with M, N >= 256, the generic
 64-bit-address path of all kernels with the buffer-descriptor (FAST) path disabled, and the single-buffer short-K kernel
 forced on every FAST plain GEMM; both flash-attention kernels (32 / 64 queries per wave) forced."""
 import os
@@ -14,8 +14,7 @@ SELECT = "gemm or conv or tconv or resblock or transformer or geglu or fused or 
 
 
 @pytest.mark.parametrize("env", [
-    {"MUDG_GEMM256": "1", "MUDG_GEMM256P": "2"},
-    {"MUDG_GEMM256": "1", "MUDG_GEMM256P": "0"},
+    {"MUDG_GEMM256": "1"},
     {"MUDG_GEMM256": "0"},
     {"MUDG_GEMM_FAST": "0"},
     {"MUDG_GEMM_FAST": "0", "MUDG_GEMM256": "1"},
@@ -24,9 +23,9 @@ SELECT = "gemm or conv or tconv or resblock or transformer or geglu or fused or 
     {"MUDG_ATTN_Q": "64"},
 ], ids=lambda e: ",".join(f"{k[5:]}={v}" for k, v in e.items()))
 def test_kernel_parity_under_variant(cuda, env):
-    if any(k in os.environ for k in ("MUDG_GEMM256", "MUDG_GEMM256P", "MUDG_GEMM_FAST", "MUDG_GEMM_SB", "MUDG_ATTN_Q")):
+    if any(k in os.environ for k in ("MUDG_GEMM256", "MUDG_GEMM_FAST", "MUDG_GEMM_SB", "MUDG_ATTN_Q")):
         pytest.skip("already running under a variant switch")
-    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_kernels_gpu.py", "tests/test_unet_gpu.py", "-m", "gpu",
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_kernels_gpu.py", "tests/test_operand_modes_gpu.py", "tests/test_unet_gpu.py", "-m", "gpu",
                         "-q", "-k", SELECT, "-p", "no:cacheprovider"],
                        cwd=ROOT, env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
     print("\n".join(l for l in r.stdout.splitlines() if "passed" in l or "failed" in l))

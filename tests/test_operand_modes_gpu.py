@@ -266,3 +266,33 @@ def test_softmax_rows_and_layout_kernels(cuda):
     dst = ops.empty_rows(2 * 3 * 24, 8, None, cuda)
     ops.copy_rows(rows, dst)
     assert torch.equal(value(dst), v)
+
+
+def test_residual_stream_storage(cuda):
+    """The residual stream's storage (ops.STREAM(): fp16 in the 16-bit builds, fp32 in the split builds) through the
+    kernels that touch it: GEMM epilogue reading a stream residual and writing a stream result (+ GroupNorm partials of
+    what it stored), GroupNorm / LayerNorm reading it, the stream -> operand cast and the boundary layout kernel."""
+    from mudg_amd import ops
+    S = ops.STREAM()
+    assert S == (torch.float32 if _hip.planes() > 1 else torch.float16)
+    tol_s = 1e-6 if S == torch.float32 else 4e-4          # one fp16 rounding of the result
+    M, N, K = 512, 96, 128
+    x, xv = operand(f32(M, K, seed=1), cuda)
+    w, wv = operand(f32(N, K, seed=2, scale=0.1), cuda)
+    r = (f32(M, N, seed=3) * 3).to(cuda).to(S)
+    y = ops.gemm(x, w, residual=r, out_stream=True, stats=True)
+    assert y.dtype == S
+    ref = xv @ wv.t() + r.double().cpu()
+    assert rel(y, ref) < max(tol_s, TOL_F32)
+    g, b = 1 + 0.1 * f32(N, seed=4), 0.1 * f32(N, seed=5)
+    yv = y.double().cpu()
+    want = F.group_norm(yv.reshape(2, 256, N).transpose(1, 2), 32, g.double(), b.double(), 1e-5).transpose(1, 2).reshape(-1, N)
+    fused = ops.groupnorm(y, g.to(cuda), b.to(cuda), samples=2, rows=256, eps=1e-5, silu=False)
+    plain = ops.groupnorm(y, g.to(cuda), b.to(cuda), samples=2, rows=256, eps=1e-5, silu=False, fused=False)
+    assert rel(value(fused), want) < TOL_OP and rel(value(plain), want) < TOL_OP
+    assert rel(value(ops.layernorm(y, g.to(cuda), b.to(cuda))), F.layer_norm(yv, (N,), g.double(), b.double(), 1e-5)) < TOL_OP
+    op = ops.cast_bf16(y)                                  # stream -> MFMA operand (skip / downsample conv inputs)
+    assert op.dtype == _hip.operand_dtype() and rel(value(op), yv) < TOL_OP
+    rows = torch.randn(2 * 3 * 20, 8, device=cuda).to(S)
+    back = ops.rows_to_ncthw(rows, (2, 8, 3, 4, 5))
+    assert torch.equal(back.cpu(), rows.float().cpu().reshape(2, 3, 20, 8).permute(0, 3, 1, 2).reshape(2, 8, 3, 4, 5))
