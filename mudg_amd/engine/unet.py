@@ -13,10 +13,11 @@ skip-concat ride in the implicit-GEMM loader, V is produced already transposed f
 
 Precision: MFMA operands (normalised activations, weights) are bf16 with fp32 accumulation; the RESIDUAL STREAM —
 every tensor that a later block adds onto: block outputs, the transformers' inner token stream, the encoder skips —
-is kept in ops.STREAM(): IEEE fp16 in the 16-bit operand builds (11 significand bits: three more than a bf16 operand, so
+is kept in ops.STREAM(): IEEE fp16 with bf16 operands (11 significand bits: three more than a bf16 operand, so
 the ~150 residual adds stay below the operand rounding — a bf16 stream was measured to dominate the end-to-end error,
 2.1e-2 against 1.6e-2 per forward — at half the HBM bytes of fp32; it is also what the reference's stream is under
-torch.autocast), fp32 in the split-operand precision builds.  GroupNorm / LayerNorm read it and compute in fp32.
+torch.autocast), fp32 with fp16 operands and in the split-operand precision builds.  GroupNorm / LayerNorm read it and
+compute in fp32.
 """
 import torch
 import torch.nn as nn
