@@ -122,6 +122,12 @@ typedef struct MudgAttnDesc {
     int kv_div;          /* frames sharing one K/V batch entry (T for text context, 1 otherwise) */
     float scale;         /* dim_head**-0.5 */
     int accumulate;      /* 1: O += result */
+    /* Optional second key / value set with its OWN softmax, outputs summed — the text + image cross-attention of
+     * attention.py:128-142 (out = softmax(q k_text^T) v_text + softmax(q k_ip^T) v_ip) in one launch: Q is read once and
+     * O written once.  K2 == NULL: single set.  Same layout conventions as K / Vt. */
+    const void* K2; const void* Vt2;
+    int Nk2, ldk2, ldvt2, kv_div2;
+    int64_t svt2;
 } MudgAttnDesc;
 int mudg_attention(const MudgAttnDesc* d, void* stream);
 

@@ -159,24 +159,51 @@ class DDIMSampler(object):
         return self._batched_passes(x, t, [c, uc], kwargs)
 
     def _batched_passes(self, x, t, conds, kwargs):
-        """One apply_model call over len(conds) stacked copies of the batch; None if the dicts cannot be stacked."""
+        """One apply_model call over len(conds) stacked copies of the batch; None if the dicts cannot be stacked.
+        The stacked conditioning is the same at every step of a run, so it is built once and kept while the caller keeps
+        passing the same tensors: the channel-concat pieces stacked along the batch, and the cross-attention tokens
+        stacked AND made ready for the UNet (UNetModel.prepare_context: operand rows + every cross-attention layer's
+        K / V^T projections, which the reference recomputes at each of the 50 steps although the tokens never change)."""
         first = conds[0]
         if not all(isinstance(cd, dict) and set(cd) == set(first) for cd in conds):
             return None
         b, n = x.shape[0], len(conds)
-        merged = {}
-        for key in first:
-            lists = [cd[key] for cd in conds]
-            if not all(isinstance(l, (list, tuple)) and len(l) == len(lists[0]) for l in lists):
-                return None
-            if any(v.shape != lists[0][i].shape for l in lists for i, v in enumerate(l)):
-                return None
-            merged[key] = [torch.cat([l[i] for l in lists], 0) for i in range(len(lists[0]))]
+        merged = self._merged_conditioning(conds, x.shape[2] if x.dim() == 5 else None)
+        if merged is None:
+            return None
         kw = {}
         for k, v in kwargs.items():          # per-sample tensors ride along n times; everything else is shared
             kw[k] = torch.cat([v] * n, 0) if (torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == b) else v
         out = self.model.apply_model(torch.cat([x] * n, 0), torch.cat([t] * n, 0), merged, **kw)
         return tuple(out[i * b:(i + 1) * b] for i in range(n))
+
+    def _merged_conditioning(self, conds, frames):
+        def ident(v):
+            try:
+                ver = v._version
+            except RuntimeError:
+                ver = 0
+            return (v.data_ptr(), ver, tuple(v.shape), v.dtype)
+
+        first = conds[0]
+        for key in first:
+            lists = [cd[key] for cd in conds]
+            if not all(isinstance(l, (list, tuple)) and len(l) == len(lists[0]) for l in lists):
+                return None
+            if any((not torch.is_tensor(v)) or v.shape != lists[0][i].shape for l in lists for i, v in enumerate(l)):
+                return None
+        sig = tuple((key, tuple(ident(v) for v in cd[key])) for cd in conds for key in sorted(cd))
+        cache = self.__dict__.get("_merged_cache")
+        if cache is not None and cache[0] == sig:
+            return cache[1]
+        merged = {key: [torch.cat([cd[key][i] for cd in conds], 0) for i in range(len(first[key]))] for key in first}
+        unet = getattr(getattr(self.model, "model", None), "diffusion_model", None)
+        if frames is not None and "c_crossattn" in merged and hasattr(unet, "prepare_context") \
+                and all(v.is_cuda for v in merged["c_crossattn"]):
+            tokens = merged["c_crossattn"][0] if len(merged["c_crossattn"]) == 1 else torch.cat(merged["c_crossattn"], 1)
+            merged["c_crossattn"] = [unet.prepare_context(tokens, frames)]
+        self._merged_cache = (sig, merged, [cd for cd in conds])     # the source dicts are kept alive: their addresses are the key
+        return merged
 
     def decode(self, *a, **k):
         raise NotImplementedError("DDIM latent re-decoding is not on the MuDG path")

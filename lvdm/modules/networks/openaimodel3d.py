@@ -214,3 +214,10 @@ class UNetModel(nn.Module):
         from mudg_amd.engine import unet as engine
         return engine.forward_entry(self, x, timesteps, c_label=c_label, context=context,
                                     features_adapter=features_adapter, fs=fs)
+
+    def prepare_context(self, context, temporal_length=None):
+        """Not in the reference: make a (B, L, D) context ready once for many forward calls — operand rows plus every
+        cross-attention layer's K / V^T projections of the (step-invariant) tokens.  Pass the result as `context=`."""
+        from mudg_amd.engine import unet as engine
+        with torch.no_grad():
+            return engine.PreparedContext(self, context, temporal_length or self.temporal_length)

@@ -33,6 +33,9 @@ constexpr int KB = 64;      // keys per tile
 constexpr int ALD = 72;     // LDS row stride in h16 (64 + 8 pad -> 144 B)
 constexpr int ATILE = 64 * ALD;
 
+// TWO: a second key / value set (p.K2 / p.Vt2: the image tokens) with its own softmax follows the first; the two
+// normalised results are summed in registers and stored once.
+template <bool TWO>
 __global__ __launch_bounds__(256, 2) void attn_kernel(const MudgAttnDesc p, const int nqt, const int total) {
     __shared__ __attribute__((aligned(16))) h16 Ks[2 * ATILE];
     __shared__ __attribute__((aligned(16))) h16 Vs[2 * ATILE];
@@ -49,12 +52,12 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const MudgAttnDesc p, cons
     }
     const int pair = w / nqt, qt = w - pair * nqt;
     const int f = pair / p.heads, h = pair - f * p.heads;
-    const int kvb = f / p.kv_div;
-
     const h16* Qp = reinterpret_cast<const h16*>(p.Q) + (int64_t)f * p.Nq * p.ldq + h * 64;
-    const h16* Kp = reinterpret_cast<const h16*>(p.K) + (int64_t)kvb * p.Nk * p.ldk + h * 64;
-    const h16* Vp = reinterpret_cast<const h16*>(p.Vt) + (int64_t)kvb * p.svt + (int64_t)(h * 64) * p.ldvt;
     h16* Op = reinterpret_cast<h16*>(p.O) + (int64_t)f * p.Nq * p.ldo + h * 64;
+    // the key / value set being walked (set 0, then set 1 when TWO)
+    const h16* Kp = reinterpret_cast<const h16*>(p.K) + (int64_t)(f / p.kv_div) * p.Nk * p.ldk + h * 64;
+    const h16* Vp = reinterpret_cast<const h16*>(p.Vt) + (int64_t)(f / p.kv_div) * p.svt + (int64_t)(h * 64) * p.ldvt;
+    int Nk = p.Nk, ldk = p.ldk, ldvt = p.ldvt;
 
     const int q = qt * QB + wave * 32 + l31;
     const bool qok = q < p.Nq;
@@ -72,15 +75,15 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const MudgAttnDesc p, cons
         for (int i = 0; i < 2; ++i) {
             const int row = lrow + 32 * i;
             const int j = j0 + row;                       // key index for the K tile row
-            kr[i] = (j < p.Nk) ? ld16(Kp + (int64_t)j * p.ldk + kc * 8) : zero16();
+            kr[i] = (j < Nk) ? ld16(Kp + (int64_t)j * ldk + kc * 8) : zero16();
             const int jc = j0 + kc * 8;                   // first key of this V^T chunk (row = head-dim index)
             u32x4 v = zero16();
-            if (jc < p.Nk) {
-                v = ld16(Vp + (int64_t)row * p.ldvt + jc);
-                if (jc + 8 > p.Nk) {                       // ragged tail: keys >= Nk must contribute exactly 0
+            if (jc < Nk) {
+                v = ld16(Vp + (int64_t)row * ldvt + jc);
+                if (jc + 8 > Nk) {                       // ragged tail: keys >= Nk must contribute exactly 0
                     h16x8 hv = as_h16x8(v);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) if (jc + e >= p.Nk) hv[e] = (h16)0.f;
+                    for (int e = 0; e < 8; ++e) if (jc + e >= Nk) hv[e] = (h16)0.f;
                     v = as_u32x4(hv);
                 }
             }
@@ -95,13 +98,21 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const MudgAttnDesc p, cons
         }
     };
 
-    f32x16 o[2];
+    f32x16 o[2], res[TWO ? 2 : 1];
+    const float c = p.scale * 1.4426950408889634f;   // scores are exponentiated in base 2
+    float inv = 0.f;
+#pragma unroll
+    for (int set = 0; set < (TWO ? 2 : 1); ++set) {
+    if (TWO && set == 1) {
+        Kp = reinterpret_cast<const h16*>(p.K2) + (int64_t)(f / p.kv_div2) * p.Nk2 * p.ldk2 + h * 64;
+        Vp = reinterpret_cast<const h16*>(p.Vt2) + (int64_t)(f / p.kv_div2) * p.svt2 + (int64_t)(h * 64) * p.ldvt2;
+        Nk = p.Nk2; ldk = p.ldk2; ldvt = p.ldvt2;
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
     float m_run = -INFINITY, l_run = 0.f;
-    const float c = p.scale * 1.4426950408889634f;   // scores are exponentiated in base 2
 
-    const int nkt = (p.Nk + KB - 1) / KB;
+    const int nkt = (Nk + KB - 1) / KB;
     load_tiles(0);
     stage(0);
     __syncthreads();
@@ -124,13 +135,13 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const MudgAttnDesc p, cons
                 s[sub] = MFMA_32x32x16(kf, qf[ks], s[sub]);
             }
         }
-        if (kt * KB + KB > p.Nk) {   // ragged last tile
+        if (kt * KB + KB > Nk) {   // ragged last tile
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int j = kt * KB + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    if (j >= p.Nk) s[sub][r] = -INFINITY;
+                    if (j >= Nk) s[sub][r] = -INFINITY;
                 }
         }
 
@@ -186,9 +197,21 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const MudgAttnDesc p, cons
         __syncthreads();
     }
 
-    // ---- normalise and store: lane holds, for its query row, head-dim columns dt*32 + 8g + 4*hi + {0..3}
+    // ---- normalise this set's result
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = 1.f / l_tot;
+    inv = 1.f / l_tot;
+    if (TWO) {
+        if (set == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { res[0][r] = o[0][r] * inv; res[1][r] = o[1][r] * inv; }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { o[0][r] = fmaf(o[0][r], inv, res[0][r]); o[1][r] = fmaf(o[1][r], inv, res[1][r]); }
+            inv = 1.f;
+        }
+    }
+    }   // sets
+    // ---- store: lane holds, for its query row, head-dim columns dt*32 + 8g + 4*hi + {0..3}
     if (qok) {
         h16* orow = Op + (int64_t)q * p.ldo;
 #pragma unroll
@@ -514,6 +537,7 @@ __global__ __launch_bounds__(256, TP == 16 ? 3 : 1) void tattn_kernel(const h16*
 // input matrices, the probabilities are split in registers, and both contractions accumulate the kept (piece, piece)
 // partial products — NSEG MFMAs where the 16-bit kernel issues one.  Exponentials and the output normalisation are the
 // same fp32 arithmetic.  One K / V^T tile per piece in LDS; precision first: 32 queries per wave, no 64-query variant.
+template <bool TWO>
 __global__ __launch_bounds__(256, 1) void attn_split_kernel(const MudgAttnDesc p, const int nqt, const int total) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     h16* Ks = reinterpret_cast<h16*>(smem_raw);                   // [2 buffers][PLANES][ATILE]
@@ -529,13 +553,14 @@ __global__ __launch_bounds__(256, 1) void attn_split_kernel(const MudgAttnDesc p
     }
     const int pair = w / nqt, qt = w - pair * nqt;
     const int f = pair / p.heads, h = pair - f * p.heads;
-    const int kvb = f / p.kv_div;
-    const int psq = p.ldq / PLANES, psk = p.ldk / PLANES, psv = p.ldvt / PLANES, pso = p.ldo / PLANES;
+    const int psq = p.ldq / PLANES, pso = p.ldo / PLANES;
+    int psk = p.ldk / PLANES, psv = p.ldvt / PLANES;
 
     const h16* Qp = reinterpret_cast<const h16*>(p.Q) + (int64_t)f * p.Nq * p.ldq + h * 64;
-    const h16* Kp = reinterpret_cast<const h16*>(p.K) + (int64_t)kvb * p.Nk * p.ldk + h * 64;
-    const h16* Vp = reinterpret_cast<const h16*>(p.Vt) + (int64_t)kvb * p.svt + (int64_t)(h * 64) * p.ldvt;
     h16* Op = reinterpret_cast<h16*>(p.O) + (int64_t)f * p.Nq * p.ldo + h * 64;
+    const h16* Kp = reinterpret_cast<const h16*>(p.K) + (int64_t)(f / p.kv_div) * p.Nk * p.ldk + h * 64;
+    const h16* Vp = reinterpret_cast<const h16*>(p.Vt) + (int64_t)(f / p.kv_div) * p.svt + (int64_t)(h * 64) * p.ldvt;
+    int Nk = p.Nk, ldk = p.ldk, ldvt = p.ldvt;
 
     const int q = qt * QB + wave * 32 + l31;
     const bool qok = q < p.Nq;
@@ -556,15 +581,15 @@ __global__ __launch_bounds__(256, 1) void attn_split_kernel(const MudgAttnDesc p
             for (int i = 0; i < 2; ++i) {
                 const int row = lrow + 32 * i;
                 const int j = j0 + row;
-                kr[pl][i] = (j < p.Nk) ? ld16(Kp + (int64_t)j * p.ldk + pl * psk + kc * 8) : zero16();
+                kr[pl][i] = (j < Nk) ? ld16(Kp + (int64_t)j * ldk + pl * psk + kc * 8) : zero16();
                 const int jc = j0 + kc * 8;
                 u32x4 v = zero16();
-                if (jc < p.Nk) {
-                    v = ld16(Vp + (int64_t)row * p.ldvt + pl * psv + jc);
-                    if (jc + 8 > p.Nk) {
+                if (jc < Nk) {
+                    v = ld16(Vp + (int64_t)row * ldvt + pl * psv + jc);
+                    if (jc + 8 > Nk) {
                         h16x8 hv = as_h16x8(v);
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) if (jc + e >= p.Nk) hv[e] = (h16)0.f;
+                        for (int e = 0; e < 8; ++e) if (jc + e >= Nk) hv[e] = (h16)0.f;
                         v = as_u32x4(hv);
                     }
                 }
@@ -581,13 +606,20 @@ __global__ __launch_bounds__(256, 1) void attn_split_kernel(const MudgAttnDesc p
             }
     };
 
-    f32x16 o[2];
+    f32x16 o[2], res[TWO ? 2 : 1];
+    const float c = p.scale * 1.4426950408889634f;
+#pragma unroll
+    for (int set = 0; set < (TWO ? 2 : 1); ++set) {
+    if (TWO && set == 1) {
+        Kp = reinterpret_cast<const h16*>(p.K2) + (int64_t)(f / p.kv_div2) * p.Nk2 * p.ldk2 + h * 64;
+        Vp = reinterpret_cast<const h16*>(p.Vt2) + (int64_t)(f / p.kv_div2) * p.svt2 + (int64_t)(h * 64) * p.ldvt2;
+        Nk = p.Nk2; ldk = p.ldk2; ldvt = p.ldvt2; psk = ldk / PLANES; psv = ldvt / PLANES;
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
     float m_run = -INFINITY, l_run = 0.f;
-    const float c = p.scale * 1.4426950408889634f;
 
-    const int nkt = (p.Nk + KB - 1) / KB;
+    const int nkt = (Nk + KB - 1) / KB;
     load_tiles(0);
     stage(0);
     __syncthreads();
@@ -612,13 +644,13 @@ __global__ __launch_bounds__(256, 1) void attn_split_kernel(const MudgAttnDesc p
                 }
             }
         }
-        if (kt * KB + KB > p.Nk) {
+        if (kt * KB + KB > Nk) {
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int j = kt * KB + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    if (j >= p.Nk) s[sub][r] = -INFINITY;
+                    if (j >= Nk) s[sub][r] = -INFINITY;
                 }
         }
 
@@ -673,6 +705,18 @@ __global__ __launch_bounds__(256, 1) void attn_split_kernel(const MudgAttnDesc p
     }
 
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o[0][r] /= l_tot; o[1][r] /= l_tot; }
+    if (TWO) {
+        if (set == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { res[0][r] = o[0][r]; res[1][r] = o[1][r]; }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { o[0][r] += res[0][r]; o[1][r] += res[1][r]; }
+        }
+    }
+    }   // sets
     if (qok) {
         h16* orow = Op + (int64_t)q * p.ldo;
 #pragma unroll
@@ -682,7 +726,7 @@ __global__ __launch_bounds__(256, 1) void attn_split_kernel(const MudgAttnDesc p
                 h16* dst = orow + dt * 32 + 8 * g + 4 * hi;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    float v = o[dt][4 * g + j] / l_tot;
+                    float v = o[dt][4 * g + j];
                     if (p.accumulate) v += load1_operand(dst + j, pso);
                     store1_operand(dst + j, pso, v);
                 }
@@ -781,6 +825,12 @@ extern "C" int mudg_attention(const MudgAttnDesc* dp, void* stream) {
     MUDG_REQUIRE(d.ldq / PLANES >= d.heads * 64 && d.ldk / PLANES >= d.heads * 64 && d.ldo / PLANES >= d.heads * 64,
                  "mudg_attention: row strides too small for %d heads", d.heads);
     MUDG_REQUIRE(aligned16(d.Q) && aligned16(d.K) && aligned16(d.Vt) && aligned16(d.O), "mudg_attention: alignment");
+    if (d.K2) {
+        MUDG_REQUIRE(d.Vt2 && d.Nk2 > 0 && d.kv_div2 >= 1 && d.F % d.kv_div2 == 0, "mudg_attention: second key/value set");
+        MUDG_REQUIRE(d.ldk2 % (8 * PLANES) == 0 && d.ldvt2 % (8 * PLANES) == 0 && (d.svt2 & 7) == 0 && d.ldvt2 / PLANES >= d.Nk2 &&
+                     d.ldk2 / PLANES >= d.heads * 64 && aligned16(d.K2) && aligned16(d.Vt2), "mudg_attention: second key/value set strides");
+        MUDG_REQUIRE(!d.accumulate, "mudg_attention: accumulate and a second key/value set are exclusive");
+    }
     const int nqt = (d.Nq + QB - 1) / QB;
     const int64_t total = (int64_t)nqt * d.F * d.heads;
     MUDG_REQUIRE(total < (1ll << 31), "mudg_attention: grid too large");
@@ -790,7 +840,7 @@ extern "C" int mudg_attention(const MudgAttnDesc* dp, void* stream) {
     // image cross-attention) and small query counts keep the 32-query kernel.  MUDG_ATTN_Q=32 / 64 forces one of them.
     static int var = -1;
     if (var < 0) { const char* e = getenv("MUDG_ATTN_Q"); var = e ? atoi(e) : 0; }
-    const bool wide = var == 64 ? d.Nq >= 256 : (var == 32 ? false : (d.Nq >= 512 && d.Nk >= 256));
+    const bool wide = !d.K2 && (var == 64 ? d.Nq >= 256 : (var == 32 ? false : (d.Nq >= 512 && d.Nk >= 256)));
 #if MUDG_PLANES > 1
     {
         constexpr int smem = 4 * PLANES * ATILE * (int)sizeof(h16);
@@ -798,26 +848,30 @@ extern "C" int mudg_attention(const MudgAttnDesc* dp, void* stream) {
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) MUDG_FAIL(MUDG_ELAUNCH, "mudg_attention: hipGetDevice");
         if (!attr_done[dev]) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_split_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_split_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_split_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
             if (e != hipSuccess) MUDG_FAIL(MUDG_ELAUNCH, "mudg_attention: hipFuncSetAttribute: %s", hipGetErrorString(e));
             attr_done[dev] = true;
         }
         (void)wide;
-        hipLaunchKernelGGL(attn_split_kernel, dim3((unsigned)total), dim3(256), smem, s, d, nqt, (int)total);
+        if (d.K2) hipLaunchKernelGGL(attn_split_kernel<true>, dim3((unsigned)total), dim3(256), smem, s, d, nqt, (int)total);
+        else hipLaunchKernelGGL(attn_split_kernel<false>, dim3((unsigned)total), dim3(256), smem, s, d, nqt, (int)total);
     }
 #else
     if (wide) {
         const int nqt2 = (d.Nq + 255) / 256;
         const int64_t total2 = (int64_t)nqt2 * d.F * d.heads;
         hipLaunchKernelGGL(attn64q_kernel, dim3((unsigned)total2), dim3(256), 0, s, d, nqt2, (int)total2);
+    } else if (d.K2) {
+        hipLaunchKernelGGL(attn_kernel<true>, dim3((unsigned)total), dim3(256), 0, s, d, nqt, (int)total);
     } else {
-        hipLaunchKernelGGL(attn_kernel, dim3((unsigned)total), dim3(256), 0, s, d, nqt, (int)total);
+        hipLaunchKernelGGL(attn_kernel<false>, dim3((unsigned)total), dim3(256), 0, s, d, nqt, (int)total);
     }
 #endif
     const int rc = mudg_check_launch("mudg_attention");
     const double bh = (double)d.F * d.heads;
-    mudg_prof_end(slot, s, 4.0 * bh * d.Nq * (double)d.Nk * 64.0,
-                  bh * (2.0 * d.Nq + 2.0 * d.Nk / d.kv_div) * 64.0 * 2.0);
+    mudg_prof_end(slot, s, 4.0 * bh * d.Nq * (double)(d.Nk + (d.K2 ? d.Nk2 : 0)) * 64.0,
+                  bh * (2.0 * d.Nq + 2.0 * d.Nk / d.kv_div + (d.K2 ? 2.0 * d.Nk2 / d.kv_div2 : 0.0)) * 64.0 * 2.0);
     return rc;
 }
 

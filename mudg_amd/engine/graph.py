@@ -30,9 +30,9 @@ class UNetGraphs:
         self.signature = None
 
     def _key(self, parts, timesteps, c_label, context, fs):
+        ctx_key = ("prepared", context.shape, context.T) if isinstance(context, U.PreparedContext) else (tuple(context.shape), context.dtype)
         return (tuple((tuple(p.shape), p.dtype) for p in parts), tuple(timesteps.shape),
-                None if c_label is None else tuple(c_label.shape), tuple(context.shape), context.dtype,
-                None if fs is None else tuple(fs.shape))
+                None if c_label is None else tuple(c_label.shape), ctx_key, None if fs is None else tuple(fs.shape))
 
     def __call__(self, parts, timesteps, c_label, context, fs):
         sig = _params_signature(self.model)
@@ -46,7 +46,10 @@ class UNetGraphs:
             static = {
                 "parts": [p.clone() for p in parts], "t": timesteps.clone(),
                 "label": None if c_label is None else torch.as_tensor(c_label, device=parts[0].device).clone(),
-                "ctx": context.clone(), "fs": None if fs is None else torch.as_tensor(fs, device=parts[0].device).clone(),
+                # a PreparedContext is cloned into buffers the graph owns (token rows + per-layer K / V^T); a replay with a
+                # DIFFERENT prepared context copies that one's buffers over them first — once per sampling run, not per step
+                "ctx": context.clone(), "ctx_src": context,
+                "fs": None if fs is None else torch.as_tensor(fs, device=parts[0].device).clone(),
             }
             run = lambda: U.forward(self.model, static["parts"], static["t"], c_label=static["label"],
                                     context=static["ctx"], fs=static["fs"])
@@ -63,7 +66,12 @@ class UNetGraphs:
         static["t"].copy_(timesteps)
         if c_label is not None:
             static["label"].copy_(torch.as_tensor(c_label, device=static["label"].device))
-        static["ctx"].copy_(context)
+        if isinstance(context, U.PreparedContext):
+            if static["ctx_src"] is not context or static["ctx"].signature != context.signature:
+                static["ctx"].copy_from(context)
+                static["ctx_src"] = context
+        else:
+            static["ctx"].copy_(context)
         if fs is not None:
             static["fs"].copy_(torch.as_tensor(fs, device=static["fs"].device))
         graph.replay()

@@ -137,13 +137,13 @@ def spatial_block(blk, hcur, frames, hw, ctx, last):
         ctx.kv_cache[key] = _cross_kv(a2, ctx)
     k_text, vt_text, ld_text, k_img, vt_img, ld_img = ctx.kv_cache[key]
     att2 = ops.empty_rows(frames * hw, c, ops.H16(), hcur.device)
+    if k_img is not None and a2.image_cross_attention_scale != 1.0:
+        raise NotImplementedError("image_cross_attention_scale != 1.0")
+    # both softmaxes (text keys, image keys) in ONE launch: q2 is read once, the summed result written once
     ops.attention(q2, k_text, vt_text, att2, frames=frames, heads=heads, nq=hw, nk=ctx.n_text, ldvt=ld_text,
-                  svt=c * ld_text, kv_div=ctx.T, scale=a2.scale)
-    if k_img is not None:
-        if a2.image_cross_attention_scale != 1.0:
-            raise NotImplementedError("image_cross_attention_scale != 1.0")
-        ops.attention(q2, k_img, vt_img, att2, frames=frames, heads=heads, nq=hw, nk=ctx.n_img, ldvt=ld_img,
-                      svt=c * ld_img, kv_div=ctx.img_div, scale=a2.scale, accumulate=True)
+                  svt=c * ld_text, kv_div=ctx.T, scale=a2.scale, k2=k_img, vt2=vt_img, nk2=ctx.n_img,
+                  ldvt2=ld_img if k_img is not None else None, svt2=c * ld_img if k_img is not None else None,
+                  kv_div2=ctx.img_div)
     hcur = _linear(a2.to_out[0], att2, residual=hcur, stream=True)
     # the last block's output only feeds proj_out (an MFMA operand), so it is written as bf16 directly
     return _feed_forward(blk.ff, _ln(blk.norm3, hcur), hcur, stream=not last)
@@ -218,32 +218,105 @@ def _to_long(v, n, device, what):
     return v.reshape(n).to(torch.int64)
 
 
+class PreparedContext:
+    """The cross-attention conditioning of one sampling run, made ready ONCE: the (B, L, D) context tokens as MFMA operand
+    rows (text / image tokens in their own matrices) and every attn2 layer's K and V^T projections of them.  The tokens
+    are the same at all 50 DDIM steps and in every pass of the guidance batch, so a sampler hands the same
+    PreparedContext to every UNet call (UNetModel.prepare_context; DDIMSampler does) instead of having each forward
+    re-project them (the reference recomputes to_k / to_v per layer per call, attention.py:87-94).
+    The projections are redone when any model parameter changed since they were made (`signature`)."""
+
+    def __init__(self, model, context, t_len, device=None, project=True):
+        if context is None:
+            raise AssertionError("context is required (text + per-frame image tokens)")
+        if context.dim() != 3:
+            raise ValueError(f"context must be (B, L, D), got {tuple(context.shape)}")
+        if not context.is_cuda:
+            raise RuntimeError("context must be a GPU tensor")
+        device = device or context.device
+        self.B, L, D = context.shape
+        if L <= 77:
+            raise ValueError("context needs more than the 77 text tokens (image tokens follow them)")
+        flat = context.contiguous()
+        if flat.dtype != torch.float32:
+            flat = flat.float()
+        self.shape, self.T, self.n_text = tuple(context.shape), t_len, 77
+        # openaimodel3d.py:581-587: per-frame image tokens when L == 77 + 16 T, otherwise the whole context per frame
+        if L == 77 + 16 * t_len:
+            self.n_img, self.img_div = 16, 1
+        else:
+            self.n_img, self.img_div = L - 77, t_len
+        text = ops.empty_rows(self.B * 77, D, ops.H16(), device)
+        img = ops.empty_rows(self.B * (L - 77), D, ops.H16(), device)
+        for b in range(self.B):       # fp32 tokens -> MFMA operand rows, text and image tokens into their own matrices
+            ops.cast_rows(flat[b, :77], text[b * 77:(b + 1) * 77])
+            ops.cast_rows(flat[b, 77:], img[b * (L - 77):(b + 1) * (L - 77)])
+        self.text, self.img = text, img
+        self.kv, self.signature = {}, None
+        if project:
+            self.project(model)
+
+    def project(self, model):
+        """K / V^T of the text and image tokens for every spatial transformer's attn2, in module order."""
+        from .graph import _params_signature
+        self.kv = {}
+        for m in model.modules():
+            if type(m).__name__ == "SpatialTransformer":
+                for blk in m.transformer_blocks:
+                    self.kv[id(blk.attn2)] = _cross_kv(blk.attn2, self)
+        self.signature = _params_signature(model)
+
+    def tensors(self):
+        """Every device buffer, in a fixed order (graph replays copy a new context's buffers over the captured one's)."""
+        out = [self.text, self.img]
+        for key in self.kv:
+            out += [t for t in self.kv[key] if torch.is_tensor(t)]
+        return out
+
+    def clone(self):
+        twin = object.__new__(PreparedContext)
+        twin.__dict__.update(self.__dict__)
+        twin.text, twin.img = _clone_rows(self.text), _clone_rows(self.img)
+        twin.kv = {k: tuple(_clone_rows(t) if torch.is_tensor(t) else t for t in v) for k, v in self.kv.items()}
+        return twin
+
+    def copy_from(self, other):
+        mine, theirs = self.tensors(), other.tensors()
+        if len(mine) != len(theirs) or self.shape != other.shape:
+            raise RuntimeError("PreparedContext.copy_from: different layouts")
+        for dst, src in zip(mine, theirs):
+            _base(dst).copy_(_base(src))
+        self.signature = other.signature
+
+    def bind(self, ctx, model):
+        """Attach to a forward's state; stale projections (parameters changed since they were made) are redone."""
+        from .graph import _params_signature
+        if ctx.B != self.B:
+            raise ValueError(f"context prepared for batch {self.B}, forward has batch {ctx.B}")
+        if self.signature != _params_signature(model):
+            self.project(model)
+        ctx.text, ctx.img, ctx.n_text, ctx.n_img, ctx.img_div, ctx.kv_cache = self.text, self.img, self.n_text, self.n_img, \
+            self.img_div, self.kv
+
+
+def _base(t):
+    """The whole allocation behind an operand view (split-operand builds: the [rows, planes * cols] buffer)."""
+    return t if t._base is None else t._base
+
+
+def _clone_rows(t):
+    full = _base(t).clone()
+    return full if t._base is None else full[:, :t.shape[1]]
+
+
 def make_context(model, ctx, context, t_len, device):
-    """Split (B, L, D) context into text rows [B*77, D] and image rows, cast to bf16 by the layout kernel."""
-    if context is None:
-        raise AssertionError("context is required (text + per-frame image tokens)")
-    if context.dim() != 3 or context.shape[0] != ctx.B:
+    """Per-forward conditioning state from a raw (B, L, D) context tensor (a one-shot PreparedContext)."""
+    if context is not None and context.dim() == 3 and context.shape[0] != ctx.B:
         raise ValueError(f"context must be (B, L, D), got {tuple(context.shape)}")
-    if not context.is_cuda:
-        raise RuntimeError("context must be a GPU tensor")
-    L, D = context.shape[1], context.shape[2]
-    if L <= 77:
-        raise ValueError("context needs more than the 77 text tokens (image tokens follow them)")
-    flat = context.contiguous()
-    if flat.dtype != torch.float32:
-        flat = flat.float()
-    ctx.n_text = 77
-    # openaimodel3d.py:581-587: per-frame image tokens when L == 77 + 16 T, otherwise the whole context per frame
-    if L == 77 + 16 * t_len:
-        ctx.n_img, ctx.img_div = 16, 1
-    else:
-        ctx.n_img, ctx.img_div = L - 77, t_len
-    text = ops.empty_rows(ctx.B * 77, D, ops.H16(), device)
-    img = ops.empty_rows(ctx.B * (L - 77), D, ops.H16(), device)
-    for b in range(ctx.B):       # fp32 tokens -> MFMA operand rows, text and image tokens into their own matrices
-        ops.cast_rows(flat[b, :77], text[b * 77:(b + 1) * 77])
-        ops.cast_rows(flat[b, 77:], img[b * (L - 77):(b + 1) * (L - 77)])
-    ctx.text, ctx.img = text, img
+    prepared = PreparedContext(model, context, t_len, device, project=False)
+    prepared.T = ctx.T
+    ctx.text, ctx.img, ctx.n_text, ctx.n_img, ctx.img_div, ctx.kv_cache = prepared.text, prepared.img, prepared.n_text, \
+        prepared.n_img, prepared.img_div, {}
 
 
 @torch.no_grad()
@@ -256,7 +329,7 @@ def forward_entry(model, x, timesteps, c_label=None, context=None, features_adap
         if graphs is None:
             graphs = model.__dict__["_mudg_graphs"] = UNetGraphs(model)
         parts = list(x) if isinstance(x, (list, tuple)) else [x]
-        if all(p.is_cuda for p in parts):
+        if all(p.is_cuda for p in parts) and (isinstance(context, PreparedContext) or context.is_cuda):
             from .. import hip
             if not hip.prof_enabled():           # per-kernel hipEvents cannot be recorded inside a graph
                 return graphs(parts, timesteps, c_label, context, fs)
@@ -294,7 +367,10 @@ def forward(model, x, timesteps, c_label=None, context=None, features_adapter=No
         fsv = torch.full((B,), model.default_fs, dtype=torch.int64, device=device) if fs is None else _to_long(fs, B, device, "fs")
         ops.add_(emb, _embed_mlp(model.fps_embedding, ops.timestep_embedding(fsv, mc)))
     ctx.emb = emb
-    make_context(model, ctx, context, T, device)
+    if isinstance(context, PreparedContext):
+        context.bind(ctx, model)
+    else:
+        make_context(model, ctx, context, T, device)
 
     # ---- input: (b c t h w) pieces -> rows with channels side by side (replaces torch.cat + rearrange, 591 / ddpm3d 1317)
     rows = ops.empty_rows(B * T * H * W, cpad, ops.H16(), device)

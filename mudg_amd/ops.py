@@ -197,8 +197,11 @@ def tconv3(x, w, *, clips, t, hw, cin, out=None, bias=None, residual=None, out_f
 
 
 # ------------------------------------------------------------------------------------------------ attention
-def attention(q, k, vt, out, *, frames, heads, nq, nk, ldvt=None, svt=None, kv_div=1, scale=0.125, accumulate=False):
-    """vt: V^T as [kv batches * heads * 64, keys] rows (row stride = ldvt, batch stride = heads * 64 rows by default)."""
+def attention(q, k, vt, out, *, frames, heads, nq, nk, ldvt=None, svt=None, kv_div=1, scale=0.125, accumulate=False,
+              k2=None, vt2=None, nk2=0, ldvt2=None, svt2=None, kv_div2=1):
+    """vt: V^T as [kv batches * heads * 64, keys] rows (row stride = ldvt, batch stride = heads * 64 rows by default).
+    k2 / vt2 / nk2: an optional second key / value set with its own softmax whose output is added (the image tokens of
+    the text + image cross-attention), in the same launch."""
     if ldvt is None:
         ldvt = vt.stride(0)
     if svt is None:
@@ -209,6 +212,11 @@ def attention(q, k, vt, out, *, frames, heads, nq, nk, ldvt=None, svt=None, kv_d
     d.F, d.heads, d.Nq, d.Nk = frames, heads, nq, nk
     d.ldq, d.ldk, d.ldvt, d.ldo = q.stride(0), k.stride(0), ldvt, out.stride(0)
     d.svt, d.kv_div, d.scale, d.accumulate = svt, kv_div, scale, int(accumulate)
+    if k2 is not None:
+        d.K2, d.Vt2, d.Nk2, d.ldk2 = k2.data_ptr(), vt2.data_ptr(), nk2, k2.stride(0)
+        d.ldvt2 = vt2.stride(0) if ldvt2 is None else ldvt2
+        d.svt2 = heads * 64 * d.ldvt2 if svt2 is None else svt2
+        d.kv_div2 = kv_div2
     hip.check(hip.lib().mudg_attention(C.byref(d), _stream()), "mudg_attention")
     return out
 

@@ -296,3 +296,25 @@ def test_residual_stream_storage(cuda):
     rows = torch.randn(2 * 3 * 20, 8, device=cuda).to(S)
     back = ops.rows_to_ncthw(rows, (2, 8, 3, 4, 5))
     assert torch.equal(back.cpu(), rows.float().cpu().reshape(2, 3, 20, 8).permute(0, 3, 1, 2).reshape(2, 8, 3, 4, 5))
+
+
+def test_attention_two_key_sets_in_one_launch(cuda):
+    """softmax(q k_t^T) v_t + softmax(q k_i^T) v_i (text + image cross-attention, attention.py:128-142) in ONE launch
+    against the fp64 reference and against the two-launch (accumulate) form."""
+    from mudg_amd import ops
+    frames, heads, nq, T = 4, 2, 150, 2
+    c = heads * 64
+    q, qv = operand(f32(frames * nq, c, seed=1), cuda)
+    kt, ktv = operand(f32(frames // T * 77, c, seed=2), cuda)
+    _, vtv = operand(f32(frames // T * 77, c, seed=3), cuda)
+    ki, kiv = operand(f32(frames * 16, c, seed=4), cuda)
+    _, viv = operand(f32(frames * 16, c, seed=5), cuda)
+    vt_t, vt_i = _vt(vtv, frames // T, 77, c, cuda), _vt(viv, frames, 16, c, cuda)
+    one = ops.empty_rows(frames * nq, c, None, cuda)
+    ops.attention(q, kt, vt_t, one, frames=frames, heads=heads, nq=nq, nk=77, kv_div=T, scale=0.125, k2=ki, vt2=vt_i, nk2=16)
+    ref = _attention_ref(qv, ktv, vtv, frames, heads, nq, 77, 0.125, T) + _attention_ref(qv, kiv, viv, frames, heads, nq, 16, 0.125, 1)
+    assert rel(value(one), ref) < 2 * TOL_OP
+    two = ops.empty_rows(frames * nq, c, None, cuda)
+    ops.attention(q, kt, vt_t, two, frames=frames, heads=heads, nq=nq, nk=77, kv_div=T, scale=0.125)
+    ops.attention(q, ki, vt_i, two, frames=frames, heads=heads, nq=nq, nk=16, scale=0.125, accumulate=True)
+    assert rel(value(one), value(two)) < 2 * TOL_OP

@@ -106,3 +106,35 @@ def test_hip_graph_replay_matches_eager_and_tracks_weight_changes(cuda):
     changed = net(*args, **kw)
     net.use_hip_graph = False
     assert torch.equal(changed, net(*args, **kw)) and not torch.equal(changed, eager)
+
+
+def test_prepared_context_equals_raw_context_and_graphs_are_shared_across_contexts(cuda):
+    """UNetModel.prepare_context (tokens + every cross-attention layer's K / V^T made once per sampling run) gives the very
+    same output as passing the raw tensor; one captured hipGraph serves successive prepared contexts (their buffers are
+    copied over the graph's own), and a parameter update re-projects a prepared context."""
+    g = golden("unet_b.pt")
+    sd = seeded_sd(g["param_shapes"], g["seed"], g["checksum"])
+    net = build_unet(g["cfg"], sd, cuda)
+    x, ctx = unet_inputs(g["cfg"], g["shape"], g["seed"])
+    case = g["cases"][0]
+    T = g["shape"]["T"]
+    args = (x.to(cuda), case["t"].to(cuda))
+    kw = dict(c_label=case["c_label"].to(cuda), fs=case["fs"].to(cuda))
+    raw1 = net(*args, context=ctx.to(cuda), **kw)
+    ctx2 = (ctx * 0.5 + 0.1).to(cuda)
+    raw2 = net(*args, context=ctx2, **kw)
+    p1, p2 = net.prepare_context(ctx.to(cuda), T), net.prepare_context(ctx2, T)
+    assert torch.equal(net(*args, context=p1, **kw), raw1) and torch.equal(net(*args, context=p2, **kw), raw2)
+    net.use_hip_graph = True
+    a = net(*args, context=p1, **kw)          # captures
+    b = net(*args, context=p2, **kw)          # same graph, other context's buffers copied in
+    c = net(*args, context=p1, **kw)
+    assert torch.equal(a, raw1) and torch.equal(b, raw2) and torch.equal(c, raw1)
+    assert len(net.__dict__["_mudg_graphs"].entries) == 1
+    net.use_hip_graph = False
+    with torch.no_grad():
+        for m in net.modules():
+            if type(m).__name__ == "SpatialTransformer":
+                m.transformer_blocks[0].attn2.to_k.weight.mul_(1.5)
+    changed = net(*args, context=p1, **kw)
+    assert torch.equal(changed, net(*args, context=ctx.to(cuda), **kw)) and not torch.equal(changed, raw1)
