@@ -128,6 +128,11 @@ typedef struct MudgAttnDesc {
     const void* K2; const void* Vt2;
     int Nk2, ldk2, ldvt2, kv_div2;
     int64_t svt2;
+    int q_prescaled;     /* 1: Q already carries scale * log2(e) (folded into the q-projection weights when they are packed),
+                            so Q K^T is directly the base-2 exponent and `scale` is ignored.  The long self-attention kernel
+                            then runs its lean softmax: the running reference maximum enters as the score accumulator's
+                            initial value, one v_exp + one add per score, and the rescale of O only happens when a row sum
+                            outgrows 2^40 (never on real data after the first tile). */
 } MudgAttnDesc;
 int mudg_attention(const MudgAttnDesc* d, void* stream);
 

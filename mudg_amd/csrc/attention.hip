@@ -25,6 +25,7 @@
 //   dot products with K/V of that pixel in LDS; no MFMA.
 #include "common.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const MudgAttnDesc p, cons
     };
 
     f32x16 o[2], res[TWO ? 2 : 1];
-    const float c = p.scale * 1.4426950408889634f;   // scores are exponentiated in base 2
+    const float c = p.q_prescaled ? 1.0f : p.scale * 1.4426950408889634f;   // scores are exponentiated in base 2
     float inv = 0.f;
 #pragma unroll
     for (int set = 0; set < (TWO ? 2 : 1); ++set) {
@@ -237,6 +238,14 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const MudgAttnDesc p, cons
 
 // Variant with 64 query rows per wave (two 32-row blocks): every K / V^T fragment read from LDS feeds two MFMAs instead
 // of one — half the LDS traffic per FLOP — and the two blocks' softmax chains are independent.  Workgroup = 256 queries.
+// LEAN (p.q_prescaled: Q carries scale * log2 e, so S = K Q^T is the base-2 exponent): the softmax chain — the kernel is
+// bound by VALU issue, not MFMA, at head width 64 — is cut from {max, fma, exp, add, cvt} to {exp, add, cvt} per score:
+// a reference maximum m_ref per query row (the row maximum over the first key tile, from one extra set of score MFMAs per
+// block) enters as the INITIAL VALUE of the score accumulators, so S - m_ref comes straight out of the MFMA; the per-tile
+// maximum is not computed and O / l are never rescaled.  Should a row's tile sum exceed 2^40 (a later score 40 binary
+// orders above the first tile's maximum) the workgroup redoes its block with the classic online softmax — exact, merely
+// slower, and not observed on real data.
+template <bool LEAN>
 __global__ __launch_bounds__(256, 2) void attn64q_kernel(const MudgAttnDesc p, const int nqt, const int total) {
     __shared__ __attribute__((aligned(16))) h16 Ks[2 * ATILE];
     __shared__ __attribute__((aligned(16))) h16 Vs[2 * ATILE];
@@ -307,93 +316,167 @@ __global__ __launch_bounds__(256, 2) void attn64q_kernel(const MudgAttnDesc p, c
     };
 
     f32x16 o[2][2];
-#pragma unroll
-    for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { o[qb][0][r] = 0.f; o[qb][1][r] = 0.f; }
-    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
-    const float c = p.scale * 1.4426950408889634f;
-
+    float m_run[2], l_run[2];
+    const float c = p.q_prescaled ? 1.0f : p.scale * 1.4426950408889634f;
     const int nkt = (p.Nk + KB - 1) / KB;
-    load_tiles(0);
-    stage(0);
-    __syncthreads();
+    bool overflow = false;          // lean loop only: a row sum left the safe range -> the classic loop redoes the block
 
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int cur = kt & 1;
-        const bool more = kt + 1 < nkt;
-        if (more) load_tiles(kt + 1);
-
-        f32x16 s[2][2];        // [qb][sub]
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
-#pragma unroll
-            for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) s[qb][sub][r] = 0.f;
-            const h16* kp = Ks + cur * ATILE + (sub * 32 + l31) * ALD + hi * 8;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const h16x8 kf = *reinterpret_cast<const h16x8*>(kp + ks * 16);
-                s[0][sub] = MFMA_32x32x16(kf, qf[0][ks], s[0][sub]);
-                s[1][sub] = MFMA_32x32x16(kf, qf[1][ks], s[1][sub]);
-            }
-        }
-        if (kt * KB + KB > p.Nk) {
-#pragma unroll
-            for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int j = kt * KB + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    if (j >= p.Nk) { s[0][sub][r] = -INFINITY; s[1][sub][r] = -INFINITY; }
-                }
-        }
-
-        h16x8 pk[2][2][2];     // [qb][sub][jj]
+    // The key loop.  lean_tag = true_type: lean softmax (see the kernel's header comment); false_type: the classic online
+    // softmax with a per-tile maximum.  The lean loop keeps m_run as the reference (the first tile's row maximum).
+    auto key_loop = [&](auto lean_tag) {
+        constexpr bool LN = decltype(lean_tag)::value;
 #pragma unroll
         for (int qb = 0; qb < 2; ++qb) {
-            float mx = s[qb][0][0];
 #pragma unroll
-            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[qb][0][r]);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[qb][1][r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const bool grew = !__all(mx <= m_run[qb]);
-            const float m_new = grew ? fmaxf(m_run[qb], mx) : m_run[qb];
-            const float alpha = grew ? __builtin_amdgcn_exp2f((m_run[qb] - m_new) * c) : 1.0f;
-            const float mc = m_new * c;
-            m_run[qb] = m_new;
-            float ps = 0.f;
-#pragma unroll
-            for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float e = __builtin_amdgcn_exp2f(fmaf(s[qb][sub][r], c, -mc));
-                    ps += e;
-                    pk[qb][sub][r >> 3][r & 7] = (h16)e;
-                }
-            l_run[qb] = l_run[qb] * alpha + ps;
-            if (grew) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { o[qb][0][r] *= alpha; o[qb][1][r] *= alpha; }
-            }
+            for (int r = 0; r < 16; ++r) { o[qb][0][r] = 0.f; o[qb][1][r] = 0.f; }
+            m_run[qb] = LN ? 0.f : -INFINITY;
+            l_run[qb] = 0.f;
         }
-
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-            const h16* vp = Vs + cur * ATILE + (dt * 32 + l31) * ALD + 8 * hi;
-#pragma unroll
-            for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-                for (int jj = 0; jj < 2; ++jj) {
-                    const h16x8 vf = *reinterpret_cast<const h16x8*>(vp + sub * 32 + jj * 16);
-                    o[0][dt] = MFMA_32x32x16(vf, pk[0][sub][jj], o[0][dt]);
-                    o[1][dt] = MFMA_32x32x16(vf, pk[1][sub][jj], o[1][dt]);
-                }
-        }
-
-        if (more) stage(cur ^ 1);
+        load_tiles(0);
+        stage(0);
         __syncthreads();
+
+        // one key tile; MODE 0 = classic online softmax, 2 = lean (the accumulators start at -m_ref)
+        auto tile = [&](const int kt, auto mode_tag) {
+            constexpr int MODE = decltype(mode_tag)::value;
+            const int cur = kt & 1;
+            const bool more = kt + 1 < nkt;
+            if (more) load_tiles(kt + 1);
+
+            f32x16 s[2][2];        // [qb][sub]
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) {
+                    const float init = MODE == 2 ? -m_run[qb] : 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s[qb][sub][r] = init;
+                }
+                const h16* kp = Ks + cur * ATILE + (sub * 32 + l31) * ALD + hi * 8;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const h16x8 kf = *reinterpret_cast<const h16x8*>(kp + ks * 16);
+                    s[0][sub] = MFMA_32x32x16(kf, qf[0][ks], s[0][sub]);
+                    s[1][sub] = MFMA_32x32x16(kf, qf[1][ks], s[1][sub]);
+                }
+            }
+            if (kt * KB + KB > p.Nk) {
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int j = kt * KB + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                        if (j >= p.Nk) { s[0][sub][r] = -INFINITY; s[1][sub][r] = -INFINITY; }
+                    }
+            }
+
+            h16x8 pk[2][2][2];     // [qb][sub][jj]
+            if constexpr (MODE == 2) {
+                // lean tile: the accumulators already hold S - m_ref
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) {
+                    float ps = 0.f;
+#pragma unroll
+                    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const float e = __builtin_amdgcn_exp2f(s[qb][sub][r]);
+                            ps += e;
+                            pk[qb][sub][r >> 3][r & 7] = (h16)e;
+                        }
+                    l_run[qb] += ps;
+                    overflow = overflow || !(ps <= 1099511627776.f);        // 2^40; true for inf / nan as well
+                }
+            } else {
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) {
+                    float mx = s[qb][0][0];
+#pragma unroll
+                    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[qb][0][r]);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[qb][1][r]);
+                    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                    {
+                        const bool grew = !__all(mx <= m_run[qb]);
+                        const float m_new = grew ? fmaxf(m_run[qb], mx) : m_run[qb];
+                        const float alpha = grew ? __builtin_amdgcn_exp2f((m_run[qb] - m_new) * c) : 1.0f;
+                        const float mc = m_new * c;
+                        m_run[qb] = m_new;
+                        float ps = 0.f;
+#pragma unroll
+                        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const float e = __builtin_amdgcn_exp2f(fmaf(s[qb][sub][r], c, -mc));
+                                ps += e;
+                                pk[qb][sub][r >> 3][r & 7] = (h16)e;
+                            }
+                        l_run[qb] = l_run[qb] * alpha + ps;
+                        if (grew) {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) { o[qb][0][r] *= alpha; o[qb][1][r] *= alpha; }
+                        }
+                    }
+                }
+            }
+
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const h16* vp = Vs + cur * ATILE + (dt * 32 + l31) * ALD + 8 * hi;
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        const h16x8 vf = *reinterpret_cast<const h16x8*>(vp + sub * 32 + jj * 16);
+                        o[0][dt] = MFMA_32x32x16(vf, pk[0][sub][jj], o[0][dt]);
+                        o[1][dt] = MFMA_32x32x16(vf, pk[1][sub][jj], o[1][dt]);
+                    }
+            }
+
+            if (more) stage(cur ^ 1);
+            __syncthreads();
+        };
+        if constexpr (LN) {
+            {   // reference maxima = the first tile's row maxima (one extra set of score MFMAs per block)
+                f32x16 s0[2][2];
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+                    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) s0[qb][sub][r] = 0.f;
+                    const h16* kp = Ks + (sub * 32 + l31) * ALD + hi * 8;
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        const h16x8 kf = *reinterpret_cast<const h16x8*>(kp + ks * 16);
+                        s0[0][sub] = MFMA_32x32x16(kf, qf[0][ks], s0[0][sub]);
+                        s0[1][sub] = MFMA_32x32x16(kf, qf[1][ks], s0[1][sub]);
+                    }
+                }
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb) {
+                    float mx = -INFINITY;
+#pragma unroll
+                    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int j = sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                            if (j < p.Nk) mx = fmaxf(mx, s0[qb][sub][r]);
+                        }
+                    m_run[qb] = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                }
+            }
+            for (int kt = 0; kt < nkt; ++kt) tile(kt, std::integral_constant<int, 2>{});
+        } else {
+            for (int kt = 0; kt < nkt; ++kt) tile(kt, std::integral_constant<int, 0>{});
+        }
+    };
+
+    if constexpr (LEAN) {
+        key_loop(std::true_type{});
+        if (__syncthreads_or(overflow ? 1 : 0)) key_loop(std::false_type{});      // cold: exact, merely slower
+    } else {
+        key_loop(std::false_type{});
     }
 
 #pragma unroll
@@ -607,7 +690,7 @@ __global__ __launch_bounds__(256, 1) void attn_split_kernel(const MudgAttnDesc p
     };
 
     f32x16 o[2], res[TWO ? 2 : 1];
-    const float c = p.scale * 1.4426950408889634f;
+    const float c = p.q_prescaled ? 1.0f : p.scale * 1.4426950408889634f;
 #pragma unroll
     for (int set = 0; set < (TWO ? 2 : 1); ++set) {
     if (TWO && set == 1) {
@@ -861,7 +944,8 @@ extern "C" int mudg_attention(const MudgAttnDesc* dp, void* stream) {
     if (wide) {
         const int nqt2 = (d.Nq + 255) / 256;
         const int64_t total2 = (int64_t)nqt2 * d.F * d.heads;
-        hipLaunchKernelGGL(attn64q_kernel, dim3((unsigned)total2), dim3(256), 0, s, d, nqt2, (int)total2);
+        if (d.q_prescaled) hipLaunchKernelGGL(attn64q_kernel<true>, dim3((unsigned)total2), dim3(256), 0, s, d, nqt2, (int)total2);
+        else hipLaunchKernelGGL(attn64q_kernel<false>, dim3((unsigned)total2), dim3(256), 0, s, d, nqt2, (int)total2);
     } else if (d.K2) {
         hipLaunchKernelGGL(attn_kernel<true>, dim3((unsigned)total), dim3(256), 0, s, d, nqt, (int)total);
     } else {

@@ -83,6 +83,19 @@ def linear_cat(owner, name, mods):
     return cached(owner, name, ws, lambda: operand(torch.cat([w.detach().float() for w in ws], 0)))
 
 
+def qk_prescaled(owner, to_q, to_k, scale):
+    """[q | k] projection rows with the attention scale AND log2(e) folded into the q rows (in fp32, before the one cast
+    to the operand type — no extra rounding): Q K^T then is the base-2 exponent of the softmax directly
+    (MudgAttnDesc.q_prescaled)."""
+    import math
+    ws = (to_q.weight, to_k.weight)
+    for w in ws:
+        _need_cuda(w, "qk")
+    c = float(scale) * math.log2(math.e)
+    return cached(owner, f"qk_prescaled:{c!r}", ws,
+                  lambda: operand(torch.cat([to_q.weight.detach().float() * c, to_k.weight.detach().float()], 0)))
+
+
 def conv3x3(mod):
     """(Cout, Cin, 3, 3) -> bf16 [Cout][K]; returns (matrix, padded Cin, korder).  K is ordered [Cin/64][tap][64]
     when Cin is a multiple of 64 (korder 1: the nine taps of a channel slab are adjacent K tiles, which keeps the

@@ -27,6 +27,10 @@ from . import packing as pk
 
 
 
+import os as _os
+_LEAN_ATTENTION = _os.environ.get("MUDG_ATTN_LEAN", "1") != "0"       # A/B switch, read once
+
+
 class _Ctx:
     """Per-forward state shared by all blocks."""
     __slots__ = ("B", "T", "emb", "text", "img", "n_text", "n_img", "img_div", "kv_cache")
@@ -123,11 +127,13 @@ def spatial_block(blk, hcur, frames, hw, ctx, last):
     c, heads = hcur.shape[1], a1.heads
     # self-attention over the hw tokens of each frame
     n1 = _ln(blk.norm1, hcur)
-    qk = ops.gemm(n1, pk.linear_cat(a1, "qk", (a1.to_q, a1.to_k)))
+    lean = _LEAN_ATTENTION and ops.hip.planes() == 1     # 16-bit builds: scale * log2(e) rides in the packed q weights
+    wqk = pk.qk_prescaled(a1, a1.to_q, a1.to_k, a1.scale) if lean else pk.linear_cat(a1, "qk", (a1.to_q, a1.to_k))
+    qk = ops.gemm(n1, wqk)
     vt, ldv = _vt_projection(a1.to_v, n1, frames, hw)
     att = ops.empty_rows(frames * hw, c, ops.H16(), hcur.device)
     ops.attention(qk[:, :c], qk[:, c:], vt, att, frames=frames, heads=heads, nq=hw, nk=hw, ldvt=ldv, svt=c * ldv,
-                  scale=a1.scale)
+                  scale=a1.scale, q_prescaled=lean)
     hcur = _linear(a1.to_out[0], att, residual=hcur, stream=True)
     # text (+ image) cross-attention: two softmaxes, outputs summed (image_cross_attention_scale == 1)
     n2 = _ln(blk.norm2, hcur)

@@ -80,7 +80,7 @@ class AttnDesc(C.Structure):
         ("ldq", C.c_int), ("ldk", C.c_int), ("ldvt", C.c_int), ("ldo", C.c_int),
         ("svt", C.c_int64), ("kv_div", C.c_int), ("scale", C.c_float), ("accumulate", C.c_int),
         ("K2", C.c_void_p), ("Vt2", C.c_void_p), ("Nk2", C.c_int), ("ldk2", C.c_int), ("ldvt2", C.c_int), ("kv_div2", C.c_int),
-        ("svt2", C.c_int64),
+        ("svt2", C.c_int64), ("q_prescaled", C.c_int),
     ]
 
 

@@ -198,10 +198,11 @@ def tconv3(x, w, *, clips, t, hw, cin, out=None, bias=None, residual=None, out_f
 
 # ------------------------------------------------------------------------------------------------ attention
 def attention(q, k, vt, out, *, frames, heads, nq, nk, ldvt=None, svt=None, kv_div=1, scale=0.125, accumulate=False,
-              k2=None, vt2=None, nk2=0, ldvt2=None, svt2=None, kv_div2=1):
+              k2=None, vt2=None, nk2=0, ldvt2=None, svt2=None, kv_div2=1, q_prescaled=False):
     """vt: V^T as [kv batches * heads * 64, keys] rows (row stride = ldvt, batch stride = heads * 64 rows by default).
     k2 / vt2 / nk2: an optional second key / value set with its own softmax whose output is added (the image tokens of
-    the text + image cross-attention), in the same launch."""
+    the text + image cross-attention), in the same launch.  q_prescaled: q already carries scale * log2(e) (folded into
+    the packed q-projection weights); `scale` is then ignored and long self-attention runs its lean softmax."""
     if ldvt is None:
         ldvt = vt.stride(0)
     if svt is None:
@@ -212,6 +213,7 @@ def attention(q, k, vt, out, *, frames, heads, nq, nk, ldvt=None, svt=None, kv_d
     d.F, d.heads, d.Nq, d.Nk = frames, heads, nq, nk
     d.ldq, d.ldk, d.ldvt, d.ldo = q.stride(0), k.stride(0), ldvt, out.stride(0)
     d.svt, d.kv_div, d.scale, d.accumulate = svt, kv_div, scale, int(accumulate)
+    d.q_prescaled = int(q_prescaled)
     if k2 is not None:
         d.K2, d.Vt2, d.Nk2, d.ldk2 = k2.data_ptr(), vt2.data_ptr(), nk2, k2.stride(0)
         d.ldvt2 = vt2.stride(0) if ldvt2 is None else ldvt2

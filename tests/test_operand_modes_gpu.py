@@ -318,3 +318,34 @@ def test_attention_two_key_sets_in_one_launch(cuda):
     ops.attention(q, kt, vt_t, two, frames=frames, heads=heads, nq=nq, nk=77, kv_div=T, scale=0.125)
     ops.attention(q, ki, vt_i, two, frames=frames, heads=heads, nq=nq, nk=16, scale=0.125, accumulate=True)
     assert rel(value(one), value(two)) < 2 * TOL_OP
+
+
+@pytest.mark.skipif(_hip.planes() > 1, reason="the lean softmax belongs to the 16-bit builds' long self-attention kernel")
+@pytest.mark.parametrize("spread", [1.0, 12.0])
+def test_attention_lean_softmax_with_prescaled_q(cuda, spread):
+    """q_prescaled: Q carries scale * log2(e), the kernel exponentiates Q K^T directly with the first tile's row maximum
+    as the accumulators' initial value.  spread = 12 puts later scores far above the first tile's maximum (the deferred
+    reference has to cope; beyond 2^40 the classic loop takes over — forced here by a third, extreme case)."""
+    import math
+    from mudg_amd import ops
+    frames, heads, n = 2, 2, 768
+    c = heads * 64
+    cl2 = 0.125 * math.log2(math.e)
+    qs = f32(frames * n, c, seed=1)
+    ks = f32(frames * n, c, seed=2) * spread
+    ks[n // 2:] *= 1.5                                    # later keys score higher than the first tile's
+    q, qv = operand(qs * cl2, cuda)
+    k, kv = operand(ks, cuda)
+    _, vv = operand(f32(frames * n, c, seed=3), cuda)
+    vt = _vt(vv, frames, n, c, cuda)
+    out = ops.empty_rows(frames * n, c, None, cuda)
+    ops.attention(q, k, vt, out, frames=frames, heads=heads, nq=n, nk=n, q_prescaled=True)
+    ref = _attention_ref(qv, kv, vv, frames, heads, n, n, math.log(2.0))       # softmax of 2^(q k)
+    assert rel(value(out), ref) < 2 * TOL_OP
+    if spread > 1:      # extreme: one key per row 2^60 above everything in the first tile -> the classic loop redoes the block
+        kbig = ks.clone()
+        kbig[n - 1] = qs[0] * 50.0
+        k2, k2v = operand(kbig, cuda)
+        ops.attention(q, k2, vt, out, frames=frames, heads=heads, nq=n, nk=n, q_prescaled=True)
+        assert torch.isfinite(value(out)).all()
+        assert rel(value(out), _attention_ref(qv, k2v, vv, frames, heads, n, n, math.log(2.0))) < 2 * TOL_OP
