@@ -238,14 +238,6 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const MudgAttnDesc p, cons
 
 // Variant with 64 query rows per wave (two 32-row blocks): every K / V^T fragment read from LDS feeds two MFMAs instead
 // of one — half the LDS traffic per FLOP — and the two blocks' softmax chains are independent.  Workgroup = 256 queries.
-// LEAN (p.q_prescaled: Q carries scale * log2 e, so S = K Q^T is the base-2 exponent): the softmax chain — the kernel is
-// bound by VALU issue, not MFMA, at head width 64 — is cut from {max, fma, exp, add, cvt} to {exp, add, cvt} per score:
-// a reference maximum m_ref per query row (the row maximum over the first key tile, from one extra set of score MFMAs per
-// block) enters as the INITIAL VALUE of the score accumulators, so S - m_ref comes straight out of the MFMA; the per-tile
-// maximum is not computed and O / l are never rescaled.  Should a row's tile sum exceed 2^40 (a later score 40 binary
-// orders above the first tile's maximum) the workgroup redoes its block with the classic online softmax — exact, merely
-// slower, and not observed on real data.
-template <bool LEAN>
 __global__ __launch_bounds__(256, 2) void attn64q_kernel(const MudgAttnDesc p, const int nqt, const int total) {
     __shared__ __attribute__((aligned(16))) h16 Ks[2 * ATILE];
     __shared__ __attribute__((aligned(16))) h16 Vs[2 * ATILE];
@@ -316,13 +308,214 @@ __global__ __launch_bounds__(256, 2) void attn64q_kernel(const MudgAttnDesc p, c
     };
 
     f32x16 o[2][2];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o[qb][0][r] = 0.f; o[qb][1][r] = 0.f; }
+    float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+    const float c = p.q_prescaled ? 1.0f : p.scale * 1.4426950408889634f;
+
+    const int nkt = (p.Nk + KB - 1) / KB;
+    load_tiles(0);
+    stage(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        const bool more = kt + 1 < nkt;
+        if (more) load_tiles(kt + 1);
+
+        f32x16 s[2][2];        // [qb][sub]
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[qb][sub][r] = 0.f;
+            const h16* kp = Ks + cur * ATILE + (sub * 32 + l31) * ALD + hi * 8;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const h16x8 kf = *reinterpret_cast<const h16x8*>(kp + ks * 16);
+                s[0][sub] = MFMA_32x32x16(kf, qf[0][ks], s[0][sub]);
+                s[1][sub] = MFMA_32x32x16(kf, qf[1][ks], s[1][sub]);
+            }
+        }
+        if (kt * KB + KB > p.Nk) {
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int j = kt * KB + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (j >= p.Nk) { s[0][sub][r] = -INFINITY; s[1][sub][r] = -INFINITY; }
+                }
+        }
+
+        h16x8 pk[2][2][2];     // [qb][sub][jj]
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+            float mx = s[qb][0][0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[qb][0][r]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[qb][1][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const bool grew = !__all(mx <= m_run[qb]);
+            const float m_new = grew ? fmaxf(m_run[qb], mx) : m_run[qb];
+            const float alpha = grew ? __builtin_amdgcn_exp2f((m_run[qb] - m_new) * c) : 1.0f;
+            const float mc = m_new * c;
+            m_run[qb] = m_new;
+            float ps = 0.f;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float e = __builtin_amdgcn_exp2f(fmaf(s[qb][sub][r], c, -mc));
+                    ps += e;
+                    pk[qb][sub][r >> 3][r & 7] = (h16)e;
+                }
+            l_run[qb] = l_run[qb] * alpha + ps;
+            if (grew) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { o[qb][0][r] *= alpha; o[qb][1][r] *= alpha; }
+            }
+        }
+
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            const h16* vp = Vs + cur * ATILE + (dt * 32 + l31) * ALD + 8 * hi;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const h16x8 vf = *reinterpret_cast<const h16x8*>(vp + sub * 32 + jj * 16);
+                    o[0][dt] = MFMA_32x32x16(vf, pk[0][sub][jj], o[0][dt]);
+                    o[1][dt] = MFMA_32x32x16(vf, pk[1][sub][jj], o[1][dt]);
+                }
+        }
+
+        if (more) stage(cur ^ 1);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
+        const float inv = 1.f / l_tot;
+        if (qok[qb]) {
+            h16* orow = Op + (int64_t)qrow[qb] * p.ldo;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    h16* dst = orow + dt * 32 + 8 * g + 4 * hi;
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = o[qb][dt][4 * g + j] * inv;
+                    if (p.accumulate) {
+                        Pack8 old; old.u = *reinterpret_cast<const u32x2*>(dst);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] += (float)old.h[j];
+                    }
+                    Pack8 nw;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) nw.h[j] = (h16)v[j];
+                    *reinterpret_cast<u32x2*>(dst) = nw.u;
+                }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ LDS-DMA variant
+// attn64q_kernel with the K / V^T tiles staged by LDS-DMA (buffer_load_dwordx4 ... lds: no VGPR round trip, no ds_write
+// pass, 16 fewer live registers) and, on top of that, the lean softmax (template LEAN; in the register-staged kernel it
+// spilled).  Needs Nk % 64 == 0.
+// LEAN (p.q_prescaled: Q carries scale * log2 e, so S = K Q^T is the base-2 exponent): the softmax chain — at head width
+// 64 the kernel is bound by VALU issue, not by MFMA — is cut from {max, fma, exp, add, cvt} to {exp, add, cvt} per score:
+// a reference maximum m_ref per query row (the row maximum over the first key tile, from one extra set of score MFMAs per
+// block) enters as the INITIAL VALUE of the score accumulators, so S - m_ref comes straight out of the MFMA; the per-tile
+// maximum is not computed and O / l are never rescaled.  Should a row's tile sum exceed 2^40 (a later score 40 binary
+// orders above the first tile's maximum) the workgroup redoes its block with the classic online softmax — exact, merely
+// slower, and not observed on real data.
+//  * A DMA instruction writes 1 KiB lane-linear (8 rows x 128 B), so the tiles are unpadded [64][64] h16 with the XOR
+//    swizzle of the GEMM kernel applied on the SOURCE side (which 16-byte chunk of the row a lane fetches) and mirrored on
+//    the fragment reads: chunk c of row r lives in slot c ^ ((r >> 1) & 7).
+//  * The score MFMA leaves a lane's keys in the order {0-3, 8-11 | 4-7, 12-15} per 16; instead of permuting V^T's columns
+//    (8-byte granules — impossible for a 16-byte DMA) the K tile's ROWS are permuted at the source by the involution that
+//    swaps the two middle 4-blocks of every 16: softmax does not care in which order keys arrive, and a lane's 8
+//    contraction slots of a PV MFMA are then 8 consecutive keys = one natural 16-byte chunk of V^T.
+//  * Tile t + 1 is requested at the top of iteration t into the other buffer; the barrier that closes the iteration
+//    (vmcnt(0) + s_barrier) is the only synchronisation.
+constexpr int DTILE = 64 * 64;          // h16 per unpadded tile
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t attn_rsrc(const h16* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<h16*>(base), 0, (int)0x80000000u, 0x00020000);
+}
+typedef __attribute__((address_space(3))) void* attn_lptr_t;
+
+template <bool LEAN>
+__global__ __launch_bounds__(256, 2) void attn64d_kernel(const MudgAttnDesc p, const int nqt, const int total) {
+    __shared__ __attribute__((aligned(1024))) h16 Ks[2 * DTILE];
+    __shared__ __attribute__((aligned(1024))) h16 Vs[2 * DTILE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    int w;
+    {
+        const int q8 = total >> 3, r8 = total & 7;
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        w = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    }
+    const int pair = w / nqt, qt = w - pair * nqt;
+    const int f = pair / p.heads, h = pair - f * p.heads;
+    const int kvb = f / p.kv_div;
+
+    const h16* Qp = reinterpret_cast<const h16*>(p.Q) + (int64_t)f * p.Nq * p.ldq + h * 64;
+    const h16* Kp = reinterpret_cast<const h16*>(p.K) + (int64_t)kvb * p.Nk * p.ldk + h * 64;
+    const h16* Vp = reinterpret_cast<const h16*>(p.Vt) + (int64_t)kvb * p.svt + (int64_t)(h * 64) * p.ldvt;
+    h16* Op = reinterpret_cast<h16*>(p.O) + (int64_t)f * p.Nq * p.ldo + h * 64;
+
+    int qrow[2];
+    bool qok[2];
+    h16x8 qf[2][4];
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+        qrow[qb] = qt * 256 + wave * 64 + qb * 32 + l31;
+        qok[qb] = qrow[qb] < p.Nq;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            qf[qb][ks] = as_h16x8(qok[qb] ? ld16(Qp + (int64_t)qrow[qb] * p.ldq + ks * 16 + hi * 8) : zero16());
+    }
+
+    // DMA geometry: wave w stages rows [16w, 16w + 16) of both tiles, two 1-KiB instructions each; in instruction i lane l
+    // lands in row 16w + 8i + (l >> 3), slot l & 7.
+    const __amdgpu_buffer_rsrc_t rK = attn_rsrc(Kp), rV = attn_rsrc(Vp);
+    unsigned vk[2], vv[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = 16 * wave + 8 * i + (lane >> 3), slot = lane & 7;
+        const int chunk = slot ^ ((row >> 1) & 7);
+        const int i16 = row & 15;
+        const int key = (row & ~15) | (i16 & 3) | ((i16 & 8) >> 1) | ((i16 & 4) << 1);     // swap the middle 4-blocks
+        vk[i] = (unsigned)key * (unsigned)p.ldk * 2u + (unsigned)chunk * 16u;
+        vv[i] = (unsigned)row * (unsigned)p.ldvt * 2u + (unsigned)chunk * 16u;
+    }
+    auto request = [&](int kt, int buf) {
+        const int sk = kt * 64 * p.ldk * 2, sv = kt * 128;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rK, (attn_lptr_t)(Ks + buf * DTILE + (16 * wave + 8 * i) * 64), 16, (int)vk[i], sk, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rV, (attn_lptr_t)(Vs + buf * DTILE + (16 * wave + 8 * i) * 64), 16, (int)vv[i], sv, 0, 0);
+        }
+    };
+    const int sw = (l31 >> 1) & 7;          // read-side swizzle (row bases are multiples of 32)
+
+    f32x16 o[2][2];
     float m_run[2], l_run[2];
     const float c = p.q_prescaled ? 1.0f : p.scale * 1.4426950408889634f;
-    const int nkt = (p.Nk + KB - 1) / KB;
-    bool overflow = false;          // lean loop only: a row sum left the safe range -> the classic loop redoes the block
+    const int nkt = p.Nk / KB;
+    bool overflow = false;
 
-    // The key loop.  lean_tag = true_type: lean softmax (see the kernel's header comment); false_type: the classic online
-    // softmax with a per-tile maximum.  The lean loop keeps m_run as the reference (the first tile's row maximum).
     auto key_loop = [&](auto lean_tag) {
         constexpr bool LN = decltype(lean_tag)::value;
 #pragma unroll
@@ -332,49 +525,61 @@ __global__ __launch_bounds__(256, 2) void attn64q_kernel(const MudgAttnDesc p, c
             m_run[qb] = LN ? 0.f : -INFINITY;
             l_run[qb] = 0.f;
         }
-        load_tiles(0);
-        stage(0);
+        request(0, 0);
         __syncthreads();
+        if constexpr (LN) {   // reference maxima = the first tile's row maxima (one extra set of score MFMAs per block)
+            f32x16 s0[2][2];
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+                for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) s0[qb][sub][r] = 0.f;
+                const h16* kp = Ks + (sub * 32 + l31) * 64;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const h16x8 kf = *reinterpret_cast<const h16x8*>(kp + (((ks * 2 + hi) ^ sw) << 3));
+                    s0[0][sub] = MFMA_32x32x16(kf, qf[0][ks], s0[0][sub]);
+                    s0[1][sub] = MFMA_32x32x16(kf, qf[1][ks], s0[1][sub]);
+                }
+            }
+#pragma unroll
+            for (int qb = 0; qb < 2; ++qb) {
+                float mx = s0[qb][0][0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s0[qb][0][r]);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s0[qb][1][r]);
+                m_run[qb] = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            }
+        }
 
-        // one key tile; MODE 0 = classic online softmax, 2 = lean (the accumulators start at -m_ref)
-        auto tile = [&](const int kt, auto mode_tag) {
-            constexpr int MODE = decltype(mode_tag)::value;
+        for (int kt = 0; kt < nkt; ++kt) {
             const int cur = kt & 1;
-            const bool more = kt + 1 < nkt;
-            if (more) load_tiles(kt + 1);
+            if (kt + 1 < nkt) request(kt + 1, cur ^ 1);
 
             f32x16 s[2][2];        // [qb][sub]
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll
                 for (int qb = 0; qb < 2; ++qb) {
-                    const float init = MODE == 2 ? -m_run[qb] : 0.f;
+                    const float init = LN ? -m_run[qb] : 0.f;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) s[qb][sub][r] = init;
                 }
-                const h16* kp = Ks + cur * ATILE + (sub * 32 + l31) * ALD + hi * 8;
+                const h16* kp = Ks + cur * DTILE + (sub * 32 + l31) * 64;
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
-                    const h16x8 kf = *reinterpret_cast<const h16x8*>(kp + ks * 16);
+                    const h16x8 kf = *reinterpret_cast<const h16x8*>(kp + (((ks * 2 + hi) ^ sw) << 3));
                     s[0][sub] = MFMA_32x32x16(kf, qf[0][ks], s[0][sub]);
                     s[1][sub] = MFMA_32x32x16(kf, qf[1][ks], s[1][sub]);
                 }
             }
-            if (kt * KB + KB > p.Nk) {
-#pragma unroll
-                for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int j = kt * KB + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                        if (j >= p.Nk) { s[0][sub][r] = -INFINITY; s[1][sub][r] = -INFINITY; }
-                    }
-            }
 
             h16x8 pk[2][2][2];     // [qb][sub][jj]
-            if constexpr (MODE == 2) {
-                // lean tile: the accumulators already hold S - m_ref
 #pragma unroll
-                for (int qb = 0; qb < 2; ++qb) {
+            for (int qb = 0; qb < 2; ++qb) {
+                if constexpr (LN) {
                     float ps = 0.f;
 #pragma unroll
                     for (int sub = 0; sub < 2; ++sub)
@@ -386,89 +591,49 @@ __global__ __launch_bounds__(256, 2) void attn64q_kernel(const MudgAttnDesc p, c
                         }
                     l_run[qb] += ps;
                     overflow = overflow || !(ps <= 1099511627776.f);        // 2^40; true for inf / nan as well
-                }
-            } else {
-#pragma unroll
-                for (int qb = 0; qb < 2; ++qb) {
+                } else {
                     float mx = s[qb][0][0];
 #pragma unroll
                     for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[qb][0][r]);
 #pragma unroll
                     for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[qb][1][r]);
                     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-                    {
-                        const bool grew = !__all(mx <= m_run[qb]);
-                        const float m_new = grew ? fmaxf(m_run[qb], mx) : m_run[qb];
-                        const float alpha = grew ? __builtin_amdgcn_exp2f((m_run[qb] - m_new) * c) : 1.0f;
-                        const float mc = m_new * c;
-                        m_run[qb] = m_new;
-                        float ps = 0.f;
-#pragma unroll
-                        for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) {
-                                const float e = __builtin_amdgcn_exp2f(fmaf(s[qb][sub][r], c, -mc));
-                                ps += e;
-                                pk[qb][sub][r >> 3][r & 7] = (h16)e;
-                            }
-                        l_run[qb] = l_run[qb] * alpha + ps;
-                        if (grew) {
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) { o[qb][0][r] *= alpha; o[qb][1][r] *= alpha; }
-                        }
-                    }
-                }
-            }
-
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
-                const h16* vp = Vs + cur * ATILE + (dt * 32 + l31) * ALD + 8 * hi;
-#pragma unroll
-                for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-                    for (int jj = 0; jj < 2; ++jj) {
-                        const h16x8 vf = *reinterpret_cast<const h16x8*>(vp + sub * 32 + jj * 16);
-                        o[0][dt] = MFMA_32x32x16(vf, pk[0][sub][jj], o[0][dt]);
-                        o[1][dt] = MFMA_32x32x16(vf, pk[1][sub][jj], o[1][dt]);
-                    }
-            }
-
-            if (more) stage(cur ^ 1);
-            __syncthreads();
-        };
-        if constexpr (LN) {
-            {   // reference maxima = the first tile's row maxima (one extra set of score MFMAs per block)
-                f32x16 s0[2][2];
-#pragma unroll
-                for (int sub = 0; sub < 2; ++sub) {
-#pragma unroll
-                    for (int qb = 0; qb < 2; ++qb)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) s0[qb][sub][r] = 0.f;
-                    const h16* kp = Ks + (sub * 32 + l31) * ALD + hi * 8;
-#pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) {
-                        const h16x8 kf = *reinterpret_cast<const h16x8*>(kp + ks * 16);
-                        s0[0][sub] = MFMA_32x32x16(kf, qf[0][ks], s0[0][sub]);
-                        s0[1][sub] = MFMA_32x32x16(kf, qf[1][ks], s0[1][sub]);
-                    }
-                }
-#pragma unroll
-                for (int qb = 0; qb < 2; ++qb) {
-                    float mx = -INFINITY;
+                    const bool grew = !__all(mx <= m_run[qb]);
+                    const float m_new = grew ? fmaxf(m_run[qb], mx) : m_run[qb];
+                    const float alpha = grew ? __builtin_amdgcn_exp2f((m_run[qb] - m_new) * c) : 1.0f;
+                    const float mc = m_new * c;
+                    m_run[qb] = m_new;
+                    float ps = 0.f;
 #pragma unroll
                     for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
-                            const int j = sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                            if (j < p.Nk) mx = fmaxf(mx, s0[qb][sub][r]);
+                            const float e = __builtin_amdgcn_exp2f(fmaf(s[qb][sub][r], c, -mc));
+                            ps += e;
+                            pk[qb][sub][r >> 3][r & 7] = (h16)e;
                         }
-                    m_run[qb] = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                    l_run[qb] = l_run[qb] * alpha + ps;
+                    if (grew) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) { o[qb][0][r] *= alpha; o[qb][1][r] *= alpha; }
+                    }
                 }
             }
-            for (int kt = 0; kt < nkt; ++kt) tile(kt, std::integral_constant<int, 2>{});
-        } else {
-            for (int kt = 0; kt < nkt; ++kt) tile(kt, std::integral_constant<int, 0>{});
+
+            // the K rows were permuted at the source: register group (sub, jj) of half hi holds keys 32 sub + 16 jj + 8 hi ..+7
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const h16* vp = Vs + cur * DTILE + (dt * 32 + l31) * 64;
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        const h16x8 vf = *reinterpret_cast<const h16x8*>(vp + (((4 * sub + 2 * jj + hi) ^ sw) << 3));
+                        o[0][dt] = MFMA_32x32x16(vf, pk[0][sub][jj], o[0][dt]);
+                        o[1][dt] = MFMA_32x32x16(vf, pk[1][sub][jj], o[1][dt]);
+                    }
+            }
+            __syncthreads();         // tile kt + 1 has landed (vmcnt(0)) and everyone is done reading tile kt
         }
     };
 
@@ -944,8 +1109,15 @@ extern "C" int mudg_attention(const MudgAttnDesc* dp, void* stream) {
     if (wide) {
         const int nqt2 = (d.Nq + 255) / 256;
         const int64_t total2 = (int64_t)nqt2 * d.F * d.heads;
-        if (d.q_prescaled) hipLaunchKernelGGL(attn64q_kernel<true>, dim3((unsigned)total2), dim3(256), 0, s, d, nqt2, (int)total2);
-        else hipLaunchKernelGGL(attn64q_kernel<false>, dim3((unsigned)total2), dim3(256), 0, s, d, nqt2, (int)total2);
+        // LDS-DMA staging (+ the lean softmax when Q is prescaled) for whole key tiles whose tiles stay inside the 2-GiB
+        // window of a buffer descriptor; the register-staged kernel otherwise.  MUDG_ATTN_DMA=0 / MUDG_ATTN_LEAN=0: A/B.
+        static int dma = -1, lean = -1;
+        if (dma < 0) { const char* e = getenv("MUDG_ATTN_DMA"); dma = e ? atoi(e) : 1; }
+        if (lean < 0) { const char* e = getenv("MUDG_ATTN_LEAN"); lean = e ? atoi(e) : 1; }
+        const bool dma_ok = dma && d.Nk % 64 == 0 && (int64_t)d.Nk * d.ldk * 2 < (1ll << 31) && (int64_t)64 * d.ldvt * 2 + (int64_t)d.Nk * 2 < (1ll << 31);
+        if (dma_ok && d.q_prescaled && lean) hipLaunchKernelGGL(attn64d_kernel<true>, dim3((unsigned)total2), dim3(256), 0, s, d, nqt2, (int)total2);
+        else if (dma_ok) hipLaunchKernelGGL(attn64d_kernel<false>, dim3((unsigned)total2), dim3(256), 0, s, d, nqt2, (int)total2);
+        else hipLaunchKernelGGL(attn64q_kernel, dim3((unsigned)total2), dim3(256), 0, s, d, nqt2, (int)total2);
     } else if (d.K2) {
         hipLaunchKernelGGL(attn_kernel<true>, dim3((unsigned)total), dim3(256), 0, s, d, nqt, (int)total);
     } else {
