@@ -128,6 +128,13 @@ typedef struct MudgAttnDesc {
     const void* K2; const void* Vt2;
     int Nk2, ldk2, ldvt2, kv_div2;
     int64_t svt2;
+    /* MX-fp8 scores (BASELINE config 5; needs q_prescaled, Nk % 64 == 0, Nq >= 512): when Q8 is not NULL, Q K^T runs on
+     * v_mfma_scale_f32_32x32x64_f8f6f4 — twice the bf16 MFMA rate — from OCP e4m3 copies of Q and K with one E8M0 power-of-two
+     * scale per 32 consecutive head dims (mudg_quantize_mxfp8 makes both); softmax and P V stay as in the bf16 kernel
+     * (P and V^T are bf16).  Q8 / K8: fp8 rows with the row -> (frame, token) and column -> (head, dim) conventions of
+     * Q / K, row strides ldq8 / ldk8 BYTES; Qs / Ks: scale bytes, column 2 * head + (dim / 32), row strides ldqs / ldks. */
+    const void* Q8; const void* K8; const void* Qs; const void* Ks;
+    int ldq8, ldk8, ldqs, ldks;
     int q_prescaled;     /* 1: Q already carries scale * log2(e) (folded into the q-projection weights when they are packed),
                             so Q K^T is directly the base-2 exponent and `scale` is ignored.  The long self-attention kernel
                             then runs its lean softmax: the running reference maximum enters as the score accumulator's
@@ -135,6 +142,10 @@ typedef struct MudgAttnDesc {
                             outgrows 2^40 (never on real data after the first tile). */
 } MudgAttnDesc;
 int mudg_attention(const MudgAttnDesc* d, void* stream);
+/* OCP microscaling quantisation of an operand matrix (16-bit builds): every 32 consecutive columns of a row share one
+ * E8M0 scale 2^(floor(log2 amax) - 8) and are stored as e4m3 (saturating): Y8[r][c] (row stride ldy bytes),
+ * S[r][c / 32] (row stride lds bytes).  cols % 32 == 0. */
+int mudg_quantize_mxfp8(const void* X, int ldx, int64_t rows, int cols, void* Y8, int ldy, void* S, int lds, void* stream);
 
 /* Temporal self-attention over T <= 32 frames per pixel (attention.py:529-576 via 81-144):
  * QKV rows are ((b*T + t)*HW + p); q at columns [h*64..], k at C + h*64, v at 2C + h*64. */

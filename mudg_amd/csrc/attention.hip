@@ -452,9 +452,17 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t attn_rsrc(const h16* base) {
 }
 typedef __attribute__((address_space(3))) void* attn_lptr_t;
 
-template <bool LEAN>
+// F8 (needs LEAN): the scores come from MX-fp8 copies of Q and K (MudgAttnDesc.Q8 ...): one
+// v_mfma_scale_f32_32x32x64_f8f6f4 per (32 keys x 32 queries) block covers the whole head width at twice the bf16 MFMA
+// rate; the K tile is 64 keys x 64 bytes, staged by DMA with a 4-slot XOR swizzle, its E8M0 scales come straight from L2
+// one tile ahead.  Softmax and P V are the bf16 kernel's.  (Operand / scale layout of that MFMA: measured with
+// tools/ubench/mxfp8_layout.hip.)
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+
+template <bool LEAN, bool F8>
 __global__ __launch_bounds__(256, 2) void attn64d_kernel(const MudgAttnDesc p, const int nqt, const int total) {
-    __shared__ __attribute__((aligned(1024))) h16 Ks[2 * DTILE];
+    static_assert(LEAN || !F8, "the fp8 score path builds on the lean softmax");
+    __shared__ __attribute__((aligned(1024))) h16 Ks[F8 ? DTILE : 2 * DTILE];      // F8: 2 x (64 keys x 64 B) = one bf16 tile's worth
     __shared__ __attribute__((aligned(1024))) h16 Vs[2 * DTILE];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -477,19 +485,40 @@ __global__ __launch_bounds__(256, 2) void attn64d_kernel(const MudgAttnDesc p, c
 
     int qrow[2];
     bool qok[2];
-    h16x8 qf[2][4];
+    h16x8 qf[2][F8 ? 1 : 4];
+    i32x8 qf8[2];                 // F8: the lane's 32 fp8 dims [32 hi, 32 hi + 32) of its query row, and their scale
+    int qsc[2] = {127, 127};
+    const unsigned char* K8p = nullptr;
+    const unsigned char* Ksp = nullptr;
 #pragma unroll
     for (int qb = 0; qb < 2; ++qb) {
         qrow[qb] = qt * 256 + wave * 64 + qb * 32 + l31;
         qok[qb] = qrow[qb] < p.Nq;
+        if constexpr (F8) {
+            // operand layout of the f8f6f4 MFMA (tools/ubench/mxfp8_layout.hip): a lane's first 16 bytes are K elements
+            // 16 half + [0, 16) — scaled by the scale lanes 0-31 supply — its second 16 bytes 32 + 16 half + [0, 16), scaled by
+            // lanes 32-63's: lane half `hi` therefore fetches dims [16 hi, +16) and [32 + 16 hi, +16), and carries the scale
+            // of dims [32 hi, +32)
+            const unsigned char* q8 = reinterpret_cast<const unsigned char*>(p.Q8) + ((int64_t)f * p.Nq + qrow[qb]) * p.ldq8 + h * 64 + hi * 16;
+            const u32x4 a = qok[qb] ? ld16(q8) : zero16(), b = qok[qb] ? ld16(q8 + 32) : zero16();
+            qf8[qb] = i32x8{(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
+            if (qok[qb]) qsc[qb] = reinterpret_cast<const unsigned char*>(p.Qs)[((int64_t)f * p.Nq + qrow[qb]) * p.ldqs + h * 2 + hi];
+        } else {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-            qf[qb][ks] = as_h16x8(qok[qb] ? ld16(Qp + (int64_t)qrow[qb] * p.ldq + ks * 16 + hi * 8) : zero16());
+            for (int ks = 0; ks < 4; ++ks)
+                qf[qb][ks] = as_h16x8(qok[qb] ? ld16(Qp + (int64_t)qrow[qb] * p.ldq + ks * 16 + hi * 8) : zero16());
+        }
+    }
+    if constexpr (F8) {
+        K8p = reinterpret_cast<const unsigned char*>(p.K8) + (int64_t)kvb * p.Nk * p.ldk8 + h * 64;
+        Ksp = reinterpret_cast<const unsigned char*>(p.Ks) + (int64_t)kvb * p.Nk * p.ldks + h * 2;
     }
 
     // DMA geometry: wave w stages rows [16w, 16w + 16) of both tiles, two 1-KiB instructions each; in instruction i lane l
-    // lands in row 16w + 8i + (l >> 3), slot l & 7.
-    const __amdgpu_buffer_rsrc_t rK = attn_rsrc(Kp), rV = attn_rsrc(Vp);
+    // lands in row 16w + 8i + (l >> 3), slot l & 7.  (F8 K tile: ONE instruction per wave, row 16w + (l >> 2), slot l & 3.)
+    const __amdgpu_buffer_rsrc_t rK = F8 ? __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(K8p), 0, (int)0x80000000u, 0x00020000)
+                                         : attn_rsrc(Kp);
+    const __amdgpu_buffer_rsrc_t rV = attn_rsrc(Vp);
     unsigned vk[2], vv[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -500,15 +529,53 @@ __global__ __launch_bounds__(256, 2) void attn64d_kernel(const MudgAttnDesc p, c
         vk[i] = (unsigned)key * (unsigned)p.ldk * 2u + (unsigned)chunk * 16u;
         vv[i] = (unsigned)row * (unsigned)p.ldvt * 2u + (unsigned)chunk * 16u;
     }
+    int kscale_off[2] = {0, 0};      // F8: byte offsets (inside a tile) of this lane's K scales for sub-tiles 0 / 1
+    if constexpr (F8) {
+        const int row = 16 * wave + (lane >> 2), slot = lane & 3;
+        const int chunk = slot ^ ((row >> 2) & 3);
+        const int i16 = row & 15;
+        const int key = (row & ~15) | (i16 & 3) | ((i16 & 8) >> 1) | ((i16 & 4) << 1);
+        vk[0] = (unsigned)key * (unsigned)p.ldk8 + (unsigned)chunk * 16u;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const int r = sub * 32 + l31, j16 = r & 15;
+            const int k = (r & ~15) | (j16 & 3) | ((j16 & 8) >> 1) | ((j16 & 4) << 1);      // the key LDS row r holds
+            kscale_off[sub] = k * p.ldks + hi;
+        }
+    }
     auto request = [&](int kt, int buf) {
-        const int sk = kt * 64 * p.ldk * 2, sv = kt * 128;
+        const int sv = kt * 128;
+        if constexpr (F8) {
+            unsigned char* ks8 = reinterpret_cast<unsigned char*>(Ks);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rK, (attn_lptr_t)(ks8 + buf * 4096 + (16 * wave) * 64), 16, (int)vk[0], kt * 64 * p.ldk8, 0, 0);
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rK, (attn_lptr_t)(Ks + buf * DTILE + (16 * wave + 8 * i) * 64), 16, (int)vk[i], sk, 0, 0);
+            if constexpr (!F8)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rK, (attn_lptr_t)(Ks + buf * DTILE + (16 * wave + 8 * i) * 64), 16, (int)vk[i], kt * 64 * p.ldk * 2, 0, 0);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rV, (attn_lptr_t)(Vs + buf * DTILE + (16 * wave + 8 * i) * 64), 16, (int)vv[i], sv, 0, 0);
         }
     };
     const int sw = (l31 >> 1) & 7;          // read-side swizzle (row bases are multiples of 32)
+    const int sw8 = (l31 >> 2) & 3;         // F8 K tile: 64-byte rows, 4 slots
+    // one (32 keys x 32 queries) score block for both query blocks from K tile `buf`, sub-tile `sub`
+    auto score_block = [&](int buf, int sub, f32x16& s0, f32x16& s1, int kscale) {
+        if constexpr (F8) {
+            const unsigned char* kp = reinterpret_cast<const unsigned char*>(Ks) + buf * 4096 + (sub * 32 + l31) * 64;
+            const u32x4 a = ld16(kp + ((hi ^ sw8) << 4)), b = ld16(kp + (((2 + hi) ^ sw8) << 4));
+            const i32x8 kf = {(int)a[0], (int)a[1], (int)a[2], (int)a[3], (int)b[0], (int)b[1], (int)b[2], (int)b[3]};
+            s0 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(kf, qf8[0], s0, 0, 0, 0, kscale, 0, qsc[0]);
+            s1 = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(kf, qf8[1], s1, 0, 0, 0, kscale, 0, qsc[1]);
+        } else {
+            const h16* kp = Ks + buf * DTILE + (sub * 32 + l31) * 64;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const h16x8 kf = *reinterpret_cast<const h16x8*>(kp + (((ks * 2 + hi) ^ sw) << 3));
+                s0 = MFMA_32x32x16(kf, qf[0][ks], s0);
+                s1 = MFMA_32x32x16(kf, qf[1][ks], s1);
+            }
+        }
+    };
 
     f32x16 o[2][2];
     float m_run[2], l_run[2];
@@ -535,13 +602,7 @@ __global__ __launch_bounds__(256, 2) void attn64d_kernel(const MudgAttnDesc p, c
                 for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) s0[qb][sub][r] = 0.f;
-                const h16* kp = Ks + (sub * 32 + l31) * 64;
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    const h16x8 kf = *reinterpret_cast<const h16x8*>(kp + (((ks * 2 + hi) ^ sw) << 3));
-                    s0[0][sub] = MFMA_32x32x16(kf, qf[0][ks], s0[0][sub]);
-                    s0[1][sub] = MFMA_32x32x16(kf, qf[1][ks], s0[1][sub]);
-                }
+                score_block(0, sub, s0[0][sub], s0[1][sub], F8 ? (int)Ksp[kscale_off[sub]] : 127);
             }
 #pragma unroll
             for (int qb = 0; qb < 2; ++qb) {
@@ -554,9 +615,18 @@ __global__ __launch_bounds__(256, 2) void attn64d_kernel(const MudgAttnDesc p, c
             }
         }
 
+        int ksc[2] = {127, 127};          // F8: this tile's K scales (requested one tile ahead)
+        if constexpr (F8) { ksc[0] = Ksp[kscale_off[0]]; ksc[1] = Ksp[kscale_off[1]]; }
         for (int kt = 0; kt < nkt; ++kt) {
             const int cur = kt & 1;
             if (kt + 1 < nkt) request(kt + 1, cur ^ 1);
+            int ksn[2] = {127, 127};
+            if constexpr (F8) {
+                if (kt + 1 < nkt) {
+                    ksn[0] = Ksp[(int64_t)(kt + 1) * 64 * p.ldks + kscale_off[0]];
+                    ksn[1] = Ksp[(int64_t)(kt + 1) * 64 * p.ldks + kscale_off[1]];
+                }
+            }
 
             f32x16 s[2][2];        // [qb][sub]
 #pragma unroll
@@ -567,14 +637,9 @@ __global__ __launch_bounds__(256, 2) void attn64d_kernel(const MudgAttnDesc p, c
 #pragma unroll
                     for (int r = 0; r < 16; ++r) s[qb][sub][r] = init;
                 }
-                const h16* kp = Ks + cur * DTILE + (sub * 32 + l31) * 64;
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    const h16x8 kf = *reinterpret_cast<const h16x8*>(kp + (((ks * 2 + hi) ^ sw) << 3));
-                    s[0][sub] = MFMA_32x32x16(kf, qf[0][ks], s[0][sub]);
-                    s[1][sub] = MFMA_32x32x16(kf, qf[1][ks], s[1][sub]);
-                }
+                score_block(cur, sub, s[0][sub], s[1][sub], ksc[sub]);
             }
+            if constexpr (F8) { ksc[0] = ksn[0]; ksc[1] = ksn[1]; }
 
             h16x8 pk[2][2][2];     // [qb][sub][jj]
 #pragma unroll
@@ -1106,6 +1171,7 @@ extern "C" int mudg_attention(const MudgAttnDesc* dp, void* stream) {
         else hipLaunchKernelGGL(attn_split_kernel<false>, dim3((unsigned)total), dim3(256), smem, s, d, nqt, (int)total);
     }
 #else
+    MUDG_REQUIRE(!d.Q8 || wide, "mudg_attention: the MX-fp8 score path serves the long self-attention kernel only (Nq >= 512, Nk >= 256)");
     if (wide) {
         const int nqt2 = (d.Nq + 255) / 256;
         const int64_t total2 = (int64_t)nqt2 * d.F * d.heads;
@@ -1115,8 +1181,16 @@ extern "C" int mudg_attention(const MudgAttnDesc* dp, void* stream) {
         if (dma < 0) { const char* e = getenv("MUDG_ATTN_DMA"); dma = e ? atoi(e) : 1; }
         if (lean < 0) { const char* e = getenv("MUDG_ATTN_LEAN"); lean = e ? atoi(e) : 1; }
         const bool dma_ok = dma && d.Nk % 64 == 0 && (int64_t)d.Nk * d.ldk * 2 < (1ll << 31) && (int64_t)64 * d.ldvt * 2 + (int64_t)d.Nk * 2 < (1ll << 31);
-        if (dma_ok && d.q_prescaled && lean) hipLaunchKernelGGL(attn64d_kernel<true>, dim3((unsigned)total2), dim3(256), 0, s, d, nqt2, (int)total2);
-        else if (dma_ok) hipLaunchKernelGGL(attn64d_kernel<false>, dim3((unsigned)total2), dim3(256), 0, s, d, nqt2, (int)total2);
+        if (d.Q8) {
+            MUDG_REQUIRE(dma_ok && d.q_prescaled && d.K8 && d.Qs && d.Ks && !d.accumulate, "mudg_attention: the MX-fp8 score path needs "
+                         "q_prescaled, Nk %% 64 == 0 and all four of Q8 / K8 / Qs / Ks");
+            MUDG_REQUIRE((d.ldq8 & 15) == 0 && (d.ldk8 & 15) == 0 && aligned16(d.Q8) && aligned16(d.K8) && d.ldq8 >= d.heads * 64 &&
+                         d.ldk8 >= d.heads * 64 && d.ldqs >= d.heads * 2 && d.ldks >= d.heads * 2 && (int64_t)d.Nk * d.ldk8 < (1ll << 31),
+                         "mudg_attention: fp8 strides");
+            hipLaunchKernelGGL((attn64d_kernel<true, true>), dim3((unsigned)total2), dim3(256), 0, s, d, nqt2, (int)total2);
+        }
+        else if (dma_ok && d.q_prescaled && lean) hipLaunchKernelGGL((attn64d_kernel<true, false>), dim3((unsigned)total2), dim3(256), 0, s, d, nqt2, (int)total2);
+        else if (dma_ok) hipLaunchKernelGGL((attn64d_kernel<false, false>), dim3((unsigned)total2), dim3(256), 0, s, d, nqt2, (int)total2);
         else hipLaunchKernelGGL(attn64q_kernel, dim3((unsigned)total2), dim3(256), 0, s, d, nqt2, (int)total2);
     } else if (d.K2) {
         hipLaunchKernelGGL(attn_kernel<true>, dim3((unsigned)total), dim3(256), 0, s, d, nqt, (int)total);
@@ -1129,6 +1203,69 @@ extern "C" int mudg_attention(const MudgAttnDesc* dp, void* stream) {
     mudg_prof_end(slot, s, 4.0 * bh * d.Nq * (double)(d.Nk + (d.K2 ? d.Nk2 : 0)) * 64.0,
                   bh * (2.0 * d.Nq + 2.0 * d.Nk / d.kv_div + (d.K2 ? 2.0 * d.Nk2 / d.kv_div2 : 0.0)) * 64.0 * 2.0);
     return rc;
+}
+
+#if MUDG_PLANES == 1
+namespace {
+// One thread per (row, 32-column block): OCP MX e4m3 with an E8M0 block scale.
+__global__ __launch_bounds__(256) void quantize_mxfp8_kernel(const h16* __restrict__ X, int ldx, int64_t rows, int nblk,
+                                                              unsigned char* __restrict__ Y, int ldy, unsigned char* __restrict__ S, int lds) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * nblk) return;
+    const int64_t r = i / nblk;
+    const int b = (int)(i - r * nblk);
+    const h16* src = X + r * ldx + b * 32;
+    float v[32];
+    float amax = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const h16x8 t = as_h16x8(ld16(src + q * 8));
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { v[q * 8 + e] = (float)t[e]; amax = fmaxf(amax, fabsf(v[q * 8 + e])); }
+    }
+    int E = 0;                                   // shared exponent: floor(log2 amax) - emax(e4m3) = ... - 8
+    if (amax > 0.f) {
+        E = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 127 - 8;
+        E = E < -127 ? -127 : (E > 127 ? 127 : E);
+    }
+    const float inv = __uint_as_float((unsigned)(127 - E) << 23);           // 2^-E
+    u32x4 lo, hi4;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        float a[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[e] = fminf(fmaxf(v[q * 4 + e] * inv, -448.f), 448.f);
+        int w = 0;
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(a[0], a[1], w, false);
+        w = __builtin_amdgcn_cvt_pk_fp8_f32(a[2], a[3], w, true);
+        if (q < 4) lo[q] = (unsigned)w; else hi4[q - 4] = (unsigned)w;
+    }
+    unsigned char* dst = Y + r * ldy + b * 32;
+    st16(dst, lo);
+    st16(dst + 16, hi4);
+    S[r * lds + b] = (unsigned char)(E + 127);
+}
+}  // namespace
+#endif
+
+extern "C" int mudg_quantize_mxfp8(const void* X, int ldx, int64_t rows, int cols, void* Y8, int ldy, void* S, int lds, void* stream) {
+#if MUDG_PLANES == 1
+    MUDG_REQUIRE(X && Y8 && S && rows > 0 && cols > 0 && cols % 32 == 0, "mudg_quantize_mxfp8: bad arguments");
+    MUDG_REQUIRE((ldx & 7) == 0 && (ldy & 15) == 0 && ldx >= cols && ldy >= cols && lds >= cols / 32 && aligned16(X) && aligned16(Y8),
+                 "mudg_quantize_mxfp8: strides / alignment");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const int nblk = cols / 32;
+    const int64_t n = rows * nblk;
+    const int slot = mudg_prof_begin(MUDG_FAM_MISC, s);
+    hipLaunchKernelGGL(quantize_mxfp8_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (const h16*)X, ldx, rows, nblk,
+                       (unsigned char*)Y8, ldy, (unsigned char*)S, lds);
+    const int rc = mudg_check_launch("mudg_quantize_mxfp8");
+    mudg_prof_end(slot, s, 0.0, (double)rows * cols * 3.0);
+    return rc;
+#else
+    (void)X; (void)ldx; (void)rows; (void)cols; (void)Y8; (void)ldy; (void)S; (void)lds; (void)stream;
+    MUDG_FAIL(MUDG_EUNSUPPORTED, "mudg_quantize_mxfp8: fp8 scores belong to the 16-bit operand builds");
+#endif
 }
 
 extern "C" int mudg_temporal_attention(const void* QKV, void* O, int B, int T, int HW, int heads,

@@ -29,6 +29,7 @@ from . import packing as pk
 
 import os as _os
 _LEAN_ATTENTION = _os.environ.get("MUDG_ATTN_LEAN", "1") != "0"       # A/B switch, read once
+_FP8_ATTENTION = _os.environ.get("MUDG_ATTN_FP8", "0") == "1"         # opt-in: MX-fp8 scores in the long self-attention
 
 
 class _Ctx:
@@ -132,8 +133,12 @@ def spatial_block(blk, hcur, frames, hw, ctx, last):
     qk = ops.gemm(n1, wqk)
     vt, ldv = _vt_projection(a1.to_v, n1, frames, hw)
     att = ops.empty_rows(frames * hw, c, ops.H16(), hcur.device)
+    fp8 = None
+    if lean and _FP8_ATTENTION and hw >= 512 and hw % 64 == 0:      # BASELINE config 5: Q K^T on the MX-fp8 MFMA
+        q8, s8 = ops.quantize_mxfp8(qk)
+        fp8 = (q8[:, :c], s8[:, :c // 32], q8[:, c:], s8[:, c // 32:])
     ops.attention(qk[:, :c], qk[:, c:], vt, att, frames=frames, heads=heads, nq=hw, nk=hw, ldvt=ldv, svt=c * ldv,
-                  scale=a1.scale, q_prescaled=lean)
+                  scale=a1.scale, q_prescaled=lean, fp8=fp8)
     hcur = _linear(a1.to_out[0], att, residual=hcur, stream=True)
     # text (+ image) cross-attention: two softmaxes, outputs summed (image_cross_attention_scale == 1)
     n2 = _ln(blk.norm2, hcur)

@@ -80,7 +80,10 @@ class AttnDesc(C.Structure):
         ("ldq", C.c_int), ("ldk", C.c_int), ("ldvt", C.c_int), ("ldo", C.c_int),
         ("svt", C.c_int64), ("kv_div", C.c_int), ("scale", C.c_float), ("accumulate", C.c_int),
         ("K2", C.c_void_p), ("Vt2", C.c_void_p), ("Nk2", C.c_int), ("ldk2", C.c_int), ("ldvt2", C.c_int), ("kv_div2", C.c_int),
-        ("svt2", C.c_int64), ("q_prescaled", C.c_int),
+        ("svt2", C.c_int64),
+        ("Q8", C.c_void_p), ("K8", C.c_void_p), ("Qs", C.c_void_p), ("Ks", C.c_void_p),
+        ("ldq8", C.c_int), ("ldk8", C.c_int), ("ldqs", C.c_int), ("ldks", C.c_int),
+        ("q_prescaled", C.c_int),
     ]
 
 
@@ -92,6 +95,7 @@ SIGNATURES = {
     "mudg_last_error": (C.c_char_p, []),
     "mudg_gemm": (_I, [C.POINTER(GemmDesc), _P]),
     "mudg_attention": (_I, [C.POINTER(AttnDesc), _P]),
+    "mudg_quantize_mxfp8": (_I, [_P, _I, _L, _I, _P, _I, _P, _I, _P]),
     "mudg_temporal_attention": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _F, _P]),
     "mudg_groupnorm_ws_floats": (_L, [_I, _I, _I]),
     "mudg_groupnorm": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P, _P]),

@@ -198,11 +198,12 @@ def tconv3(x, w, *, clips, t, hw, cin, out=None, bias=None, residual=None, out_f
 
 # ------------------------------------------------------------------------------------------------ attention
 def attention(q, k, vt, out, *, frames, heads, nq, nk, ldvt=None, svt=None, kv_div=1, scale=0.125, accumulate=False,
-              k2=None, vt2=None, nk2=0, ldvt2=None, svt2=None, kv_div2=1, q_prescaled=False):
+              k2=None, vt2=None, nk2=0, ldvt2=None, svt2=None, kv_div2=1, q_prescaled=False, fp8=None):
     """vt: V^T as [kv batches * heads * 64, keys] rows (row stride = ldvt, batch stride = heads * 64 rows by default).
     k2 / vt2 / nk2: an optional second key / value set with its own softmax whose output is added (the image tokens of
     the text + image cross-attention), in the same launch.  q_prescaled: q already carries scale * log2(e) (folded into
-    the packed q-projection weights); `scale` is then ignored and long self-attention runs its lean softmax."""
+    the packed q-projection weights); `scale` is then ignored and long self-attention runs its lean softmax.
+    fp8 = (q8, qs, k8, ks) from quantize_mxfp8: Q K^T on the MX-fp8 MFMA (long self-attention, needs q_prescaled)."""
     if ldvt is None:
         ldvt = vt.stride(0)
     if svt is None:
@@ -214,6 +215,10 @@ def attention(q, k, vt, out, *, frames, heads, nq, nk, ldvt=None, svt=None, kv_d
     d.ldq, d.ldk, d.ldvt, d.ldo = q.stride(0), k.stride(0), ldvt, out.stride(0)
     d.svt, d.kv_div, d.scale, d.accumulate = svt, kv_div, scale, int(accumulate)
     d.q_prescaled = int(q_prescaled)
+    if fp8 is not None:
+        q8, qs, k8, ks = fp8
+        d.Q8, d.Qs, d.K8, d.Ks = q8.data_ptr(), qs.data_ptr(), k8.data_ptr(), ks.data_ptr()
+        d.ldq8, d.ldqs, d.ldk8, d.ldks = q8.stride(0), qs.stride(0), k8.stride(0), ks.stride(0)
     if k2 is not None:
         d.K2, d.Vt2, d.Nk2, d.ldk2 = k2.data_ptr(), vt2.data_ptr(), nk2, k2.stride(0)
         d.ldvt2 = vt2.stride(0) if ldvt2 is None else ldvt2
@@ -221,6 +226,18 @@ def attention(q, k, vt, out, *, frames, heads, nq, nk, ldvt=None, svt=None, kv_d
         d.kv_div2 = kv_div2
     hip.check(hip.lib().mudg_attention(C.byref(d), _stream()), "mudg_attention")
     return out
+
+
+def quantize_mxfp8(x):
+    """Operand rows [rows, cols] (cols % 32 == 0) -> (e4m3 bytes [rows, cols] uint8, E8M0 scales [rows, cols / 32] uint8):
+    OCP microscaling, one power-of-two scale per 32 consecutive columns (mudg_quantize_mxfp8)."""
+    _rows(x)
+    rows, cols = x.shape
+    y = torch.empty((rows, cols), dtype=torch.uint8, device=x.device)
+    sc = torch.empty((rows, cols // 32), dtype=torch.uint8, device=x.device)
+    hip.check(hip.lib().mudg_quantize_mxfp8(x.data_ptr(), x.stride(0), rows, cols, y.data_ptr(), y.stride(0), sc.data_ptr(),
+                                            sc.stride(0), _stream()), "mudg_quantize_mxfp8")
+    return y, sc
 
 
 def temporal_attention(qkv, out, *, clips, t, hw, heads, scale=0.125):

@@ -349,3 +349,37 @@ def test_attention_lean_softmax_with_prescaled_q(cuda, spread):
         ops.attention(q, k2, vt, out, frames=frames, heads=heads, nq=n, nk=n, q_prescaled=True)
         assert torch.isfinite(value(out)).all()
         assert rel(value(out), _attention_ref(qv, k2v, vv, frames, heads, n, n, math.log(2.0))) < 2 * TOL_OP
+
+
+@pytest.mark.skipif(_hip.planes() > 1, reason="fp8 scores belong to the 16-bit builds")
+def test_mxfp8_quantiser_and_fp8_score_attention(cuda):
+    """BASELINE config 5's kernel: OCP MX-fp8 quantisation (e4m3 + one E8M0 scale per 32 dims) checked against a numpy-style
+    restatement, and the long self-attention with Q K^T on the fp8 MFMA against the fp64 softmax of the DEQUANTISED q / k
+    (so the kernel's arithmetic is what is measured; the quantisation error itself is printed against the bf16 inputs)."""
+    import math
+    from mudg_amd import ops
+    frames, heads, n = 2, 2, 640
+    c = heads * 64
+    cl2 = 0.125 * math.log2(math.e)
+    qk_src = torch.cat([f32(frames * n, c, seed=1) * cl2, f32(frames * n, c, seed=2)], 1)
+    qk, qkv = operand(qk_src, cuda)
+    y8, s8 = ops.quantize_mxfp8(qk)
+    # restatement: block amax -> shared exponent floor(log2 amax) - 8 -> e4m3 round-to-nearest-even of x / 2^E, saturating
+    blocks = qkv.reshape(frames * n, -1, 32)
+    amax = blocks.abs().amax(-1)
+    E = torch.where(amax > 0, torch.floor(torch.log2(amax.clamp_min(1e-300))) - 8, torch.zeros_like(amax))
+    assert torch.equal(s8.cpu().to(torch.int64), (E + 127).to(torch.int64).reshape(frames * n, -1))
+    want = (blocks / torch.pow(2.0, E)[..., None]).clamp(-448, 448).float().to(torch.float8_e4m3fn).float().reshape(frames * n, -1)
+    got = y8.cpu().view(torch.float8_e4m3fn).float()
+    assert torch.equal(got, want)
+    deq = (got.reshape(frames * n, -1, 32).double() * torch.pow(2.0, E)[..., None]).reshape(frames * n, -1)
+    print(f"MX-fp8 quantisation error of q|k: rel-L2 {rel(deq, qkv):.3e}")
+    _, vv = operand(f32(frames * n, c, seed=3), cuda)
+    vt = _vt(vv, frames, n, c, cuda)
+    out = ops.empty_rows(frames * n, c, None, cuda)
+    fp8 = (y8[:, :c], s8[:, :c // 32], y8[:, c:], s8[:, c // 32:])
+    ops.attention(qk[:, :c], qk[:, c:], vt, out, frames=frames, heads=heads, nq=n, nk=n, q_prescaled=True, fp8=fp8)
+    ref = _attention_ref(deq[:, :c], deq[:, c:], vv, frames, heads, n, n, math.log(2.0))
+    assert rel(value(out), ref) < 2 * TOL_OP
+    exact = _attention_ref(qkv[:, :c], qkv[:, c:], vv, frames, heads, n, n, math.log(2.0))
+    print(f"fp8-score attention vs exact attention on the bf16 q / k: rel-L2 {rel(value(out), exact):.3e}")
