@@ -100,17 +100,51 @@ __global__ void copy_rows_kernel(const h16* __restrict__ src, int64_t lds, h16* 
     }
 }
 
-// dst[r][c] = src[r][c] between operand (h16 planes) and fp32 rows matrices, any direction.
-template <typename ST, typename DT>
+// dst[r][c] = src[r][c] between rows matrices of any storage kind, any direction.  VEC: 8 consecutive columns per thread
+// with 16-byte accesses (cols, both row strides and both bases 8-element aligned).
+template <typename T> struct Row8;
+template <> struct Row8<h16> {
+    static __device__ __forceinline__ void get(const h16* p, int64_t ld, float (&v)[8]) { load8_operand(p, ld / PLANES, v); }
+    static __device__ __forceinline__ void put(h16* p, int64_t ld, const float (&v)[8]) { store8_operand(p, ld / PLANES, v); }
+};
+template <> struct Row8<float> {
+    static __device__ __forceinline__ void get(const float* p, int64_t, float (&v)[8]) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = b[e]; }
+    }
+    static __device__ __forceinline__ void put(float* p, int64_t, const float (&v)[8]) {
+        f32x4 a, b;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a[e] = v[e]; b[e] = v[4 + e]; }
+        *reinterpret_cast<f32x4*>(p) = a;
+        *reinterpret_cast<f32x4*>(p + 4) = b;
+    }
+};
+template <> struct Row8<StreamH> {
+    static __device__ __forceinline__ void get(const StreamH* p, int64_t, float (&v)[8]) { load8_f16(reinterpret_cast<const _Float16*>(p), v); }
+    static __device__ __forceinline__ void put(StreamH* p, int64_t, const float (&v)[8]) { store8_f16(reinterpret_cast<_Float16*>(p), v); }
+};
+
+template <typename ST, typename DT, bool VEC>
 __global__ void cast_rows_kernel(const ST* __restrict__ src, int64_t lds, DT* __restrict__ dst, int64_t ldd, int64_t rows,
                                  int64_t cols) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rows * cols) return;
-    const int64_t r = i / cols, c = i - r * cols;
-    const float v = row_value(src + r * lds + c, (int)lds);
-    if constexpr (sizeof(DT) == 4) dst[r * ldd + c] = v;
-    else if constexpr (__is_same(DT, StreamH)) dst[r * ldd + c].v = (_Float16)v;
-    else store1_operand(dst + r * ldd + c, ldd / PLANES, v);
+    if constexpr (VEC) {
+        const int64_t cv = cols >> 3;
+        if (i >= rows * cv) return;
+        const int64_t r = i / cv, c = (i - r * cv) << 3;
+        float v[8];
+        Row8<ST>::get(src + r * lds + c, lds, v);
+        Row8<DT>::put(dst + r * ldd + c, ldd, v);
+    } else {
+        if (i >= rows * cols) return;
+        const int64_t r = i / cols, c = i - r * cols;
+        const float v = row_value(src + r * lds + c, (int)lds);
+        if constexpr (sizeof(DT) == 4) dst[r * ldd + c] = v;
+        else if constexpr (__is_same(DT, StreamH)) dst[r * ldd + c].v = (_Float16)v;
+        else store1_operand(dst + r * ldd + c, ldd / PLANES, v);
+    }
 }
 
 __global__ void cast_kernel(const float* __restrict__ src, h16* __restrict__ dst, int64_t n8, int64_t n) {
@@ -298,12 +332,24 @@ extern "C" int mudg_zero_channels(void* dst, int rows, int ld, int c0, int c1, v
     return mudg_check_launch("mudg_zero_channels");
 }
 
+template <typename ST, typename DT>
+static void launch_cast_rows2(const ST* src, int64_t lds, DT* dst, int64_t ldd, int64_t rows, int64_t cols, hipStream_t s) {
+    const int sg = __is_same(ST, h16) ? 8 * PLANES : 8, dg = __is_same(DT, h16) ? 8 * PLANES : 8;      // row-stride granules
+    const bool vec = (cols & 7) == 0 && lds % sg == 0 && ldd % dg == 0 && aligned16(src) && aligned16(dst);
+    if (vec) {
+        const dim3 grid((unsigned)((rows * (cols >> 3) + 255) / 256));
+        hipLaunchKernelGGL((cast_rows_kernel<ST, DT, true>), grid, dim3(256), 0, s, src, lds, dst, ldd, rows, cols);
+    } else {
+        const dim3 grid((unsigned)((rows * cols + 255) / 256));
+        hipLaunchKernelGGL((cast_rows_kernel<ST, DT, false>), grid, dim3(256), 0, s, src, lds, dst, ldd, rows, cols);
+    }
+}
+
 template <typename ST>
 static void launch_cast_rows(const ST* src, int64_t lds, void* dst, int dst_kind, int64_t ldd, int64_t rows, int64_t cols, hipStream_t s) {
-    const dim3 grid((unsigned)((rows * cols + 255) / 256));
-    if (dst_kind == KIND_F32) hipLaunchKernelGGL((cast_rows_kernel<ST, float>), grid, dim3(256), 0, s, src, lds, (float*)dst, ldd, rows, cols);
-    else if (dst_kind == KIND_F16) hipLaunchKernelGGL((cast_rows_kernel<ST, StreamH>), grid, dim3(256), 0, s, src, lds, (StreamH*)dst, ldd, rows, cols);
-    else hipLaunchKernelGGL((cast_rows_kernel<ST, h16>), grid, dim3(256), 0, s, src, lds, (h16*)dst, ldd, rows, cols);
+    if (dst_kind == KIND_F32) launch_cast_rows2(src, lds, (float*)dst, ldd, rows, cols, s);
+    else if (dst_kind == KIND_F16) launch_cast_rows2(src, lds, (StreamH*)dst, ldd, rows, cols, s);
+    else launch_cast_rows2(src, lds, (h16*)dst, ldd, rows, cols, s);
 }
 
 extern "C" int mudg_cast_rows(const void* src, int src_fp32, int64_t lds, void* dst, int dst_fp32, int64_t ldd, int64_t rows,

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round evidence on the GPU box: kernel trace, PMC passes, bench lines -> gpurun_out/<round>/ (copy to profiles/<round>/).
-#   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh r1'
+#   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh r2 [cpufull]'
 R=${1:-r1}
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/$R
@@ -11,6 +11,18 @@ python bench.py > $OUT/bench_n1.raw 2> $OUT/bench_n1.err; tail -1 $OUT/bench_n1.
 python bench.py --no-cpu-baseline --resolution 512 2>/dev/null | tail -1 > $OUT/bench_m512.json
 python bench.py --no-cpu-baseline --batch 3 --steps 4 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_b3.json
 python bench.py --no-cpu-baseline --operand fp16 2>/dev/null | tail -1 > $OUT/bench_fp16.json
+# the cost of exactness: the split-operand precision modes (the ones that meet the 1e-3 decoded-frame tolerance)
+python bench.py --no-cpu-baseline --operand bf16x3 --steps 4 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_bf16x3.json
+python bench.py --no-cpu-baseline --operand bf16x6 --steps 3 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_bf16x6.json
+# BASELINE config 5: MX-fp8 scores in the long self-attention
+MUDG_ATTN_FP8=1 python bench.py --no-cpu-baseline 2>/dev/null | tail -1 > $OUT/bench_fp8attn.json
+# the CPU baseline as a measurement: one full MDM512 oracle forward on this host
+if [ "$2" = "cpufull" ]; then
+  python bench.py --steps 3 --warmup 1 --cpu-baseline full --no-decode 2>/dev/null | tail -1 | python -c "
+import json, sys
+d = json.loads(sys.stdin.read())['cpu_baseline']
+json.dump({'tflops': d['tflops'], 'cores': d['cores'], 'seconds': d['seconds'], 'sample': d['sample']}, open('$OUT/cpu_baseline_full.json', 'w'), indent=1)"
+fi
 rocprofv3 --kernel-trace --stats -d /tmp/pt -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile > /tmp/pt.log 2>&1
 python tools/rocprof_summary.py trace $(find /tmp/pt -name "*.db" | head -1) > $OUT/kernel_trace.md
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pf -- python bench.py --steps 1 --warmup 0 --no-graph --no-cpu-baseline --no-profile --no-decode > /tmp/pf.log 2>&1
