@@ -36,6 +36,9 @@ def main():
         w = write.get(fam, {"kib": 0.0, "launches": f["launches"]})
         n = f["launches"]
         rec["families"][fam] = {"kernels": sorted(set(f["kernels"])), "launches": n,
+                                # the traced run is ONE step (plus its one-off cross-attention K / V projections, which are
+                                # small): bench.py divides this by the live launches per step
+                                "bytes_per_step": round((2 * f["kib"] + w["kib"]) * 1024),
                                 "fetch_bytes_per_launch": round(2 * f["kib"] * 1024 / n),
                                 "write_bytes_per_launch": round(w["kib"] * 1024 / n),
                                 "bytes_per_launch": round((2 * f["kib"] + w["kib"]) * 1024 / n)}
