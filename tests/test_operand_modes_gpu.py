@@ -352,6 +352,8 @@ def test_attention_lean_softmax_with_prescaled_q(cuda, spread):
 
 
 @pytest.mark.skipif(_hip.planes() > 1, reason="fp8 scores belong to the 16-bit builds")
+@pytest.mark.skipif(__import__("os").environ.get("MUDG_ATTN_Q") == "32" or __import__("os").environ.get("MUDG_ATTN_DMA") == "0",
+                    reason="the fp8 score path lives in the LDS-DMA staged 64-query kernel, which this variant switch turns off")
 def test_mxfp8_quantiser_and_fp8_score_attention(cuda):
     """BASELINE config 5's kernel: OCP MX-fp8 quantisation (e4m3 + one E8M0 scale per 32 dims) checked against a numpy-style
     restatement, and the long self-attention with Q K^T on the fp8 MFMA against the fp64 softmax of the DEQUANTISED q / k
