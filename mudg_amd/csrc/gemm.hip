@@ -89,7 +89,7 @@ __device__ __forceinline__ float gelu_lut(float x, const float* __restrict__ T) 
 
 template <int MODE, bool FAST, bool SB>
 __global__ __launch_bounds__(256, SB ? 4 : 2) void gemm_kernel(const MudgGemmDesc p, const int vflags, const h16* __restrict__ zpage,
-                                                                const float* __restrict__ phi, const int ksplit) {
+                                                                const float* __restrict__ phi) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     h16* Xs = reinterpret_cast<h16*>(smem);
     h16* Ws = Xs + (SB ? 1 : 2) * TILE;
@@ -127,7 +127,6 @@ __global__ __launch_bounds__(256, SB ? 4 : 2) void gemm_kernel(const MudgGemmDes
     }
     const int m0 = tm * BM, n0 = tn * BN;
     const int64_t bz = blockIdx.z;
-    const int64_t ysplit = (int64_t)blockIdx.y * p.M * (int64_t)p.ldy;      // split-K: slice of the fp32 workspace (0 otherwise)
     const h16* X = reinterpret_cast<const h16*>(p.X) + bz * p.sX;
     const h16* X2 = p.X2 ? reinterpret_cast<const h16*>(p.X2) + bz * p.sX : nullptr;
     const h16* W = reinterpret_cast<const h16*>(p.W) + bz * p.sW;
@@ -165,16 +164,6 @@ __global__ __launch_bounds__(256, SB ? 4 : 2) void gemm_kernel(const MudgGemmDes
     int tap_s = 0, c_s = 0;                                      // tap / channel of the next K-tile to issue
     int seg_s = 0, kt_s = 0;                                     // split operands: (x plane, w plane) pass and K-tile inside it
     const int nk = (p.K + BK - 1) / BK;
-    // Split-K (ksplit > 0: K-tiles per slice, blockIdx.y = slice; 16-bit builds, host-selected for problems with too few
-    // tiles to fill the chip): this workgroup contracts K-tiles [kt0, kt1) only and its epilogue — redirected by the host to
-    // raw fp32 partials in a workspace — is followed by splitk_reduce_kernel, which adds the slices in a fixed order.
-    const int kt0 = ksplit > 0 ? (int)blockIdx.y * ksplit : 0;
-    const int kt1 = ksplit > 0 ? (kt0 + ksplit < nk ? kt0 + ksplit : nk) : nk * NSEG;
-    if (ksplit > 0 && FAST) {
-        if (MODE == 0) c_s = kt0 * BK;
-        else if (MODE == 1 && p.korder) { tap_s = kt0 % 9; c_s = (kt0 / 9) * 64; }
-        else { tap_s = (kt0 * BK) / p.Cin; c_s = kt0 * BK - tap_s * p.Cin; }
-    }
     if constexpr (FAST) {
         int64_t pix0 = m0;                                       // source pixel (row of X) of output row m0, before the tap shift
         if (MODE == 1) {
@@ -317,7 +306,7 @@ __global__ __launch_bounds__(256, SB ? 4 : 2) void gemm_kernel(const MudgGemmDes
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    (void)0;
+    const int nkt = nk * NSEG;           // K-tiles over all (x plane, w plane) passes
     const int sw = (l31 >> 1) & 7;       // read-side swizzle: the row bases are multiples of 32, so only lane bits count
     // A wave whose 64 output columns (or rows) all lie beyond N (M) has nothing to multiply: it still stages its share
     // of the operand tiles but leaves its SIMD's MFMA pipe to the other resident workgroups (N = 320: 1/6 of the waves).
@@ -342,18 +331,18 @@ __global__ __launch_bounds__(256, SB ? 4 : 2) void gemm_kernel(const MudgGemmDes
         }
     };
     if constexpr (SB) {
-        for (int kt = kt0; kt < kt1; ++kt) {
+        for (int kt = 0; kt < nkt; ++kt) {
             issue_tiles(kt, 0);
             __syncthreads();                 // vmcnt(0) + barrier: the tile has landed
             multiply(0);
             __syncthreads();                 // every wave is done reading before the next fetch overwrites the buffer
         }
     } else {
-        issue_tiles(kt0, 0);
+        issue_tiles(0, 0);
         __syncthreads();                     // drains the DMA (vmcnt(0)) before anyone reads the tile
-        for (int kt = kt0; kt < kt1; ++kt) {
-            const int cur = (kt - kt0) & 1;
-            if (kt + 1 < kt1) issue_tiles(kt + 1, cur ^ 1);
+        for (int kt = 0; kt < nkt; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < nkt) issue_tiles(kt + 1, cur ^ 1);
             multiply(cur);
             __syncthreads();
         }
@@ -484,7 +473,7 @@ __global__ __launch_bounds__(256, SB ? 4 : 2) void gemm_kernel(const MudgGemmDes
                 for (int j = 0; j < 8; ++j) if (j < nvalid) yp[j] = (_Float16)v[j];
             }
         } else if (p.out_fp32) {
-            float* yp = reinterpret_cast<float*>(p.Y) + bz * p.sY + ysplit + (int64_t)m * p.ldy + n;
+            float* yp = reinterpret_cast<float*>(p.Y) + bz * p.sY + (int64_t)m * p.ldy + n;
             if (nvalid == 8 && (vflags & VF_Y)) {
                 f32x4 a, b;
 #pragma unroll
