@@ -405,11 +405,15 @@ __global__ __launch_bounds__(256, SB ? 4 : 2) void gemm_kernel(const MudgGemmDes
     }
     __syncthreads();
 
-    for (int c = tid; c < PROWS * cpr; c += 256) {
-        const int row = c / cpr, cc = c - row * cpr;
-        const int m = m0 + pass * PROWS + row, n = nout0 + cc * 8;
-        if (m >= p.M || n >= Nout) continue;
-        const int nvalid = (Nout - n) < 8 ? (Nout - n) : 8;
+    // cpr is 16 (or 8 with GEGLU): a thread keeps ONE 8-channel chunk (tid & (cpr - 1)) and walks rows 256 / cpr apart — no
+    // per-chunk division / modulo (the short-K GEMMs spent 8-12 VALU instructions per MFMA, most of them here)
+    const int cshift = p.geglu ? 3 : 4;
+    const int cc = tid & (cpr - 1);
+    const int n = nout0 + cc * 8;
+    const int nvalid = n >= Nout ? 0 : ((Nout - n) < 8 ? (Nout - n) : 8);
+    for (int row = tid >> cshift; row < PROWS; row += (256 >> cshift)) {
+        const int m = m0 + pass * PROWS + row;
+        if (m >= p.M || nvalid == 0) break;
         float v[8];
         {
             const f32x4 a = *reinterpret_cast<const f32x4*>(&stg[row * STGLD + cc * 8]);
