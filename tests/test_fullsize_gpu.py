@@ -184,17 +184,18 @@ def test_config0_two_ddim_steps_and_decode_at_mdm512_match_the_cpu_oracle(cuda, 
     from oracle import ddim as o_ddim, schedule as o_sched, unet as o_unet, vae as o_vae
     model = factory.build_synthetic_model("512", cuda, seed=7)
     inp = factory.synthetic_inputs(model, "512", 1, cuda, seed=31)
+    steps = int(os.environ.get("MUDG_CONFIG0_STEPS", "2"))          # 2 = the config as stated; more = error growth at full size
     g = torch.Generator(device=cuda).manual_seed(5)
-    noises = [torch.randn(inp["x_T"].shape, generator=g, device=cuda) for _ in range(2)]
+    noises = [torch.randn(inp["x_T"].shape, generator=g, device=cuda) for _ in range(steps)]
     it = iter(noises)
     monkeypatch.setattr(my_ddim, "noise_like", lambda shape, device, repeat=False: next(it))
     sampler = my_ddim.DDIMSampler(model)
-    samples, _ = sampler.sample(S=2, conditioning=inp["cond"], batch_size=1, shape=list(inp["x_T"].shape[1:]), verbose=False,
+    samples, _ = sampler.sample(S=steps, conditioning=inp["cond"], batch_size=1, shape=list(inp["x_T"].shape[1:]), verbose=False,
                                 unconditional_guidance_scale=7.5, unconditional_conditioning=inp["uc"], eta=1.0, mask=None, x0=None,
                                 fs=inp["fs"], x_T=inp["x_T"], timestep_spacing="uniform_trailing", guidance_rescale=0.7,
                                 sparse_x=inp["sparse_x"], class_label=inp["class_label"], cfg_img=None,
                                 unconditional_conditioning_img_nonetext=None)
-    assert list(sampler.ddim_timesteps) == [499, 999]
+    assert steps != 2 or list(sampler.ddim_timesteps) == [499, 999]
     decoded = model.decode_first_stage(samples)
     # ---- the same run on the CPU oracle
     t0 = time.perf_counter()
@@ -206,12 +207,12 @@ def test_config0_two_ddim_steps_and_decode_at_mdm512_match_the_cpu_oracle(cuda, 
     concat, lab, fs = inp["cond"]["c_concat"][0].cpu(), inp["class_label"][:, 0].cpu(), inp["fs"].cpu()
     apply_model = lambda x, t, ctx: o_unet.unet_forward(usd, dict(configs.UNET_MDM), torch.cat([x, concat], 1), t, lab, ctx, fs, head_chunk=8)
     want = o_ddim.ddim_sample(apply_model, sched, inp["x_T"].cpu(), inp["cond"]["c_crossattn"][0].cpu(), inp["uc"]["c_crossattn"][0].cpu(),
-                              2, [n.cpu() for n in noises], 1.0, 7.5, 0.7, "uniform_trailing")
+                              steps, [n.cpu() for n in noises], 1.0, 7.5, 0.7, "uniform_trailing")
     want_dec = o_vae.decode_first_stage(vsd, configs.VAE_DDCONFIG, want, kw["scale_factor"])
     dt = time.perf_counter() - t0
     rel = lambda a, b: ((a.double().cpu() - b.double()).norm() / b.double().norm()).item()
     e_s, e_d = rel(samples, want), rel(decoded, want_dec)
-    print(f"[{hip.operand_name()}] config 0 at full size (MDM512, 2 DDIM steps + 16-frame decode) vs CPU oracle: latents {e_s:.3e}  "
+    print(f"[{hip.operand_name()}] config 0 at full size (MDM512, {steps} DDIM steps + 16-frame decode) vs CPU oracle: latents {e_s:.3e}  "
           f"decoded frames {e_d:.3e}; oracle {dt:.0f} s on {torch.get_num_threads()} threads")
     assert decoded.shape == (1, 3, 16, 320, 512) and torch.isfinite(decoded).all()
     if hip.operand_name() in ("bf16x3", "bf16x6"):
