@@ -23,54 +23,62 @@ def get_latent_z(model, videos):
     return z.reshape(b, t, *z.shape[1:]).permute(0, 2, 1, 3, 4)
 
 
+class GuidanceInputs:
+    """Everything the guided sampler needs for one batch of modality streams, built once: the conditional dict, the
+    unconditional dict (empty prompt + tokens of an all-zero image) and — for three-way guidance — the image-only dict
+    (empty prompt + the real image tokens).  All of them share the channel-concat conditioning (the VAE latents of the
+    sparse colour and sparse depth renderings); the dict layout is the one LatentDiffusion.apply_model / DiffusionWrapper
+    consume ({"c_crossattn": [tokens], "c_concat": [latents]}, virtual_pose_render.py:75-112 in the reference)."""
+
+    def __init__(self, model, prompts, sparse_x, sparse_depth, guided, three_way):
+        self.batch = sparse_x.shape[0]
+        key_frame = sparse_x[:, :, 0]                                      # the conditioning image of every stream
+        tokens = lambda image: model.image_proj_model(model.embedder(image))          # CLIP tower -> Resampler, (b, 16 t, d)
+        text = model.get_learned_conditioning(prompts)                     # (b, 77, d)
+        image_tokens = tokens(key_frame)
+        self.hybrid = model.model.conditioning_key == "hybrid"
+        self.concat = None
+        self.sparse_z = None
+        if self.hybrid:
+            self.sparse_z = get_latent_z(model, sparse_x)
+            self.concat = torch.cat([self.sparse_z, get_latent_z(model, sparse_depth)], dim=1)
+        self.cond = self._entry(text, image_tokens)
+        self.uncond = self.image_only = None
+        if guided:
+            blank = model.get_learned_conditioning(self.batch * [""]) if model.uncond_type == "empty_seq" else torch.zeros_like(text)
+            self.uncond = self._entry(blank, tokens(torch.zeros_like(key_frame)))
+            if three_way:
+                self.image_only = self._entry(blank, image_tokens)
+
+    def _entry(self, text, image_tokens):
+        entry = {"c_crossattn": [torch.cat([text, image_tokens], dim=1)]}
+        if self.hybrid:
+            entry["c_concat"] = [self.concat]
+        return entry
+
+
 def image_guided_synthesis(model, prompts, sparse_x, sparse_depth, class_label, noise_shape, n_samples=1, ddim_steps=50,
                            ddim_eta=1., unconditional_guidance_scale=1.0, cfg_img=None, fs=None, text_input=False,
                            multiple_cond_cfg=False, timestep_spacing="uniform", guidance_rescale=0.0, **kwargs):
-    sampler = DDIMSampler(model) if not multiple_cond_cfg else DDIMSampler_multicond(model)
-    batch_size = sparse_x.shape[0]
-    fs = torch.tensor([fs] * batch_size, dtype=torch.long, device=model.device)
-    if not text_input:
-        prompts = [""] * batch_size
-
-    img = sparse_x[:, :, 0]                                   # conditioning frame, (b, c, h, w)
-    img_emb = model.image_proj_model(model.embedder(img))     # (b, 16 t, d)
-    cond_emb = model.get_learned_conditioning(prompts)        # (b, 77, d)
-    cond = {"c_crossattn": [torch.cat([cond_emb, img_emb], dim=1)]}
-    hybrid = model.model.conditioning_key == "hybrid"
-    if hybrid:
-        sparse_z = get_latent_z(model, sparse_x)
-        sparse_depth_z = get_latent_z(model, sparse_depth)
-        kwargs.update({"sparse_x": sparse_z, "class_label": class_label})
-        img_cat_cond = torch.cat([sparse_z, sparse_depth_z], dim=1)
-        cond["c_concat"] = [img_cat_cond]
-
-    uc = None
-    if unconditional_guidance_scale != 1.0:
-        if model.uncond_type == "empty_seq":
-            uc_emb = model.get_learned_conditioning(batch_size * [""])
-        else:
-            uc_emb = torch.zeros_like(cond_emb)
-        uc_img_emb = model.image_proj_model(model.embedder(torch.zeros_like(img)))
-        uc = {"c_crossattn": [torch.cat([uc_emb, uc_img_emb], dim=1)]}
-        if hybrid:
-            uc["c_concat"] = [img_cat_cond]
-    if multiple_cond_cfg and cfg_img != 1.0:
-        uc_2 = {"c_crossattn": [torch.cat([uc_emb, img_emb], dim=1)]}
-        if hybrid:
-            uc_2["c_concat"] = [img_cat_cond]
-        kwargs.update({"unconditional_conditioning_img_nonetext": uc_2})
-    else:
-        kwargs.update({"unconditional_conditioning_img_nonetext": None})
-
+    """Same signature and return value as the reference's function (virtual_pose_render.py:62-147): guided DDIM sampling
+    of `n_samples` variants for a batch of modality streams, decoded to pixels, (batch, variants, c, t, h, w)."""
+    batch = sparse_x.shape[0]
+    guided = unconditional_guidance_scale != 1.0
+    three_way = bool(multiple_cond_cfg) and cfg_img != 1.0
+    inputs = GuidanceInputs(model, prompts if text_input else [""] * batch, sparse_x, sparse_depth, guided, three_way)
+    sampler = (DDIMSampler_multicond if multiple_cond_cfg else DDIMSampler)(model)
+    extra = dict(kwargs, unconditional_conditioning_img_nonetext=inputs.image_only)
+    if inputs.hybrid:
+        extra.update(sparse_x=inputs.sparse_z, class_label=class_label)
+    frame_rate = torch.tensor([fs] * batch, dtype=torch.long, device=model.device)
     variants = []
     for _ in range(n_samples):
-        samples, _ = sampler.sample(S=ddim_steps, conditioning=cond, batch_size=batch_size, shape=noise_shape[1:],
+        latents, _ = sampler.sample(S=ddim_steps, conditioning=inputs.cond, batch_size=batch, shape=noise_shape[1:],
                                     verbose=False, unconditional_guidance_scale=unconditional_guidance_scale,
-                                    unconditional_conditioning=uc, eta=ddim_eta, cfg_img=cfg_img, mask=None, x0=None,
-                                    fs=fs, timestep_spacing=timestep_spacing, guidance_rescale=guidance_rescale,
-                                    **kwargs)
-        variants.append(model.decode_first_stage(samples))
-    return torch.stack(variants).permute(1, 0, 2, 3, 4, 5)    # (batch, variants, c, t, h, w)
+                                    unconditional_conditioning=inputs.uncond, eta=ddim_eta, cfg_img=cfg_img, mask=None, x0=None,
+                                    fs=frame_rate, timestep_spacing=timestep_spacing, guidance_rescale=guidance_rescale, **extra)
+        variants.append(model.decode_first_stage(latents))
+    return torch.stack(variants).permute(1, 0, 2, 3, 4, 5)
 
 
 def synthesize_windows(model, windows, noise_shape, video_length=16, **synthesis_kwargs):
