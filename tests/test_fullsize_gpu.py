@@ -138,21 +138,13 @@ def test_guided_ddim_steps_are_clip_independent_at_mdm1024(big):
         assert rel < 1e-6, (i, rel)
 
 
-def test_mdm512_unet_forward_matches_the_cpu_oracle_at_full_size(big):
-    """Full-size NUMERICAL parity (not a property): one UNet forward of the real 1.44 B-parameter topology at MDM512
-    (latents (1, 12, 16, 40, 64), context (1, 333, 1024); 12.6 TFLOP) on the HIP path against the CPU oracle on the GPU
-    box's host cores (fp32 eager, about a minute on the 128-thread host).  Same bound as the small-topology UNet tests:
-    the operand mode's per-forward floor.  MUDG_SKIP_FULLSIZE_ORACLE=1 skips it."""
-    import os
+def _forward_vs_oracle(model, res, seed):
     import time
-    if os.environ.get("MUDG_SKIP_FULLSIZE_ORACLE") == "1":
-        pytest.skip("MUDG_SKIP_FULLSIZE_ORACLE=1")
     from mudg_amd import configs, factory, hip
     from oracle import unet as o_unet
-    model, _ = big
     unet = model.model.diffusion_model
     dev = next(unet.parameters()).device
-    inp = factory.synthetic_inputs(model, "512", 1, dev, seed=21)
+    inp = factory.synthetic_inputs(model, res, 1, dev, seed=seed)
     x = torch.cat([inp["x_T"], inp["cond"]["c_concat"][0]], dim=1)
     ts = torch.full((1,), 499, device=dev, dtype=torch.long)
     lab, fs, ctx = inp["class_label"][:, 0], inp["fs"], inp["cond"]["c_crossattn"][0]
@@ -164,9 +156,30 @@ def test_mdm512_unet_forward_matches_the_cpu_oracle_at_full_size(big):
     dt = time.perf_counter() - t0
     err = ((got - want).double().norm() / want.double().norm()).item()
     tol = {"bf16": 2.5e-2, "fp16": 4e-3, "bf16x3": 2e-4, "bf16x6": 2e-5}[hip.operand_name()]
-    print(f"[{hip.operand_name()}] MDM512 full-size UNet forward vs CPU oracle: rel-L2 {err:.3e} (bound {tol:g}); oracle "
-          f"{dt:.1f} s on {torch.get_num_threads()} threads = {configs.UNET_TFLOP['512'] / dt:.3f} TFLOP/s")
-    assert got.shape == want.shape == (1, 4, 16, 40, 64) and err < tol
+    print(f"[{hip.operand_name()}] MDM{res} full-size UNet forward vs CPU oracle: rel-L2 {err:.3e} (bound {tol:g}); oracle "
+          f"{dt:.1f} s on {torch.get_num_threads()} threads = {configs.UNET_TFLOP[res] / dt:.3f} TFLOP/s")
+    assert got.shape == want.shape and err < tol
+
+
+def test_mdm512_unet_forward_matches_the_cpu_oracle_at_full_size(big):
+    """Full-size NUMERICAL parity (not a property): one UNet forward of the real 1.44 B-parameter topology at MDM512
+    (latents (1, 12, 16, 40, 64), context (1, 333, 1024); 12.6 TFLOP) on the HIP path against the CPU oracle on the GPU
+    box's host cores (fp32 eager, about a minute on the 128-thread host).  Same bound as the small-topology UNet tests:
+    the operand mode's per-forward floor.  MUDG_SKIP_FULLSIZE_ORACLE=1 skips it."""
+    import os
+    if os.environ.get("MUDG_SKIP_FULLSIZE_ORACLE") == "1":
+        pytest.skip("MUDG_SKIP_FULLSIZE_ORACLE=1")
+    _forward_vs_oracle(big[0], "512", 21)
+
+
+def test_mdm1024_unet_forward_matches_the_cpu_oracle_at_the_benchmark_size(big):
+    """The same at the benchmarked configuration itself — MDM1024, latents (1, 12, 16, 72, 128), 52.3 TFLOP: the oracle's
+    einsum attention is chunked over (frame, head) pairs to keep its 9216 x 9216 score tensors at 2.7 GB; about four
+    minutes of host time.  OPT-IN (MUDG_RUN_MDM1024_ORACLE=1); the log of a run is kept under profiles/."""
+    import os
+    if os.environ.get("MUDG_RUN_MDM1024_ORACLE") != "1":
+        pytest.skip("opt-in: MUDG_RUN_MDM1024_ORACLE=1 (four minutes of CPU oracle)")
+    _forward_vs_oracle(big[0], "1024", 23)
 
 
 def test_config0_two_ddim_steps_and_decode_at_mdm512_match_the_cpu_oracle(cuda, monkeypatch):
