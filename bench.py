@@ -100,6 +100,15 @@ def cpu_baseline(model, inputs, resolution, mode):
                                                    "steps_per_s_at_this_config": rec["tflops"] / full}
         except Exception:
             pass
+    rec1024 = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "cpu_baseline_mdm1024.json")))
+    if rec1024 and resolution == "1024":
+        try:
+            with open(rec1024[-1]) as f:
+                rec = json.load(f)
+            out["recorded_full_mdm1024_forward"] = {"file": os.path.relpath(rec1024[-1], ROOT), "tflops": rec["tflops"], "cores": rec["cores"],
+                                                    "seconds": rec["seconds"], "steps_per_s_at_this_config": rec["tflops"] / full}
+        except Exception:
+            pass
     out["seconds"] = dt
     return out
 
