@@ -225,9 +225,12 @@ int mudg_zero_channels(void* dst, int rows, int ld, int c0, int c1, void* stream
  *   v  = e_u + cfg*(e_c - e_u)                      two-way guidance, or with e_m (image-only conditioning) the
  *        e_u + cfg_img*(e_m - e_u) + cfg*(e_c - e_m) three-way form of ddim_multiplecond.py:226-233;
  *   v = phi*v*std(e_c)/std(v) + (1-phi)*v            (utils_diffusion.py:147-157)
- *   e  = sqrt_ac*v + sqrt_1mac*x ;  x0 = sqrt_ac*x - sqrt_1mac*v          (ddpm3d.py:239-251)
+ *   e  = sqrt_ac*v + sqrt_1mac*x ;  x0 = sqrt_ac*x - sqrt_1mac*v          (v-prediction, ddpm3d.py:239-251; eps_form = 0)
+ *   e  = v ;                        x0 = (x - sqrt_1mac*e) / sqrt_ac      (eps-prediction, ddim.py:227-258; eps_form = 1,
+ *                                                                          sqrt_ac = sqrt(a_t), sqrt_1mac = sqrt(1 - a_t))
  *   x0 *= rescale ;  x_prev = sqrt(a_prev)*x0 + dir_coef*e + sigma*noise
- * host_coef = {cfg, phi, sqrt_ac, sqrt_1mac, rescale, sqrt_a_prev, dir_coef, sigma, cfg_img} (HOST pointer, 9 floats).
+ * host_coef = {cfg, phi, sqrt_ac, sqrt_1mac, rescale, sqrt_a_prev, dir_coef, sigma, cfg_img, eps_form}
+ *             (HOST pointer, 10 floats).
  * ws: fp64 device scratch of mudg_ddim_ws_doubles(B) doubles. e_u may be NULL (no guidance: v = e_c);
  * noise may be NULL (eta = 0). */
 int64_t mudg_ddim_ws_doubles(int B);

@@ -1,18 +1,21 @@
 """DDIM sampler at the drop-in boundary (reference: lvdm/models/samplers/ddim.py, DDIMSampler 10-317).
 
-Same constructor, `make_schedule`, `sample`, `ddim_sampling` and `p_sample_ddim` signatures and return values.
-What differs is where the arithmetic runs: the schedule is derived once on the host (same float64/float32 mix as
-the reference, see utils_diffusion), each step's scalars are kept as host floats instead of 1-element device
-tensors, and the whole per-step update — classifier-free guidance, guidance rescale (per-sample std), v -> (eps, x0),
-dynamic rescale and the x_{t-1} formula — is ONE fused HIP launch (mudg_ddim_step) after the two UNet passes.
-Options MuDG's drivers never use (mask blending, x0 quantisation, score correctors, noise dropout, the full
-1000-step "original steps" mode) raise NotImplementedError instead of falling back to eager PyTorch.
+Same constructor, `make_schedule`, `sample`, `ddim_sampling`, `p_sample_ddim`, `decode` and `stochastic_encode` signatures
+and return values.  What differs is where the arithmetic runs: the schedule is derived once on the host (same
+float64/float32 mix as the reference, see utils_diffusion), each step's scalars are kept as host floats instead of
+1-element device tensors, and the whole per-step update — classifier-free guidance, guidance rescale (per-sample std),
+v or eps -> (eps, x0), dynamic rescale and the x_{t-1} formula — is ONE fused HIP launch (mudg_ddim_step) after the UNet
+passes.  The options MuDG's own drivers leave at their defaults are implemented too, around the same launch: mask
+blending against a (noised) original latent, a `timesteps` prefix of the DDIM schedule, the full-schedule "original
+steps" mode, temperature, noise dropout, eps-parameterised models with an optional score corrector, and x0 quantisation
+for first stages that have a `quantize` method (AutoencoderKL has none — there, as in the reference, it is an
+AttributeError).
 """
 import numpy as np
 import torch
 
 from lvdm.common import noise_like
-from lvdm.models.utils_diffusion import make_ddim_sampling_parameters, make_ddim_timesteps
+from lvdm.models.utils_diffusion import make_ddim_sampling_parameters, make_ddim_timesteps, rescale_noise_cfg
 
 
 class DDIMSampler(object):
@@ -41,7 +44,9 @@ class DDIMSampler(object):
             sa = self.model.scale_arr.detach().float().cpu()[self.ddim_timesteps]
             self.ddim_scale_arr = sa
             self.ddim_scale_arr_prev = torch.cat([sa[0:1], sa[:-1]])
+        prev = self.model.alphas_cumprod_prev.detach().float().cpu()
         self.register_buffer("alphas_cumprod", ac)
+        self.register_buffer("alphas_cumprod_prev", prev)
         self.register_buffer("sqrt_alphas_cumprod", self.model.sqrt_alphas_cumprod.detach().float().cpu())
         self.register_buffer("sqrt_one_minus_alphas_cumprod",
                              self.model.sqrt_one_minus_alphas_cumprod.detach().float().cpu())
@@ -50,22 +55,33 @@ class DDIMSampler(object):
         self.register_buffer("ddim_alphas", alphas)
         self.register_buffer("ddim_alphas_prev", alphas_prev)
         self.register_buffer("ddim_sqrt_one_minus_alphas", torch.sqrt(1. - alphas))
+        # the full-schedule ("original steps") walk has its own sigma table (ddim.py:55-58)
+        self.register_buffer("ddim_sigmas_for_original_num_steps",
+                             ddim_eta * torch.sqrt((1 - prev) / (1 - ac) * (1 - ac / prev)))
 
-    def step_coefficients(self, index, cfg_scale, guidance_rescale, temperature=1.0):
-        """The eight host scalars of mudg_ddim_step for DDIM index `index`, each rounded to fp32 where the reference
-        rounds it (torch.full((b,1,1,1,1), value) of a python/np/tensor scalar, ddim.py:251-254,262-266)."""
+    def step_coefficients(self, index, cfg_scale, guidance_rescale, temperature=1.0, use_original_steps=False):
+        """The host scalars of mudg_ddim_step for schedule position `index`, each rounded to fp32 where the reference
+        rounds it (torch.full((b,1,1,1,1), value) of a python/np/tensor scalar, ddim.py:251-254,262-266).
+        use_original_steps: `index` is a DDPM timestep and the full-schedule tables apply (ddim.py:241-246)."""
         f32 = lambda v: torch.full((1,), float(v), dtype=torch.float32)
-        t = int(self.ddim_timesteps[index])
-        a_prev, sigma = f32(self.ddim_alphas_prev[index]), f32(self.ddim_sigmas[index])
+        if use_original_steps:
+            t = int(index)
+            a_t, a_prev = f32(self.alphas_cumprod[t]), f32(self.alphas_cumprod_prev[t])
+            sqrt_1m_at, sigma = f32(self.sqrt_one_minus_alphas_cumprod[t]), f32(self.ddim_sigmas_for_original_num_steps[t])
+        else:
+            t = int(self.ddim_timesteps[index])
+            a_t, a_prev = f32(self.ddim_alphas[index]), f32(self.ddim_alphas_prev[index])
+            sqrt_1m_at, sigma = f32(self.ddim_sqrt_one_minus_alphas[index]), f32(self.ddim_sigmas[index])
         rescale = torch.ones(1)
         if self.model.use_dynamic_rescale:
             rescale = f32(self.ddim_scale_arr_prev[index]) / f32(self.ddim_scale_arr[index])
         dir_coef = (1. - a_prev - sigma ** 2).sqrt()
-        if self.model.parameterization != "v":
-            raise NotImplementedError("the MI355X sampler implements the v-parameterisation MuDG uses")
-        return [float(cfg_scale), float(guidance_rescale), float(self.sqrt_alphas_cumprod[t]),
-                float(self.sqrt_one_minus_alphas_cumprod[t]), float(rescale), float(a_prev.sqrt()), float(dir_coef),
-                float(sigma * temperature)]
+        if self.model.parameterization == "v":         # x0 / eps from the model's own tables at timestep t (ddpm3d.py:239-251)
+            ca, cb, eps_form = self.sqrt_alphas_cumprod[t], self.sqrt_one_minus_alphas_cumprod[t], 0.0
+        else:                                          # eps-prediction: x0 = (x - sqrt(1 - a_t) e) / sqrt(a_t)  (ddim.py:257-258)
+            ca, cb, eps_form = a_t.sqrt(), sqrt_1m_at, 1.0
+        return [float(cfg_scale), float(guidance_rescale), float(ca), float(cb), float(rescale), float(a_prev.sqrt()),
+                float(dir_coef), float(sigma * temperature), 0.0, eps_form]
 
     # ------------------------------------------------------------------ sampling
     @torch.no_grad()
@@ -91,31 +107,47 @@ class DDIMSampler(object):
                                   unconditional_conditioning=unconditional_conditioning, verbose=verbose,
                                   precision=precision, fs=fs, guidance_rescale=guidance_rescale, **kwargs)
 
+    def _walk(self, timesteps, original):
+        """(timestep values in sampling order, their count) for the three ways the reference picks the walk
+        (ddim.py:152-160): the whole DDIM schedule, a prefix of it (`timesteps` = how many of its entries, minus one as
+        the reference counts), or t = timesteps-1 .. 0 of the DDPM schedule."""
+        if original:
+            count = self.ddpm_num_timesteps if timesteps is None else int(timesteps)
+            return list(range(count - 1, -1, -1)), count
+        steps = self.ddim_timesteps
+        if timesteps is not None:
+            full = steps.shape[0]
+            steps = steps[:int(min(timesteps / full, 1) * full) - 1]
+        return [int(v) for v in np.flip(steps)], int(steps.shape[0])
+
     @torch.no_grad()
     def ddim_sampling(self, cond, shape, x_T=None, ddim_use_original_steps=False, callback=None, timesteps=None,
                       quantize_denoised=False, mask=None, x0=None, img_callback=None, log_every_t=100, temperature=1.,
                       noise_dropout=0., score_corrector=None, corrector_kwargs=None, unconditional_guidance_scale=1.,
                       unconditional_conditioning=None, verbose=True, precision=None, fs=None, guidance_rescale=0.0,
                       **kwargs):
-        if ddim_use_original_steps or timesteps is not None:
-            raise NotImplementedError("sampling on the full DDPM schedule / a timestep subset is not on the MuDG path")
-        if mask is not None:
-            raise NotImplementedError("mask blending (inpainting-style sampling) is not on the MuDG path")
-        kwargs.pop("clean_cond", None)
+        clean_cond = kwargs.pop("clean_cond", False)
         device = self.model.betas.device
         b = shape[0]
         img = torch.randn(shape, device=device) if x_T is None else x_T.to(device=device, dtype=torch.float32)
-        steps = self.ddim_timesteps
-        total = steps.shape[0]
+        walk, total = self._walk(timesteps, ddim_use_original_steps)
         intermediates = {"x_inter": [img], "pred_x0": [img]}
-        iterator = np.flip(steps)
+        if mask is not None:
+            assert x0 is not None, "mask blending needs the original latent x0"
+            mask = mask.to(device=device, dtype=torch.float32)
+            x0 = x0.to(device=device, dtype=torch.float32)
+        iterator = walk
         if verbose:
             from tqdm import tqdm
-            iterator = tqdm(iterator, desc="DDIM Sampler", total=total)
+            iterator = tqdm(walk, desc="DDIM Sampler", total=total)
         for i, step in enumerate(iterator):
             index = total - i - 1
             ts = torch.full((b,), int(step), device=device, dtype=torch.long)
-            img, pred_x0 = self.p_sample_ddim(img, cond, ts, index=index, quantize_denoised=quantize_denoised,
+            if mask is not None:        # keep the masked region on the original's trajectory (ddim.py:173-180)
+                keep = x0 if clean_cond else self.model.q_sample(x0, ts)
+                img = keep * mask + (1. - mask) * img
+            img, pred_x0 = self.p_sample_ddim(img, cond, ts, index=index, use_original_steps=ddim_use_original_steps,
+                                              quantize_denoised=quantize_denoised,
                                               temperature=temperature, noise_dropout=noise_dropout,
                                               score_corrector=score_corrector, corrector_kwargs=corrector_kwargs,
                                               unconditional_guidance_scale=unconditional_guidance_scale,
@@ -130,29 +162,61 @@ class DDIMSampler(object):
                 intermediates["pred_x0"].append(pred_x0)
         return img, intermediates
 
+    # ------------------------------------------------------------------ one step
+    def _model_outputs(self, x, t, c, unconditional_conditioning, unconditional_guidance_scale, kwargs):
+        """The UNet passes of one step: (e_cond, e_uncond or None, e_image_only or None, cfg_img coefficient).  Two-way
+        guidance here (ddim.py:213-225); ddim_multiplecond overrides it with the three-way form."""
+        guided = unconditional_conditioning is not None and unconditional_guidance_scale != 1.
+        if not guided:
+            return self.model.apply_model(x, t, c, **kwargs), None, None, 0.0
+        if not isinstance(c, (torch.Tensor, dict)):
+            raise NotImplementedError("guided sampling needs a tensor or dict conditioning")     # as ddim.py:223-224
+        pair = self._batched_cfg(x, t, c, unconditional_conditioning, kwargs) if self.batch_cfg else None
+        if pair is None:
+            pair = (self.model.apply_model(x, t, c, **kwargs),
+                    self.model.apply_model(x, t, unconditional_conditioning, **kwargs))
+        return pair[0], pair[1], None, 0.0
+
     @torch.no_grad()
     def p_sample_ddim(self, x, c, t, index, repeat_noise=False, use_original_steps=False, quantize_denoised=False,
                       temperature=1., noise_dropout=0., score_corrector=None, corrector_kwargs=None,
                       unconditional_guidance_scale=1., unconditional_conditioning=None, uc_type=None,
                       conditional_guidance_scale_temporal=None, mask=None, x0=None, guidance_rescale=0.0, **kwargs):
-        if use_original_steps or quantize_denoised or score_corrector is not None or noise_dropout > 0.:
-            raise NotImplementedError("original-steps / quantised x0 / score corrector / noise dropout are not on the "
-                                      "MuDG path")
         from mudg_amd import ops
-        guided = unconditional_conditioning is not None and unconditional_guidance_scale != 1.
-        pair = self._batched_cfg(x, t, c, unconditional_conditioning, kwargs) if (guided and self.batch_cfg) else None
-        if pair is not None:
-            e_c, e_u = pair
-        else:
-            e_c = self.model.apply_model(x, t, c, **kwargs)
-            e_u = self.model.apply_model(x, t, unconditional_conditioning, **kwargs) if guided else None
+        x = x.float().contiguous()
+        e_c, e_u, e_m, cfg_img = self._model_outputs(x, t, c, unconditional_conditioning, unconditional_guidance_scale,
+                                                     kwargs)
+        guided = e_u is not None
         coef = self.step_coefficients(index, unconditional_guidance_scale if guided else 1.0,
-                                      guidance_rescale if guided else 0.0, temperature)
+                                      guidance_rescale if guided else 0.0, temperature, use_original_steps)
+        coef[8] = float(cfg_img)
+        if score_corrector is not None:
+            # the corrector edits eps AFTER guidance (ddim.py:233-235), so the guided output is formed here and the fused
+            # update runs unguided on the corrected eps
+            assert self.model.parameterization == "eps", "not implemented"
+            e_c = self._guided_output(e_c, e_u, e_m, coef)
+            e_c = score_corrector.modify_score(self.model, e_c, x, t, c, **(corrector_kwargs or {}))
+            e_u = e_m = None
+            coef[0], coef[1] = 1.0, 0.0
         # always drawn, as the reference does (ddim.py:272: sigma_t * noise_like(...)): with eta = 0 the term is 0 * noise, but
         # the device generator advances identically, so later draws under the same seed (n_samples > 1) match
         noise = noise_like(x.shape, x.device, repeat_noise)
-        return ops.ddim_step(x.float().contiguous(), e_c.float().contiguous(),
-                             None if e_u is None else e_u.float().contiguous(), noise, coef)
+        if noise_dropout > 0.:
+            noise = torch.nn.functional.dropout(noise, p=noise_dropout)
+        x_prev, pred_x0 = ops.ddim_step(x, e_c, e_u, noise, coef, e_m=e_m)
+        if quantize_denoised:           # first stages with a codebook only; x_{t-1} follows the quantised x0 (ddim.py:267-275)
+            snapped, _, *_ = self.model.first_stage_model.quantize(pred_x0)
+            x_prev = x_prev + coef[5] * (snapped - pred_x0)
+            pred_x0 = snapped
+        return x_prev, pred_x0
+
+    @staticmethod
+    def _guided_output(e_c, e_u, e_m, coef):
+        if e_u is None:
+            return e_c
+        s, phi, s_img = coef[0], coef[1], coef[8]
+        out = e_u + s * (e_c - e_u) if e_m is None else e_u + s_img * (e_m - e_u) + s * (e_c - e_m)
+        return rescale_noise_cfg(out, e_c, phi) if phi > 0.0 else out
 
     def _batched_cfg(self, x, t, c, uc, kwargs):
         """[cond | uncond] in one apply_model call; None when the conditionings cannot be stacked."""
@@ -205,8 +269,35 @@ class DDIMSampler(object):
         self._merged_cache = (sig, merged, [cd for cd in conds])     # the source dicts are kept alive: their addresses are the key
         return merged
 
-    def decode(self, *a, **k):
-        raise NotImplementedError("DDIM latent re-decoding is not on the MuDG path")
+    @torch.no_grad()
+    def decode(self, x_latent, cond, t_start, unconditional_guidance_scale=1.0, unconditional_conditioning=None,
+               use_original_steps=False, callback=None):
+        """Denoise a latent from schedule position t_start down to 0 (ddim.py:281-301): the counterpart of
+        stochastic_encode for image-to-image style use."""
+        steps = np.arange(self.ddpm_num_timesteps) if use_original_steps else self.ddim_timesteps
+        steps = steps[:t_start]
+        total = int(steps.shape[0])
+        print(f"Running DDIM Sampling with {total} timesteps")
+        x_dec = x_latent
+        for i, step in enumerate(np.flip(steps)):
+            ts = torch.full((x_latent.shape[0],), int(step), device=x_latent.device, dtype=torch.long)
+            x_dec, _ = self.p_sample_ddim(x_dec, cond, ts, index=total - i - 1, use_original_steps=use_original_steps,
+                                          unconditional_guidance_scale=unconditional_guidance_scale,
+                                          unconditional_conditioning=unconditional_conditioning)
+            if callback:
+                callback(i)
+        return x_dec
 
-    def stochastic_encode(self, *a, **k):
-        raise NotImplementedError("DDIM stochastic encoding is not on the MuDG path")
+    @torch.no_grad()
+    def stochastic_encode(self, x0, t, use_original_steps=False, noise=None):
+        """q(x_t | x_0) at schedule position(s) `t` (a long tensor, one entry per sample) of the DDIM (or full) schedule
+        (ddim.py:303-317).  One HIP launch (the per-sample linear combination the v-parameterisation helpers use)."""
+        from mudg_amd import ops
+        if use_original_steps:
+            ca, cb = self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod
+        else:
+            ca, cb = torch.sqrt(self.ddim_alphas), self.ddim_sqrt_one_minus_alphas
+        if noise is None:
+            noise = torch.randn_like(x0)
+        pick = lambda tab: torch.as_tensor(tab, dtype=torch.float32).to(x0.device)[t]
+        return ops.lincomb(x0, noise, pick(ca), pick(cb))

@@ -78,3 +78,12 @@ def make_ddim_sampling_parameters(alphacums, ddim_timesteps, eta, verbose=True):
         print(f"For the chosen value of eta, which is {eta}, this results in the following sigma_t schedule "
               f"for ddim sampler {sigmas}")
     return sigmas, alphas, alphas_prev
+
+
+def rescale_noise_cfg(noise_cfg, noise_pred_text, guidance_rescale=0.0):
+    """Guidance rescale (reference: utils_diffusion.py:147-157): bring the guided prediction back to the per-sample
+    standard deviation of the conditional one, blended by `guidance_rescale`.  The sampler's fused update does this
+    inside mudg_ddim_step; this tensor form serves the score-corrector path, which needs the guided output itself."""
+    axes = tuple(range(1, noise_pred_text.ndim))
+    gain = noise_pred_text.std(dim=axes, keepdim=True) / noise_cfg.std(dim=axes, keepdim=True)
+    return guidance_rescale * (noise_cfg * gain) + (1 - guidance_rescale) * noise_cfg

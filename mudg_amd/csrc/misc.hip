@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void ddim_stats_kernel(const float* __restrict
         ws[((int64_t)b * DDIM_BLK + blockIdx.x) * 4 + tid] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
 }
 
-struct DdimCoef { float cfg, phi, sqrt_ac, sqrt_1mac, rescale, sqrt_a_prev, dir_coef, sigma, cfg_img; };
+struct DdimCoef { float cfg, phi, sqrt_ac, sqrt_1mac, rescale, sqrt_a_prev, dir_coef, sigma, cfg_img, eps_form; };
 
 __global__ __launch_bounds__(256) void ddim_update_kernel(const float* __restrict__ x, const float* __restrict__ ec,
                                                            const float* __restrict__ eu, const float* __restrict__ em,
@@ -256,8 +256,14 @@ __global__ __launch_bounds__(256) void ddim_update_kernel(const float* __restric
             const float resc = v * ratio;
             v = k.phi * resc + (1.f - k.phi) * v;
         }
-        const float e = k.sqrt_ac * v + k.sqrt_1mac * xv;
-        float x0 = k.sqrt_ac * xv - k.sqrt_1mac * v;
+        float e, x0;
+        if (k.eps_form != 0.f) {          // the model predicts eps: sqrt_ac = sqrt(a_t), sqrt_1mac = sqrt(1 - a_t)
+            e = v;
+            x0 = (xv - k.sqrt_1mac * e) / k.sqrt_ac;
+        } else {                          // v-prediction
+            e = k.sqrt_ac * v + k.sqrt_1mac * xv;
+            x0 = k.sqrt_ac * xv - k.sqrt_1mac * v;
+        }
         x0 *= k.rescale;
         const float dir = k.dir_coef * e;
         const float nz = noise ? k.sigma * noise[off + i] : 0.f;
@@ -423,7 +429,7 @@ extern "C" int mudg_ddim_step(const float* x, const float* e_c, const float* e_u
     DdimCoef k;
     k.cfg = host_coef[0]; k.phi = host_coef[1]; k.sqrt_ac = host_coef[2]; k.sqrt_1mac = host_coef[3];
     k.rescale = host_coef[4]; k.sqrt_a_prev = host_coef[5]; k.dir_coef = host_coef[6]; k.sigma = host_coef[7];
-    k.cfg_img = host_coef[8];
+    k.cfg_img = host_coef[8]; k.eps_form = host_coef[9];
     MUDG_REQUIRE(!e_m || e_u, "mudg_ddim_step: e_m needs e_u");
     const int slot = mudg_prof_begin(MUDG_FAM_MISC, s);
     if (k.phi > 0.f)

@@ -455,18 +455,18 @@ def gaussian_sample(moments, noise=None, scale=1.0):
 
 
 def ddim_step(x, e_c, e_u, noise, coef, e_m=None):
-    """Fused DDIM update on fp32 latents (B, ...). coef = 8 or 9 host floats, see mudg_ddim_step; e_m = the
-    image-only-conditioned pass of the three-way guidance (coef[8] = cfg_img)."""
+    """Fused DDIM update on fp32 latents (B, ...). coef = 8 to 10 host floats, see mudg_ddim_step; e_m = the
+    image-only-conditioned pass of the three-way guidance (coef[8] = cfg_img); coef[9] = 1 for eps-predicting models."""
     def dense(t):      # raw pointers are handed to the kernel: insist on dense fp32 (permuted views are copied)
         return None if t is None else t.to(torch.float32).contiguous()
 
     x, e_c, e_u, noise, e_m = dense(x), dense(e_c), dense(e_u), dense(noise), dense(e_m)
-    coef = list(coef) + [0.0] * (9 - len(coef))
+    coef = list(coef) + [0.0] * (10 - len(coef))
     b = x.shape[0]
     n = x.numel() // b
     x_prev, pred_x0 = torch.empty_like(x), torch.empty_like(x)
     ws = torch.empty(hip.lib().mudg_ddim_ws_doubles(b), dtype=torch.float64, device=x.device)
-    arr = (C.c_float * 9)(*[float(v) for v in coef])
+    arr = (C.c_float * 10)(*[float(v) for v in coef])
     hip.check(hip.lib().mudg_ddim_step(x.data_ptr(), e_c.data_ptr(), _ptr(e_u), _ptr(e_m), _ptr(noise), x_prev.data_ptr(),
                                        pred_x0.data_ptr(), b, n, arr, ws.data_ptr(), _stream()), "mudg_ddim_step")
     return x_prev, pred_x0

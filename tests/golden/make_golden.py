@@ -465,6 +465,80 @@ def golden_driver():
     save("driver.pt", dict(meta, driver=d, resampler_param_shapes=rs_shapes, resampler_checksum=rs_cks, outs=outs))
 
 
+# ---------------------------------------------------------------------------------------------- 10b. sampler options
+class DampingCorrector:
+    """A stand-in score corrector (the reference ships none): shrinks eps and pulls it towards the latent."""
+
+    def modify_score(self, model, e_t, x, t, c, gain=0.9, pull=0.05):
+        return gain * e_t + pull * x
+
+
+def golden_sampler_options():
+    """The DDIMSampler options MuDG's own driver leaves at their defaults, each run on the reference with recorded noise:
+    mask blending (noised and clean original), a `timesteps` prefix of the schedule, the full-schedule "original steps"
+    walk, temperature, an eps-parameterised model (+ score corrector), decode and stochastic_encode."""
+    s = cfgs.SAMPLER
+    model, meta = _seeded_diffusion()
+    inp, (B, T, H, W) = _pipeline_inputs(8)
+    seed = cfgs.SEED + 7
+    class_label = torch.tensor(s["class_labels"], dtype=torch.long)[:, None]
+    fs = torch.full((B,), s["fs"], dtype=torch.long)
+    cond = {"c_crossattn": [inp["ctx_c"]], "c_concat": [inp["concat"]]}
+    uc = {"c_crossattn": [inp["ctx_u"]], "c_concat": [inp["concat"]]}
+    x0_lat = seeding.seeded_input("opt_x0", (B, 4, T, H, W), seed)
+    mask = (seeding.seeded_input("opt_mask", (B, 1, T, H, W), seed) > 0).float()
+    q_noises = [seeding.seeded_input(f"opt_q{i}", (B, 4, T, H, W), seed) for i in range(8)]
+    common = dict(unconditional_guidance_scale=s["cfg_scale"], unconditional_conditioning=uc, fs=fs,
+                  guidance_rescale=s["guidance_rescale"], sparse_x=inp["concat"][:, :4], class_label=class_label,
+                  unconditional_conditioning_img_nonetext=None)
+    orig_q = model.q_sample
+
+    def fresh(steps, eta=1.0, spacing=s["spacing"]):
+        it = iter(inp["noises"])
+        ref_ddim.noise_like = lambda shape, device, repeat=False: next(it)
+        qn = iter(q_noises)
+        model.q_sample = lambda x_start, t, noise=None: orig_q(x_start, t, noise=next(qn))
+        sampler = CPUSampler(model)
+        sampler.make_schedule(ddim_num_steps=steps, ddim_discretize=spacing, ddim_eta=eta, verbose=False)
+        return sampler
+
+    out = {}
+    shape = (B, 4, T, H, W)
+    for tag, extra in (("mask", {}), ("mask_clean", {"clean_cond": True})):
+        x, _ = fresh(3).ddim_sampling(cond, shape, x_T=inp["x_T"], mask=mask, x0=x0_lat, verbose=False, **extra, **common)
+        out[tag] = x.clone()
+    x, inter = fresh(8).ddim_sampling(cond, shape, x_T=inp["x_T"], timesteps=5, verbose=False, log_every_t=1, **common)
+    out["subset"] = {"x": x.clone(), "n_inter": len(inter["x_inter"])}
+    x, _ = fresh(8).ddim_sampling(cond, shape, x_T=inp["x_T"], ddim_use_original_steps=True, timesteps=3, verbose=False,
+                                  **common)
+    out["original"] = x.clone()
+    x, _ = fresh(3).ddim_sampling(cond, shape, x_T=inp["x_T"], temperature=0.6, verbose=False, **common)
+    out["temperature"] = x.clone()
+    # eps-prediction divides by sqrt(a_t): with zero terminal SNR the trailing schedule's first step (t = 999) is 0/0 in the
+    # reference, so these two cases walk the "uniform" schedule (4 steps, t <= 751)
+    model.parameterization = "eps"
+    x, _ = fresh(4, spacing="uniform").ddim_sampling(cond, shape, x_T=inp["x_T"], verbose=False, **common)
+    out["eps"] = x.clone()
+    x, _ = fresh(4, spacing="uniform").ddim_sampling(cond, shape, x_T=inp["x_T"], verbose=False, score_corrector=DampingCorrector(),
+                                  corrector_kwargs={"gain": 0.8, "pull": 0.1}, **common)
+    out["eps_corrected"] = x.clone()
+    model.parameterization = "v"
+    # decode() passes neither fs nor the driver's extra kwargs
+    # (MuDG's apply_model insists on a class_label keyword, which decode() has no way to pass: supplied by a wrapper here,
+    # and the same wrapper in the test)
+    orig_apply = model.apply_model
+    model.apply_model = lambda x, t, c, **kw: orig_apply(x, t, c, **dict({"class_label": class_label, "fs": fs}, **kw))
+    x = fresh(6).decode(inp["x_T"], cond, 4, unconditional_guidance_scale=s["cfg_scale"], unconditional_conditioning=uc)
+    model.apply_model = orig_apply
+    out["decode"] = x.clone()
+    smp = fresh(6)
+    t_idx = torch.tensor([1, 4, 5][:B], dtype=torch.long)
+    out["encode"] = {"t": t_idx, "ddim": smp.stochastic_encode(x0_lat, t_idx, noise=q_noises[0]).clone(),
+                     "original": smp.stochastic_encode(x0_lat, t_idx * 100, use_original_steps=True, noise=q_noises[1]).clone()}
+    model.q_sample = orig_q
+    save("sampler_options.pt", dict(meta, sampler=s, seed_options=seed, cases=out))
+
+
 # ---------------------------------------------------------------------------------------------- 11. the YAML configs
 def golden_yaml():
     """model.params of the reference's two inference YAMLs as JSON: mudg_amd/configs.py is asserted equal to it, and every
@@ -491,6 +565,9 @@ if __name__ == "__main__":
     if "--only-resampler" in sys.argv:
         golden_resampler()
         sys.exit(0)
+    if "--only-options" in sys.argv:
+        golden_sampler_options()
+        sys.exit(0)
     if "--only-round2" in sys.argv:
         golden_pipeline50()
         golden_threeway()
@@ -507,4 +584,5 @@ if __name__ == "__main__":
     golden_pipeline50()
     golden_threeway()
     golden_driver()
+    golden_sampler_options()
     golden_yaml()

@@ -80,6 +80,33 @@ def test_product_schedule_matches_reference(base):
     assert coef[2] == 0.0 and coef[3] == 1.0                      # zero terminal SNR at t = 999
 
 
+def test_sampler_walks_and_step_coefficients_of_the_optional_modes():
+    """The three walks of ddim_sampling (ddim.py:152-160) and the coefficient sets of the eps-parameterised and
+    full-schedule modes (ddim.py:241-258), on the host."""
+    from lvdm.models.samplers.ddim import DDIMSampler
+    model = _tiny_diffusion()
+    sampler = DDIMSampler(model)
+    sampler.make_schedule(8, ddim_discretize="uniform_trailing", ddim_eta=1.0, verbose=False)
+    full = [int(v) for v in np.flip(sampler.ddim_timesteps)]
+    assert sampler._walk(None, False) == (full, 8)
+    assert sampler._walk(5, False) == ([int(v) for v in np.flip(sampler.ddim_timesteps[:4])], 4)   # int(5/8 * 8) - 1
+    assert sampler._walk(100, False) == ([int(v) for v in np.flip(sampler.ddim_timesteps[:7])], 7)
+    assert sampler._walk(3, True) == ([2, 1, 0], 3)
+    assert sampler._walk(None, True)[1] == 1000
+    v = sampler.step_coefficients(2, 7.5, 0.7)
+    t = int(sampler.ddim_timesteps[2])
+    assert len(v) == 10 and v[9] == 0.0 and v[2] == float(model.sqrt_alphas_cumprod[t])
+    model.parameterization = "eps"
+    e = sampler.step_coefficients(2, 7.5, 0.7, temperature=0.5)
+    assert e[9] == 1.0 and e[2] == pytest.approx(float(sampler.ddim_alphas[2]) ** 0.5, rel=1e-6)
+    assert e[3] == float(sampler.ddim_sqrt_one_minus_alphas[2]) and e[7] == pytest.approx(0.5 * v[7], rel=1e-6)
+    o = sampler.step_coefficients(5, 1.0, 0.0, use_original_steps=True)
+    ac, prev = float(model.alphas_cumprod[5]), float(model.alphas_cumprod_prev[5])
+    sigma = ((1 - prev) / (1 - ac) * (1 - ac / prev)) ** 0.5
+    assert o[7] == pytest.approx(sigma, rel=1e-4) and o[5] == pytest.approx(prev ** 0.5, rel=1e-6)
+    assert o[6] == pytest.approx((1 - prev - sigma ** 2) ** 0.5, rel=1e-3)
+
+
 def _tiny_diffusion(base=0.3):
     from lvdm.models.ddpm3d import LatentVisualDiffusion
     ident = {"target": "torch.nn.Identity"}

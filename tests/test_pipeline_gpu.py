@@ -156,8 +156,6 @@ def _sample(model, g, inp, s, cuda, monkeypatch, eta, sampler_mod=None, **extra)
     noises = iter(inp["noises"])
     fake = lambda shape, device, repeat=False: next(noises).to(device)
     monkeypatch.setattr(my_ddim, "noise_like", fake)
-    if mod is not my_ddim:
-        monkeypatch.setattr(mod, "noise_like", fake)
     sampler = mod.DDIMSampler(model)
     shp = g["shape"]
     kw = dict(cfg_img=None, unconditional_conditioning_img_nonetext=None)
@@ -218,7 +216,8 @@ def test_three_way_guidance_matches_reference(cuda, monkeypatch):
     assert err < TOL_E2E
     x = inp["x_T"]
     for i, ref in enumerate(g["trace"]):
-        coef = sampler.step_coefficients(ref["index"], s["cfg_scale"], s["guidance_rescale"]) + [float(s["cfg_img"])]
+        coef = sampler.step_coefficients(ref["index"], s["cfg_scale"], s["guidance_rescale"])
+        coef[8] = float(s["cfg_img"])
         xp, x0 = ops.ddim_step(x.to(cuda), ref["e_c"].to(cuda), ref["e_u"].to(cuda), inp["noises"][i].to(cuda), coef,
                                e_m=ref["e_m"].to(cuda))
         assert rel_l2(x0, ref["pred_x0"]) < 2e-6 and rel_l2(xp, ref["x_prev"]) < 2e-6
@@ -258,7 +257,6 @@ def test_driver_image_guided_synthesis_matches_the_reference_function(cuda, monk
         it = iter(noises)
         fake = lambda shape, device, repeat=False: next(it).to(device)
         monkeypatch.setattr(my_ddim, "noise_like", fake)
-        monkeypatch.setattr(my_mc, "noise_like", fake)
         torch.manual_seed(d["cpu_seed"])
         out = image_guided_synthesis(model, ["a street"] * B, sparse, depth, labels, [B, 4, T, H, W], x_T=x_T, **common, **extra)
         want = g["outs"][tag]

@@ -14,9 +14,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SUITES = {
     "fp16": ["tests/test_kernels_gpu.py", "tests/test_operand_modes_gpu.py", "tests/test_unet_gpu.py",
-             "tests/test_pipeline_gpu.py", "tests/test_fullsize_gpu.py"],
+             "tests/test_pipeline_gpu.py", "tests/test_sampler_options_gpu.py", "tests/test_fullsize_gpu.py"],
     # test_kernels_gpu.py builds its inputs as plain 16-bit tensors; the split modes run the mode-agnostic kernel suite
-    "bf16x3": ["tests/test_operand_modes_gpu.py", "tests/test_unet_gpu.py", "tests/test_pipeline_gpu.py"],
+    "bf16x3": ["tests/test_operand_modes_gpu.py", "tests/test_unet_gpu.py", "tests/test_pipeline_gpu.py",
+               "tests/test_sampler_options_gpu.py"],
     "bf16x6": ["tests/test_operand_modes_gpu.py", "tests/test_unet_gpu.py", "tests/test_pipeline_gpu.py"],
 }
 
