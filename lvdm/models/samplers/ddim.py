@@ -30,6 +30,9 @@ class DDIMSampler(object):
         # reference runs them back to back (ddim.py:221-222); batching halves the launch count and fills the chip at
         # the coarse levels (M = 2304 rows at ds8).  Set to False to reproduce the reference's call sequence.
         self.batch_cfg = True
+        # ... and, when those passes differ only in their cross-attention tokens, let the UNet run the part of the network
+        # that comes before the first cross-attention once for all of them (see _batched_passes).
+        self.share_guidance_prefix = True
 
     def register_buffer(self, name, attr):
         setattr(self, name, attr)
@@ -223,25 +226,33 @@ class DDIMSampler(object):
         return self._batched_passes(x, t, [c, uc], kwargs)
 
     def _batched_passes(self, x, t, conds, kwargs):
-        """One apply_model call over len(conds) stacked copies of the batch; None if the dicts cannot be stacked.
+        """One apply_model call for the len(conds) guidance passes of a step; None if the dicts cannot be stacked.
         The stacked conditioning is the same at every step of a run, so it is built once and kept while the caller keeps
-        passing the same tensors: the channel-concat pieces stacked along the batch, and the cross-attention tokens
-        stacked AND made ready for the UNet (UNetModel.prepare_context: operand rows + every cross-attention layer's
-        K / V^T projections, which the reference recomputes at each of the 50 steps although the tokens never change)."""
+        passing the same tensors: the cross-attention tokens stacked along the batch AND made ready for the UNet
+        (UNetModel.prepare_context: operand rows + every cross-attention layer's K / V^T projections, which the reference
+        recomputes at each of the 50 steps although the tokens never change).
+        When the passes differ ONLY in those tokens — MuDG's driver hands the same c_concat latents to all of them — the
+        latents are passed once (batch b) with the n b stacked contexts: the UNet then runs its context-free prefix (stem,
+        init_attn, first ResBlock, first full-resolution self-attention) once instead of n times.  Otherwise x, t and the
+        per-sample keyword tensors ride along n times."""
         first = conds[0]
         if not all(isinstance(cd, dict) and set(cd) == set(first) for cd in conds):
             return None
         b, n = x.shape[0], len(conds)
-        merged = self._merged_conditioning(conds, x.shape[2] if x.dim() == 5 else None)
+        merged, shared = self._merged_conditioning(conds, x.shape[2] if x.dim() == 5 else None)
         if merged is None:
             return None
-        kw = {}
-        for k, v in kwargs.items():          # per-sample tensors ride along n times; everything else is shared
-            kw[k] = torch.cat([v] * n, 0) if (torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == b) else v
-        out = self.model.apply_model(torch.cat([x] * n, 0), torch.cat([t] * n, 0), merged, **kw)
+        if shared:
+            out = self.model.apply_model(x, t, merged, **kwargs)
+        else:
+            kw = {}
+            for k, v in kwargs.items():          # per-sample tensors ride along n times; everything else is shared
+                kw[k] = torch.cat([v] * n, 0) if (torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == b) else v
+            out = self.model.apply_model(torch.cat([x] * n, 0), torch.cat([t] * n, 0), merged, **kw)
         return tuple(out[i * b:(i + 1) * b] for i in range(n))
 
     def _merged_conditioning(self, conds, frames):
+        """(stacked conditioning dict, shared-latents flag) — see _batched_passes; (None, False) if not stackable."""
         def ident(v):
             try:
                 ver = v._version
@@ -249,25 +260,38 @@ class DDIMSampler(object):
                 ver = 0
             return (v.data_ptr(), ver, tuple(v.shape), v.dtype)
 
+        def same(u, v):
+            return u is v or (u.data_ptr() == v.data_ptr() and u.shape == v.shape and u.stride() == v.stride() and u.dtype == v.dtype)
+
         first = conds[0]
         for key in first:
             lists = [cd[key] for cd in conds]
             if not all(isinstance(l, (list, tuple)) and len(l) == len(lists[0]) for l in lists):
-                return None
+                return None, False
             if any((not torch.is_tensor(v)) or v.shape != lists[0][i].shape for l in lists for i, v in enumerate(l)):
-                return None
+                return None, False
         sig = tuple((key, tuple(ident(v) for v in cd[key])) for cd in conds for key in sorted(cd))
         cache = self.__dict__.get("_merged_cache")
         if cache is not None and cache[0] == sig:
-            return cache[1]
-        merged = {key: [torch.cat([cd[key][i] for cd in conds], 0) for i in range(len(first[key]))] for key in first}
+            return cache[1], cache[3]
         unet = getattr(getattr(self.model, "model", None), "diffusion_model", None)
-        if frames is not None and "c_crossattn" in merged and hasattr(unet, "prepare_context") \
-                and all(v.is_cuda for v in merged["c_crossattn"]):
+        prepare = frames is not None and "c_crossattn" in first and hasattr(unet, "prepare_context") \
+            and all(v.is_cuda for cd in conds for v in cd["c_crossattn"])
+        # guidance replicas: every input but the tokens is literally the same tensor in all passes
+        shared = prepare and self.share_guidance_prefix and all(
+            same(cd[key][i], first[key][i]) for cd in conds for key in first if key != "c_crossattn"
+            for i in range(len(first[key])))
+        merged = {}
+        for key in first:
+            if shared and key != "c_crossattn":
+                merged[key] = list(first[key])
+            else:
+                merged[key] = [torch.cat([cd[key][i] for cd in conds], 0) for i in range(len(first[key]))]
+        if prepare:
             tokens = merged["c_crossattn"][0] if len(merged["c_crossattn"]) == 1 else torch.cat(merged["c_crossattn"], 1)
             merged["c_crossattn"] = [unet.prepare_context(tokens, frames)]
-        self._merged_cache = (sig, merged, [cd for cd in conds])     # the source dicts are kept alive: their addresses are the key
-        return merged
+        self._merged_cache = (sig, merged, [cd for cd in conds], shared)     # the source dicts are kept alive: their addresses are the key
+        return merged, shared
 
     @torch.no_grad()
     def decode(self, x_latent, cond, t_start, unconditional_guidance_scale=1.0, unconditional_conditioning=None,

@@ -34,7 +34,20 @@ _FP8_ATTENTION = _os.environ.get("MUDG_ATTN_FP8", "0") == "1"         # opt-in: 
 
 class _Ctx:
     """Per-forward state shared by all blocks."""
-    __slots__ = ("B", "T", "emb", "text", "img", "n_text", "n_img", "img_div", "kv_cache")
+    __slots__ = ("B", "T", "emb", "text", "img", "n_text", "n_img", "img_div", "kv_cache", "replicas", "skips")
+
+    def __init__(self):
+        self.replicas, self.skips = 1, None
+
+    def fan_out(self, rows):
+        """End of the context-free prefix of a forward over guidance replicas (see forward): the batch becomes
+        replicas * B — `rows`, the per-clip embeddings and the skip tensors made so far are repeated."""
+        r, self.replicas = self.replicas, 1
+        self.B *= r
+        self.emb = self.emb.repeat(r, 1)
+        if self.skips is not None:
+            self.skips[:] = [(ops.repeat_rows(t, r), h, w) for t, h, w in self.skips]
+        return ops.repeat_rows(rows, r)
 
 
 # ------------------------------------------------------------------------------------------------ building blocks
@@ -140,6 +153,9 @@ def spatial_block(blk, hcur, frames, hw, ctx, last):
     ops.attention(qk[:, :c], qk[:, c:], vt, att, frames=frames, heads=heads, nq=hw, nk=hw, ldvt=ldv, svt=c * ldv,
                   scale=a1.scale, q_prescaled=lean, fp8=fp8)
     hcur = _linear(a1.to_out[0], att, residual=hcur, stream=True)
+    if ctx.replicas > 1:        # first use of the context in this forward: from here on the guidance replicas differ
+        hcur = ctx.fan_out(hcur)
+        frames = ctx.B * ctx.T
     # text (+ image) cross-attention: two softmaxes, outputs summed (image_cross_attention_scale == 1)
     n2 = _ln(blk.norm2, hcur)
     q2 = ops.gemm(n2, pk.linear(a2.to_q))
@@ -161,11 +177,14 @@ def spatial_block(blk, hcur, frames, hw, ctx, last):
 
 
 def spatial_transformer(mod, x, h, w, ctx):
-    frames, hw = ctx.B * ctx.T, h * w
-    cur = _linear(mod.proj_in, _gn(mod.norm, x, None, frames, hw, False), stream=True)
+    hw = h * w
+    cur = _linear(mod.proj_in, _gn(mod.norm, x, None, ctx.B * ctx.T, hw, False), stream=True)
     n = len(mod.transformer_blocks)
     for i, blk in enumerate(mod.transformer_blocks):
-        cur = spatial_block(blk, cur, frames, hw, ctx, i == n - 1)
+        shared = ctx.replicas
+        cur = spatial_block(blk, cur, ctx.B * ctx.T, hw, ctx, i == n - 1)
+        if ctx.replicas != shared:          # the block fanned the batch out: so must the residual input
+            x = ops.repeat_rows(x, shared)
     return _linear(mod.proj_out, cur, residual=x, stream=True, stats=True)
 
 
@@ -190,9 +209,9 @@ def temporal_transformer(mod, x, h, w, ctx):
 
 def run_stage(seq, x, x2, h, w, ctx):
     """One TimestepEmbedSequential.  Returns (rows, h, w)."""
-    frames = ctx.B * ctx.T
     for m in seq:
         name = type(m).__name__
+        frames = ctx.B * ctx.T
         if name == "ResBlock":
             x, x2 = res_block(m, x, x2, h, w, ctx), None
         elif name == "SpatialTransformer":
@@ -302,8 +321,8 @@ class PreparedContext:
     def bind(self, ctx, model):
         """Attach to a forward's state; stale projections (parameters changed since they were made) are redone."""
         from .graph import _params_signature
-        if ctx.B != self.B:
-            raise ValueError(f"context prepared for batch {self.B}, forward has batch {ctx.B}")
+        if ctx.B * ctx.replicas != self.B:
+            raise ValueError(f"context prepared for batch {self.B}, forward has batch {ctx.B * ctx.replicas}")
         if self.signature != _params_signature(model):
             self.project(model)
         ctx.text, ctx.img, ctx.n_text, ctx.n_img, ctx.img_div, ctx.kv_cache = self.text, self.img, self.n_text, self.n_img, \
@@ -322,7 +341,7 @@ def _clone_rows(t):
 
 def make_context(model, ctx, context, t_len, device):
     """Per-forward conditioning state from a raw (B, L, D) context tensor (a one-shot PreparedContext)."""
-    if context is not None and context.dim() == 3 and context.shape[0] != ctx.B:
+    if context is not None and context.dim() == 3 and context.shape[0] != ctx.B * ctx.replicas:
         raise ValueError(f"context must be (B, L, D), got {tuple(context.shape)}")
     prepared = PreparedContext(model, context, t_len, device, project=False)
     prepared.T = ctx.T
@@ -367,6 +386,16 @@ def forward(model, x, timesteps, c_label=None, context=None, features_adapter=No
 
     ctx = _Ctx()
     ctx.B, ctx.T, ctx.kv_cache = B, T, {}
+    # Guidance replicas: a context of batch R * B against latents of batch B means "the same latents under R
+    # conditionings" (the cond / uncond / image-only passes of classifier-free guidance).  Everything up to the first
+    # cross-attention — stem, init_attn, the first ResBlock, the first spatial self-attention: all at full resolution —
+    # does not see the context, so it runs ONCE on B; the rows, the embeddings and the skips made so far are then
+    # repeated R times (_Ctx.fan_out) and the rest runs on R * B.  Bit-identical to running the R * B batch throughout
+    # (every kernel is per clip / per frame / per pixel).
+    cb = context.B if isinstance(context, PreparedContext) else (context.shape[0] if context is not None and context.dim() == 3 else B)
+    if cb != B and (cb % B != 0 or cb < B):
+        raise ValueError(f"context batch {cb} is not a multiple of the latent batch {B}")
+    ctx.replicas = cb // B
     # ---- embeddings: time (+ class) then + fps, all per clip (openaimodel3d.py:569-602)
     mc = model.model_channels
     ts = _to_long(timesteps, B, device, "timesteps")
@@ -396,7 +425,7 @@ def forward(model, x, timesteps, c_label=None, context=None, features_adapter=No
         ops.zero_channels(rows, off, cpad)
 
     h, w = H, W
-    skips = []
+    skips = ctx.skips = []
     cur = rows
     for i, stage in enumerate(model.input_blocks):
         cur, h, w = run_stage(stage, cur, None, h, w, ctx)
@@ -410,9 +439,11 @@ def forward(model, x, timesteps, c_label=None, context=None, features_adapter=No
             raise RuntimeError(f"skip resolution {sh}x{sw} does not match {h}x{w}: H and W must be divisible by "
                                f"{2 ** (len(model.channel_mult) - 1)}")
         cur, h, w = run_stage(stage, cur, skip, h, w, ctx)
+    if ctx.replicas > 1:                     # a UNet without any cross-attention: the replicas are plain copies
+        cur = ctx.fan_out(cur)
     norm, conv = model.out[0], model.out[2]
-    cur = _gn(norm, cur, None, B * T, h * w, True)
-    y = _conv3x3(conv, cur, B * T, h, w, fp32=True, stats=False)          # the prediction itself leaves in fp32
+    cur = _gn(norm, cur, None, ctx.B * T, h * w, True)
+    y = _conv3x3(conv, cur, ctx.B * T, h, w, fp32=True, stats=False)      # the prediction itself leaves in fp32
     out_dtype = first.dtype if first.dtype in (torch.float32, ops.H16()) else torch.float32
-    out = ops.rows_to_ncthw(y, (B, model.out_channels, T, h, w), dtype=out_dtype)
+    out = ops.rows_to_ncthw(y, (ctx.B, model.out_channels, T, h, w), dtype=out_dtype)
     return out if out.dtype == first.dtype else out.to(first.dtype)

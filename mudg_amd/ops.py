@@ -75,6 +75,27 @@ def empty_rows(rows: int, cols: int, dtype=None, device=None) -> torch.Tensor:
     return torch.empty((rows, cols), dtype=dtype, device=device or "cuda")
 
 
+def repeat_rows(t, times):
+    """`times` copies of a rows matrix stacked along the rows (batch-major rows: the batch repeated).  GroupNorm partial
+    sums hanging on `t` (one set per 128-row block) are repeated with it when the blocks line up."""
+    if times == 1:
+        return t
+    rows, cols = t.shape
+    out = empty_rows(times * rows, cols, t.dtype, t.device)
+    src, dst = t, out
+    if out._base is not None:            # an operand matrix of a split-operand build: every piece is copied
+        if t._base is None or tuple(t._base.shape) != (rows, out._base.shape[1]):
+            raise hip.MudgError("repeat_rows: not a whole operand matrix")
+        src, dst = t._base, out._base
+    for i in range(times):
+        dst[i * rows:(i + 1) * rows].copy_(src)
+    ws = getattr(t, GN_ATTR, None)
+    if ws is not None and getattr(t, GN_ATTR + "_version", -1) == _version(t) and rows % 128 == 0:
+        setattr(out, GN_ATTR, ws.repeat(times, 1, 1))
+        setattr(out, GN_ATTR + "_version", _version(out))
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ GEMM family
 GN_ATTR = "_mudg_gn_partials"      # python attribute a producer leaves on its output: fp32 [ceil(M/128)][N][2] partial sums
 

@@ -91,6 +91,47 @@ def test_batched_cfg_equals_sequential_passes(cuda):
     assert rel_l2(outs[0][0], outs[1][0]) < 1e-5 and rel_l2(outs[0][1], outs[1][1]) < 1e-5
 
 
+def test_shared_guidance_prefix_equals_the_replicated_batch(cuda, monkeypatch):
+    """DDIMSampler.share_guidance_prefix (the guidance passes get the SAME c_concat tensor, as MuDG's driver builds them:
+    latents passed once, contexts stacked, the UNet's context-free prefix run once) against the replicated batch and
+    against the reference's back-to-back passes: the same bits, two-way and three-way."""
+    from lvdm.models.samplers import ddim as my_ddim, ddim_multiplecond as my_mc
+    g = golden("threeway.pt")
+    model = build_model(g, cuda)
+    inp, s, shp = pipeline_inputs(g), g["sampler"], g["shape"]
+    concat = inp["concat"].to(cuda)
+    entry = lambda tokens: {"c_crossattn": [tokens.to(cuda)], "c_concat": [concat]}
+    cond, uc = entry(inp["ctx_c"]), entry(inp["ctx_u"])
+    uc_img = entry(torch.cat([inp["ctx_u"][:, :77], inp["ctx_c"][:, 77:]], 1))
+    finals = []
+    for mod, extra in ((my_ddim, {}), (my_mc, {"cfg_img": s["cfg_img"]})):
+        outs = []
+        for share, batch in ((True, True), (False, True), (False, False)):
+            noises = iter(inp["noises"])
+            monkeypatch.setattr(my_ddim, "noise_like", lambda shape, device, repeat=False: next(noises).to(device))
+            sampler = mod.DDIMSampler(model)
+            sampler.share_guidance_prefix, sampler.batch_cfg = share, batch
+            calls = []
+            orig = model.apply_model
+            monkeypatch.setattr(model, "apply_model", lambda x, t, c, **kw: calls.append(x.shape[0]) or orig(x, t, c, **kw))
+            samples, _ = sampler.sample(S=s["steps"], conditioning=cond, batch_size=shp["B"],
+                                        shape=[4, shp["T"], shp["H"], shp["W"]], verbose=False,
+                                        unconditional_guidance_scale=s["cfg_scale"], unconditional_conditioning=uc,
+                                        eta=s["eta"], fs=inp["fs"].to(cuda), x_T=inp["x_T"].to(cuda),
+                                        timestep_spacing=s["spacing"], guidance_rescale=s["guidance_rescale"],
+                                        sparse_x=concat[:, :4], class_label=inp["class_label"].to(cuda),
+                                        unconditional_conditioning_img_nonetext=uc_img, **extra)
+            monkeypatch.setattr(model, "apply_model", orig)
+            passes = 3 if mod is my_mc else 2
+            want_calls = [shp["B"]] * s["steps"] if share else ([passes * shp["B"]] * s["steps"] if batch else
+                                                               [shp["B"]] * (passes * s["steps"]))
+            assert calls == want_calls
+            outs.append(samples)
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+        finals.append(outs[0])
+    assert not torch.equal(finals[0], finals[1])
+
+
 def test_single_step_with_reference_unet_outputs_is_fp32_exact(cuda):
     """The fused update kernel fed the reference's own e_cond / e_uncond reproduces x_prev / pred_x0 to fp32 rounding."""
     from lvdm.models.samplers.ddim import DDIMSampler

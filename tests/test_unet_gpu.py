@@ -138,3 +138,36 @@ def test_prepared_context_equals_raw_context_and_graphs_are_shared_across_contex
                 m.transformer_blocks[0].attn2.to_k.weight.mul_(1.5)
     changed = net(*args, context=p1, **kw)
     assert torch.equal(changed, net(*args, context=ctx.to(cuda), **kw)) and not torch.equal(changed, raw1)
+
+
+def test_guidance_replicas_share_the_context_free_prefix_bit_exactly(cuda):
+    """A context of batch R * B against latents of batch B = R conditionings of the same latents (the passes of
+    classifier-free guidance): the UNet runs everything before its first cross-attention once and fans the batch out
+    there.  The result must be bit-identical to the R * B batch run throughout — raw and prepared contexts, eager and
+    hipGraph replay, R = 2 and 3."""
+    g = golden("unet_b.pt")
+    sd = seeded_sd(g["param_shapes"], g["seed"], g["checksum"])
+    net = build_unet(g["cfg"], sd, cuda)
+    x, ctx = unet_inputs(g["cfg"], g["shape"], g["seed"])
+    case = g["cases"][0]
+    T, B = g["shape"]["T"], x.shape[0]
+    xd, t = x.to(cuda), case["t"].to(cuda)
+    lab, fs = case["c_label"].to(cuda), case["fs"].to(cuda)
+    variants = [ctx.to(cuda), (ctx * 0.5 + 0.1).to(cuda), (ctx * -0.7).to(cuda)]
+    for r in (2, 3):
+        stacked = torch.cat(variants[:r], 0)
+        rep = lambda v: torch.cat([v] * r, 0)
+        full = net(rep(xd), rep(t), c_label=rep(lab), context=stacked, fs=rep(fs))
+        shared = net(xd, t, c_label=lab, context=stacked, fs=fs)
+        assert shared.shape == full.shape and torch.equal(shared, full)
+        prepared = net.prepare_context(stacked, T)
+        assert torch.equal(net(xd, t, c_label=lab, context=prepared, fs=fs), full)
+        for i in range(r):          # ... and each replica is the single-conditioning forward
+            assert torch.equal(full[i * B:(i + 1) * B], net(xd, t, c_label=lab, context=variants[i], fs=fs))
+        net.use_hip_graph = True
+        a = net(xd, t, c_label=lab, context=prepared, fs=fs)
+        b = net(xd, t, c_label=lab, context=prepared, fs=fs)
+        net.use_hip_graph = False
+        assert torch.equal(a, full) and torch.equal(b, full)
+    with pytest.raises(ValueError):
+        net(xd[:2], t[:2], c_label=lab[:2], context=variants[0], fs=fs[:2])         # 3 contexts for 2 latents
