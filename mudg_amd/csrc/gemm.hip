@@ -352,7 +352,25 @@ __global__ __launch_bounds__(256, SB ? 4 : 2) void gemm_kernel(const MudgGemmDes
     float* stg = reinterpret_cast<float*>(smem);
     constexpr int NPASS = SB ? 2 : 1, PROWS = BM / NPASS;      // SB stages the tile in two 64-row passes (wave rows wm = pass)
     float* sbias = stg + PROWS * STGLD;
-    if (tid < BN) sbias[tid] = (p.bias && n0 + tid < p.N) ? p.bias[n0 + tid] : 0.f;
+    // Per-group bias (a ResBlock's embedding term): when all rows of the tile belong to one group — always, for the
+    // UNet's shapes — it is one more per-column constant and rides in the staged bias; a tile that straddles groups adds
+    // it row by row in the store loop.
+    bool gbias_rows = p.gbias != nullptr;
+    if (p.gbias && !p.geglu) {
+        const int mlast = (m0 + BM <= p.M ? m0 + BM : p.M) - 1;
+        const int g0 = m0 / p.rows_per_group;
+        if (g0 == mlast / p.rows_per_group) {
+            gbias_rows = false;
+            if (tid < BN) {
+                float b = (p.bias && n0 + tid < p.N) ? p.bias[n0 + tid] : 0.f;
+                if (n0 + tid < p.N) b += p.gbias[(int64_t)g0 * p.N + n0 + tid];
+                sbias[tid] = b;
+            }
+        }
+    }
+    if (gbias_rows || !p.gbias || p.geglu) {
+        if (tid < BN) sbias[tid] = (p.bias && n0 + tid < p.N) ? p.bias[n0 + tid] : 0.f;
+    }
     __syncthreads();
 
     const float alpha = p.alpha;
@@ -421,7 +439,7 @@ __global__ __launch_bounds__(256, SB ? 4 : 2) void gemm_kernel(const MudgGemmDes
 #pragma unroll
             for (int j = 0; j < 4; ++j) { v[j] = a[j]; v[4 + j] = b[j]; }
         }
-        if (p.gbias) {
+        if (gbias_rows) {
             const float* gb = p.gbias + (int64_t)(m / p.rows_per_group) * Nout + n;
 #pragma unroll
             for (int j = 0; j < 8; ++j) if (j < nvalid) v[j] += gb[j];
