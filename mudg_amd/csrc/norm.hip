@@ -254,6 +254,68 @@ __global__ __launch_bounds__(256) void ln_kernel(const T* __restrict__ X, int ld
     }
 }
 
+// LayerNorm for the UNet's widths (C a multiple of 8 * LPR): LPR lanes per row, 64 / LPR rows per wave, NV 16-byte vectors
+// per lane.  The one-wave-per-row kernel above keeps a single 16-byte load per lane in flight and, at C = 320, only 40 of
+// its 64 lanes busy; here every lane has NV loads outstanding (a wave requests 64 / LPR whole rows at once), the lanes
+// of a row read consecutive 16-byte vectors (128 B per request at LPR = 8), the two reductions take log2(LPR) butterfly
+// steps, and gamma / beta are fetched once per wave instead of once per row.
+template <int LPR, int NV, typename T>
+__global__ __launch_bounds__(256) void ln_rows_kernel(const T* __restrict__ X, int ldx, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, h16* __restrict__ Y, int ldy,
+                                                       int rows, float eps) {
+    constexpr int RPW = 64 / LPR;                       // rows per wave
+    constexpr int C = LPR * NV * 8;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane & (LPR - 1);
+    int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / LPR;
+    const bool live = row < rows;
+    if (!live) row = rows - 1;                          // keeps the butterflies uniform; nothing is stored for it
+    float x[NV][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) Load8<T>::get(X + row * ldx + (sub + LPR * i) * 8, ldx, x[i]);
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += x[i][e];
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = x[i][e] - mean; q = fmaf(d, d, q); }
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    const float rstd = rsqrtf(q / (float)C + eps);
+    if (!live) return;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int v = sub + LPR * i;
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + v * 8);
+        const f32x4 g1 = *reinterpret_cast<const f32x4*>(gamma + v * 8 + 4);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + v * 8);
+        const f32x4 b1 = *reinterpret_cast<const f32x4*>(beta + v * 8 + 4);
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            o[e] = fmaf((x[i][e] - mean) * rstd, g0[e], b0[e]);
+            o[4 + e] = fmaf((x[i][4 + e] - mean) * rstd, g1[e], b1[e]);
+        }
+        store8_operand(Y + row * ldy + v * 8, ldy / PLANES, o);
+    }
+}
+
+template <int LPR, int NV>
+void launch_ln_rows(int x_fp32, const void* X, int ldx, const float* gamma, const float* beta, void* Y, int ldy, int rows,
+                    float eps, hipStream_t s) {
+    const dim3 grid((rows + 4 * (64 / LPR) - 1) / (4 * (64 / LPR)));
+    if (x_fp32 == KIND_F16) hipLaunchKernelGGL((ln_rows_kernel<LPR, NV, StreamH>), grid, dim3(256), 0, s, (const StreamH*)X, ldx, gamma, beta, (h16*)Y, ldy, rows, eps);
+    else if (x_fp32) hipLaunchKernelGGL((ln_rows_kernel<LPR, NV, float>), grid, dim3(256), 0, s, (const float*)X, ldx, gamma, beta, (h16*)Y, ldy, rows, eps);
+    else hipLaunchKernelGGL((ln_rows_kernel<LPR, NV, h16>), grid, dim3(256), 0, s, (const h16*)X, ldx, gamma, beta, (h16*)Y, ldy, rows, eps);
+}
+
 // Row softmax fp32 -> h16, one workgroup per row, three passes over the row (second and third hit L2).
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ S, int lds, h16* __restrict__ P,
                                                             int ldp, int cols) {
@@ -378,7 +440,14 @@ extern "C" int mudg_layernorm(const void* X, int ldx, int x_fp32, const float* g
     const int slot = mudg_prof_begin(MUDG_FAM_LNORM, s);
     const dim3 grid((rows + 3) / 4);
     const int nvec = C >> 3;
-    if (nvec <= 64 * 3) {
+    static int rows_kernel = -1;            // MUDG_LN_ROWS=0: the one-wave-per-row kernel for every width (A/B, tests)
+    if (rows_kernel < 0) { const char* e = getenv("MUDG_LN_ROWS"); rows_kernel = e ? atoi(e) : 1; }
+    if (rows_kernel && C == 320) launch_ln_rows<8, 5>(x_fp32, X, ldx, gamma, beta, Y, ldy, rows, eps, s);
+    else if (rows_kernel && C == 512) launch_ln_rows<8, 8>(x_fp32, X, ldx, gamma, beta, Y, ldy, rows, eps, s);
+    else if (rows_kernel && C == 640) launch_ln_rows<8, 10>(x_fp32, X, ldx, gamma, beta, Y, ldy, rows, eps, s);
+    else if (rows_kernel && C == 1024) launch_ln_rows<16, 8>(x_fp32, X, ldx, gamma, beta, Y, ldy, rows, eps, s);
+    else if (rows_kernel && C == 1280) launch_ln_rows<16, 10>(x_fp32, X, ldx, gamma, beta, Y, ldy, rows, eps, s);
+    else if (nvec <= 64 * 3) {
         if (x_fp32 == KIND_F16) hipLaunchKernelGGL((ln_kernel<3, StreamH>), grid, dim3(256), 0, s, (const StreamH*)X, ldx, gamma, beta, (h16*)Y, ldy, rows, C, eps);
         else if (x_fp32) hipLaunchKernelGGL((ln_kernel<3, float>), grid, dim3(256), 0, s, (const float*)X, ldx, gamma, beta, (h16*)Y, ldy, rows, C, eps);
         else hipLaunchKernelGGL((ln_kernel<3, h16>), grid, dim3(256), 0, s, (const h16*)X, ldx, gamma, beta, (h16*)Y, ldy, rows, C, eps);

@@ -233,6 +233,27 @@ def test_groupnorm_and_layernorm(cuda, x_fp32):
     assert rel(value(y), F.layer_norm(xv, (C,), g.double(), b.double(), 1e-5)) < TOL_OP
 
 
+@pytest.mark.parametrize("C", [320, 512, 640, 1024, 1280, 384])
+def test_layernorm_at_the_unet_widths(cuda, C):
+    """The UNet's LayerNorm widths run on the lanes-per-row kernel (8 or 16 lanes per row, several rows per wave); 384 stays
+    on the one-wave-per-row kernel.  Ragged row counts (a partly filled last wave and workgroup), every input storage
+    (operand, fp32, the residual stream's), rows independent of their neighbours."""
+    from mudg_amd import ops
+    g, b = 1 + 0.1 * f32(C, seed=2), 0.1 * f32(C, seed=3)
+    for rows in (1, 37, 259):
+        xs = f32(rows, C, seed=rows) * 1.5 + 0.25
+        want = lambda xv: F.layer_norm(xv, (C,), g.double(), b.double(), 1e-5)
+        xo, xov = operand(xs, cuda)
+        y = ops.layernorm(xo, g.to(cuda), b.to(cuda), eps=1e-5)
+        assert rel(value(y), want(xov)) < TOL_OP
+        assert rel(value(ops.layernorm(xs.to(cuda), g.to(cuda), b.to(cuda), eps=1e-5)), want(xs.double())) < TOL_OP
+        xh = xs.to(cuda).to(ops.STREAM())
+        assert rel(value(ops.layernorm(xh, g.to(cuda), b.to(cuda), eps=1e-5)), want(xh.double().cpu())) < TOL_OP
+        if rows > 1:      # a row's result does not depend on which rows share its wave
+            head = ops.layernorm(xo[:rows - 1], g.to(cuda), b.to(cuda), eps=1e-5)
+            assert torch.equal(value(head), value(y)[:rows - 1])
+
+
 def test_groupnorm_fused_statistics_from_the_producing_conv(cuda):
     """A conv writes the next GroupNorm's partial sums (over the values it stored); the fused norm must agree with the
     two-pass one on the same tensor."""
