@@ -100,8 +100,19 @@ typedef struct MudgGemmDesc {
                              channel, the sum and the sum of squares of the values it stored (as stored: after rounding to
                              bf16 when Y is bf16) — the first pass of the GroupNorm that consumes Y
                              (mudg_groupnorm_fused).  Needs batch == 1 and no GEGLU. */
+    int subpixel;         /* mode 1: 1 = the sub-pixel form of "nearest-2x upsample, then 3x3 / pad 1 conv" (openaimodel3d.py:92-106,
+                             ae_modules.py:77-92).  An output pixel (2 oy + py, 2 ox + px) of the upsampled image only ever sees a
+                             2 x 2 neighbourhood of the LOW-resolution input, its nine taps collapsing onto four summed weights:
+                             4/9 of the multiply-adds.  X is the low-resolution image (Hout x Wout == Hin x Win is the grid
+                             walked, M = frames * Hin * Win); batch = 4 with entry z = 2 py + px; W holds the four [N][4 Cin]
+                             matrices sW apart, K ordered [Cin/64][tap 0..3][64] with tap = 2 a + b reading input pixel
+                             (oy - 1 + py + a, ox - 1 + px + b); Y is the (2 Hin x 2 Win) image, row ((f 2Hin) + 2 oy + py) 2Win
+                             + 2 ox + px.  Needs what mudg_conv_subpixel_ok checks. */
 } MudgGemmDesc;
 int mudg_gemm(const MudgGemmDesc* d, void* stream);
+/* 1 when `d` (mode 1, subpixel = 1) can run: batch 4, stride 1, pad 1, korder 1, Cin % 64 == 0, no X2 / R / gbias / stats /
+ * upsample, and offsets within reach of the buffer-descriptor loader; else the caller uses upsample = 1 with 3x3 weights. */
+int mudg_conv_subpixel_ok(const MudgGemmDesc* d);
 
 /* ------------------------------------------------------------------ attention
  * Flash-style softmax(scale * Q K^T) V for head dim 64, never materialising the score matrix.

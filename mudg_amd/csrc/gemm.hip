@@ -127,6 +127,11 @@ __global__ __launch_bounds__(256, SB ? 4 : 2) void gemm_kernel(const MudgGemmDes
     }
     const int m0 = tm * BM, n0 = tn * BN;
     const int64_t bz = blockIdx.z;
+    // Sub-pixel form of "nearest-2x upsample, then 3x3 conv" (MudgGemmDesc.subpixel): batch entry z = 2 py + px computes the
+    // output pixels (2 oy + py, 2 ox + px) from the 2x2 low-resolution neighbourhood that their nine taps collapse onto.
+    const bool sub = MODE == 1 && p.subpixel;
+    const int ntaps = sub ? 4 : 9;
+    const int dy0 = sub ? (int)(blockIdx.z >> 1) : 0, dx0 = sub ? (int)(blockIdx.z & 1) : 0;
     const h16* X = reinterpret_cast<const h16*>(p.X) + bz * p.sX;
     const h16* X2 = p.X2 ? reinterpret_cast<const h16*>(p.X2) + bz * p.sX : nullptr;
     const h16* W = reinterpret_cast<const h16*>(p.W) + bz * p.sW;
@@ -187,8 +192,8 @@ __global__ __launch_bounds__(256, SB ? 4 : 2) void gemm_kernel(const MudgGemmDes
                 if (rv[i]) {
 #pragma unroll
                     for (int t = 0; t < 9; ++t) {
-                        const int iy = rb[i] + t / 3, ix = rc[i] + t % 3;
-                        if (iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win) mask |= 1u << t;
+                        const int iy = rb[i] + (sub ? (t >> 1) + dy0 : t / 3), ix = rc[i] + (sub ? (t & 1) + dx0 : t % 3);
+                        if (t < ntaps && iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win) mask |= 1u << t;
                     }
                 }
             } else if (MODE == 2) {
@@ -215,7 +220,11 @@ __global__ __launch_bounds__(256, SB ? 4 : 2) void gemm_kernel(const MudgGemmDes
         const int ld = s2 ? p.ldx2 : p.ldx;
         int soff;
         if (MODE == 0) soff = cc * 2;
-        else if (MODE == 1) { const int dy = tap_s / 3, dx = tap_s - 3 * dy; soff = ((dy * p.Win + dx) * ld + cc) * 2; }
+        else if (MODE == 1) {
+            int dy = tap_s / 3, dx = tap_s - 3 * dy;
+            if (sub) { dy = (tap_s >> 1) + dy0; dx = (tap_s & 1) + dx0; }
+            soff = ((dy * p.Win + dx) * ld + cc) * 2;
+        }
         else soff = (tap_s * p.HW * ld + cc) * 2;
         int soffw = (PLANES > 1 ? kt_s : kt) * (BK * 2);
         if constexpr (PLANES > 1) {                  // this pass's operand planes: column offsets of ld / PLANES elements
@@ -239,7 +248,7 @@ __global__ __launch_bounds__(256, SB ? 4 : 2) void gemm_kernel(const MudgGemmDes
         } else {                                   // select form: the branchy update sent tap_s / c_s to scratch memory
             const int t1 = tap_s + 1, c1 = c_s + BK;
             const bool slab = MODE == 1 && p.korder;
-            const bool wrap = slab ? (t1 == 9) : (c1 == p.Cin);
+            const bool wrap = slab ? (t1 == ntaps) : (c1 == p.Cin);
             tap_s = slab ? (wrap ? 0 : t1) : (wrap ? t1 : tap_s);
             c_s = slab ? (wrap ? c1 : c_s) : (wrap ? 0 : c1);
         }
@@ -429,6 +438,35 @@ __global__ __launch_bounds__(256, SB ? 4 : 2) void gemm_kernel(const MudgGemmDes
     const int cc = tid & (cpr - 1);
     const int n = nout0 + cc * 8;
     const int nvalid = n >= Nout ? 0 : ((Nout - n) < 8 ? (Nout - n) : 8);
+    if (sub) {
+        // sub-pixel conv: bias only (host-checked), rows scattered to this parity class's pixels of the full-resolution image
+        for (int row = tid >> 4; row < PROWS; row += 16) {
+            const int m = m0 + pass * PROWS + row;
+            if (m >= p.M || nvalid == 0) break;
+            const int hw = p.Hout * p.Wout;
+            const int f = m / hw, r = m - f * hw;
+            const int oy = r / p.Wout, ox = r - oy * p.Wout;
+            const int64_t yoff = (((int64_t)(f * p.Hout + oy) * 2 + dy0) * (2 * p.Wout) + 2 * ox + dx0) * p.ldy + n;
+            float v[8];
+            const f32x4 a = *reinterpret_cast<const f32x4*>(&stg[row * STGLD + cc * 8]);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(&stg[row * STGLD + cc * 8 + 4]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[j] = a[j]; v[4 + j] = b[j]; }
+            const bool wide = nvalid == 8 && (vflags & VF_Y);
+            if (p.out_fp32 == KIND_F16) {
+                _Float16* yp = reinterpret_cast<_Float16*>(p.Y) + yoff;
+                if (wide) store8_f16(yp, v);
+                else for (int j = 0; j < nvalid; ++j) yp[j] = (_Float16)v[j];
+            } else if (p.out_fp32) {
+                float* yp = reinterpret_cast<float*>(p.Y) + yoff;
+                for (int j = 0; j < nvalid; ++j) yp[j] = v[j];
+            } else {
+                h16* yp = reinterpret_cast<h16*>(p.Y) + yoff;
+                if (wide) store8_operand(yp, p.ldy / PLANES, v);
+                else for (int j = 0; j < nvalid; ++j) store1_operand(yp + j, p.ldy / PLANES, v[j]);
+            }
+        }
+    } else
     for (int row = tid >> cshift; row < PROWS; row += (256 >> cshift)) {
         const int m = m0 + pass * PROWS + row;
         if (m >= p.M || nvalid == 0) break;
@@ -486,8 +524,9 @@ __global__ __launch_bounds__(256, SB ? 4 : 2) void gemm_kernel(const MudgGemmDes
                 gs[j] += t; gq[j] = fmaf(t, t, gq[j]);
             }
         }
+        const int64_t yoff = bz * p.sY + (int64_t)m * p.ldy + n;
         if (p.out_fp32 == KIND_F16) {
-            _Float16* yp = reinterpret_cast<_Float16*>(p.Y) + bz * p.sY + (int64_t)m * p.ldy + n;
+            _Float16* yp = reinterpret_cast<_Float16*>(p.Y) + yoff;
             if (nvalid == 8 && (vflags & VF_Y)) {
                 store8_f16(yp, v);
             } else {
@@ -495,7 +534,7 @@ __global__ __launch_bounds__(256, SB ? 4 : 2) void gemm_kernel(const MudgGemmDes
                 for (int j = 0; j < 8; ++j) if (j < nvalid) yp[j] = (_Float16)v[j];
             }
         } else if (p.out_fp32) {
-            float* yp = reinterpret_cast<float*>(p.Y) + bz * p.sY + (int64_t)m * p.ldy + n;
+            float* yp = reinterpret_cast<float*>(p.Y) + yoff;
             if (nvalid == 8 && (vflags & VF_Y)) {
                 f32x4 a, b;
 #pragma unroll
@@ -507,7 +546,7 @@ __global__ __launch_bounds__(256, SB ? 4 : 2) void gemm_kernel(const MudgGemmDes
                 for (int j = 0; j < 8; ++j) if (j < nvalid) yp[j] = v[j];
             }
         } else {
-            h16* yp = reinterpret_cast<h16*>(p.Y) + bz * p.sY + (int64_t)m * p.ldy + n;
+            h16* yp = reinterpret_cast<h16*>(p.Y) + yoff;
             if (nvalid == 8 && (vflags & VF_Y)) {
                 store8_operand(yp, p.ldy / PLANES, v);
             } else {
@@ -611,7 +650,7 @@ bool use_gemm256(const MudgGemmDesc& d) {
         const char* e = getenv("MUDG_GEMM256");
         mode = e ? atoi(e) : 2;
     }
-    if (mode == 0 || PLANES > 1 || d.M < 256 || d.N < 256) return false;      // the 256x256 kernels are 16-bit-operand only
+    if (mode == 0 || PLANES > 1 || d.M < 256 || d.N < 256 || (d.mode == 1 && d.subpixel)) return false;      // the 256x256 kernels are 16-bit-operand only
     if (mode == 1) return true;
     const int64_t tn = (d.N + 255) / 256, tiles = ((d.M + 255) / 256) * tn * d.batch;
     const double waste = (double)(tn * 256 - d.N) / (double)(tn * 256);
@@ -665,6 +704,16 @@ bool mudg_gemm_fast_ok(const MudgGemmDesc& d) {
 
 int mudg_gemm256_dispatch(const MudgGemmDesc& d, int vflags, const h16* zpage, hipStream_t s);
 
+extern "C" int mudg_conv_subpixel_ok(const MudgGemmDesc* dp) {
+    if (!dp) return 0;
+    MudgGemmDesc d = *dp;
+    if (d.mode != 1 || !d.subpixel || d.batch != 4 || d.stride != 1 || d.pad != 1 || d.upsample || !d.korder) return 0;
+    if (d.X2 || d.R || d.gbias || d.stats || d.geglu || d.sX != 0 || d.sY != 0) return 0;
+    if (d.Hout != d.Hin || d.Wout != d.Win || d.K != 4 * d.Cin || (d.Cin & 63)) return 0;
+    d.csplit = d.Cin;
+    return mudg_gemm_fast_ok(d) ? 1 : 0;
+}
+
 extern "C" int mudg_gemm(const MudgGemmDesc* dp, void* stream) {
     MUDG_REQUIRE(dp, "mudg_gemm: null descriptor");
     MudgGemmDesc d = *dp;
@@ -689,7 +738,10 @@ extern "C" int mudg_gemm(const MudgGemmDesc* dp, void* stream) {
         MUDG_REQUIRE(!d.R || d.res_fp32 || d.ldr % PLANES == 0, "mudg_gemm: ldr=%d must be a multiple of %d", d.ldr, PLANES);
     }
     if (d.mode == 1) {
-        MUDG_REQUIRE(d.Cin > 0 && (d.Cin & 7) == 0 && d.K == 9 * d.Cin, "mudg_gemm: conv K=%d Cin=%d", d.K, d.Cin);
+        MUDG_REQUIRE(d.Cin > 0 && (d.Cin & 7) == 0 && d.K == (d.subpixel ? 4 : 9) * d.Cin, "mudg_gemm: conv K=%d Cin=%d", d.K, d.Cin);
+        if (d.subpixel)
+            MUDG_REQUIRE(mudg_conv_subpixel_ok(&d), "mudg_gemm: subpixel needs batch 4, stride 1, pad 1, korder 1, Hout x Wout == Hin x Win, "
+                         "no upsample / X2 / R / gbias / stats, and a problem the buffer-descriptor kernels accept");
         MUDG_REQUIRE(d.stride == 1 || d.stride == 2, "mudg_gemm: stride %d", d.stride);
         MUDG_REQUIRE(!(d.upsample && d.stride != 1), "mudg_gemm: upsample needs stride 1");
         MUDG_REQUIRE(d.Hin > 0 && d.Win > 0 && d.Hout > 0 && d.Wout > 0, "mudg_gemm: conv geometry");
@@ -737,7 +789,8 @@ extern "C" int mudg_gemm(const MudgGemmDesc* dp, void* stream) {
     // algorithmic bytes at 16-bit storage: activations in (taps are re-reads of the same rows), weights, the result, and the
     // residual the epilogue adds when there is one
     const double nout = d.geglu ? d.N / 2 : d.N;
-    const double bytes = ((double)d.M * cin + (double)d.N * d.K + (double)d.M * nout * (d.R ? 2.0 : 1.0)) * 2.0 * d.batch;
+    double bytes = ((double)d.M * cin + (double)d.N * d.K + (double)d.M * nout * (d.R ? 2.0 : 1.0)) * 2.0 * d.batch;
+    if (d.mode == 1 && d.subpixel) bytes = ((double)d.M * cin + 4.0 * d.N * d.K + 4.0 * d.M * nout) * 2.0;      // the low-res input once
     mudg_prof_end(slot, s, flops, bytes);
     return rc;
 }

@@ -117,6 +117,32 @@ def conv3x3(mod):
     return cached(mod, "w3x3", (w,), build), cpad, korder
 
 
+def conv3x3_subpixel(mod):
+    """(Cout, Cin, 3, 3) -> the four [Cout][4 Cin] matrices of the sub-pixel form of "nearest-2x upsample, then this conv"
+    (MudgGemmDesc.subpixel), stacked [4 Cout][4 Cin]; None when Cin is not a multiple of 64 (the caller then runs the
+    upsampling loader with the 3x3 weights).  An output pixel of parity (py, px) sees the low-resolution pixels
+    (oy - 1 + py + a, ox - 1 + px + b), a, b in {0, 1}; the 3x3 taps that land on the same one are summed (in fp32, before
+    the operand rounding): rows {0 | 1, 2} for py = 0, {0, 1 | 2} for py = 1, likewise the columns."""
+    w = mod.weight
+    _need_cuda(w, type(mod).__name__)
+    cout, cin = w.shape[0], w.shape[1]
+    if cin % 64:
+        return None
+
+    def build():
+        t = w.detach().float()                                   # Cout, Cin, ky, kx
+        sets = (((0,), (1, 2)), ((0, 1), (2,)))
+        mats = []
+        for py in range(2):
+            for px in range(2):
+                taps = [sum(t[:, :, dy, dx] for dy in sets[py][a] for dx in sets[px][b]) for a in range(2) for b in range(2)]
+                m = torch.stack(taps, 1)                         # Cout, tap (2a + b), Cin
+                mats.append(m.reshape(cout, 4, cin // 64, 64).permute(0, 2, 1, 3).reshape(cout, 4 * cin))
+        return operand(torch.cat(mats, 0))
+
+    return cached(mod, "w3x3sub", (w,), build)
+
+
 def tconv(mod):
     """(Cout, Cin, 3, 1, 1) -> [Cout][tap][Cin] bf16."""
     w = mod.weight

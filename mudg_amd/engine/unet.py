@@ -75,6 +75,24 @@ def _conv3x3(mod, x, frames, h, w, *, stride=1, upsample=False, gbias=None, rows
                        out_stream=stream, out_fp32=fp32, korder=korder, stats=stats)
 
 
+_SUBPIXEL = _os.environ.get("MUDG_SUBPIXEL", "1") != "0"          # A/B switch: sub-pixel form of the upsample convs
+
+
+def upsample_conv(mod, x, frames, h, w, stream=True):
+    """Nearest-2x upsample + 3x3 conv (openaimodel3d.py:92-106; ae_modules.py:77-92 for the VAE): as four 2x2 convs on the
+    low-resolution rows when the layer qualifies (4/9 of the multiply-adds, MudgGemmDesc.subpixel), else through the
+    upsampling loader of the 16-wave kernel.  Neither writes GroupNorm partials."""
+    wsub = pk.conv3x3_subpixel(mod) if _SUBPIXEL else None
+    if wsub is not None:
+        out = ops.conv3x3_up2(x, wsub, frames=frames, hin=h, win=w, cin=mod.weight.shape[1], bias=pk.f32(mod, "bias"),
+                              out_stream=stream)
+        if out is not None:
+            return out
+    wmat, cpad, korder = pk.conv3x3(mod)
+    return ops.conv3x3(x, wmat, frames=frames, hin=h, win=w, cin=cpad, upsample=True, bias=pk.f32(mod, "bias"),
+                       out_stream=stream, korder=korder, stats=False)
+
+
 def _vt_projection(mod, src_rows, batches, n_per_batch):
     """V^T per batch entry: out[b] = W_v (C x K) @ src[b]^T (K x n) -> [batches * C, ld] with ld = n rounded to 8."""
     w = pk.linear(mod)
@@ -223,7 +241,7 @@ def run_stage(seq, x, x2, h, w, ctx):
             h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1
         elif name == "Upsample":
             # nearest-2x convs run on the 16-wave 256x256 kernel, which does not emit GroupNorm partials
-            x = _conv3x3(m.conv, ops.cast_bf16(x), frames, h, w, upsample=True, stream=True, stats=False)
+            x = upsample_conv(m.conv, ops.cast_bf16(x), frames, h, w)
             h, w = 2 * h, 2 * w
         elif isinstance(m, nn.Conv2d):                      # the stem (possibly swapped in by training-time surgery)
             x = _conv3x3(m, x, frames, h, w, stream=True)

@@ -11,6 +11,7 @@ import torch.nn as nn
 
 from .. import ops
 from . import packing as pk
+from . import unet as U
 
 MAX_SCORE_BYTES = 8 << 30      # fp32 attention scores held at once (frames are chunked beyond this)
 
@@ -83,7 +84,7 @@ def decoder_rows(dec, x, frames, h, w):
             if len(level.attn) > 0:
                 x = attn_block(level.attn[i], x, frames, h * w)
         if lvl != 0:
-            x = _conv3x3(level.upsample.conv, ops.cast_bf16(x), frames, h, w, upsample=True, stream=True)
+            x = U.upsample_conv(level.upsample.conv, ops.cast_bf16(x), frames, h, w)
             h, w = 2 * h, 2 * w
     x = _gn(dec.norm_out, x, frames, h * w, True)
     return _conv3x3(dec.conv_out, x, frames, h, w, fp32=True), h, w          # the decoded pixels leave in fp32

@@ -70,6 +70,7 @@ class GemmDesc(C.Structure):
         ("Cin", C.c_int), ("stride", C.c_int), ("upsample", C.c_int), ("pad", C.c_int), ("korder", C.c_int),
         ("T", C.c_int), ("HW", C.c_int),
         ("stats", C.c_void_p),
+        ("subpixel", C.c_int),
     ]
 
 
@@ -94,6 +95,7 @@ SIGNATURES = {
     "mudg_operand_dtype": (_I, []),
     "mudg_last_error": (C.c_char_p, []),
     "mudg_gemm": (_I, [C.POINTER(GemmDesc), _P]),
+    "mudg_conv_subpixel_ok": (_I, [C.POINTER(GemmDesc)]),
     "mudg_attention": (_I, [C.POINTER(AttnDesc), _P]),
     "mudg_quantize_mxfp8": (_I, [_P, _I, _L, _I, _P, _I, _P, _I, _P]),
     "mudg_temporal_attention": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _F, _P]),

@@ -193,6 +193,29 @@ def conv3x3(x, w, *, frames, hin, win, cin, stride=1, upsample=False, out=None, 
     return out
 
 
+def conv3x3_up2(x, wsub, *, frames, hin, win, cin, bias=None, out_fp32=False, out_stream=False):
+    """Nearest-2x upsample followed by a 3x3 / pad 1 conv in the sub-pixel form — four 2x2 convs on the low-resolution
+    image, 4/9 of the multiply-adds (MudgGemmDesc.subpixel; `wsub` from packing.conv3x3_subpixel).  Returns None when the
+    problem is outside what the descriptor loader accepts: the caller then runs conv3x3(upsample=True) with the 3x3 weights."""
+    _rows(x); _rows(wsub)
+    N = wsub.shape[0] // 4
+    M = frames * hin * win
+    d = hip.GemmDesc()
+    d.X, d.W, d.bias = x.data_ptr(), wsub.data_ptr(), _ptr(bias)
+    d.M, d.N, d.K = M, N, 4 * cin
+    d.ldx, d.ldw = x.stride(0), wsub.stride(0)
+    d.csplit, d.batch, d.alpha, d.mode = cin, 4, 1.0, 1
+    d.sW = N * wsub.stride(0)
+    d.Hin, d.Win, d.Hout, d.Wout, d.Cin, d.stride, d.upsample = hin, win, hin, win, cin, 1, 0
+    d.korder, d.pad, d.subpixel = 1, 1, 1
+    if not hip.lib().mudg_conv_subpixel_ok(C.byref(d)):
+        return None
+    out = empty_rows(4 * M, N, _out_dtype(out_fp32, out_stream), x.device)
+    d.Y, d.ldy, d.out_fp32 = out.data_ptr(), out.stride(0), kind(out)
+    hip.check(hip.lib().mudg_gemm(C.byref(d), _stream()), "mudg_gemm[conv3x3 subpixel]")
+    return out
+
+
 def tconv3(x, w, *, clips, t, hw, cin, out=None, bias=None, residual=None, out_fp32=False, stats=False, out_stream=False):
     """(3,1,1) temporal convolution, pad (1,0,0), on rows ordered ((b t) hw); w packed [Cout][3*cin]."""
     _rows(x); _rows(w)

@@ -233,6 +233,39 @@ def test_groupnorm_and_layernorm(cuda, x_fp32):
     assert rel(value(y), F.layer_norm(xv, (C,), g.double(), b.double(), 1e-5)) < TOL_OP
 
 
+@pytest.mark.parametrize("cin,cout,frames,h,w", [(64, 96, 3, 5, 7), (128, 64, 2, 16, 16), (192, 320, 1, 9, 16), (64, 128, 5, 8, 4)])
+@pytest.mark.parametrize("stream", [False, True])
+def test_upsample_conv_in_sub_pixel_form(cuda, cin, cout, frames, h, w, stream):
+    """Nearest-2x upsample + 3x3 conv as four 2x2 convs on the low-resolution rows (MudgGemmDesc.subpixel): against
+    conv2d(interpolate(x)) in fp64 on the values the operands hold, and against the upsampling loader fed the 3x3 weights.
+    Ragged sizes: row counts that are no multiple of the 128-row tile or of the image width, Cout below / across the
+    128-column tile, several frames per tile."""
+    import torch.nn as nn
+    from mudg_amd import ops
+    from mudg_amd.engine import packing as pk, unet as U
+    conv = nn.Conv2d(cin, cout, 3, padding=1)
+    with torch.no_grad():
+        conv.weight.copy_(f32(cout, cin, 3, 3, seed=2, scale=0.05))
+        conv.bias.copy_(f32(cout, seed=3))
+    conv = conv.to(cuda)
+    x, xv = operand(_rows(f32(frames, cin, h, w, seed=1)), cuda)
+    wsub = pk.conv3x3_subpixel(conv)
+    assert wsub is not None and tuple(wsub.shape) == (4 * cout, 4 * cin)
+    y = ops.conv3x3_up2(x, wsub, frames=frames, hin=h, win=w, cin=cin, bias=pk.f32(conv, "bias"), out_stream=stream)
+    assert y is not None and tuple(y.shape) == (frames * 4 * h * w, cout)
+    assert y.dtype == (ops.STREAM() if stream else _hip.operand_dtype())
+    up = F.interpolate(_unrows(xv, frames, h, w), scale_factor=2, mode="nearest")
+    ref = _rows(F.conv2d(up, conv.weight.detach().double().cpu(), conv.bias.detach().double().cpu(), padding=1))
+    # the four summed weights are rounded to the operand precision AFTER the sum: one more operand rounding than TOL_OP prices
+    assert rel(value(y) if not stream else y, ref) < 2 * TOL_OP + (4e-4 if stream and y.dtype == torch.float16 else 0)
+    w3, cpad, korder = pk.conv3x3(conv)
+    old = ops.conv3x3(x, w3, frames=frames, hin=h, win=w, cin=cpad, upsample=True, bias=pk.f32(conv, "bias"), korder=korder,
+                      out_stream=stream)
+    assert rel(value(y) if not stream else y, value(old) if not stream else old) < 3 * TOL_OP + (8e-4 if stream and y.dtype == torch.float16 else 0)
+    assert torch.equal(U.upsample_conv(conv, x, frames, h, w, stream=stream), y) or not U._SUBPIXEL
+    assert pk.conv3x3_subpixel(nn.Conv2d(72, 8, 3, padding=1).to(cuda)) is None           # Cin % 64 != 0: the caller falls back
+
+
 @pytest.mark.parametrize("C", [320, 512, 640, 1024, 1280, 384])
 def test_layernorm_at_the_unet_widths(cuda, C):
     """The UNet's LayerNorm widths run on the lanes-per-row kernel (8 or 16 lanes per row, several rows per wave); 384 stays
