@@ -7,6 +7,8 @@ Operand outputs carry one operand rounding (2^-9 bf16, 2^-12 fp16, ~2^-18 x3, ~2
 mode drops inside the contraction (nothing in the 16-bit modes, the x1*w1 partial product in x3).
 
 This file runs in the default mode directly, and once per other mode in a child process (test_precision_modes_gpu.py)."""
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -235,6 +237,7 @@ def test_groupnorm_and_layernorm(cuda, x_fp32):
 
 @pytest.mark.parametrize("cin,cout,frames,h,w", [(64, 96, 3, 5, 7), (128, 64, 2, 16, 16), (192, 320, 1, 9, 16), (64, 128, 5, 8, 4)])
 @pytest.mark.parametrize("stream", [False, True])
+@pytest.mark.skipif(os.environ.get("MUDG_GEMM_FAST") == "0", reason="the sub-pixel form runs on the descriptor loader only")
 def test_upsample_conv_in_sub_pixel_form(cuda, cin, cout, frames, h, w, stream):
     """Nearest-2x upsample + 3x3 conv as four 2x2 convs on the low-resolution rows (MudgGemmDesc.subpixel): against
     conv2d(interpolate(x)) in fp64 on the values the operands hold, and against the upsampling loader fed the 3x3 weights.

@@ -88,7 +88,12 @@ def test_batched_cfg_equals_sequential_passes(cuda):
                                           unconditional_guidance_scale=s["cfg_scale"], unconditional_conditioning=uc,
                                           guidance_rescale=s["guidance_rescale"], fs=inp["fs"].to(cuda),
                                           class_label=inp["class_label"].to(cuda), sparse_x=inp["concat"][:, :4].to(cuda)))
-    assert rel_l2(outs[0][0], outs[1][0]) < 1e-5 and rel_l2(outs[0][1], outs[1][1]) < 1e-5
+    # another batch size may take another key split in the attention kernels: identical after the bf16 build's roundings,
+    # accumulation-order noise (amplified to about the mode's own rounding level by the layers that follow) in the others
+    tol = {"bf16": 1e-5, "fp16": 5e-3, "bf16x3": 1e-4, "bf16x6": 1e-5}[MODE]
+    drift = max(rel_l2(outs[0][0], outs[1][0]), rel_l2(outs[0][1], outs[1][1]))
+    print(f"[{MODE}] doubled batch vs sequential passes: rel-L2 {drift:.3e}")
+    assert drift < tol
 
 
 def test_shared_guidance_prefix_equals_the_replicated_batch(cuda, monkeypatch):
@@ -127,7 +132,13 @@ def test_shared_guidance_prefix_equals_the_replicated_batch(cuda, monkeypatch):
                                                                [shp["B"]] * (passes * s["steps"]))
             assert calls == want_calls
             outs.append(samples)
-        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+        assert torch.equal(outs[0], outs[1])
+        # back-to-back passes run at another batch size, where the attention kernels may split the keys differently: equal bits
+        # after the bf16 build's 16-bit roundings, equal to accumulation-order noise in the wider modes (in the fp16 build
+        # that noise flips operand roundings, which two guided steps amplify like any other operand-rounding error)
+        drift = rel_l2(outs[2], outs[0])
+        print(f"[{MODE}] back-to-back passes vs one stacked pass: rel-L2 {drift:.3e}")
+        assert torch.equal(outs[0], outs[2]) if MODE == "bf16" else drift < (5e-3 if FP16 else 1e-4)
         finals.append(outs[0])
     assert not torch.equal(finals[0], finals[1])
 

@@ -162,8 +162,10 @@ def test_guidance_replicas_share_the_context_free_prefix_bit_exactly(cuda):
         assert shared.shape == full.shape and torch.equal(shared, full)
         prepared = net.prepare_context(stacked, T)
         assert torch.equal(net(xd, t, c_label=lab, context=prepared, fs=fs), full)
-        for i in range(r):          # ... and each replica is the single-conditioning forward
-            assert torch.equal(full[i * B:(i + 1) * B], net(xd, t, c_label=lab, context=variants[i], fs=fs))
+        for i in range(r):          # ... and each replica is the single-conditioning forward (another batch size: the
+            one = net(xd, t, c_label=lab, context=variants[i], fs=fs)      # attention kernels may split the keys differently,
+            part = full[i * B:(i + 1) * B]                                 # which the bf16 build's roundings absorb)
+            assert torch.equal(part, one) if MODE == "bf16" else rel_l2(part, one) < {"fp16": 5e-3, "bf16x3": 1e-4, "bf16x6": 1e-5}[MODE]
         net.use_hip_graph = True
         a = net(xd, t, c_label=lab, context=prepared, fs=fs)
         b = net(xd, t, c_label=lab, context=prepared, fs=fs)
