@@ -270,7 +270,7 @@ class DDIMSampler(object):
                 return None, False
             if any((not torch.is_tensor(v)) or v.shape != lists[0][i].shape for l in lists for i, v in enumerate(l)):
                 return None, False
-        sig = tuple((key, tuple(ident(v) for v in cd[key])) for cd in conds for key in sorted(cd))
+        sig = (bool(self.share_guidance_prefix),) + tuple((key, tuple(ident(v) for v in cd[key])) for cd in conds for key in sorted(cd))
         cache = self.__dict__.get("_merged_cache")
         if cache is not None and cache[0] == sig:
             return cache[1], cache[3]
