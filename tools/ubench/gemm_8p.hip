@@ -20,7 +20,11 @@
 // Result on MI355X (random operands in [-1, 1)): 1184 TFLOP/s at 4096^3 (one tile per CU: prologue / epilogue exposed; 1029 with
 // s_setprio 1 around the MFMA sections), 1277 at 8192^3, 1328 with s_setprio — against 1031 / 1076 of the 128x128 kernels in
 // mudg_amd/csrc and 1476 / 1545 of the vendor library's assembly kernels (tools/exp_blas.py); results equal a reference
-// GEMM to 4e-7 over repeated runs at 256^3 ... 2048^3.  Not wired into mudg_gemm yet: it needs the epilogue family (GEGLU,
+// GEMM to 4e-7 over repeated runs at 256^3 ... 2048^3.  On the path's own plain-GEMM shapes (bf16 result, 8-byte stores
+// straight from the accumulators) the margin over the 128x128 kernels shrinks to +2...9 %: 18432 x 10240 x 1280 988-1037
+// (947), x 1280 x 5120 1046 (994), x 3840 x 1280 958 (936), 73728 x 5120 x 640 850 (818), 294912 x 2560 x 320 607 (630) — at
+// K = 320 ... 1280 a tile is 5-20 K-tiles and its prologue / epilogue weigh as much as in the small-tile kernels; the
+// schedule pays where K is long (the 3x3 convs, K = 2880 ... 23040).  Not wired into mudg_gemm yet: it needs the epilogue family (GEGLU,
 // residual / output storage kinds, GroupNorm partials) and the implicit-GEMM loaders of gemm.hip underneath it.
 // Plain bf16 GEMM C[M][N] (fp32) = A[M][K] B[N][K]^T, M, N % 256 == 0, K % 64 == 0.  Build + run:
 //   hipcc --offload-arch=gfx950 -O3 tools/ubench/gemm_8p.hip -o tools/ubench/gemm_8p && tools/ubench/gemm_8p
@@ -48,7 +52,7 @@ constexpr int SMEM = 2 * BUF;            // 128 KiB
         __builtin_amdgcn_sched_barrier(0);     \
     } while (0)
 
-template <int PRIO>
+template <int PRIO, bool OUT16 = false>
 __global__ __launch_bounds__(512, 2) void gemm_8p(const h16* __restrict__ A, const h16* __restrict__ B, float* __restrict__ C,
                                                   int M, int N, int K) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -186,12 +190,26 @@ __global__ __launch_bounds__(512, 2) void gemm_8p(const h16* __restrict__ A, con
     if (wr == 0) RAW_BARRIER();                      // evens out the stagger barrier
 
     // C: lane l holds, per fragment, row m = l % 16 and the 4 consecutive columns n = 4 (l / 16) .. + 3
-    float* cw = C + (size_t)(m0 + wr * 128 + (lane & 15)) * N + n0 + wc * 64 + (lane >> 4) * 4;
+    if constexpr (OUT16) {           // bf16 result (C reinterpreted): 8 bytes per lane, 32-byte runs per row and fragment
+        h16* cw = reinterpret_cast<h16*>(C) + (size_t)(m0 + wr * 128 + (lane & 15)) * N + n0 + wc * 64 + (lane >> 4) * 4;
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            *reinterpret_cast<f32x4*>(cw + (size_t)(i * 16) * N + j * 16) = acc[i][j];
+            for (int j = 0; j < 4; ++j) {
+                typedef __attribute__((ext_vector_type(4))) h16 h16x4;
+                h16x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (h16)acc[i][j][e];
+                *reinterpret_cast<h16x4*>(cw + (size_t)(i * 16) * N + j * 16) = v;
+            }
+    } else {
+        float* cw = C + (size_t)(m0 + wr * 128 + (lane & 15)) * N + n0 + wc * 64 + (lane >> 4) * 4;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                *reinterpret_cast<f32x4*>(cw + (size_t)(i * 16) * N + j * 16) = acc[i][j];
+    }
 }
 
 __global__ void ref_kernel(const h16* A, const h16* B, float* R, int M, int N, int K, int rows) {
@@ -204,21 +222,21 @@ __global__ void ref_kernel(const h16* A, const h16* B, float* R, int M, int N, i
 }
 
 template <int PRIO>
-static void run(int n, const h16* A, const h16* B, float* C) {
+static void run(int m, int n, int k, const h16* A, const h16* B, float* C) {
     (void)hipFuncSetAttribute((const void*)&gemm_8p<PRIO>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-    const int grid = (n / 256) * (n / 256);
-    for (int i = 0; i < 3; ++i) gemm_8p<PRIO><<<grid, 512, SMEM>>>(A, B, C, n, n, n);
+    const int grid = (m / 256) * (n / 256);
+    for (int i = 0; i < 3; ++i) gemm_8p<PRIO><<<grid, 512, SMEM>>>(A, B, C, m, n, k);
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     (void)hipEventRecord(e0);
     const int it = 20;
-    for (int i = 0; i < it; ++i) gemm_8p<PRIO><<<grid, 512, SMEM>>>(A, B, C, n, n, n);
+    for (int i = 0; i < it; ++i) gemm_8p<PRIO><<<grid, 512, SMEM>>>(A, B, C, m, n, k);
     (void)hipEventRecord(e1);
     (void)hipEventSynchronize(e1);
     float ms = 0;
     (void)hipEventElapsedTime(&ms, e0, e1);
-    printf("gemm_8p<prio %d> %d^3: %.1f us  %.1f TFLOP/s (%s)\n", PRIO, n, ms / it * 1e3, 2.0 * n * n * (double)n / (ms / it * 1e-3) / 1e12,
-           hipGetErrorString(hipGetLastError()));
+    printf("gemm_8p<prio %d> %d x %d x %d: %.1f us  %.1f TFLOP/s (%s)\n", PRIO, m, n, k, ms / it * 1e3,
+           2.0 * m * n * (double)k / (ms / it * 1e-3) / 1e12, hipGetErrorString(hipGetLastError()));
 }
 
 int main() {
@@ -251,9 +269,40 @@ int main() {
         }
         printf("check %d^3: worst rel-L2 %.3e (%s)\n", n, worst, hipGetErrorString(hipGetLastError()));
     }
-    run<0>(4096, A, B, C);
-    run<1>(4096, A, B, C);
-    run<0>(8192, A, B, C);
-    run<1>(8192, A, B, C);
+    run<0>(4096, 4096, 4096, A, B, C);
+    run<1>(4096, 4096, 4096, A, B, C);
+    run<0>(8192, 8192, 8192, A, B, C);
+    run<1>(8192, 8192, 8192, A, B, C);
+    // the path's plain-GEMM shapes whose M and N are multiples of 256, bf16 result as in the product
+    {
+        const size_t amax = (size_t)294912 * 320 > (size_t)18432 * 5120 ? (size_t)294912 * 320 : (size_t)18432 * 5120;
+        h16 *A2, *B2; float* C2;
+        (void)hipMalloc(&A2, amax * 2); (void)hipMalloc(&B2, (size_t)10240 * 1280 * 2); (void)hipMalloc(&C2, (size_t)294912 * 2560 * 2);
+        for (size_t off = 0; off < amax; off += ha.size())
+            (void)hipMemcpy(A2 + off, ha.data(), (amax - off < ha.size() ? amax - off : ha.size()) * 2, hipMemcpyHostToDevice);
+        (void)hipMemcpy(B2, hb.data(), (size_t)10240 * 1280 * 2, hipMemcpyHostToDevice);
+        const int shapes[][3] = {{18432, 10240, 1280}, {18432, 1280, 5120}, {18432, 3840, 1280}, {18432, 1280, 1280}, {73728, 5120, 640},
+                                 {73728, 1280, 640}, {294912, 2560, 320}};
+        for (auto& sh : shapes) {
+            (void)hipFuncSetAttribute((const void*)&gemm_8p<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+            (void)hipFuncSetAttribute((const void*)&gemm_8p<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+            const int grid = (sh[0] / 256) * (sh[1] / 256);
+            for (int prio = 0; prio < 2; ++prio) {
+                hipEvent_t e0, e1;
+                (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+                for (int i = 0; i < 23; ++i) {
+                    if (i == 3) (void)hipEventRecord(e0);
+                    if (prio) gemm_8p<1, true><<<grid, 512, SMEM>>>(A2, B2, C2, sh[0], sh[1], sh[2]);
+                    else gemm_8p<0, true><<<grid, 512, SMEM>>>(A2, B2, C2, sh[0], sh[1], sh[2]);
+                }
+                (void)hipEventRecord(e1);
+                (void)hipEventSynchronize(e1);
+                float ms = 0;
+                (void)hipEventElapsedTime(&ms, e0, e1);
+                printf("gemm_8p<prio %d, bf16 out> %d x %d x %d: %.1f us  %.1f TFLOP/s (%s)\n", prio, sh[0], sh[1], sh[2], ms / 20 * 1e3,
+                       2.0 * sh[0] * sh[1] * (double)sh[2] / (ms / 20 * 1e-3) / 1e12, hipGetErrorString(hipGetLastError()));
+            }
+        }
+    }
     return 0;
 }
