@@ -44,6 +44,9 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="issue every kernel from Python instead of replaying a hipGraph")
     ap.add_argument("--profile-steps", type=int, default=2, help="eager steps re-run with hipEvents for the roofline")
     ap.add_argument("--no-decode", action="store_true", help="skip the (untimed) 16-frame VAE decode used for clips/min")
+    ap.add_argument("--no-at-tolerance", action="store_true",
+                    help="skip the bf16x3 child run (the operand mode that meets the 1e-3 decoded-frame tolerance) whose "
+                         "steps/s is reported as `at_tolerance` next to the bf16 line")
     ap.add_argument("--operand", default=os.environ.get("MUDG_OPERAND", "bf16"), choices=["bf16", "fp16", "bf16x3", "bf16x6"],
                     help="MFMA operand type: bf16 (the BASELINE dtype), fp16 (the reference's autocast dtype), or the "
                          "split-operand precision modes bf16x3 / bf16x6 (2 / 3 bf16 pieces per value, 3 / 6 MFMAs per product "
@@ -110,6 +113,15 @@ def cpu_baseline(model, inputs, resolution, mode):
         except Exception:
             pass
     out["seconds"] = dt
+    out["live_sample_steps_per_s"] = out["value"]
+    key = "recorded_full_mdm1024_forward" if resolution == "1024" else "recorded_full_mdm512_forward"
+    if key in out:
+        # a whole forward at the benchmarked size on the same host class is the better estimate of the CPU path than the
+        # 4-frame sample extrapolated by FLOPs (the two differ by 1.6x: short clips use the cores worse); the live sample stays
+        # in the record as `live_sample_steps_per_s`
+        out["value"] = out[key]["steps_per_s_at_this_config"]
+        out["sample"] += f"; value = the recorded full {key[14:-8].upper()} oracle forward ({out[key]['file']}: " \
+                         f"{out[key]['tflops']:.3f} TFLOP/s on {out[key]['cores']} threads), live sample kept beside it"
     return out
 
 
@@ -117,8 +129,8 @@ def pmc_traffic(family, args, launches_per_step=None):
     """HBM-side bytes per launch of `family` from the committed rocprofv3 PMC passes (profiles/rN/traffic.json: FETCH_SIZE
     and WRITE_SIZE collected in separate passes of this same command, FETCH doubled per the gfx950 correction).  PMC
     counters cannot be read from inside the process, so this is the recorded figure for the default workload only."""
-    if args.resolution != "1024" or args.batch != 1:
-        return {}
+    if args.resolution != "1024" or args.batch != 1 or args.operand != "bf16":
+        return {}            # the counters were collected on the default bf16 workload only
     rounds = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*", "traffic.json")))
     if not rounds:
         return {}
@@ -133,6 +145,40 @@ def pmc_traffic(family, args, launches_per_step=None):
                                   "re-read once the 4-MB L2 of an XCD has lost them count although they never reach HBM"}
     except Exception:
         return {}
+
+
+def at_tolerance(args):
+    """The same workload in the operand mode that meets north_star's tolerance (decoded frames within 1e-3 rel-L2 of the
+    reference): bf16x3, in a child process (the operand type is a property of the loaded library, one per process).  A few
+    steps after one warm-up; its own roofline record rides along.  The parity figures quoted are the last measured ones of
+    that mode (profiles/rN/parity_modes.json, written from the `-m gpu` run of tests/test_pipeline_gpu.py and
+    tests/test_fullsize_gpu.py, which assert the literal 1e-3 in that mode)."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--operand", "bf16x3", "--steps", "4", "--warmup", "1", "--resolution", args.resolution,
+           "--batch", str(args.batch), "--no-cpu-baseline", "--no-decode", "--no-at-tolerance", "--profile-steps", "1"]
+    if args.no_graph:
+        cmd.append("--no-graph")
+    env = dict(os.environ, MUDG_OPERAND="bf16x3")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    try:
+        r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+        rec = json.loads(line)
+    except Exception as e:
+        return {"operand": "bf16x3", "value": None, "error": f"{type(e).__name__}: {e}"}
+    out = {"operand": "bf16x3", "value": rec["value"], "unit": rec["unit"], "ms_per_step": rec["ms_per_step"], "steps": rec["steps"],
+           "warmup": rec["warmup"], "output_finite": rec.get("output_finite"), "roofline": rec.get("roofline"),
+           "kernels": [{k: f[k] for k in ("family", "ms_per_step", "achieved", "unit", "frac")} for f in rec.get("kernels", [])],
+           "tolerance": "decoded frames within 1e-3 rel-L2 of the reference (BASELINE.json north_star)"}
+    recs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "parity_modes.json")))
+    if recs:
+        try:
+            with open(recs[-1]) as f:
+                out["parity_last_measured"] = dict(json.load(f).get("bf16x3", {}), file=os.path.relpath(recs[-1], ROOT))
+        except Exception:
+            pass
+    return out
 
 
 def main():
@@ -227,6 +273,8 @@ def main():
         return
 
     steps_per_s = world * args.batch * args.steps / elapsed
+    from mudg_amd import ops as _ops
+    stream_name = {torch.float16: "fp16", torch.float32: "fp32"}[_ops.STREAM()]
     step_tflop = 2 * configs.UNET_TFLOP[args.resolution]
     out = {
         "metric": "DDIM denoise steps/sec, MDM1024 576x1024x16f (CFG: 2 UNet forwards + fused update per step, per clip)"
@@ -241,10 +289,12 @@ def main():
                    "clips_per_gpu": args.batch, "parallelism": f"clip-DP x{world} (no in-step collective)",
                    "launch": "hipGraph replay of each UNet pass (cond+uncond batched)" if use_graph else "eager launches",
                    "weights": f"seeded N(0,0.02^2) incl. zero-init tensors, fp32 params -> {args.operand} MFMA operands, "
-                              "fp32 accumulate / norms / softmax / residual stream"},
+                              f"fp32 accumulate / norms / softmax, residual stream {stream_name}"},
         "algorithmic_tflop_per_step": step_tflop,
-        "achieved_tflops_per_gpu": round(step_tflop * args.batch * args.steps / elapsed, 2),
-        "frac_of_bf16_mfma_peak": round(step_tflop * args.batch * args.steps / elapsed / PEAK_TFLOPS_BF16, 4),
+        # the REFERENCE's FLOPs per step over the measured time: the build issues fewer (the guidance passes share the
+        # context-free prefix, 3.4 T; the sub-pixel upsample convs issue 4/9 of theirs), so this is a reference-equivalent rate
+        "reference_equivalent_tflops_per_gpu": round(step_tflop * args.batch * args.steps / elapsed, 2),
+        "reference_equivalent_frac_of_bf16_mfma_peak": round(step_tflop * args.batch * args.steps / elapsed / PEAK_TFLOPS_BF16, 4),
         "clips_per_min": round(60.0 * world * args.batch / (50.0 * elapsed / args.steps + (decode_ms or 0.0) / 1000.0), 4),
         "vae_decode_ms_per_clip": None if decode_ms is None else round(decode_ms, 2),
         "output_finite": finite,
@@ -283,6 +333,8 @@ def main():
             out["roofline"]["frac_of_measured_peak"] = round(dom["achieved"] / MEASURED_MFMA_PEAK_TFLOPS, 4)
         out["kernels"] = kernels
         out["kernel_time_ms_per_step"] = round(total_ms / prof_steps, 3)
+    if world == 1 and args.operand == "bf16" and not args.no_at_tolerance:
+        out["at_tolerance"] = at_tolerance(args)      # child process; this one idles meanwhile (288 GB hold both replicas)
     if world == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(model, inp, args.resolution, args.cpu_baseline)

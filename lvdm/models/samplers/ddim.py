@@ -163,6 +163,7 @@ class DDIMSampler(object):
             if index % log_every_t == 0 or index == total - 1:
                 intermediates["x_inter"].append(img)
                 intermediates["pred_x0"].append(pred_x0)
+        self.clear_conditioning_cache()          # the run is over: do not pin its K / V^T buffers and cond dicts on the sampler
         return img, intermediates
 
     # ------------------------------------------------------------------ one step
@@ -270,11 +271,15 @@ class DDIMSampler(object):
                 return None, False
             if any((not torch.is_tensor(v)) or v.shape != lists[0][i].shape for l in lists for i, v in enumerate(l)):
                 return None, False
-        sig = (bool(self.share_guidance_prefix),) + tuple((key, tuple(ident(v) for v in cd[key])) for cd in conds for key in sorted(cd))
-        cache = self.__dict__.get("_merged_cache")
-        if cache is not None and cache[0] == sig:
-            return cache[1], cache[3]
         unet = getattr(getattr(self.model, "model", None), "diffusion_model", None)
+        # the key names the tensors (address, version, shape, dtype), the frame count the prepared context was laid out for
+        # and the UNet whose projections it holds; inference-mode tensors do not track versions, so an in-place update of
+        # one would go unseen — such conditionings are stacked afresh at every call instead of being cached
+        cacheable = not any(v.is_inference() for cd in conds for key in cd for v in cd[key])
+        sig = (bool(self.share_guidance_prefix), frames, id(unet)) + tuple((key, tuple(ident(v) for v in cd[key])) for cd in conds for key in sorted(cd))
+        cache = self.__dict__.get("_merged_cache")
+        if cacheable and cache is not None and cache[0] == sig:
+            return cache[1], cache[3]
         prepare = frames is not None and "c_crossattn" in first and hasattr(unet, "prepare_context") \
             and all(v.is_cuda for cd in conds for v in cd["c_crossattn"])
         # guidance replicas: every input but the tokens is literally the same tensor in all passes
@@ -290,8 +295,14 @@ class DDIMSampler(object):
         if prepare:
             tokens = merged["c_crossattn"][0] if len(merged["c_crossattn"]) == 1 else torch.cat(merged["c_crossattn"], 1)
             merged["c_crossattn"] = [unet.prepare_context(tokens, frames)]
-        self._merged_cache = (sig, merged, [cd for cd in conds], shared)     # the source dicts are kept alive: their addresses are the key
+        # the source dicts are kept alive while cached (their addresses are the key); ONE entry, replaced by the next run's
+        # and dropped by clear_conditioning_cache() (sample() / decode() call it when they return)
+        self._merged_cache = (sig, merged, [cd for cd in conds], shared) if cacheable else None
         return merged, shared
+
+    def clear_conditioning_cache(self):
+        """Drop the stacked / projected conditioning of the last run (per-layer K / V^T buffers and the caller's cond dicts)."""
+        self._merged_cache = None
 
     @torch.no_grad()
     def decode(self, x_latent, cond, t_start, unconditional_guidance_scale=1.0, unconditional_conditioning=None,
@@ -310,6 +321,7 @@ class DDIMSampler(object):
                                           unconditional_conditioning=unconditional_conditioning)
             if callback:
                 callback(i)
+        self.clear_conditioning_cache()
         return x_dec
 
     @torch.no_grad()

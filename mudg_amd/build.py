@@ -19,7 +19,8 @@ OUT = os.path.join(HERE, "libmudg_hip.so")
 OUT_FP16 = os.path.join(HERE, "libmudg_hip_fp16.so")
 OUT_X3 = os.path.join(HERE, "libmudg_hip_x3.so")
 OUT_X6 = os.path.join(HERE, "libmudg_hip_x6.so")
-SOURCES = ["capi.hip", "gemm.hip", "gemm256.hip", "attention.hip", "norm.hip", "misc.hip", "post.hip"]
+OUT_DBG = os.path.join(HERE, "libmudg_hip_dbg.so")      # bf16 + kernel-variant switches (tests / tools only; hip.py loads it under MUDG_DEBUG_VARIANTS=1)
+SOURCES = ["capi.hip", "gemm.hip", "attention.hip", "norm.hip", "misc.hip", "post.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-ffp-contract=off"]
 
@@ -73,11 +74,14 @@ def _build_one(out: str, extra, tag: str, force: bool, verbose: bool) -> str:
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
-    """Every operand-type build of the same sources: bf16 (default), fp16 (-DMUDG_OPERAND_FP16) and the split-operand
-    precision modes bf16x3 / bf16x6 (-DMUDG_PLANES=2 / 3; csrc/common.h)."""
+    """Every operand-type build of the same sources: bf16 (default), fp16 (-DMUDG_OPERAND_FP16), the split-operand
+    precision modes bf16x3 / bf16x6 (-DMUDG_PLANES=2 / 3; csrc/common.h), and the bf16 build with the kernel-variant
+    switches compiled in (-DMUDG_DEBUG_VARIANTS: the only library in which an environment variable can change which
+    kernel runs; the variant tests and the A/B tools load it)."""
     _build_one(OUT_FP16, ["-DMUDG_OPERAND_FP16"], "fp16", force, verbose)
     _build_one(OUT_X3, ["-DMUDG_PLANES=2"], "x3", force, verbose)
     _build_one(OUT_X6, ["-DMUDG_PLANES=3"], "x6", force, verbose)
+    _build_one(OUT_DBG, ["-DMUDG_DEBUG_VARIANTS"], "dbg", force, verbose)
     return _build_one(OUT, [], "bf16", force, verbose)
 
 

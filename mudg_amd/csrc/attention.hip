@@ -433,8 +433,8 @@ __global__ __launch_bounds__(256, 2) void attn64q_kernel(const MudgAttnDesc p, c
 // 64 the kernel is bound by VALU issue, not by MFMA — is cut from {max, fma, exp, add, cvt} to {exp, add, cvt} per score:
 // a reference maximum m_ref per query row (the row maximum over the first key tile, from one extra set of score MFMAs per
 // block) enters as the INITIAL VALUE of the score accumulators, so S - m_ref comes straight out of the MFMA; the per-tile
-// maximum is not computed and O / l are never rescaled.  Should a row's tile sum exceed 2^40 (a later score 40 binary
-// orders above the first tile's maximum) the workgroup redoes its block with the classic online softmax — exact, merely
+// maximum is not computed and O / l are never rescaled.  Should a row's tile sum exceed LEAN_LIMIT (2^40 — a later score 40
+// binary orders above the first tile's maximum — with bf16 operands, 2^15 with fp16 ones) the workgroup redoes its block with the classic online softmax — exact, merely
 // slower, and not observed on real data.
 //  * A DMA instruction writes 1 KiB lane-linear (8 rows x 128 B), so the tiles are unpadded [64][64] h16 with the XOR
 //    swizzle of the GEMM kernel applied on the SOURCE side (which 16-byte chunk of the row a lane fetches) and mirrored on
@@ -446,6 +446,14 @@ __global__ __launch_bounds__(256, 2) void attn64q_kernel(const MudgAttnDesc p, c
 //  * Tile t + 1 is requested at the top of iteration t into the other buffer; the barrier that closes the iteration
 //    (vmcnt(0) + s_barrier) is the only synchronisation.
 constexpr int DTILE = 64 * 64;          // h16 per unpadded tile
+// Largest per-lane tile sum of 2^(s - m_ref) the lean softmax accepts before the workgroup falls back to the classic loop.
+// P is stored as h16: a bf16 P has fp32's exponent range (2^40 leaves room for the row sum), an IEEE-half P overflows to
+// inf beyond 65504 — there the limit is 2^15, so that no single exponential can reach the h16 maximum undetected.
+#ifdef MUDG_OPERAND_FP16
+constexpr float LEAN_LIMIT = 32768.f;
+#else
+constexpr float LEAN_LIMIT = 1099511627776.f;      // 2^40
+#endif
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t attn_rsrc(const h16* base) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<h16*>(base), 0, (int)0x80000000u, 0x00020000);
@@ -655,7 +663,7 @@ __global__ __launch_bounds__(256, 2) void attn64d_kernel(const MudgAttnDesc p, c
                             pk[qb][sub][r >> 3][r & 7] = (h16)e;
                         }
                     l_run[qb] += ps;
-                    overflow = overflow || !(ps <= 1099511627776.f);        // 2^40; true for inf / nan as well
+                    overflow = overflow || !(ps <= LEAN_LIMIT);             // true for inf / nan as well
                 } else {
                     float mx = s[qb][0][0];
 #pragma unroll
@@ -1152,7 +1160,7 @@ extern "C" int mudg_attention(const MudgAttnDesc* dp, void* stream) {
     // Long self-attention runs 64 queries per wave (attn64q_kernel: +4.7 % at N = 9216); short key sequences (the text /
     // image cross-attention) and small query counts keep the 32-query kernel.  MUDG_ATTN_Q=32 / 64 forces one of them.
     static int var = -1;
-    if (var < 0) { const char* e = getenv("MUDG_ATTN_Q"); var = e ? atoi(e) : 0; }
+    if (var < 0) var = mudg_variant("ATTN_Q", 0);
     const bool wide = !d.K2 && (var == 64 ? d.Nq >= 256 : (var == 32 ? false : (d.Nq >= 512 && d.Nk >= 256)));
 #if MUDG_PLANES > 1
     {
@@ -1178,8 +1186,8 @@ extern "C" int mudg_attention(const MudgAttnDesc* dp, void* stream) {
         // LDS-DMA staging (+ the lean softmax when Q is prescaled) for whole key tiles whose tiles stay inside the 2-GiB
         // window of a buffer descriptor; the register-staged kernel otherwise.  MUDG_ATTN_DMA=0 / MUDG_ATTN_LEAN=0: A/B.
         static int dma = -1, lean = -1;
-        if (dma < 0) { const char* e = getenv("MUDG_ATTN_DMA"); dma = e ? atoi(e) : 1; }
-        if (lean < 0) { const char* e = getenv("MUDG_ATTN_LEAN"); lean = e ? atoi(e) : 1; }
+        if (dma < 0) dma = mudg_variant("ATTN_DMA", 1);
+        if (lean < 0) lean = mudg_variant("ATTN_LEAN", 1);
         const bool dma_ok = dma && d.Nk % 64 == 0 && (int64_t)d.Nk * d.ldk * 2 < (1ll << 31) && (int64_t)64 * d.ldvt * 2 + (int64_t)d.Nk * 2 < (1ll << 31);
         if (d.Q8) {
             MUDG_REQUIRE(dma_ok && d.q_prescaled && d.K8 && d.Qs && d.Ks && !d.accumulate, "mudg_attention: the MX-fp8 score path needs "

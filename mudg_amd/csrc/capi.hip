@@ -2,6 +2,8 @@
 #include "common.h"
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <mutex>
 #include <vector>
 
@@ -21,6 +23,15 @@ void mudg_set_error(const char* fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
+
+#ifdef MUDG_DEBUG_VARIANTS
+int mudg_variant(const char* name, int dflt) {
+    char key[64] = "MUDG_";
+    strncat(key, name, sizeof(key) - 6);
+    const char* e = getenv(key);
+    return e ? atoi(e) : dflt;
+}
+#endif
 
 int mudg_prof_begin(int fam, hipStream_t s) {
     if (!(g_mask & (1 << fam))) return -1;

@@ -71,10 +71,14 @@ __device__ __forceinline__ void load8_f16(const _Float16* p, float (&v)[8]) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = (float)t.h[e];
 }
+// Stream stores saturate: a residual sum beyond the IEEE-half range becomes +-65504 (one v_med3 per value), never inf —
+// an inf in the stream turns the next GroupNorm / LayerNorm into NaN for the whole sample.  MUDG_STREAM=fp32 (ops.STREAM) is
+// the escape hatch for checkpoints whose stream really leaves the half range.
+__device__ __forceinline__ _Float16 f16_sat(float v) { return (_Float16)__builtin_amdgcn_fmed3f(v, -65504.f, 65504.f); }
 __device__ __forceinline__ void store8_f16(_Float16* p, const float (&v)[8]) {
     union { u32x4 u; f16x8 h; } t;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) t.h[e] = (_Float16)v[e];
+    for (int e = 0; e < 8; ++e) t.h[e] = f16_sat(v[e]);
     st16(p, t.u);
 }
 
@@ -146,6 +150,14 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 }
 
 // ---- host side ---------------------------------------------------------------------------------
+// Kernel-variant switches (A/B measurements, tests that force a particular kernel): compiled in only with
+// -DMUDG_DEBUG_VARIANTS (libmudg_hip_dbg.so, used by tests/test_gemm_variants_gpu.py and tools/); the shipped libraries
+// take the default — no environment variable changes which kernel they run.
+#ifdef MUDG_DEBUG_VARIANTS
+int mudg_variant(const char* name, int dflt);         // getenv("MUDG_" name), read at every call (call sites cache it)
+#else
+static inline int mudg_variant(const char*, int dflt) { return dflt; }
+#endif
 void mudg_set_error(const char* fmt, ...);
 #define MUDG_FAIL(code, ...) do { mudg_set_error(__VA_ARGS__); return (code); } while (0)
 #define MUDG_REQUIRE(cond, ...) do { if (!(cond)) MUDG_FAIL(MUDG_EINVAL, __VA_ARGS__); } while (0)

@@ -37,6 +37,13 @@ constexpr int SMEM_BYTES = SMEM_MAIN > SMEM_STG ? SMEM_MAIN : SMEM_STG;
 // Single-buffer variant (short K): one K-tile buffer, the epilogue staged in two 64-row passes -> 4 workgroups per CU.
 constexpr int SMEM_STG_SB = (BM / 2) * STGLD * 4 + BN * 4;
 constexpr int SMEM_BYTES_SB = 2 * TILE * 2 > SMEM_STG_SB ? 2 * TILE * 2 : SMEM_STG_SB;
+// bf16x3 build, descriptor loader (FUSED): ONE K-tile stage holds both pieces of both operands — x0, x1, w0, w1, 4 x 16 KiB —
+// and every fragment read feeds the three kept products x1 w0 + x0 w1 + x0 w0: each piece is fetched once per K-tile (4 tile
+// fetches instead of the 6 of three whole passes over K) and 12 MFMAs follow 8 fragment reads instead of 4 following 4.
+// Single K-buffer + two-pass epilogue = 64 KiB -> 2 workgroups per CU.
+constexpr bool fused_planes(bool fast) { return PLANES == 2 && fast; }
+constexpr int SMEM_BYTES_FUSED = 2 * PLANES * TILE * 2;
+constexpr int smem_main(bool fast, bool sb) { return fused_planes(fast) ? SMEM_BYTES_FUSED : (sb ? SMEM_BYTES_SB : SMEM_BYTES); }
 
 constexpr int VF_Y = 1, VF_R = 2;               // 16-byte access allowed on Y / R
 
@@ -88,12 +95,15 @@ __device__ __forceinline__ float gelu_lut(float x, const float* __restrict__ T) 
 }
 
 template <int MODE, bool FAST, bool SB>
-__global__ __launch_bounds__(256, SB ? 4 : 2) void gemm_kernel(const MudgGemmDesc p, const int vflags, const h16* __restrict__ zpage,
+__global__ __launch_bounds__(256, (SB && !fused_planes(FAST)) ? 4 : 2) void gemm_kernel(const MudgGemmDesc p, const int vflags, const h16* __restrict__ zpage,
                                                                 const float* __restrict__ phi) {
+    constexpr bool FUSED = fused_planes(FAST);          // all pieces of a K-tile staged at once (see SMEM_BYTES_FUSED)
+    constexpr bool ONEBUF = SB || FUSED;                // one K-tile stage, two-pass epilogue
+    constexpr int XT = FUSED ? PLANES : 1;              // tiles per operand per stage
     extern __shared__ __attribute__((aligned(16))) char smem[];
     h16* Xs = reinterpret_cast<h16*>(smem);
-    h16* Ws = Xs + (SB ? 1 : 2) * TILE;
-    float* phis = reinterpret_cast<float*>(smem + (SB ? SMEM_BYTES_SB : SMEM_BYTES));     // beyond every other LDS use
+    h16* Ws = Xs + (ONEBUF ? 1 : 2) * XT * TILE;
+    float* phis = reinterpret_cast<float*>(smem + smem_main(FAST, SB));     // beyond every other LDS use
     if (p.geglu && phi) {            // visible after the K loop's barriers
         const int t4 = threadIdx.x * 4;
         *reinterpret_cast<f32x4*>(&phis[t4]) = *reinterpret_cast<const f32x4*>(&phi[t4]);
@@ -226,22 +236,26 @@ __global__ __launch_bounds__(256, SB ? 4 : 2) void gemm_kernel(const MudgGemmDes
             soff = ((dy * p.Win + dx) * ld + cc) * 2;
         }
         else soff = (tap_s * p.HW * ld + cc) * 2;
-        int soffw = (PLANES > 1 ? kt_s : kt) * (BK * 2);
-        if constexpr (PLANES > 1) {                  // this pass's operand planes: column offsets of ld / PLANES elements
+        int soffw = ((PLANES > 1 && !FUSED) ? kt_s : kt) * (BK * 2);
+        if constexpr (PLANES > 1 && !FUSED) {        // this pass's operand planes: column offsets of ld / PLANES elements
             soff += seg_xp(seg_s) * (ld / PLANES) * 2;
             soffw += seg_wp(seg_s) * (p.ldw / PLANES) * 2;
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            unsigned v = s2 ? vx2[i] : vx[i];
-            if (MODE != 0) v = ((vmask[i] >> tap_s) & 1u) ? v : OOB;
-            lptr_t lx = (lptr_t)(Xs + buf * TILE + (32 * wave + 8 * i) * LDSLD);
-            if (s2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rX2, lx, 16, (int)v, soff, 0, 0);
-            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, lx, 16, (int)v, soff, 0, 0);
-            // W rows beyond N are never multiplied (their waves are idle, see wave_live): skip the zero-fill pieces
-            if (n0 + 32 * wave + 8 * i < p.N || (32 * wave + 8 * i) < 64)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(Ws + buf * TILE + (32 * wave + 8 * i) * LDSLD), 16,
-                                                         (int)vw[i], soffw, 0, 0);
+        for (int pl = 0; pl < XT; ++pl) {            // FUSED: piece pl of both operands into its own tile of the stage
+            const int so = soff + pl * (ld / PLANES) * 2, sow = soffw + pl * (p.ldw / PLANES) * 2;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                unsigned v = s2 ? vx2[i] : vx[i];
+                if (MODE != 0) v = ((vmask[i] >> tap_s) & 1u) ? v : OOB;
+                lptr_t lx = (lptr_t)(Xs + (buf * XT + pl) * TILE + (32 * wave + 8 * i) * LDSLD);
+                if (s2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rX2, lx, 16, (int)v, so, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, lx, 16, (int)v, so, 0, 0);
+                // W rows beyond N are never multiplied (their waves are idle, see wave_live): skip the zero-fill pieces
+                if (n0 + 32 * wave + 8 * i < p.N || (32 * wave + 8 * i) < 64)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(Ws + (buf * XT + pl) * TILE + (32 * wave + 8 * i) * LDSLD), 16,
+                                                             (int)vw[i], sow, 0, 0);
+            }
         }
         if (MODE == 0) {
             c_s += BK;
@@ -252,7 +266,7 @@ __global__ __launch_bounds__(256, SB ? 4 : 2) void gemm_kernel(const MudgGemmDes
             tap_s = slab ? (wrap ? 0 : t1) : (wrap ? t1 : tap_s);
             c_s = slab ? (wrap ? c1 : c_s) : (wrap ? 0 : c1);
         }
-        if constexpr (PLANES > 1) {                  // end of a pass over K: next plane pair, K walk restarts (select form)
+        if constexpr (PLANES > 1 && !FUSED) {        // end of a pass over K: next plane pair, K walk restarts (select form)
             const bool last = kt_s + 1 == nk;
             kt_s = last ? 0 : kt_s + 1;
             seg_s = last ? seg_s + 1 : seg_s;
@@ -315,15 +329,41 @@ __global__ __launch_bounds__(256, SB ? 4 : 2) void gemm_kernel(const MudgGemmDes
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    const int nkt = nk * NSEG;           // K-tiles over all (x plane, w plane) passes
+    const int nkt = FUSED ? nk : nk * NSEG;      // K-tiles over all (x plane, w plane) passes; FUSED: all pieces per K-tile
     const int sw = (l31 >> 1) & 7;       // read-side swizzle: the row bases are multiples of 32, so only lane bits count
     // A wave whose 64 output columns (or rows) all lie beyond N (M) has nothing to multiply: it still stages its share
     // of the operand tiles but leaves its SIMD's MFMA pipe to the other resident workgroups (N = 320: 1/6 of the waves).
     const bool wave_live = (n0 + wn * 64 < p.N) && (m0 + wm * 64 < p.M);
     auto multiply = [&](int cur) {
         if (!wave_live) return;
-        const h16* xs = Xs + cur * TILE + (wm * 64 + l31) * LDSLD;
-        const h16* ws = Ws + cur * TILE + (wn * 64 + l31) * LDSLD;
+        const h16* xs = Xs + cur * XT * TILE + (wm * 64 + l31) * LDSLD;
+        const h16* ws = Ws + cur * XT * TILE + (wn * 64 + l31) * LDSLD;
+        if constexpr (FUSED) {
+            // x = x0 + x1, w = w0 + w1 (bf16 pieces): x1 w0 + x0 w1 + x0 w0 per fragment pair — the bf16 x bf16 products are
+            // exact in the fp32 accumulator; what is dropped (x1 w1) is 2^-18 relative.  Small terms first within a k-step.
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                const int off = ((ks * 2 + hi) ^ sw) << 3;
+                h16x8 wf[2][2], xf[2][2];          // [piece][32-row block]
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) {
+                    wf[pl][0] = *reinterpret_cast<const h16x8*>(ws + pl * TILE + off);
+                    wf[pl][1] = *reinterpret_cast<const h16x8*>(ws + pl * TILE + 32 * LDSLD + off);
+                    xf[pl][0] = *reinterpret_cast<const h16x8*>(xs + pl * TILE + off);
+                    xf[pl][1] = *reinterpret_cast<const h16x8*>(xs + pl * TILE + 32 * LDSLD + off);
+                }
+#pragma unroll
+                for (int term = 0; term < 3; ++term) {
+                    const int wp = term == 1 ? 1 : 0, xp = term == 0 ? 1 : 0;
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                        for (int mi = 0; mi < 2; ++mi)
+                            acc[ni][mi] = MFMA_32x32x16(wf[wp][ni], xf[xp][mi], acc[ni][mi]);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
             const int off = ((ks * 2 + hi) ^ sw) << 3;
@@ -339,7 +379,7 @@ __global__ __launch_bounds__(256, SB ? 4 : 2) void gemm_kernel(const MudgGemmDes
                     acc[ni][mi] = MFMA_32x32x16(wf[ni], xf[mi], acc[ni][mi]);
         }
     };
-    if constexpr (SB) {
+    if constexpr (ONEBUF) {
         for (int kt = 0; kt < nkt; ++kt) {
             issue_tiles(kt, 0);
             __syncthreads();                 // vmcnt(0) + barrier: the tile has landed
@@ -359,7 +399,7 @@ __global__ __launch_bounds__(256, SB ? 4 : 2) void gemm_kernel(const MudgGemmDes
 
     // ------------------------------------------------------------------ epilogue
     float* stg = reinterpret_cast<float*>(smem);
-    constexpr int NPASS = SB ? 2 : 1, PROWS = BM / NPASS;      // SB stages the tile in two 64-row passes (wave rows wm = pass)
+    constexpr int NPASS = ONEBUF ? 2 : 1, PROWS = BM / NPASS;  // SB / FUSED stage the tile in two 64-row passes (wave rows wm = pass)
     float* sbias = stg + PROWS * STGLD;
     // Per-group bias (a ResBlock's embedding term): when all rows of the tile belong to one group — always, for the
     // UNet's shapes — it is one more per-column constant and rides in the staged bias; a tile that straddles groups adds
@@ -456,7 +496,7 @@ __global__ __launch_bounds__(256, SB ? 4 : 2) void gemm_kernel(const MudgGemmDes
             if (p.out_fp32 == KIND_F16) {
                 _Float16* yp = reinterpret_cast<_Float16*>(p.Y) + yoff;
                 if (wide) store8_f16(yp, v);
-                else for (int j = 0; j < nvalid; ++j) yp[j] = (_Float16)v[j];
+                else for (int j = 0; j < nvalid; ++j) yp[j] = f16_sat(v[j]);
             } else if (p.out_fp32) {
                 float* yp = reinterpret_cast<float*>(p.Y) + yoff;
                 for (int j = 0; j < nvalid; ++j) yp[j] = v[j];
@@ -520,7 +560,7 @@ __global__ __launch_bounds__(256, SB ? 4 : 2) void gemm_kernel(const MudgGemmDes
         if (p.stats) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float t = (j < nvalid) ? (p.out_fp32 == KIND_F32 ? v[j] : (p.out_fp32 == KIND_F16 ? (float)(_Float16)v[j] : operand_round(v[j]))) : 0.f;
+                const float t = (j < nvalid) ? (p.out_fp32 == KIND_F32 ? v[j] : (p.out_fp32 == KIND_F16 ? (float)f16_sat(v[j]) : operand_round(v[j]))) : 0.f;
                 gs[j] += t; gq[j] = fmaf(t, t, gq[j]);
             }
         }
@@ -531,7 +571,7 @@ __global__ __launch_bounds__(256, SB ? 4 : 2) void gemm_kernel(const MudgGemmDes
                 store8_f16(yp, v);
             } else {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) if (j < nvalid) yp[j] = (_Float16)v[j];
+                for (int j = 0; j < 8; ++j) if (j < nvalid) yp[j] = f16_sat(v[j]);
             }
         } else if (p.out_fp32) {
             float* yp = reinterpret_cast<float*>(p.Y) + yoff;
@@ -596,11 +636,11 @@ const h16* zero_page() {
 }
 
 // Phi(x) = 0.5 erfc(-x / sqrt 2) at x = -8 + i / 64, i = 0..1024, built once on the host in double precision.
-// MUDG_GELU_LUT=0 keeps the erf polynomial (A/B measurements).
+// Variant switch GELU_LUT=0 keeps the erf polynomial (A/B measurements).
 const float* phi_table() {
     static float* tabs[MAX_DEVICES] = {};
     static int mode = -1;
-    if (mode < 0) { const char* e = getenv("MUDG_GELU_LUT"); mode = e ? atoi(e) : 1; }
+    if (mode < 0) mode = mudg_variant("GELU_LUT", 1);
     if (!mode || PLANES > 1) return nullptr;          // the split-operand builds evaluate erf exactly
     const int dev = current_device();
     if (dev < 0) return nullptr;
@@ -627,49 +667,26 @@ int launch(const MudgGemmDesc& d, int vflags, hipStream_t s) {
     bool& attr_set = attr_done[current_device()];
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<MODE, FAST, SB>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (SB ? SMEM_BYTES_SB : SMEM_BYTES) + PHI_BYTES);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, smem_main(FAST, SB) + PHI_BYTES);
         if (e != hipSuccess) MUDG_FAIL(MUDG_ELAUNCH, "gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
     const int tiles = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
     dim3 grid(tiles, 1, d.batch);
     const float* phi = d.geglu ? phi_table() : nullptr;
-    hipLaunchKernelGGL((gemm_kernel<MODE, FAST, SB>), grid, dim3(256), (SB ? SMEM_BYTES_SB : SMEM_BYTES) + (phi ? PHI_BYTES : 0), s, d, vflags, zp, phi);
+    hipLaunchKernelGGL((gemm_kernel<MODE, FAST, SB>), grid, dim3(256), smem_main(FAST, SB) + (phi ? PHI_BYTES : 0), s, d, vflags, zp, phi);
     return mudg_check_launch("mudg_gemm");
-}
-
-// Large-tile path (gemm256.hip): 256x256 tiles stage half the bytes per FLOP.  Measured per shape
-// family on MI355X (tools/exp_tiles.py) against the 128x128 kernels: once the conv loaders kept their tap state in
-// registers, two or four resident 128x128 workgroups per CU beat both 256x256 kernels on every FAST 3x3 conv of the
-// UNet (1050-1120 vs 920-1070 TFLOP/s), on the temporal convs and on the plain / GEGLU GEMMs; the large tiles remain for
-// the nearest-2x upsample convs (generic address path).
-// MUDG_GEMM256=0 disables it, =1 forces it whenever M, N >= 256.
-bool use_gemm256(const MudgGemmDesc& d) {
-    static int mode = -1;
-    if (mode < 0) {
-        const char* e = getenv("MUDG_GEMM256");
-        mode = e ? atoi(e) : 2;
-    }
-    if (mode == 0 || PLANES > 1 || d.M < 256 || d.N < 256 || (d.mode == 1 && d.subpixel)) return false;      // the 256x256 kernels are 16-bit-operand only
-    if (mode == 1) return true;
-    const int64_t tn = (d.N + 255) / 256, tiles = ((d.M + 255) / 256) * tn * d.batch;
-    const double waste = (double)(tn * 256 - d.N) / (double)(tn * 256);
-    if (tiles < 128) return false;
-    if (d.mode == 1) return !mudg_gemm_fast_ok(d) && d.N >= 512 && waste <= 0.2;
-    if (d.mode == 2) return false;
-    return false;          // plain / GEGLU GEMMs: the 128x128 kernels win everywhere since the table GELU (744 vs 780 TFLOP/s at ds4)
 }
 
 // Problems with at least three tiles per CU (eight for the 3x3 convs) go to the single-buffer / 4-workgroups-per-CU
 // variant (see gemm_kernel): measured faster at every K (MDM1024 shapes: +3...+20 %); with fewer tiles the
 // double-buffered 2-per-CU kernel wins.
-// MUDG_GEMM_SB=0 disables it, =2 forces it for every FAST problem.
+// Variant switch GEMM_SB=0 disables it, =2 forces it for every FAST problem.  (bf16x3 build: the fused-piece kernel is the
+// only FAST kernel, see fused_planes.)
 bool use_single_buffer(const MudgGemmDesc& d) {
+    if (fused_planes(true)) return true;
     static int mode = -1;
-    if (mode < 0) {
-        const char* e = getenv("MUDG_GEMM_SB");
-        mode = e ? atoi(e) : 1;
-    }
+    if (mode < 0) mode = mudg_variant("GEMM_SB", 1);
     if (mode == 0) return false;
     if (mode == 2) return true;
     const int64_t tiles = (int64_t)((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN) * d.batch;
@@ -678,14 +695,11 @@ bool use_single_buffer(const MudgGemmDesc& d) {
 
 }  // namespace
 
-// Whether the buffer-descriptor (FAST) kernels can run this problem; also used by gemm256.hip.  MUDG_GEMM_FAST=0
-// forces the generic address path (for A/B measurements and tests of both paths).
+// Whether the buffer-descriptor (FAST) kernels can run this problem.  Variant switch GEMM_FAST=0 forces the generic
+// address path (for A/B measurements and tests of both paths).
 bool mudg_gemm_fast_ok(const MudgGemmDesc& d) {
     static int en = -1;
-    if (en < 0) {
-        const char* e = getenv("MUDG_GEMM_FAST");
-        en = e ? atoi(e) : 1;
-    }
+    if (en < 0) en = mudg_variant("GEMM_FAST", 1);
     if (!en) return false;
     const int cin = d.mode == 0 ? d.K : d.Cin;
     if ((d.K & 63) || (cin & 63) || (d.csplit & 63)) return false;
@@ -701,8 +715,6 @@ bool mudg_gemm_fast_ok(const MudgGemmDesc& d) {
     const int64_t lim = (int64_t)1 << 31;
     return rel * ld * 2 + 128 + soff + 16 < lim && (int64_t)(255 + (PLANES > 1)) * d.ldw * 2 + (int64_t)d.K * 2 + 144 < lim;
 }
-
-int mudg_gemm256_dispatch(const MudgGemmDesc& d, int vflags, const h16* zpage, hipStream_t s);
 
 extern "C" int mudg_conv_subpixel_ok(const MudgGemmDesc* dp) {
     if (!dp) return 0;
@@ -767,23 +779,17 @@ extern "C" int mudg_gemm(const MudgGemmDesc* dp, void* stream) {
     const int fam = d.mode == 0 ? MUDG_FAM_GEMM : (d.mode == 1 ? MUDG_FAM_CONV : MUDG_FAM_TCONV);
     const int slot = mudg_prof_begin(fam, s);
     int rc;
-    // GroupNorm partials (d.stats) are written by the 128x128 kernels; the 16-wave 256x256
-    // kernel has no registers left for them (1024 threads -> 128 VGPRs) and declines such problems (returns 1).
-    rc = 1;
-    if (use_gemm256(d)) {
-        const h16* zp = zero_page();
-        if (!zp) MUDG_FAIL(MUDG_ELAUNCH, "gemm: could not allocate the zero page");
-        rc = mudg_gemm256_dispatch(d, vflags, zp, s);
-    }
-    if (rc == 1) {
-        if (mudg_gemm_fast_ok(d)) {
-            if (use_single_buffer(d))
-                rc = d.mode == 0 ? launch<0, true, true>(d, vflags, s) : (d.mode == 1 ? launch<1, true, true>(d, vflags, s) : launch<2, true, true>(d, vflags, s));
-            else
-                rc = d.mode == 0 ? launch<0, true, false>(d, vflags, s) : (d.mode == 1 ? launch<1, true, false>(d, vflags, s) : launch<2, true, false>(d, vflags, s));
-        } else {
-            rc = d.mode == 0 ? launch<0, false>(d, vflags, s) : (d.mode == 1 ? launch<1, false>(d, vflags, s) : launch<2, false>(d, vflags, s));
-        }
+    if (mudg_gemm_fast_ok(d)) {
+        bool sb = use_single_buffer(d);
+        if constexpr (fused_planes(true)) sb = true;
+        if (sb)
+            rc = d.mode == 0 ? launch<0, true, true>(d, vflags, s) : (d.mode == 1 ? launch<1, true, true>(d, vflags, s) : launch<2, true, true>(d, vflags, s));
+        else if constexpr (!fused_planes(true))
+            rc = d.mode == 0 ? launch<0, true, false>(d, vflags, s) : (d.mode == 1 ? launch<1, true, false>(d, vflags, s) : launch<2, true, false>(d, vflags, s));
+        else
+            rc = MUDG_EINVAL;
+    } else {
+        rc = d.mode == 0 ? launch<0, false>(d, vflags, s) : (d.mode == 1 ? launch<1, false>(d, vflags, s) : launch<2, false>(d, vflags, s));
     }
     const double flops = 2.0 * d.M * (double)d.N * d.K * d.batch;          // algorithmic (the split builds issue NSEG times as many)
     // algorithmic bytes at 16-bit storage: activations in (taps are re-reads of the same rows), weights, the result, and the

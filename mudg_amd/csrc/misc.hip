@@ -142,7 +142,7 @@ __global__ void cast_rows_kernel(const ST* __restrict__ src, int64_t lds, DT* __
         const int64_t r = i / cols, c = i - r * cols;
         const float v = row_value(src + r * lds + c, (int)lds);
         if constexpr (sizeof(DT) == 4) dst[r * ldd + c] = v;
-        else if constexpr (__is_same(DT, StreamH)) dst[r * ldd + c].v = (_Float16)v;
+        else if constexpr (__is_same(DT, StreamH)) dst[r * ldd + c].v = f16_sat(v);
         else store1_operand(dst + r * ldd + c, ldd / PLANES, v);
     }
 }

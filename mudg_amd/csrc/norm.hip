@@ -441,7 +441,7 @@ extern "C" int mudg_layernorm(const void* X, int ldx, int x_fp32, const float* g
     const dim3 grid((rows + 3) / 4);
     const int nvec = C >> 3;
     static int rows_kernel = -1;            // MUDG_LN_ROWS=0: the one-wave-per-row kernel for every width (A/B, tests)
-    if (rows_kernel < 0) { const char* e = getenv("MUDG_LN_ROWS"); rows_kernel = e ? atoi(e) : 1; }
+    if (rows_kernel < 0) rows_kernel = mudg_variant("LN_ROWS", 1);
     if (rows_kernel && C == 320) launch_ln_rows<8, 5>(x_fp32, X, ldx, gamma, beta, Y, ldy, rows, eps, s);
     else if (rows_kernel && C == 512) launch_ln_rows<8, 8>(x_fp32, X, ldx, gamma, beta, Y, ldy, rows, eps, s);
     else if (rows_kernel && C == 640) launch_ln_rows<8, 10>(x_fp32, X, ldx, gamma, beta, Y, ldy, rows, eps, s);

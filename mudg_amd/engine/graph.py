@@ -40,6 +40,13 @@ class UNetGraphs:
             self.entries.clear()
             self.signature = sig
         timesteps = torch.as_tensor(timesteps, device=parts[0].device)
+        # A prepared context whose projections were made with other parameter values (load_state_dict / LoRA swap between two
+        # runs that reuse the same cond tensors) is re-projected HERE, at the source: the graph's own copy is only ever
+        # filled from a context whose signature is the current one, never from stale K / V^T.
+        refreshed = False
+        if isinstance(context, U.PreparedContext) and context.signature != sig:
+            context.project(self.model)
+            refreshed = True
         key = self._key(parts, timesteps, c_label, context, fs)
         entry = self.entries.get(key)
         if entry is None:
@@ -67,7 +74,7 @@ class UNetGraphs:
         if c_label is not None:
             static["label"].copy_(torch.as_tensor(c_label, device=static["label"].device))
         if isinstance(context, U.PreparedContext):
-            if static["ctx_src"] is not context or static["ctx"].signature != context.signature:
+            if static["ctx_src"] is not context or refreshed or static["ctx"].signature != context.signature:
                 static["ctx"].copy_from(context)
                 static["ctx_src"] = context
         else:

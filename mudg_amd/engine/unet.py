@@ -370,7 +370,11 @@ def make_context(model, ctx, context, t_len, device):
 @torch.no_grad()
 def forward_entry(model, x, timesteps, c_label=None, context=None, features_adapter=None, fs=None):
     """UNetModel.forward: eager launch sequence, or hipGraph replay when `model.use_hip_graph` is set."""
-    if getattr(model, "use_hip_graph", False) and features_adapter is None and context is not None \
+    if context is None:
+        raise AssertionError("context is required (text + per-frame image tokens)")
+    if not isinstance(context, PreparedContext) and (not torch.is_tensor(context) or context.dim() != 3):
+        raise ValueError(f"context must be (B, L, D), got {tuple(context.shape) if torch.is_tensor(context) else type(context)}")
+    if getattr(model, "use_hip_graph", False) and features_adapter is None \
             and not torch.cuda.is_current_stream_capturing():
         from .graph import UNetGraphs
         graphs = model.__dict__.get("_mudg_graphs")

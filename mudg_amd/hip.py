@@ -138,6 +138,11 @@ def lib() -> C.CDLL:
         if _operand not in LIB_PATHS:
             raise MudgError(f"MUDG_OPERAND={_operand!r}: expected one of {', '.join(LIB_PATHS)}")
         path = LIB_PATHS[_operand]
+        if os.environ.get("MUDG_DEBUG_VARIANTS") == "1":
+            # tests / A/B tools: the bf16 build that honours the MUDG_<switch> kernel-variant variables (csrc/common.h)
+            if _operand != "bf16":
+                raise MudgError("MUDG_DEBUG_VARIANTS=1 exists for the bf16 build only")
+            path = os.path.join(_HERE, "libmudg_hip_dbg.so")
         if not os.path.exists(path):
             raise MudgError(
                 f"{path} is missing: build it with `python -m mudg_amd.build` (hipcc, gfx950). "

@@ -58,3 +58,46 @@ def pipeline_inputs(g, steps=None):
         "class_label": torch.tensor(s["class_labels"], dtype=torch.long)[:, None],
         "fs": torch.full((B,), s["fs"], dtype=torch.long),
     }
+
+
+def cached_oracle(key, compute):
+    """`compute()` (a CPU-oracle result: a tensor or a tuple / dict of tensors) memoised on disk for the lifetime of the
+    box's temp directory.  The same full-size oracle run is needed by the default-mode test and by its re-runs in the
+    operand-mode child processes (tests/test_precision_modes_gpu.py) — minutes of host time each; `key` must name
+    everything the result depends on (test, sizes, seeds)."""
+    import tempfile
+    d = os.path.join(tempfile.gettempdir(), "mudg_oracle_cache")
+    path = os.path.join(d, key + ".pt")
+    if os.path.exists(path):
+        try:
+            return torch.load(path, map_location="cpu", weights_only=True), True
+        except Exception:
+            pass
+    out = compute()
+    try:
+        os.makedirs(d, exist_ok=True)
+        tmp = path + f".{os.getpid()}.tmp"
+        torch.save(out, tmp)
+        os.replace(tmp, path)
+    except Exception:
+        pass
+    return out, False
+
+
+def record_parity(mode, name, value, **extra):
+    """Measured parity figures, merged into gpurun_out/parity_modes.json ({mode: {name: value}}): the record bench.py's
+    `at_tolerance` quotes once it has been copied to profiles/rN/ (tools/collect_profiles.sh)."""
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, "gpurun_out", "parity_modes.json")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        rec = {}
+        if os.path.exists(path):
+            with open(path) as f:
+                rec = json.load(f)
+        rec.setdefault(mode, {})[name] = dict(extra, value=float(value)) if extra else float(value)
+        with open(path, "w") as f:
+            json.dump(rec, f, indent=1, sort_keys=True)
+    except Exception:
+        pass

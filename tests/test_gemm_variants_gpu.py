@@ -1,7 +1,8 @@
-"""Every contraction-kernel variant through the same kernel parity tests, in child processes (the variant switches are
-read once per process): the 16-wave 256x256 kernel forced on every shape with M, N >= 256, the generic
-64-bit-address path of all kernels with the buffer-descriptor (FAST) path disabled, and the single-buffer short-K kernel
-forced on every FAST plain GEMM; both flash-attention kernels (32 / 64 queries per wave) forced."""
+"""Every contraction-kernel variant through the same kernel parity tests, in child processes on the debug-variants build
+(libmudg_hip_dbg.so, MUDG_DEBUG_VARIANTS=1: the only library that reads the MUDG_<switch> variables, once per process):
+the generic 64-bit-address path of all kernels with the buffer-descriptor (FAST) path disabled, the single-buffer
+short-K kernel forced on / off for every FAST problem, the phase-scheduled large-tile kernel forced on / off, both
+flash-attention kernels (32 / 64 queries per wave) forced."""
 import os
 import subprocess
 import sys
@@ -14,19 +15,17 @@ SELECT = "gemm or conv or tconv or resblock or transformer or geglu or fused or 
 
 
 @pytest.mark.parametrize("env", [
-    {"MUDG_GEMM256": "1"},
-    {"MUDG_GEMM256": "0"},
     {"MUDG_GEMM_FAST": "0"},
-    {"MUDG_GEMM_FAST": "0", "MUDG_GEMM256": "1"},
-    {"MUDG_GEMM_SB": "2", "MUDG_GEMM256": "0"},
+    {"MUDG_GEMM_SB": "2"},
+    {"MUDG_GEMM_SB": "0"},
     {"MUDG_ATTN_Q": "32"},
     {"MUDG_ATTN_Q": "64"},
 ], ids=lambda e: ",".join(f"{k[5:]}={v}" for k, v in e.items()))
 def test_kernel_parity_under_variant(cuda, env):
-    if any(k in os.environ for k in ("MUDG_GEMM256", "MUDG_GEMM_FAST", "MUDG_GEMM_SB", "MUDG_ATTN_Q")):
+    if os.environ.get("MUDG_DEBUG_VARIANTS") == "1":
         pytest.skip("already running under a variant switch")
     r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_kernels_gpu.py", "tests/test_operand_modes_gpu.py", "tests/test_unet_gpu.py", "-m", "gpu",
                         "-q", "-k", SELECT, "-p", "no:cacheprovider"],
-                       cwd=ROOT, env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+                       cwd=ROOT, env=dict(os.environ, MUDG_DEBUG_VARIANTS="1", **env), capture_output=True, text=True, timeout=900)
     print("\n".join(l for l in r.stdout.splitlines() if "passed" in l or "failed" in l))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

@@ -380,8 +380,8 @@ def test_fp32_residual_stream_variants(cuda):
     assert torch.equal(ops.cast_bf16(odd.to(cuda)).cpu(), odd.to(BF))
 
 
-# ---- large-tile (256x256, 8-wave, counted-vmcnt) GEMM path: shapes with >= 192 tiles select it automatically
-def test_gemm256_plain_epilogues(cuda):
+# ---- large problems (many tiles: the high-occupancy single-buffer kernels and, where it applies, the phase-scheduled large tile)
+def test_large_gemm_plain_epilogues(cuda):
     from mudg_amd import ops
     M, N, K = 4096 + 40, 3072, 200                      # ragged M, K tail (200 = 3 tiles + 8)
     x, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05)
@@ -398,7 +398,7 @@ def test_gemm256_plain_epilogues(cuda):
     assert rel_l2(y3, x.float() @ w.float().t() + rb.float() + gb.repeat_interleave(8, 0)[:M]) < TOL_BF16
 
 
-def test_gemm256_transpose_detecting_and_two_sources(cuda):
+def test_large_gemm_transpose_detecting_and_two_sources(cuda):
     from mudg_amd import ops
     n = 4096
     w = ((torch.arange(n * 256).reshape(n, 256) * 7) % 251).float().to(BF)      # asymmetric
@@ -414,7 +414,7 @@ def test_gemm256_transpose_detecting_and_two_sources(cuda):
     assert rel_l2(y2, torch.cat([x1, x2], 1).float() @ w2.float().t()) < TOL_BF16
 
 
-def test_gemm256_geglu(cuda):
+def test_large_gemm_geglu(cuda):
     from mudg_amd import ops
     M, C = 8192, 192                                      # N = 8C = 1536: 32 x 6 = 192 tiles
     x, w = rnd(M, C, seed=1), rnd(8 * C, C, seed=2, scale=0.1)
@@ -426,7 +426,7 @@ def test_gemm256_geglu(cuda):
 
 
 @pytest.mark.parametrize("korder,stride,ups", [(0, 1, False), (1, 1, False), (1, 2, False), (1, 1, True)])
-def test_gemm256_conv3x3(cuda, korder, stride, ups):
+def test_large_gemm_conv3x3(cuda, korder, stride, ups):
     from mudg_amd import ops
     frames, h, w, cin, cout = (16, 32, 32, 64, 768) if not ups else (4, 32, 32, 64, 768)
     if stride == 2:
@@ -442,7 +442,7 @@ def test_gemm256_conv3x3(cuda, korder, stride, ups):
     assert rel_l2(from_rows(y.cpu().float(), frames, ref.shape[2], ref.shape[3]), ref) < TOL_BF16
 
 
-def test_gemm256_tconv3(cuda):
+def test_large_gemm_tconv3(cuda):
     from mudg_amd import ops
     clips, t, h, w, c = 2, 8, 32, 32, 256                 # M = 16384, N = 256 -> 64 tiles: forced below
     x = rnd(clips, c, t, h, w, seed=1)

@@ -378,11 +378,13 @@ def test_attention_two_key_sets_in_one_launch(cuda):
 
 
 @pytest.mark.skipif(_hip.planes() > 1, reason="the lean softmax belongs to the 16-bit builds' long self-attention kernel")
-@pytest.mark.parametrize("spread", [1.0, 12.0])
+@pytest.mark.parametrize("spread", [1.0, 4.0, 12.0])
 def test_attention_lean_softmax_with_prescaled_q(cuda, spread):
     """q_prescaled: Q carries scale * log2(e), the kernel exponentiates Q K^T directly with the first tile's row maximum
     as the accumulators' initial value.  spread = 12 puts later scores far above the first tile's maximum (the deferred
-    reference has to cope; beyond 2^40 the classic loop takes over — forced here by a third, extreme case)."""
+    reference has to cope; beyond 2^40 the classic loop takes over — forced here by a third, extreme case); spread = 4 puts
+    them 2^16 ... 2^30 above it: inside the bf16 kernel's lean range, beyond what an IEEE-half P can hold — the fp16 build
+    must take the classic loop there (its limit is 2^15) instead of storing inf."""
     import math
     from mudg_amd import ops
     frames, heads, n = 2, 2, 768
@@ -399,7 +401,8 @@ def test_attention_lean_softmax_with_prescaled_q(cuda, spread):
     ops.attention(q, k, vt, out, frames=frames, heads=heads, nq=n, nk=n, q_prescaled=True)
     ref = _attention_ref(qv, kv, vv, frames, heads, n, n, math.log(2.0))       # softmax of 2^(q k)
     assert rel(value(out), ref) < 2 * TOL_OP
-    if spread > 1:      # extreme: one key per row 2^60 above everything in the first tile -> the classic loop redoes the block
+    assert torch.isfinite(value(out)).all()
+    if spread > 4:      # extreme: one key per row 2^60 above everything in the first tile -> the classic loop redoes the block
         kbig = ks.clone()
         kbig[n - 1] = qs[0] * 50.0
         k2, k2v = operand(kbig, cuda)

@@ -1,7 +1,8 @@
 """The other operand-type builds of the library through the parity suites, each in a child process (the operand type is
-fixed per process when the library loads): fp16 (libmudg_hip_fp16.so) and the split-operand precision modes bf16x3 /
+fixed per process when the library loads): fp16 (libmudg_hip_fp16.so), the split-operand precision modes bf16x3 /
 bf16x6 (libmudg_hip_x3.so / _x6.so), which are the modes that must meet north_star's 1e-3 decoded-frame tolerance — the
-pipeline tests assert it with the literal constant there.  The children's measured errors are echoed."""
+pipeline tests and the full-size config-0 cut assert it with the literal constant there — and the bf16 build with MX-fp8
+attention scores switched on (BASELINE.json configs[4]) end to end.  The children's measured errors are echoed."""
 import os
 import subprocess
 import sys
@@ -12,22 +13,37 @@ from mudg_amd import hip
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SUITES = {
-    "fp16": ["tests/test_kernels_gpu.py", "tests/test_operand_modes_gpu.py", "tests/test_unet_gpu.py",
-             "tests/test_pipeline_gpu.py", "tests/test_sampler_options_gpu.py", "tests/test_fullsize_gpu.py"],
-    # test_kernels_gpu.py builds its inputs as plain 16-bit tensors; the split modes run the mode-agnostic kernel suite
-    "bf16x3": ["tests/test_operand_modes_gpu.py", "tests/test_unet_gpu.py", "tests/test_pipeline_gpu.py",
-               "tests/test_sampler_options_gpu.py"],
-    "bf16x6": ["tests/test_operand_modes_gpu.py", "tests/test_unet_gpu.py", "tests/test_pipeline_gpu.py"],
+CUT = "tests/test_fullsize_gpu.py::test_config0_cut_one_ddim_step_and_4_frame_decode_at_mdm512_match_the_cpu_oracle"
+FWD512 = "tests/test_fullsize_gpu.py::test_mdm512_unet_forward_matches_the_cpu_oracle_at_full_size"
+# mode -> (environment of the child, what it runs).  The full-size CPU-oracle results are memoised on disk by the default-mode
+# run of tests/test_fullsize_gpu.py (helpers.cached_oracle), so the children only pay for their own GPU work.
+MODES = {
+    "fp16": ({"MUDG_OPERAND": "fp16"},
+             ["tests/test_kernels_gpu.py", "tests/test_operand_modes_gpu.py", "tests/test_unet_gpu.py",
+              "tests/test_pipeline_gpu.py", "tests/test_sampler_options_gpu.py", "tests/test_fullsize_gpu.py"]),
+    # test_kernels_gpu.py builds its inputs as plain 16-bit tensors; the split modes run the mode-agnostic kernel suite.
+    # bf16x3 is the mode that carries the contract: the full-size config-0 cut asserts the literal 1e-3 there
+    "bf16x3": ({"MUDG_OPERAND": "bf16x3"},
+               ["tests/test_operand_modes_gpu.py", "tests/test_unet_gpu.py", "tests/test_pipeline_gpu.py",
+                "tests/test_sampler_options_gpu.py", CUT, FWD512]),
+    "bf16x6": ({"MUDG_OPERAND": "bf16x6"},
+               ["tests/test_operand_modes_gpu.py", "tests/test_unet_gpu.py", "tests/test_pipeline_gpu.py"]),
+    # BASELINE.json configs[4]: MX-fp8 scores in the long self-attention (>= 512 tokens of head width 64: the full-size
+    # topology, not the small fixtures), END TO END: the full-size MDM512 UNet forward and the config-0 cut (guided DDIM step
+    # + decode) against the CPU oracle under the switch, next to the kernel-level test of the fp8 score path
+    "bf16+fp8scores": ({"MUDG_OPERAND": "bf16", "MUDG_ATTN_FP8": "1"},
+                       [FWD512, CUT, "tests/test_operand_modes_gpu.py::test_mxfp8_quantiser_and_fp8_score_attention"]),
 }
 
 
-@pytest.mark.parametrize("mode", list(SUITES))
+@pytest.mark.parametrize("mode", list(MODES))
 def test_parity_suites_in_operand_mode(cuda, mode):
-    if hip.operand_name() == mode:
-        pytest.skip("already running in this mode")
-    env = dict(os.environ, MUDG_OPERAND=mode, MUDG_SKIP_FULLSIZE_ORACLE="1")     # the minute-long CPU oracle forward runs once, in the default mode
-    r = subprocess.run([sys.executable, "-m", "pytest", *SUITES[mode], "-m", "gpu", "-q", "-s", "-p", "no:cacheprovider"],
+    env_add, suites = MODES[mode]
+    if os.environ.get("MUDG_PARITY_CHILD") == "1":
+        pytest.skip("already inside a mode child")
+    skip = {} if (CUT in suites or mode == "fp16") else {"MUDG_SKIP_FULLSIZE_ORACLE": "1", "MUDG_SKIP_CONFIG0_CUT": "1"}
+    env = dict(os.environ, MUDG_PARITY_CHILD="1", **env_add, **skip)
+    r = subprocess.run([sys.executable, "-m", "pytest", *suites, "-m", "gpu", "-q", "-s", "-p", "no:cacheprovider"],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
     tail = "\n".join(l for l in r.stdout.splitlines() if "rel-L2" in l or "passed" in l or "failed" in l)
     print(tail)
