@@ -22,28 +22,60 @@
 #include "common.h"
 #include <cstdlib>
 #include <cmath>
+#include <type_traits>
 
 bool mudg_gemm_fast_ok(const MudgGemmDesc& d);
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int BK = 64;
 constexpr int LDSLD = 64;                       // h16 elements per LDS row: unpadded, XOR-swizzled (see header)
-constexpr int STGLD = 132;                      // fp32 per staging row (128 + 4 pad)
-constexpr int TILE = BM * LDSLD;                // elements per operand per buffer
-constexpr int SMEM_MAIN = 4 * TILE * 2;         // X[2] + W[2], bytes
-constexpr int SMEM_STG = BM * STGLD * 4 + BN * 4;
-constexpr int SMEM_BYTES = SMEM_MAIN > SMEM_STG ? SMEM_MAIN : SMEM_STG;
-// Single-buffer variant (short K): one K-tile buffer, the epilogue staged in two 64-row passes -> 4 workgroups per CU.
-constexpr int SMEM_STG_SB = (BM / 2) * STGLD * 4 + BN * 4;
-constexpr int SMEM_BYTES_SB = 2 * TILE * 2 > SMEM_STG_SB ? 2 * TILE * 2 : SMEM_STG_SB;
+
+// Tile geometry.  Every variant is waves laid out WM (rows) x 2 (columns), a wave owning 64 rows x 32 NI columns as
+// 2 x NI v_mfma_f32_32x32x16 tiles:
+//   G128  (4 waves, 2 x 2, NI = 2): 128 x 128 — the high-occupancy tile (2 or 4 workgroups per CU); serves everything.
+//   G320  (8 waves, 4 x 2, NI = 5): 256 x 320 — every channel count of the UNet is a multiple of 320, so no column of the tile
+//         is wasted; 144 KiB of LDS (two K-tile stages), one workgroup per CU, two waves per SIMD.  Per FLOP it pulls 2.2x
+//         fewer bytes through L2 -> LDS than the 128 x 128 tile (142 against 64 FLOP per staged byte: at 1 PFLOP/s the small
+//         tile asks the L2s for 15.6 TB/s, close to half of what they deliver and more than the LDS-DMA path of a CU sustains)
+//         and a wave issues 10 MFMAs per 7 fragment reads instead of 4 per 4.
+//   G256  (8 waves, 4 x 2, NI = 4): 256 x 256 — the same for GEGLU problems, whose [32 value | 32 gate] row blocks must pair up
+//         inside one wave (NI even).
+template <int NWAVES_, int NI_>
+struct Geo {
+    static constexpr int NWAVES = NWAVES_, NI = NI_, MI = 2, WN = 2, WM = NWAVES_ / 2;
+    static constexpr int NTH = NWAVES * 64;
+    static constexpr int BM = WM * MI * 32, BN = WN * NI * 32;
+    static constexpr int XI = BM / NWAVES / 8, WI = BN / NWAVES / 8;       // 1-KiB DMA instructions per wave per operand tile
+    static constexpr int TILE_X = BM * LDSLD, TILE_W = BN * LDSLD;         // elements per operand per stage
+    static constexpr int STGLD = BN + 4;                                   // fp32 per staging row (the 128-wide kernels)
+    static constexpr bool WIDE = NWAVES > 4;
+    // Which 32-column blocks of the tile a wave column wn owns, as rows of the W tile: block(ni, wn) = WSTRIDE wn + nioff(ni).
+    // The 128 x 128 tile gives a wave NI consecutive blocks.  The wide tiles interleave them, so that the blocks 2 q and 2 q + 1
+    // of both wave columns together are the 128 consecutive output columns [128 q, 128 q + 128) — what one epilogue pass stages:
+    // NI = 5: block = 2 ni + wn;  NI = 4: block = 4 (ni / 2) + 2 wn + (ni & 1) (a GEGLU [value | gate] pair stays in one wave).
+    static constexpr int WSTRIDE = !WIDE ? NI : (NI & 1 ? 1 : 2);
+    static constexpr int nioff(int ni) { return !WIDE ? ni : (NI & 1 ? 2 * ni : 4 * (ni >> 1) + (ni & 1)); }
+};
+using G128 = Geo<4, 2>;
+using G320 = Geo<8, 5>;
+using G256 = Geo<8, 4>;
+
 // bf16x3 build, descriptor loader (FUSED): ONE K-tile stage holds both pieces of both operands — x0, x1, w0, w1, 4 x 16 KiB —
 // and every fragment read feeds the three kept products x1 w0 + x0 w1 + x0 w0: each piece is fetched once per K-tile (4 tile
 // fetches instead of the 6 of three whole passes over K) and 12 MFMAs follow 8 fragment reads instead of 4 following 4.
 // Single K-buffer + two-pass epilogue = 64 KiB -> 2 workgroups per CU.
 constexpr bool fused_planes(bool fast) { return PLANES == 2 && fast; }
-constexpr int SMEM_BYTES_FUSED = 2 * PLANES * TILE * 2;
-constexpr int smem_main(bool fast, bool sb) { return fused_planes(fast) ? SMEM_BYTES_FUSED : (sb ? SMEM_BYTES_SB : SMEM_BYTES); }
+// Stages: the single-buffer variant (SB, short K: one K-tile stage, the epilogue in 64-row passes -> 34 KiB, 4 workgroups per
+// CU) and the fused-piece variant hold one stage, everything else two.
+template <typename G> constexpr int stage_elems(bool fast) { return (fused_planes(fast) ? PLANES : 1) * (G::TILE_X + G::TILE_W); }
+template <typename G> constexpr int epi_rows(bool fast, bool sb) { return (G::WIDE || sb || fused_planes(fast)) ? 64 : G::BM; }
+constexpr int WSTG = 132;                        // wide tiles: fp32 per staging row of a 128-column pass (128 + 4 pad)
+template <typename G> constexpr int smem_main(bool fast, bool sb) {
+    const int loop = ((sb || fused_planes(fast)) ? 1 : 2) * stage_elems<G>(fast) * 2;
+    const int stg = G::WIDE ? G::BM * WSTG * 4 + G::BN * 4 : epi_rows<G>(fast, sb) * G::STGLD * 4 + G::BN * 4;
+    return loop > stg ? loop : stg;
+}
 
 constexpr int VF_Y = 1, VF_R = 2;               // 16-byte access allowed on Y / R
 
@@ -94,26 +126,30 @@ __device__ __forceinline__ float gelu_lut(float x, const float* __restrict__ T) 
     return x * fmaf(f, b - a, a);
 }
 
-template <int MODE, bool FAST, bool SB>
-__global__ __launch_bounds__(256, (SB && !fused_planes(FAST)) ? 4 : 2) void gemm_kernel(const MudgGemmDesc p, const int vflags, const h16* __restrict__ zpage,
-                                                                const float* __restrict__ phi) {
-    constexpr bool FUSED = fused_planes(FAST);          // all pieces of a K-tile staged at once (see SMEM_BYTES_FUSED)
-    constexpr bool ONEBUF = SB || FUSED;                // one K-tile stage, two-pass epilogue
+template <typename G, int MODE, bool FAST, bool SB>
+__global__ __launch_bounds__(G::NTH, G::WIDE ? 2 : ((SB && !fused_planes(FAST)) ? 4 : 2)) void gemm_kernel(const MudgGemmDesc p, const int vflags,
+                                                                const h16* __restrict__ zpage, const float* __restrict__ phi) {
+    static_assert(!G::WIDE || (FAST && !SB && PLANES == 1), "the wide tiles exist for the descriptor loader of the 16-bit builds");
+    constexpr int BM = G::BM, BN = G::BN, NI = G::NI, MI = G::MI, NTH = G::NTH, STGLD = G::STGLD;
+    constexpr int XI = G::XI, WI = G::WI, TILE_X = G::TILE_X, TILE_W = G::TILE_W;
+    constexpr int XROWS = 8 * XI, WROWS = 8 * WI;       // operand-tile rows a wave stages
+    constexpr bool FUSED = fused_planes(FAST);          // all pieces of a K-tile staged at once
+    constexpr bool ONEBUF = SB || FUSED;                // one K-tile stage
     constexpr int XT = FUSED ? PLANES : 1;              // tiles per operand per stage
     extern __shared__ __attribute__((aligned(16))) char smem[];
     h16* Xs = reinterpret_cast<h16*>(smem);
-    h16* Ws = Xs + (ONEBUF ? 1 : 2) * XT * TILE;
-    float* phis = reinterpret_cast<float*>(smem + smem_main(FAST, SB));     // beyond every other LDS use
+    h16* Ws = Xs + (ONEBUF ? 1 : 2) * XT * TILE_X;
+    float* phis = reinterpret_cast<float*>(smem + smem_main<G>(FAST, SB));     // beyond every other LDS use
     if (p.geglu && phi) {            // visible after the K loop's barriers
-        const int t4 = threadIdx.x * 4;
-        *reinterpret_cast<f32x4*>(&phis[t4]) = *reinterpret_cast<const f32x4*>(&phi[t4]);
+        for (int t4 = threadIdx.x * 4; t4 < PHI_N; t4 += NTH * 4)
+            *reinterpret_cast<f32x4*>(&phis[t4]) = *reinterpret_cast<const f32x4*>(&phi[t4]);
         if (threadIdx.x == 0) phis[PHI_N] = phi[PHI_N];
     }
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave & 1, wn = wave >> 1;
+    const int wm = wave % G::WM, wn = wave / G::WM;
     const int l31 = lane & 31, hi = lane >> 5;
 
     // XCD-aware tile numbering: hardware puts workgroup b on XCD b % 8; give every XCD a contiguous tile range.
@@ -146,15 +182,17 @@ __global__ __launch_bounds__(256, (SB && !fused_planes(FAST)) ? 4 : 2) void gemm
     const h16* X2 = p.X2 ? reinterpret_cast<const h16*>(p.X2) + bz * p.sX : nullptr;
     const h16* W = reinterpret_cast<const h16*>(p.W) + bz * p.sW;
 
-    // DMA geometry: wave w stages rows [32w, 32w+32) of both operand tiles with four 1-KiB instructions each;
-    // in instruction i, lane l lands in row 32w + 8i + (l >> 3), slot l & 7, and therefore fetches the logical
-    // chunk (l & 7) ^ ((row >> 1) & 7) of that row.
+    // DMA geometry: wave w stages rows [XROWS w, XROWS (w + 1)) of the X tile and [WROWS w, WROWS (w + 1)) of the W tile, one
+    // 1-KiB instruction per 8 rows; in instruction i, lane l lands in row 8 i + (l >> 3) of the wave's slice, slot l & 7, and
+    // therefore fetches the logical chunk (l & 7) ^ ((row >> 1) & 7) of that row.
     const int rsub = lane >> 3, slot = lane & 7;
-    int rm[4], ra[4], rb[4], rc[4], ch[4];
-    bool rv[4];
+    int rm[XI], ra[XI], rb[XI], rc[XI], ch[XI], chw[WI];
+    bool rv[XI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int rl = 32 * wave + 8 * i + rsub;
+    for (int i = 0; i < WI; ++i) chw[i] = slot ^ (((WROWS * wave + 8 * i + rsub) >> 1) & 7);
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+        const int rl = XROWS * wave + 8 * i + rsub;
         ch[i] = slot ^ ((rl >> 1) & 7);
         const int m = m0 + rl;
         rm[i] = m;
@@ -175,7 +213,7 @@ __global__ __launch_bounds__(256, (SB && !fused_planes(FAST)) ? 4 : 2) void gemm
 
     // FAST path state: descriptors based at the block's first source row, invariant lane offsets, tap validity bits.
     __amdgpu_buffer_rsrc_t rX, rX2, rW;
-    unsigned vx[4], vx2[4], vw[4], vmask[4];
+    unsigned vx[XI], vx2[XI], vw[WI], vmask[XI];
     int tap_s = 0, c_s = 0;                                      // tap / channel of the next K-tile to issue
     int seg_s = 0, kt_s = 0;                                     // split operands: (x plane, w plane) pass and K-tile inside it
     const int nk = (p.K + BK - 1) / BK;
@@ -192,8 +230,13 @@ __global__ __launch_bounds__(256, (SB && !fused_planes(FAST)) ? 4 : 2) void gemm
         rX2 = X2 ? make_rsrc(X2 + (pix0 + shift) * p.ldx2) : rX;
         rW = make_rsrc(W + (int64_t)n0 * p.ldw);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int rl = 32 * wave + 8 * i + rsub;
+        for (int i = 0; i < WI; ++i) {
+            const int rl = WROWS * wave + 8 * i + rsub;
+            vw[i] = (n0 + rl < p.N) ? (unsigned)rl * (unsigned)p.ldw * 2u + (unsigned)chw[i] * 16u : OOB;
+        }
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+            const int rl = XROWS * wave + 8 * i + rsub;
             int rel = rl;
             unsigned mask = rv[i] ? 1u : 0u;
             if (MODE == 1) {
@@ -220,7 +263,6 @@ __global__ __launch_bounds__(256, (SB && !fused_planes(FAST)) ? 4 : 2) void gemm
             const unsigned cb = (unsigned)ch[i] * 16u;
             vx[i] = (MODE == 0 && !rv[i]) ? OOB : (unsigned)rel * (unsigned)p.ldx * 2u + cb;
             vx2[i] = (MODE == 0 && !rv[i]) ? OOB : (unsigned)rel * (unsigned)(X2 ? p.ldx2 : p.ldx) * 2u + cb;
-            vw[i] = (n0 + rl < p.N) ? (unsigned)rl * (unsigned)p.ldw * 2u + cb : OOB;
         }
     }
 
@@ -245,15 +287,18 @@ __global__ __launch_bounds__(256, (SB && !fused_planes(FAST)) ? 4 : 2) void gemm
         for (int pl = 0; pl < XT; ++pl) {            // FUSED: piece pl of both operands into its own tile of the stage
             const int so = soff + pl * (ld / PLANES) * 2, sow = soffw + pl * (p.ldw / PLANES) * 2;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < XI; ++i) {
                 unsigned v = s2 ? vx2[i] : vx[i];
                 if (MODE != 0) v = ((vmask[i] >> tap_s) & 1u) ? v : OOB;
-                lptr_t lx = (lptr_t)(Xs + (buf * XT + pl) * TILE + (32 * wave + 8 * i) * LDSLD);
+                lptr_t lx = (lptr_t)(Xs + (buf * XT + pl) * TILE_X + (XROWS * wave + 8 * i) * LDSLD);
                 if (s2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rX2, lx, 16, (int)v, so, 0, 0);
                 else __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, lx, 16, (int)v, so, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < WI; ++i) {
                 // W rows beyond N are never multiplied (their waves are idle, see wave_live): skip the zero-fill pieces
-                if (n0 + 32 * wave + 8 * i < p.N || (32 * wave + 8 * i) < 64)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(Ws + (buf * XT + pl) * TILE + (32 * wave + 8 * i) * LDSLD), 16,
+                if (G::WIDE || n0 + WROWS * wave + 8 * i < p.N || (WROWS * wave + 8 * i) < 64)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(Ws + (buf * XT + pl) * TILE_W + (WROWS * wave + 8 * i) * LDSLD), 16,
                                                              (int)vw[i], sow, 0, 0);
             }
         }
@@ -287,7 +332,7 @@ __global__ __launch_bounds__(256, (SB && !fused_planes(FAST)) ? 4 : 2) void gemm
             else { tap_u = k0 / p.Cin; c_u = k0 - tap_u * p.Cin; }
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < XI; ++i) {
             const int k = k0 + ch[i] * 8;
             const bool kv = k < p.K;
             const h16* src = zpage;
@@ -314,51 +359,55 @@ __global__ __launch_bounds__(256, (SB && !fused_planes(FAST)) ? 4 : 2) void gemm
                         src = base + ((int64_t)rm[i] + (int64_t)(tap - 1) * p.HW) * ld + cc;
                 }
             }
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Xs + buf * TILE + (32 * wave + 8 * i) * LDSLD), 16, 0, 0);
-            const int n = n0 + 32 * wave + 8 * i + rsub;
-            const h16* wsrc = (n < p.N && kv) ? W + (int64_t)n * p.ldw + k + wo : zpage;
-            __builtin_amdgcn_global_load_lds((gptr_t)wsrc, (lptr_t)(Ws + buf * TILE + (32 * wave + 8 * i) * LDSLD), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Xs + buf * TILE_X + (XROWS * wave + 8 * i) * LDSLD), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < WI; ++i) {
+            const int k = k0 + chw[i] * 8;
+            const int n = n0 + WROWS * wave + 8 * i + rsub;
+            const h16* wsrc = (n < p.N && k < p.K) ? W + (int64_t)n * p.ldw + k + wo : zpage;
+            __builtin_amdgcn_global_load_lds((gptr_t)wsrc, (lptr_t)(Ws + buf * TILE_W + (WROWS * wave + 8 * i) * LDSLD), 16, 0, 0);
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[NI][MI];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < NI; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < MI; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     const int nkt = FUSED ? nk : nk * NSEG;      // K-tiles over all (x plane, w plane) passes; FUSED: all pieces per K-tile
     const int sw = (l31 >> 1) & 7;       // read-side swizzle: the row bases are multiples of 32, so only lane bits count
-    // A wave whose 64 output columns (or rows) all lie beyond N (M) has nothing to multiply: it still stages its share
+    // A wave whose output columns (or rows) all lie beyond N (M) has nothing to multiply: it still stages its share
     // of the operand tiles but leaves its SIMD's MFMA pipe to the other resident workgroups (N = 320: 1/6 of the waves).
-    const bool wave_live = (n0 + wn * 64 < p.N) && (m0 + wm * 64 < p.M);
+    const bool wave_live = (G::WIDE || n0 + wn * (32 * NI) < p.N) && (m0 + wm * 64 < p.M);
     auto multiply = [&](int cur) {
         if (!wave_live) return;
-        const h16* xs = Xs + cur * XT * TILE + (wm * 64 + l31) * LDSLD;
-        const h16* ws = Ws + cur * XT * TILE + (wn * 64 + l31) * LDSLD;
+        const h16* xs = Xs + cur * XT * TILE_X + (wm * 64 + l31) * LDSLD;
+        const h16* ws = Ws + cur * XT * TILE_W + (wn * (32 * G::WSTRIDE) + l31) * LDSLD;
         if constexpr (FUSED) {
             // x = x0 + x1, w = w0 + w1 (bf16 pieces): x1 w0 + x0 w1 + x0 w0 per fragment pair — the bf16 x bf16 products are
             // exact in the fp32 accumulator; what is dropped (x1 w1) is 2^-18 relative.  Small terms first within a k-step.
 #pragma unroll
             for (int ks = 0; ks < BK / 16; ++ks) {
                 const int off = ((ks * 2 + hi) ^ sw) << 3;
-                h16x8 wf[2][2], xf[2][2];          // [piece][32-row block]
+                h16x8 wf[2][NI], xf[2][MI];          // [piece][32-row block]
 #pragma unroll
                 for (int pl = 0; pl < 2; ++pl) {
-                    wf[pl][0] = *reinterpret_cast<const h16x8*>(ws + pl * TILE + off);
-                    wf[pl][1] = *reinterpret_cast<const h16x8*>(ws + pl * TILE + 32 * LDSLD + off);
-                    xf[pl][0] = *reinterpret_cast<const h16x8*>(xs + pl * TILE + off);
-                    xf[pl][1] = *reinterpret_cast<const h16x8*>(xs + pl * TILE + 32 * LDSLD + off);
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) wf[pl][ni] = *reinterpret_cast<const h16x8*>(ws + pl * TILE_W + G::nioff(ni) * 32 * LDSLD + off);
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) xf[pl][mi] = *reinterpret_cast<const h16x8*>(xs + pl * TILE_X + mi * 32 * LDSLD + off);
                 }
 #pragma unroll
                 for (int term = 0; term < 3; ++term) {
                     const int wp = term == 1 ? 1 : 0, xp = term == 0 ? 1 : 0;
 #pragma unroll
-                    for (int ni = 0; ni < 2; ++ni)
+                    for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-                        for (int mi = 0; mi < 2; ++mi)
+                        for (int mi = 0; mi < MI; ++mi)
                             acc[ni][mi] = MFMA_32x32x16(wf[wp][ni], xf[xp][mi], acc[ni][mi]);
                 }
             }
@@ -367,15 +416,15 @@ __global__ __launch_bounds__(256, (SB && !fused_planes(FAST)) ? 4 : 2) void gemm
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
             const int off = ((ks * 2 + hi) ^ sw) << 3;
-            h16x8 wf[2], xf[2];
-            wf[0] = *reinterpret_cast<const h16x8*>(ws + off);
-            wf[1] = *reinterpret_cast<const h16x8*>(ws + 32 * LDSLD + off);
-            xf[0] = *reinterpret_cast<const h16x8*>(xs + off);
-            xf[1] = *reinterpret_cast<const h16x8*>(xs + 32 * LDSLD + off);
+            h16x8 wf[NI], xf[MI];
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
+            for (int ni = 0; ni < NI; ++ni) wf[ni] = *reinterpret_cast<const h16x8*>(ws + G::nioff(ni) * 32 * LDSLD + off);
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
+            for (int mi = 0; mi < MI; ++mi) xf[mi] = *reinterpret_cast<const h16x8*>(xs + mi * 32 * LDSLD + off);
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
                     acc[ni][mi] = MFMA_32x32x16(wf[ni], xf[mi], acc[ni][mi]);
         }
     };
@@ -397,9 +446,219 @@ __global__ __launch_bounds__(256, (SB && !fused_planes(FAST)) ? 4 : 2) void gemm
         }
     }
 
+    // ------------------------------------------------------------------ epilogue of the wide tiles
+    // One workgroup per CU: nothing else hides this tile's store latency, so the epilogue is built for memory-level parallelism.
+    // A pass stages 128 output columns of ALL 256 rows (every wave writes the two blocks 2 q, 2 q + 1 it owns: see Geo::nioff) as
+    // fp32 in LDS; then thread t keeps the 8-channel chunk t & 15 and the rows (t >> 8) 128 + ((t >> 4) & 15) + 16 k, k = 0..7 —
+    // for GroupNorm partials exactly the rows, in exactly the order, that a thread of the 128 x 128 kernels sums, so both kernels
+    // write bit-identical partials — in two batches of four rows whose residual loads are all in flight before the first is used.
+    if constexpr (G::WIDE) {
+        float* stg = reinterpret_cast<float*>(smem);
+        float* sbias = stg + BM * WSTG;
+        bool gbias_rows = p.gbias != nullptr;
+        if (p.gbias && !p.geglu) {
+            const int mlast = (m0 + BM <= p.M ? m0 + BM : p.M) - 1;
+            const int g0 = m0 / p.rows_per_group;
+            if (g0 == mlast / p.rows_per_group) {
+                gbias_rows = false;
+                for (int t = tid; t < BN; t += NTH) {
+                    float b = (p.bias && n0 + t < p.N) ? p.bias[n0 + t] : 0.f;
+                    if (n0 + t < p.N) b += p.gbias[(int64_t)g0 * p.N + n0 + t];
+                    sbias[t] = b;
+                }
+            }
+        }
+        if (gbias_rows || !p.gbias || p.geglu) {
+            for (int t = tid; t < BN; t += NTH) sbias[t] = (p.bias && n0 + t < p.N) ? p.bias[n0 + t] : 0.f;
+        }
+        __syncthreads();
+
+        const float alpha = p.alpha;
+        const int Nout = p.geglu ? p.N / 2 : p.N;
+        const int nout0 = p.geglu ? n0 / 2 : n0;
+        const int cc = tid & 15, rr = (tid >> 4) & 15, half = tid >> 8;
+        const int hw_o = MODE == 1 ? p.Hout * p.Wout : 1;
+        constexpr int NPASSW = (NI + 1) / 2;
+        const int RK = p.R ? p.res_fp32 : 3, OK = p.out_fp32;          // storage kinds of the residual (3 = none) and of Y
+        const char* Rb = reinterpret_cast<const char*>(p.R) + bz * p.sR * (RK == KIND_F32 ? 4 : 2);
+        const int rsz = RK == KIND_F32 ? 4 : 2;
+        auto run_pass = [&](auto qtag) __attribute__((always_inline)) {
+            constexpr int q = decltype(qtag)::value;
+            // ---- accumulators -> staging (fp32, + bias, GEGLU)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int ml = wm * 64 + mi * 32 + l31;
+                if (!p.geglu) {
+#pragma unroll
+                    for (int d = 0; d < 2; ++d) {
+                        constexpr int dummy = 0; (void)dummy;
+                        const int ni = 2 * q + d;
+                        if (ni < NI) {
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                const int bl = (NI & 1) ? 2 * d + wn : 2 * wn + d;          // block inside the pass's 128 columns
+                                const int nl = bl * 32 + 8 * g + 4 * hi;
+                                const int nb = q * 128 + nl;                               // column inside the tile (bias index)
+                                f32x4 v;
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) v[j] = alpha * acc[ni < NI ? ni : 0][mi][4 * g + j] + sbias[nb + j];
+                                if (p.act) {
+#pragma unroll
+                                    for (int j = 0; j < 4; ++j) v[j] = gelu_fast(v[j]);
+                                }
+                                *reinterpret_cast<f32x4*>(&stg[ml * WSTG + nl]) = v;
+                            }
+                        }
+                    }
+                } else if constexpr (NI % 2 == 0) {
+                    // the pass's pair of this wave: value block 4 q + 2 wn, gate block 4 q + 2 wn + 1 -> output columns 64 q + 32 wn ..
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int nb = q * 128 + wn * 64 + 8 * g + 4 * hi;                 // value columns inside the tile
+                        f32x4 v;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float val = alpha * acc[2 * q][mi][4 * g + j] + sbias[nb + j];
+                            const float gate = alpha * acc[2 * q + 1][mi][4 * g + j] + sbias[nb + 32 + j];
+                            v[j] = val * (phi ? gelu_lut(gate, phis) : gelu_fast(gate));
+                        }
+                        *reinterpret_cast<f32x4*>(&stg[ml * WSTG + wn * 32 + 8 * g + 4 * hi]) = v;
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- staging -> HBM
+            const int ncols = p.geglu ? 64 : 128;                                         // output columns of this pass
+            const int n = nout0 + q * ncols + cc * 8;
+            const int nvalid = (cc * 8 >= ncols || (!p.geglu && q * 128 + cc * 8 >= BN) || n >= Nout) ? 0 : ((Nout - n) < 8 ? (Nout - n) : 8);
+            float gs[8], gq[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { gs[j] = 0.f; gq[j] = 0.f; }
+            const bool wideY = nvalid == 8 && (vflags & VF_Y), wideR = nvalid == 8 && (vflags & VF_R);
+#pragma unroll
+            for (int kb = 0; kb < 8; kb += 4) {
+                float v[4][8];
+                u32x4 ra[4], rb[4];
+                int64_t mrow[4];
+                bool ok[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int row = half * 128 + rr + 16 * (kb + u);
+                    const int m = m0 + row;
+                    mrow[u] = m;
+                    ok[u] = m < p.M && nvalid > 0;
+                    ra[u] = zero16(); rb[u] = zero16();
+                    if (RK != 3 && ok[u] && wideR) {             // 16 bytes whatever the kind (fp32: the second half follows)
+                        const char* rp = Rb + ((int64_t)m * p.ldr + n) * rsz;
+                        ra[u] = ld16(rp);
+                        if (RK == KIND_F32) rb[u] = ld16(rp + 16);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int row = half * 128 + rr + 16 * (kb + u);
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(&stg[row * WSTG + cc * 8]);
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(&stg[row * WSTG + cc * 8 + 4]);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { v[u][j] = a[j]; v[u][4 + j] = b[j]; }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (!ok[u]) continue;
+                    const int64_t m = mrow[u];
+                    if (gbias_rows) {
+                        const float* gb = p.gbias + (int64_t)(m / p.rows_per_group) * Nout + n;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) if (j < nvalid) v[u][j] += gb[j];
+                    }
+                    if (RK != 3) {
+                        if (wideR) {
+                            if (RK == KIND_F32) {
+                                union { u32x4 w; f32x4 f; } ta, tb; ta.w = ra[u]; tb.w = rb[u];
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) { v[u][j] += ta.f[j]; v[u][4 + j] += tb.f[j]; }
+                            } else if (RK == KIND_F16) {
+                                union { u32x4 w; f16x8 h; } t; t.w = ra[u];
+#pragma unroll
+                                for (int j = 0; j < 8; ++j) v[u][j] += (float)t.h[j];
+                            } else {
+                                const h16x8 t = as_h16x8(ra[u]);
+#pragma unroll
+                                for (int j = 0; j < 8; ++j) v[u][j] += (float)t[j];
+                            }
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) if (j < nvalid) {
+                                const int64_t ro = bz * p.sR + m * p.ldr + n + j;
+                                v[u][j] += RK == KIND_F32 ? reinterpret_cast<const float*>(p.R)[ro]
+                                         : (RK == KIND_F16 ? (float)reinterpret_cast<const _Float16*>(p.R)[ro] : (float)reinterpret_cast<const h16*>(p.R)[ro]);
+                            }
+                        }
+                    }
+                    if (p.stats) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const float t = (j < nvalid) ? (OK == KIND_F32 ? v[u][j] : (OK == KIND_F16 ? (float)f16_sat(v[u][j]) : (float)(h16)v[u][j])) : 0.f;
+                            gs[j] += t; gq[j] = fmaf(t, t, gq[j]);
+                        }
+                    }
+                    int64_t yoff;
+                    if (sub) {
+                        const int f = (int)(m / hw_o), r = (int)(m - (int64_t)f * hw_o);
+                        const int oy = r / p.Wout, ox = r - oy * p.Wout;
+                        yoff = (((int64_t)(f * p.Hout + oy) * 2 + dy0) * (2 * p.Wout) + 2 * ox + dx0) * p.ldy + n;
+                    } else {
+                        yoff = bz * p.sY + m * p.ldy + n;
+                    }
+                    if (OK == KIND_F16) {
+                        _Float16* yp = reinterpret_cast<_Float16*>(p.Y) + yoff;
+                        if (wideY) store8_f16(yp, v[u]);
+                        else for (int j = 0; j < nvalid; ++j) yp[j] = f16_sat(v[u][j]);
+                    } else if (OK == KIND_F32) {
+                        float* yp = reinterpret_cast<float*>(p.Y) + yoff;
+                        if (wideY) {
+                            f32x4 a, b;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) { a[j] = v[u][j]; b[j] = v[u][4 + j]; }
+                            *reinterpret_cast<f32x4*>(yp) = a;
+                            *reinterpret_cast<f32x4*>(yp + 4) = b;
+                        } else for (int j = 0; j < nvalid; ++j) yp[j] = v[u][j];
+                    } else {
+                        h16* yp = reinterpret_cast<h16*>(p.Y) + yoff;
+                        if (wideY) store8_operand(yp, p.ldy, v[u]);
+                        else for (int j = 0; j < nvalid; ++j) yp[j] = (h16)v[u][j];
+                    }
+                }
+            }
+            __syncthreads();                      // staging is free again
+            if (p.stats) {
+                // fold the sixteen row classes of each (half, chunk) in a fixed order — the 128 x 128 kernels' fold
+                float* red = stg;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { red[tid * 17 + j] = gs[j]; red[tid * 17 + 8 + j] = gq[j]; }
+                __syncthreads();
+                {
+                    const int hf = tid >> 8, c2 = (tid >> 4) & 15, j = tid & 15;
+                    float t = 0.f;
+                    for (int k = 0; k < 16; ++k) t += red[((hf * 16 + k) * 16 + c2) * 17 + j];
+                    const int n2 = nout0 + q * 128 + c2 * 8 + (j & 7);
+                    const int64_t blk = (int64_t)(m0 / 128) + hf;
+                    if (q * 128 + c2 * 8 < BN && n2 < Nout && blk * 128 < p.M) p.stats[(blk * Nout + n2) * 2 + (j >> 3)] = t;
+                }
+                __syncthreads();
+            }
+        };
+        run_pass(std::integral_constant<int, 0>{});
+        if constexpr (NPASSW > 1) run_pass(std::integral_constant<int, 1>{});
+        if constexpr (NPASSW > 2) run_pass(std::integral_constant<int, 2>{});
+        return;
+    }
+
     // ------------------------------------------------------------------ epilogue
+    // The tile goes through an fp32 LDS staging area in passes of PROWS rows (a pass = the wave row(s) wm whose 64 rows it holds),
+    // then leaves in coalesced 16-byte row pieces: thread t keeps ONE 8-channel chunk (t % cpr) and walks the rows.
     float* stg = reinterpret_cast<float*>(smem);
-    constexpr int NPASS = ONEBUF ? 2 : 1, PROWS = BM / NPASS;  // SB / FUSED stage the tile in two 64-row passes (wave rows wm = pass)
+    constexpr int PROWS = epi_rows<G>(FAST, SB), NPASS = BM / PROWS;
     float* sbias = stg + PROWS * STGLD;
     // Per-group bias (a ResBlock's embedding term): when all rows of the tile belong to one group — always, for the
     // UNet's shapes — it is one more per-column constant and rides in the staged bias; a tile that straddles groups adds
@@ -410,15 +669,15 @@ __global__ __launch_bounds__(256, (SB && !fused_planes(FAST)) ? 4 : 2) void gemm
         const int g0 = m0 / p.rows_per_group;
         if (g0 == mlast / p.rows_per_group) {
             gbias_rows = false;
-            if (tid < BN) {
-                float b = (p.bias && n0 + tid < p.N) ? p.bias[n0 + tid] : 0.f;
-                if (n0 + tid < p.N) b += p.gbias[(int64_t)g0 * p.N + n0 + tid];
-                sbias[tid] = b;
+            for (int t = tid; t < BN; t += NTH) {
+                float b = (p.bias && n0 + t < p.N) ? p.bias[n0 + t] : 0.f;
+                if (n0 + t < p.N) b += p.gbias[(int64_t)g0 * p.N + n0 + t];
+                sbias[t] = b;
             }
         }
     }
     if (gbias_rows || !p.gbias || p.geglu) {
-        if (tid < BN) sbias[tid] = (p.bias && n0 + tid < p.N) ? p.bias[n0 + tid] : 0.f;
+        for (int t = tid; t < BN; t += NTH) sbias[t] = (p.bias && n0 + t < p.N) ? p.bias[n0 + t] : 0.f;
     }
     __syncthreads();
 
@@ -426,25 +685,36 @@ __global__ __launch_bounds__(256, (SB && !fused_planes(FAST)) ? 4 : 2) void gemm
     const int NT = p.geglu ? BN / 2 : BN;
     const int Nout = p.geglu ? p.N / 2 : p.N;
     const int nout0 = p.geglu ? n0 / 2 : n0;
-    const int cpr = NT / 8;
+    const int cpr = NT / 8;                        // 8-channel chunks per staged row
+    // thread -> (chunk, first row, row step): no per-chunk division in the store loop (the short-K GEMMs spent 8-12 VALU
+    // instructions per MFMA, most of them there).  NTH / cpr rows per sweep; the threads beyond rstep * cpr (BN = 320 only) idle.
+    int cc, r0, rstep;
+    if constexpr ((BN & (BN - 1)) == 0) {          // power-of-two tile widths: shifts
+        const int cshift = __builtin_ctz(cpr);
+        cc = tid & (cpr - 1); r0 = tid >> cshift; rstep = NTH >> cshift;
+    } else {
+        rstep = NTH / cpr; r0 = tid / cpr; cc = tid - r0 * cpr;
+        if (r0 >= rstep) r0 = PROWS;               // idle
+    }
     const h16* R = (p.R && p.res_fp32 == KIND_OPERAND) ? reinterpret_cast<const h16*>(p.R) + bz * p.sR : nullptr;
     const float* Rf = (p.R && p.res_fp32 == KIND_F32) ? reinterpret_cast<const float*>(p.R) + bz * p.sR : nullptr;
     const _Float16* Rh = (p.R && p.res_fp32 == KIND_F16) ? reinterpret_cast<const _Float16*>(p.R) + bz * p.sR : nullptr;
     float gs[8], gq[8];            // GroupNorm partials of this thread's 8 output channels (p.stats)
 #pragma unroll
     for (int j = 0; j < 8; ++j) { gs[j] = 0.f; gq[j] = 0.f; }
-#pragma unroll
+    constexpr int PASS_UNROLL = NPASS > 2 ? 1 : NPASS;      // four passes stay a loop (4x the code of the store branches otherwise)
+#pragma unroll PASS_UNROLL
     for (int pass = 0; pass < NPASS; ++pass) {
     if (NPASS == 1 || wm == pass) {
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
+    for (int mi = 0; mi < MI; ++mi) {
         const int ml = (NPASS == 1 ? wm * 64 : 0) + mi * 32 + l31;
         if (!p.geglu) {
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
+            for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int nl = wn * 64 + ni * 32 + 8 * g + 4 * hi;
+                    const int nl = wn * (32 * NI) + ni * 32 + 8 * g + 4 * hi;
                     f32x4 v;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = alpha * acc[ni][mi][4 * g + j] + sbias[nl + j];
@@ -454,33 +724,31 @@ __global__ __launch_bounds__(256, (SB && !fused_planes(FAST)) ? 4 : 2) void gemm
                     }
                     *reinterpret_cast<f32x4*>(&stg[ml * STGLD + nl]) = v;
                 }
-        } else {
+        } else if constexpr (NI % 2 == 0) {
+#pragma unroll
+            for (int q = 0; q < NI / 2; ++q)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int nl = wn * 64 + 8 * g + 4 * hi;      // value columns; gates sit 32 further
+                const int nl = wn * (32 * NI) + q * 64 + 8 * g + 4 * hi;      // value columns of pair q; its gates sit 32 further
                 f32x4 v;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float val = alpha * acc[0][mi][4 * g + j] + sbias[nl + j];
-                    const float gate = alpha * acc[1][mi][4 * g + j] + sbias[nl + 32 + j];
+                    const float val = alpha * acc[2 * q][mi][4 * g + j] + sbias[nl + j];
+                    const float gate = alpha * acc[2 * q + 1][mi][4 * g + j] + sbias[nl + 32 + j];
                     v[j] = val * (PLANES > 1 ? gelu_erf_f(gate) : (phi ? gelu_lut(gate, phis) : gelu_fast(gate)));
                 }
-                *reinterpret_cast<f32x4*>(&stg[ml * STGLD + wn * 32 + 8 * g + 4 * hi]) = v;
+                *reinterpret_cast<f32x4*>(&stg[ml * STGLD + wn * (16 * NI) + q * 32 + 8 * g + 4 * hi]) = v;
             }
         }
     }
     }
     __syncthreads();
 
-    // cpr is 16 (or 8 with GEGLU): a thread keeps ONE 8-channel chunk (tid & (cpr - 1)) and walks rows 256 / cpr apart — no
-    // per-chunk division / modulo (the short-K GEMMs spent 8-12 VALU instructions per MFMA, most of them here)
-    const int cshift = p.geglu ? 3 : 4;
-    const int cc = tid & (cpr - 1);
     const int n = nout0 + cc * 8;
     const int nvalid = n >= Nout ? 0 : ((Nout - n) < 8 ? (Nout - n) : 8);
     if (sub) {
         // sub-pixel conv: bias only (host-checked), rows scattered to this parity class's pixels of the full-resolution image
-        for (int row = tid >> 4; row < PROWS; row += 16) {
+        for (int row = r0; row < PROWS; row += rstep) {
             const int m = m0 + pass * PROWS + row;
             if (m >= p.M || nvalid == 0) break;
             const int hw = p.Hout * p.Wout;
@@ -507,7 +775,7 @@ __global__ __launch_bounds__(256, (SB && !fused_planes(FAST)) ? 4 : 2) void gemm
             }
         }
     } else
-    for (int row = tid >> cshift; row < PROWS; row += (256 >> cshift)) {
+    for (int row = r0; row < PROWS; row += rstep) {
         const int m = m0 + pass * PROWS + row;
         if (m >= p.M || nvalid == 0) break;
         float v[8];
@@ -595,22 +863,26 @@ __global__ __launch_bounds__(256, (SB && !fused_planes(FAST)) ? 4 : 2) void gemm
             }
         }
     }
-    if (NPASS > 1) __syncthreads();
-    }
-    if (p.stats) {
-        // thread t always handled channel chunk t % cpr: fold the 256 / cpr threads of a chunk in a fixed order
-        if (NPASS == 1) __syncthreads();
+    // GroupNorm partials are per 128-row block of Y (MudgGemmDesc.stats): flush whenever the passes done so far end one.
+    constexpr bool STATS_FLUSH_EVERY_128 = true;
+    const bool flush = p.stats && STATS_FLUSH_EVERY_128 && (((pass + 1) * PROWS) % 128 == 0 || pass == NPASS - 1);
+    if (NPASS > 1 || flush) __syncthreads();
+    if (flush) {
+        // thread t always handled channel chunk t % cpr: fold the threads of a chunk in a fixed order
         float* red = stg;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { red[tid * 17 + j] = gs[j]; red[tid * 17 + 8 + j] = gq[j]; }
+        for (int j = 0; j < 8; ++j) { red[tid * 17 + j] = gs[j]; red[tid * 17 + 8 + j] = gq[j]; gs[j] = 0.f; gq[j] = 0.f; }
         __syncthreads();
-        if (tid < cpr * 16) {
-            const int cc = tid >> 4, j = tid & 15;
+        const int blk = (m0 + (pass + 1) * PROWS - 1) / 128;           // the 128-row block these rows belong to
+        for (int u = tid; u < cpr * 16; u += NTH) {
+            const int c2 = u >> 4, j = u & 15;
             float t = 0.f;
-            for (int k = cc; k < 256; k += cpr) t += red[k * 17 + j];
-            const int n = nout0 + cc * 8 + (j & 7);
-            if (n < Nout) p.stats[((int64_t)(m0 / BM) * Nout + n) * 2 + (j >> 3)] = t;
+            for (int k = c2; k < rstep * cpr; k += cpr) t += red[k * 17 + j];
+            const int n2 = nout0 + c2 * 8 + (j & 7);
+            if (n2 < Nout && (int64_t)blk * 128 < p.M) p.stats[((int64_t)blk * Nout + n2) * 2 + (j >> 3)] = t;
         }
+        if (pass + 1 < NPASS) __syncthreads();
+    }
     }
 }
 
@@ -659,22 +931,23 @@ const float* phi_table() {
     return tab;
 }
 
-template <int MODE, bool FAST, bool SB = false>
+template <typename G, int MODE, bool FAST, bool SB = false>
 int launch(const MudgGemmDesc& d, int vflags, hipStream_t s) {
     static bool attr_done[MAX_DEVICES] = {};
     const h16* zp = zero_page();
     if (!zp) MUDG_FAIL(MUDG_ELAUNCH, "gemm: could not allocate the zero page");
     bool& attr_set = attr_done[current_device()];
+    constexpr int smem = smem_main<G>(FAST, SB);
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<MODE, FAST, SB>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, smem_main(FAST, SB) + PHI_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<G, MODE, FAST, SB>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, smem + PHI_BYTES);
         if (e != hipSuccess) MUDG_FAIL(MUDG_ELAUNCH, "gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
-    const int tiles = ((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN);
+    const int tiles = ((d.M + G::BM - 1) / G::BM) * ((d.N + G::BN - 1) / G::BN);
     dim3 grid(tiles, 1, d.batch);
     const float* phi = d.geglu ? phi_table() : nullptr;
-    hipLaunchKernelGGL((gemm_kernel<MODE, FAST, SB>), grid, dim3(256), smem_main(FAST, SB) + (phi ? PHI_BYTES : 0), s, d, vflags, zp, phi);
+    hipLaunchKernelGGL((gemm_kernel<G, MODE, FAST, SB>), grid, dim3(G::NTH), smem + (phi ? PHI_BYTES : 0), s, d, vflags, zp, phi);
     return mudg_check_launch("mudg_gemm");
 }
 
@@ -689,9 +962,34 @@ bool use_single_buffer(const MudgGemmDesc& d) {
     if (mode < 0) mode = mudg_variant("GEMM_SB", 1);
     if (mode == 0) return false;
     if (mode == 2) return true;
-    const int64_t tiles = (int64_t)((d.M + BM - 1) / BM) * ((d.N + BN - 1) / BN) * d.batch;
+    const int64_t tiles = (int64_t)((d.M + G128::BM - 1) / G128::BM) * ((d.N + G128::BN - 1) / G128::BN) * d.batch;
     return tiles >= (d.mode == 1 ? 2048 : 768);
 }
+
+// The wide tiles (G320 / G256, 16-bit builds, descriptor loader): 0 = the 128 x 128 kernels, 5 / 4 = NI of the wide tile.
+// Measured per shape on MI355X (tools/exp_tiles.py, profiles/r3/tiles_*.txt): with all 256 CUs holding one wide tile each the
+// main loop runs at 1280-1370 TFLOP/s against 980-1070 of the 128 x 128 kernels (long K), but a wide tile is alone on its CU —
+// nothing overlaps its epilogue, and a last round that is partly empty costs a whole tile time — so over a whole problem it
+// only wins where K is long AND the rounds are full enough: the 3x3 convs with K >= 8000 at N = 320 (+ 6.7 %), parity at
+// K = 5760, and it loses on every plain / GEGLU GEMM of the UNet (K <= 5120: - 15 ... - 55 %).  The rule below is that measurement.
+// Variant switch GEMM_WIDE=0 disables them, =1 forces them wherever the columns fit (tests run every epilogue that way).
+int use_wide(const MudgGemmDesc& d) {
+    static int mode = -1;
+    if (mode < 0) mode = mudg_variant("GEMM_WIDE", 2);
+    if (mode == 0) return 0;
+    int ni = 0;
+    if (d.geglu) ni = (d.N % 256 == 0) ? 4 : 0;
+    else if (d.N % 320 == 0) ni = 5;
+    else if (d.N % 256 == 0) ni = 4;
+    if (!ni) return 0;
+    if (mode == 1) return ni;
+    const int64_t tiles = (int64_t)((d.M + 255) / 256) * (d.N / (64 * ni)) * d.batch;
+    const int64_t rounds = (tiles + 255) / 256;
+    if (d.mode != 1 || d.geglu || d.K < 8000) return 0;
+    if (tiles < 4 * 256 || tiles * 10 < rounds * 256 * 9) return 0;        // >= 4 rounds, >= 90 % of the slots of the rounds used
+    return ni;
+}
+#endif
 
 }  // namespace
 
@@ -778,18 +1076,24 @@ extern "C" int mudg_gemm(const MudgGemmDesc* dp, void* stream) {
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int fam = d.mode == 0 ? MUDG_FAM_GEMM : (d.mode == 1 ? MUDG_FAM_CONV : MUDG_FAM_TCONV);
     const int slot = mudg_prof_begin(fam, s);
-    int rc;
+    int rc = MUDG_EINVAL;
+    auto by_mode = [&](auto g, auto fast, auto sb) {
+        using G = decltype(g);
+        constexpr bool F = decltype(fast)::value, S = decltype(sb)::value;
+        return d.mode == 0 ? launch<G, 0, F, S>(d, vflags, s) : (d.mode == 1 ? launch<G, 1, F, S>(d, vflags, s) : launch<G, 2, F, S>(d, vflags, s));
+    };
     if (mudg_gemm_fast_ok(d)) {
-        bool sb = use_single_buffer(d);
-        if constexpr (fused_planes(true)) sb = true;
-        if (sb)
-            rc = d.mode == 0 ? launch<0, true, true>(d, vflags, s) : (d.mode == 1 ? launch<1, true, true>(d, vflags, s) : launch<2, true, true>(d, vflags, s));
-        else if constexpr (!fused_planes(true))
-            rc = d.mode == 0 ? launch<0, true, false>(d, vflags, s) : (d.mode == 1 ? launch<1, true, false>(d, vflags, s) : launch<2, true, false>(d, vflags, s));
+#if MUDG_PLANES == 1
+        const int wide = use_wide(d);
+        if (wide) rc = wide == 5 ? by_mode(G320{}, std::true_type{}, std::false_type{}) : by_mode(G256{}, std::true_type{}, std::false_type{});
         else
-            rc = MUDG_EINVAL;
+#endif
+        if (use_single_buffer(d)) rc = by_mode(G128{}, std::true_type{}, std::true_type{});
+#if MUDG_PLANES != 2
+        else rc = by_mode(G128{}, std::true_type{}, std::false_type{});
+#endif
     } else {
-        rc = d.mode == 0 ? launch<0, false>(d, vflags, s) : (d.mode == 1 ? launch<1, false>(d, vflags, s) : launch<2, false>(d, vflags, s));
+        rc = by_mode(G128{}, std::false_type{}, std::false_type{});
     }
     const double flops = 2.0 * d.M * (double)d.N * d.K * d.batch;          // algorithmic (the split builds issue NSEG times as many)
     // algorithmic bytes at 16-bit storage: activations in (taps are re-reads of the same rows), weights, the result, and the

@@ -11,13 +11,15 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SELECT = "gemm or conv or tconv or resblock or transformer or geglu or fused or attention or attn"
+SELECT = "gemm or conv or tconv or resblock or transformer or geglu or fused or attention or attn or wide"
 
 
 @pytest.mark.parametrize("env", [
     {"MUDG_GEMM_FAST": "0"},
     {"MUDG_GEMM_SB": "2"},
     {"MUDG_GEMM_SB": "0"},
+    {"MUDG_GEMM_WIDE": "1"},
+    {"MUDG_GEMM_WIDE": "0"},
     {"MUDG_ATTN_Q": "32"},
     {"MUDG_ATTN_Q": "64"},
 ], ids=lambda e: ",".join(f"{k[5:]}={v}" for k, v in e.items()))

@@ -520,3 +520,117 @@ def test_groupnorm_fused_from_tconv_and_large_tiles(cuda):
     upd = ops.groupnorm(y, gam, bet, samples=clips, rows=t * hw, eps=1e-5, silu=False)
     upd_ref = F.group_norm(y.float().cpu().reshape(clips, t * hw, 3 * c).transpose(1, 2), 32, None, None, 1e-5)
     assert rel_l2(upd, upd_ref.transpose(1, 2).reshape(-1, 3 * c)) < TOL_BF16
+
+
+# ---- the wide tiles (256 x 320 / 256 x 256, eight waves): chosen by mudg_gemm for problems with many tiles whose N is a
+# multiple of 320 (or 256 with GEGLU); the variant child GEMM_WIDE=1 (tests/test_gemm_variants_gpu.py) forces them on every
+# shape here, the last test reaches them through the library's own selection rule.
+@pytest.mark.parametrize("M,N,K", [(1000, 320, 320), (515, 640, 64), (256, 960, 1280), (70, 320, 128)])
+def test_wide_tile_plain_epilogues_ragged_rows(cuda, M, N, K):
+    from mudg_amd import ops
+    x, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05)
+    b = torch.randn(N, generator=torch.Generator().manual_seed(3))
+    r = rnd(M, N, seed=4)
+    ref = x.float() @ w.float().t() + b
+    assert rel_l2(ops.gemm(x.to(cuda), w.to(cuda), bias=b.to(cuda), residual=r.to(cuda)), ref + r.float()) < TOL_BF16
+    r32 = torch.randn(M, N, generator=torch.Generator().manual_seed(5))
+    y32 = ops.gemm(x.to(cuda), w.to(cuda), bias=b.to(cuda), residual=r32.to(cuda), out_fp32=True, alpha=0.5)
+    assert rel_l2(y32, 0.5 * (x.float() @ w.float().t()) + b + r32) < TOL_F32
+    gb = torch.randn((M + 6) // 7, N, generator=torch.Generator().manual_seed(6))       # groups of 7 rows straddle every tile
+    y3 = ops.gemm(x.to(cuda), w.to(cuda), gbias=gb.to(cuda), rows_per_group=7, out_fp32=True)
+    assert rel_l2(y3, x.float() @ w.float().t() + gb.repeat_interleave(7, 0)[:M]) < TOL_F32
+
+
+def test_wide_tile_transpose_detecting(cuda):
+    from mudg_amd import ops
+    n, k = 640, 256
+    w = ((torch.arange(n * k).reshape(n, k) * 7) % 251).float().to(BF)      # asymmetric
+    x = torch.zeros(512, k)
+    x[torch.arange(k) * 2, torch.arange(k)] = 1.0                          # row 2 j selects column j
+    y = ops.gemm(x.to(BF).to(cuda), w.to(cuda), out_fp32=True)
+    want = torch.zeros(512, n)
+    want[torch.arange(k) * 2] = w.float().t()
+    assert torch.equal(y.cpu(), want)
+
+
+def test_wide_tile_geglu_and_two_sources(cuda):
+    from mudg_amd import ops
+    M, C = 700, 128                                       # N = 8C = 1024: the 256-wide GEGLU tile
+    x, w = rnd(M, C, seed=1), rnd(8 * C, C, seed=2, scale=0.1)
+    b = torch.randn(8 * C, generator=torch.Generator().manual_seed(3)) * 0.1
+    val, gate = (x.float() @ w.float().t() + b).chunk(2, dim=-1)
+    wp, bp = pack_geglu(w, b)
+    y = ops.gemm(x.to(cuda), wp.to(cuda), bias=bp.to(cuda), geglu=True)
+    assert tuple(y.shape) == (M, 4 * C) and rel_l2(y, val * F.gelu(gate)) < TOL_BF16
+    x1, x2, w2 = rnd(M, 64, seed=4), rnd(M, 192, seed=5), rnd(320, 256, seed=6, scale=0.05)
+    y2 = ops.gemm(x1.to(cuda), w2.to(cuda), x2=x2.to(cuda))
+    assert rel_l2(y2, torch.cat([x1, x2], 1).float() @ w2.float().t()) < TOL_BF16
+
+
+@pytest.mark.parametrize("stride,two,stats", [(1, False, True), (2, False, False), (1, True, True)])
+def test_wide_tile_conv3x3_with_fused_epilogue_and_partials(cuda, stride, two, stats):
+    from mudg_amd import ops
+    frames, h, w, cin, cout = 5, 16, 24, 128, 320                         # 384 rows per frame = 3 partial blocks of 128
+    x = rnd(frames, cin, h, w, seed=1)
+    wt = rnd(cout, cin, 3, 3, seed=2, scale=0.05)
+    b = torch.randn(cout, generator=torch.Generator().manual_seed(3))
+    ref = F.conv2d(x.float(), wt.float(), b, stride=stride, padding=1)
+    ho, wo = ref.shape[2], ref.shape[3]
+    emb = torch.randn(frames, cout, generator=torch.Generator().manual_seed(5))
+    res = rnd(frames, cout, ho, wo, seed=6)
+    ref = ref + emb[:, :, None, None] + res.float()
+    rows = to_rows(x)
+    kw = dict(x2=rows[:, 64:].to(cuda)) if two else {}
+    xin = rows[:, :64].contiguous() if two else rows
+    y = ops.conv3x3(xin.to(cuda), pack_conv_slab(wt).to(cuda), frames=frames, hin=h, win=w, cin=cin, stride=stride, korder=1,
+                    bias=b.to(cuda), gbias=emb.to(cuda), rows_per_group=ho * wo, residual=to_rows(res).to(cuda), stats=stats, **kw)
+    assert rel_l2(from_rows(y.cpu().float(), frames, ho, wo), ref) < TOL_BF16
+    if stats:
+        gam, bet = torch.ones(cout, device=cuda), torch.zeros(cout, device=cuda)
+        fused = ops.groupnorm(y, gam, bet, samples=frames, rows=ho * wo, eps=1e-5, silu=True)
+        plain = ops.groupnorm(y, gam, bet, samples=frames, rows=ho * wo, eps=1e-5, silu=True, fused=False)
+        assert rel_l2(fused, plain.float().cpu()) < 5e-4
+
+
+def test_wide_tile_tconv3_and_subpixel_upsample(cuda):
+    from mudg_amd import ops
+    from mudg_amd.engine import packing
+    clips, t, h, w, c = 2, 6, 8, 10, 320
+    x = rnd(clips, c, t, h, w, seed=1)
+    wt = rnd(c, c, 3, 1, 1, seed=2, scale=0.05)
+    b = torch.randn(c, generator=torch.Generator().manual_seed(3))
+    ref = F.conv3d(x.float(), wt.float(), b, padding=(1, 0, 0)) + x.float()
+    rows = x.permute(0, 2, 3, 4, 1).reshape(-1, c).contiguous()
+    wp = wt[:, :, :, 0, 0].permute(0, 2, 1).reshape(c, 3 * c).contiguous()
+    y = ops.tconv3(rows.to(cuda), wp.to(cuda), clips=clips, t=t, hw=h * w, cin=c, bias=b.to(cuda), residual=rows.to(cuda))
+    assert rel_l2(y.cpu().float().reshape(clips, t, h, w, c).permute(0, 4, 1, 2, 3), ref) < TOL_BF16
+    # nearest-2x upsample + 3x3 conv in the sub-pixel form (four parity classes = batch 4)
+    conv = torch.nn.Conv2d(64, 320, 3, padding=1)
+    with torch.no_grad():
+        conv.weight.copy_(rnd(320, 64, 3, 3, seed=7, scale=0.05).float())
+        conv.bias.copy_(torch.randn(320, generator=torch.Generator().manual_seed(8)))
+    conv = conv.to(cuda)
+    xs = rnd(3, 64, 9, 12, seed=9)
+    wsub = packing.conv3x3_subpixel(conv)
+    if wsub is not None:
+        out = ops.conv3x3_up2(to_rows(xs).to(cuda), wsub, frames=3, hin=9, win=12, cin=64, bias=packing.f32(conv, "bias"))
+        if out is not None:
+            want = F.conv2d(F.interpolate(xs.float(), scale_factor=2, mode="nearest"), conv.weight.detach().cpu().to(BF).float(),
+                            conv.bias.detach().cpu(), padding=1)
+            assert rel_l2(from_rows(out.cpu().float(), 3, 18, 24), want) < 2 * TOL_BF16
+
+
+def test_wide_tile_is_selected_for_many_tile_problems_and_matches_the_small_tile(cuda):
+    """M = 200 000 rows x N = 320: 782 wide tiles -> the library picks the 256 x 320 kernel by itself; the same rows computed as
+    four quarter problems (196 tiles each: the 128 x 128 kernels) must agree BIT FOR BIT — every output element accumulates
+    its K-tiles in the same order through the same MFMA in both kernels (the premise of clip-independent results)."""
+    from mudg_amd import ops
+    M, N, K = 200000, 320, 192
+    x, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05)
+    b = torch.randn(N, generator=torch.Generator().manual_seed(3))
+    xd, wd, bd = x.to(cuda), w.to(cuda), b.to(cuda)
+    whole = ops.gemm(xd, wd, bias=bd)
+    q = M // 4
+    parts = torch.cat([ops.gemm(xd[i * q:(i + 1) * q], wd, bias=bd) for i in range(4)], 0)
+    assert torch.equal(whole, parts)
+    assert rel_l2(whole[::97], x[::97].float() @ w.float().t() + b) < TOL_BF16
