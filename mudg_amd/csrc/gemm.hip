@@ -966,6 +966,7 @@ bool use_single_buffer(const MudgGemmDesc& d) {
     return tiles >= (d.mode == 1 ? 2048 : 768);
 }
 
+#if MUDG_PLANES == 1
 // The wide tiles (G320 / G256, 16-bit builds, descriptor loader): 0 = the 128 x 128 kernels, 5 / 4 = NI of the wide tile.
 // Measured per shape on MI355X (tools/exp_tiles.py, profiles/r3/tiles_*.txt): with all 256 CUs holding one wide tile each the
 // main loop runs at 1280-1370 TFLOP/s against 980-1070 of the 128 x 128 kernels (long K), but a wide tile is alone on its CU —
