@@ -265,6 +265,63 @@ int mudg_frames_to_u8(const float* video, uint8_t* out, int B, int C, int T, int
 int mudg_depth_from_u8(const uint8_t* frames, float* depth, int64_t pixels, void* stream);
 int mudg_semantic_nearest(const uint8_t* img, uint8_t* vis, int64_t* labels, int64_t hw, void* stream);
 
+/* ------------------------------------------------------------------ training step
+ * Reference: lvdm/models/ddpm3d.py:741-802 (p_losses), :1267-1300 (configure_optimizers -> torch.optim.AdamW),
+ * main/utils_train.py:126-137 (data-parallel strategy).  The contractions of the backward pass (dX = dY W, dW = dY^T X,
+ * conv / temporal-conv input gradients) run on mudg_gemm; these entries are everything else the backward pass needs.
+ * Gradients and the training stream are fp32 rows matrices (row strides in elements).  Fixed-order reductions throughout. */
+/* dst[c][p] = src[srcrow(p)][c] as an MFMA operand matrix [C][ldd] (ldd / PLANES >= P rounded up to 8; the tail columns are
+ * zeroed): the transposed (and, for convolutions, tap-shifted) operand copies that weight-gradient GEMMs contract over.
+ * mode 0: srcrow = p.  mode 1 (3x3 conv tap (dy, dx)): p = (f, oy, ox) on the Hout x Wout grid reads input pixel
+ * (oy stride - pad + dy, ox stride - pad + dx) of the Hin x Win image, zero outside.  mode 2 (temporal tap dt): p = ((b T + t) HW + s)
+ * reads row p + (dt - 1) HW while 0 <= t + dt - 1 < T. */
+int mudg_transpose_gather(const float* src, int64_t lds, void* dst, int64_t ldd, int64_t P, int C, int mode, int Hin, int Win,
+                          int Hout, int Wout, int stride, int pad, int dy, int dx, int T, int HW, int dt, void* stream);
+/* out[g][c] = sum over the rows of group g (rows_per_group consecutive rows) of A[r][c] * (B ? B[r][c] : 1): bias gradients
+ * (one group), the timestep-embedding gradient of a ResBlock (one group per clip). */
+int mudg_group_colsum(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t rows, int cols, int64_t rows_per_group,
+                      float* out, void* stream);
+/* GroupNorm (+SiLU) backward.  stat = (mean, rstd) per (sample, group) (mudg_groupnorm_stats of the same X); writes dX and
+ * AB[sample][c] = (sum dz, sum dz xhat): dbeta / dgamma are its sums over the samples.  ws: mudg_groupnorm_bwd_ws_floats. */
+int64_t mudg_groupnorm_bwd_ws_floats(int samples, int rows, int C, int groups);
+int mudg_groupnorm_stats(const float* X, int64_t ldx, int samples, int rows, int C, int groups, float eps, float* stat, void* stream);
+int mudg_groupnorm_bwd(const float* X, int64_t ldx, const float* dY, int64_t ldy, const float* gamma, const float* beta,
+                       const float* stat, int samples, int rows, int C, int groups, int silu, float* dX, int64_t lddx, float* AB,
+                       float* ws, void* stream);
+/* LayerNorm backward: dX, dgamma[C], dbeta[C]; rowstat: fp32 scratch [rows][2]. */
+int mudg_layernorm_bwd(const float* X, int64_t ldx, const float* dY, int64_t ldy, const float* gamma, float* dX, int64_t lddx,
+                       float* dgamma, float* dbeta, float* rowstat, int64_t rows, int C, float eps, void* stream);
+/* GEGLU on H = [value | gate] rows [M][2 N] (attention.py:579-586): dY NULL -> out[M][N] = value * gelu(gate);
+ * else out = dH [M][2 N]. */
+int mudg_geglu(const float* H, int64_t ldh, const float* dY, int64_t lddy, float* out, int64_t ldo, int64_t M, int N, void* stream);
+/* Row softmax in fp32 and its backward dS = scale * P (dP - sum_j dP_j P_j): the recomputed probabilities of the attention
+ * backward pass. */
+int mudg_softmax_f32(const float* S, int64_t lds, float* P, int64_t ldp, int64_t rows, int cols, void* stream);
+int mudg_softmax_bwd(const float* P, int64_t ldp, const float* dP, int64_t lddp, float* dS, int64_t ldds, int64_t rows, int cols,
+                     float scale, void* stream);
+/* Backward of mudg_temporal_attention on fp32 Q / K / V / dO rows ((b T + t) HW + s), head h at columns [64 h, 64 h + 64). */
+int mudg_temporal_attention_bwd(const float* Q, const float* K, const float* V, const float* dO, int64_t ldqkv, int64_t ldo,
+                                float* dQ, float* dK, float* dV, int64_t ldg, int B, int T, int HW, int heads, float scale,
+                                void* stream);
+/* loss[b] = mean over the n elements of sample b of (pred - target)^2; grad (optional) = w[b] * 2 (pred - target) / n — the
+ * gradient of sum_b w[b] loss[b] (ddpm3d.py:766-787 folds logvar, l_simple_weight and the vlb term into w). */
+int64_t mudg_mse_ws_doubles(int B);
+int mudg_mse(const float* pred, const float* target, const float* w, int B, int64_t n, float* loss, float* grad, double* ws,
+             void* stream);
+/* Nearest-2x of channels-last fp32 rows (F, h, w, C) -> (F, 2h, 2w, C) (adjoint = 1: the sum over each 2 x 2 block, its
+ * backward), and zero insertion of a stride-2 conv's output gradient onto the input grid (its input gradient is then a
+ * stride-1 conv with the flipped filter). */
+int mudg_upsample2x(const float* src, float* dst, int F, int h, int w, int C, int adjoint, void* stream);
+int mudg_dilate2x(const float* src, float* dst, int F, int ho, int wo, int hi, int wi, int C, void* stream);
+/* torch.optim.AdamW step (decoupled weight decay, bias correction with `step` >= 1), fp32, in place. */
+int mudg_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+               float weight_decay, int step, void* stream);
+/* Inverted dropout out[i] = keep(seed, i) ? x[i] / (1 - p) : 0 with a counter-based mask (the backward pass applies the same
+ * call to the gradient: nothing is stored). */
+int mudg_dropout(const float* x, float* out, int64_t n, float p, uint64_t seed, void* stream);
+/* out = silu(x) (dy NULL) or dy * silu'(x). */
+int mudg_silu(const float* x, const float* dy, float* out, int64_t n, void* stream);
+
 /* ------------------------------------------------------------------ event profiler (bench.py roofline)
  * When enabled, every launch of kernel family `fam` is bracketed by hipEvents on its own stream. */
 enum { MUDG_FAM_GEMM = 0, MUDG_FAM_CONV = 1, MUDG_FAM_TCONV = 2, MUDG_FAM_ATTN = 3, MUDG_FAM_TATTN = 4,

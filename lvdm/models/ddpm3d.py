@@ -5,7 +5,8 @@ What the denoising path needs from the reference's Lightning classes, without Li
 DiffusionWrapper.forward 1309-1324), the v-parameterisation helpers (239-251), first-stage decode (646-671) and the
 constructor surface of LatentVisualDiffusion (1033-1055) so MuDG's YAML configs instantiate it unchanged and its
 checkpoints load with the same key prefixes (model.diffusion_model.*, first_stage_model.*, image_proj_model.*).
-Training (p_losses, optimisers, logging) is outside the hot path — those methods say so when called.
+The training step (p_losses, configure_optimizers, training_step) is delegated to mudg_amd.train; the
+Lightning loop, logging and the data pipeline around it are not built.
 """
 from functools import partial
 
@@ -86,6 +87,13 @@ class DDPM(nn.Module):
                                linear_start=linear_start, linear_end=linear_end, cosine_s=cosine_s)
         self.given_betas, self.beta_schedule, self.timesteps, self.cosine_s = given_betas, beta_schedule, timesteps, cosine_s
         self.loss_type = loss_type
+        if loss_type != "l2":
+            raise NotImplementedError("only the l2 loss of the MuDG configs is implemented")
+        # ddpm3d.py:118-121,173-186: per-timestep log-variance (a constant unless learn_logvar) and the vlb weights (ones for v)
+        self.learn_logvar = learn_logvar
+        if learn_logvar:
+            raise NotImplementedError("learn_logvar is off in every MuDG config and not implemented")
+        self.logvar = torch.full(fill_value=float(logvar_init), size=(self.num_timesteps,))
         if ckpt_path is not None:
             self.init_from_ckpt(ckpt_path, ignore_keys=ignore_keys, only_model=load_only_unet)
 
@@ -130,6 +138,17 @@ class DDPM(nn.Module):
         self.register_buffer("posterior_log_variance_clipped", f32(np.log(np.maximum(post_var, 1e-20))))
         self.register_buffer("posterior_mean_coef1", f32(coef1))
         self.register_buffer("posterior_mean_coef2", f32(coef2))
+        # ddpm3d.py:173-186 (training only, not persistent): weights of the vlb term — ones for v-prediction
+        if self.parameterization == "eps":
+            with np.errstate(divide="ignore", invalid="ignore"):
+                lvlb = betas ** 2 / (2 * post_var * (1. - betas) * (1. - abar))
+        elif self.parameterization == "x0":
+            lvlb = 0.5 * np.sqrt(abar) / (2. * 1 - abar)
+        else:
+            lvlb = np.ones_like(betas)
+        lvlb = np.array(lvlb, dtype=np.float64)
+        lvlb[0] = lvlb[1]
+        self.register_buffer("lvlb_weights", f32(lvlb), persistent=False)
 
     def init_from_ckpt(self, path, ignore_keys=list(), only_model=False):
         sd = torch.load(path, map_location="cpu")
@@ -155,10 +174,36 @@ class DDPM(nn.Module):
             noise = torch.randn_like(x_start)
         return self._combine(self.sqrt_alphas_cumprod, x_start, self.sqrt_one_minus_alphas_cumprod, noise, t)
 
-    def training_step(self, *a, **k):
-        raise NotImplementedError("training is outside the MI355X denoising path (SURVEY §8(f) rank 4)")
+    def get_v(self, x, noise, t):
+        # ddpm3d.py:310-314: sqrt(abar_t) noise - sqrt(1 - abar_t) x
+        return self._combine(self.sqrt_alphas_cumprod, noise, -self.sqrt_one_minus_alphas_cumprod, x, t)
 
-    p_losses = shared_step = configure_optimizers = training_step
+    # ---- training (reference ddpm3d.py:741-802, 1267-1300): the step itself lives in mudg_amd.train
+    def p_losses(self, x_start, cond, t, noise=None, **kwargs):
+        from mudg_amd.train import step
+        return step.p_losses(self, x_start, cond, t, noise=noise, **kwargs)
+
+    def configure_optimizers(self):
+        """AdamW over the trainable UNet (+ image-projection) parameters at `self.learning_rate`, as ddpm3d.py:1267-1300; the
+        update runs on the HIP kernel (mudg_amd.train.step.AdamW has torch.optim.AdamW's semantics and defaults)."""
+        from mudg_amd.train import step
+        params = [p for p in self.model.parameters() if p.requires_grad]
+        proj = getattr(self, "image_proj_model", None)
+        if getattr(self, "image_proj_model_trainable", False) and proj is not None:
+            params.extend(p for p in proj.parameters() if p.requires_grad)
+        return step.AdamW(params, lr=getattr(self, "learning_rate", 1e-4))
+
+    def training_step(self, batch, batch_idx=0):
+        """`batch` = dict(x_start=latents (B, 4, T, H, W), cond={c_crossattn, c_concat}, t=(B,) long, + apply_model kwargs):
+        the tensors the reference's shared_step / get_batch_input hand to p_losses (the Waymo data pipeline that makes them is
+        outside the hot path).  Returns the loss; call .backward() and the optimizer as Lightning would."""
+        kw = {k: v for k, v in batch.items() if k not in ("x_start", "cond", "t", "noise")}
+        loss, _ = self.p_losses(batch["x_start"], batch["cond"], batch["t"], noise=batch.get("noise"), **kw)
+        return loss
+
+    def shared_step(self, batch, **kwargs):
+        raise NotImplementedError("get_batch_input (VAE-encoding Waymo items, CLIP towers, random conditioning dropout) is the data "
+                                  "pipeline of the reference, outside the hot path: call p_losses / training_step with latents")
 
 
 class LatentDiffusion(DDPM):

@@ -211,6 +211,12 @@ class UNetModel(nn.Module):
         c_label (B,) long, context (B, 77 + 16 T, context_dim), fs (B,) long.  Extra kwargs the reference's callers
         pass (sparse_x, class_label, cfg_img, ...) are accepted and ignored, as in the reference.  Returns
         (B, out_channels, T, H, W) in x's dtype."""
+        if self.training and torch.is_grad_enabled():
+            # training step (SURVEY §8 f4): the same network on autograd Functions whose forward and backward are HIP kernels
+            if features_adapter is not None:
+                raise NotImplementedError("features_adapter is not used on the MuDG path")
+            from mudg_amd.train import unet as train_engine
+            return train_engine.forward(self, x, timesteps, c_label=c_label, context=context, fs=fs)
         from mudg_amd.engine import unet as engine
         return engine.forward_entry(self, x, timesteps, c_label=c_label, context=context,
                                     features_adapter=features_adapter, fs=fs)

@@ -120,6 +120,23 @@ SIGNATURES = {
     "mudg_semantic_nearest": (_I, [_P, _P, _P, _L, _P]),
     "mudg_ddim_step": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _L, C.POINTER(C.c_float), _P, _P]),
     "mudg_gaussian_sample": (_I, [_P, _P, _P, _I, _I, _I, _F, _P]),
+    "mudg_transpose_gather": (_I, [_P, _L, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "mudg_group_colsum": (_I, [_P, _L, _P, _L, _L, _I, _L, _P, _P]),
+    "mudg_groupnorm_bwd_ws_floats": (_L, [_I, _I, _I, _I]),
+    "mudg_groupnorm_stats": (_I, [_P, _L, _I, _I, _I, _I, _F, _P, _P]),
+    "mudg_groupnorm_bwd": (_I, [_P, _L, _P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _P, _L, _P, _P, _P]),
+    "mudg_layernorm_bwd": (_I, [_P, _L, _P, _L, _P, _P, _L, _P, _P, _P, _L, _I, _F, _P]),
+    "mudg_geglu": (_I, [_P, _L, _P, _L, _P, _L, _L, _I, _P]),
+    "mudg_softmax_f32": (_I, [_P, _L, _P, _L, _L, _I, _P]),
+    "mudg_softmax_bwd": (_I, [_P, _L, _P, _L, _P, _L, _L, _I, _F, _P]),
+    "mudg_temporal_attention_bwd": (_I, [_P, _P, _P, _P, _L, _L, _P, _P, _P, _L, _I, _I, _I, _I, _F, _P]),
+    "mudg_mse_ws_doubles": (_L, [_I]),
+    "mudg_mse": (_I, [_P, _P, _P, _I, _L, _P, _P, _P, _P]),
+    "mudg_upsample2x": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "mudg_dilate2x": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "mudg_adamw": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P]),
+    "mudg_silu": (_I, [_P, _P, _P, _L, _P]),
+    "mudg_dropout": (_I, [_P, _P, _L, _F, C.c_uint64, _P]),
     "mudg_prof_enable": (_I, [_I]),
     "mudg_prof_collect": (_I, [_I, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                C.POINTER(C.c_double)]),

@@ -1,0 +1,432 @@
+"""autograd Functions of the training step: every forward and every backward is a sequence of HIP kernel launches.
+
+Activations and gradients travel between Functions as fp32 rows matrices ((b t) h w) x channels; each Function casts what its
+MFMA kernels consume to operand matrices (bf16, or the bf16 pieces of the precision builds) on the way in.  How the backward
+contractions map onto the forward GEMM kernel (mudg_gemm: Y[m][n] = sum_k X[m][k] W[n][k]):
+
+    linear      dX = dY W                 X = dY,            W = W^T            (transpose_gather of the weight)
+                dW = dY^T X               X = dY^T,          W = X^T            (contraction over the rows)
+    conv 3x3    dX = conv(dY, flip(W))    the same implicit-GEMM kernel, filter rotated by 180 degrees, channels swapped;
+                                          stride 2: dY is first laid onto the input grid with zeros in between (dilate2x)
+                dW[tap] = dY^T X_tap      X_tap^T = transpose_gather(mode 1): the input pixels tap (dy, dx) reads, transposed
+    temporal    the same with the three temporal taps (mode 2)
+    attention   recomputed: S = scale Q K^T, P = softmax(S) (fp32), dP = dO V^T, dS = P (dP - rowsum(dP P)) scale,
+                dQ = dS K, dK = dS^T Q, dV = P^T dO — per head, batched over the key / value batches
+
+Reference semantics: lvdm/modules/attention.py, lvdm/modules/networks/openaimodel3d.py (forward), torch.autograd (backward);
+checked against autograd of the CPU oracle in tests/test_training_gpu.py."""
+import torch
+
+from .. import ops
+from . import kernels as K
+
+
+def op(t):
+    """fp32 rows (any row stride) -> MFMA operand rows."""
+    return ops.cast_bf16(t)
+
+
+def _pad8(n):
+    return (n + 7) // 8 * 8
+
+
+def _pad_cols(t, cols):
+    """Zero-pad the channel axis of fp32 rows to `cols` (layout only)."""
+    if t.shape[1] == cols:
+        return t
+    out = torch.zeros((t.shape[0], cols), dtype=t.dtype, device=t.device)
+    out[:, :t.shape[1]].copy_(t)
+    return out
+
+
+def _need(ctx, i):
+    return ctx.needs_input_grad[i]
+
+
+# ------------------------------------------------------------------------------------------------ linear
+class Linear(torch.autograd.Function):
+    """y = x W^T (+ b) (+ residual); x [M][K], W [N][K] (nn.Linear / 1x1 conv weight), fp32 in and out."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, residual):
+        w2 = w.reshape(w.shape[0], -1)
+        ctx.save_for_backward(x, w2)
+        ctx.wshape, ctx.has_b, ctx.has_r = w.shape, b is not None, residual is not None
+        return ops.gemm(op(x), op(w2), bias=None if b is None else b.float().contiguous(), residual=residual, out_fp32=True)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w2 = ctx.saved_tensors
+        dy = dy.contiguous()
+        n, k = w2.shape
+        dx = dw = db = None
+        npad = _pad8(n)
+        dyo = op(_pad_cols(dy, npad))
+        if _need(ctx, 0):
+            wt = K.transpose_gather(w2)                                  # [K][N padded]
+            dx = ops.gemm(dyo, wt, out_fp32=True)
+        if _need(ctx, 1):
+            dyt, xt = K.transpose_gather(dy), K.transpose_gather(x)      # [N][M padded], [K][M padded]
+            dw = ops.gemm(dyt, xt, out_fp32=True).reshape(ctx.wshape)
+        if ctx.has_b and _need(ctx, 2):
+            db = K.group_colsum(dy)[0]
+        return dx, dw, db, (dy if ctx.has_r else None)
+
+
+# ------------------------------------------------------------------------------------------------ 3x3 conv
+def _conv_weight(w, cin_pad):
+    """(Cout, Cin, 3, 3) -> [Cout][tap][Cin padded] fp32 (korder 0)."""
+    co, ci = w.shape[:2]
+    m = torch.zeros((co, 9, cin_pad), dtype=torch.float32, device=w.device)
+    m[:, :, :ci].copy_(w.permute(0, 2, 3, 1).reshape(co, 9, ci))
+    return m.reshape(co, 9 * cin_pad)
+
+
+def _conv_weight_flipped(w, cout_pad):
+    """Filter of the input-gradient conv: [Cin][tap'][Cout padded] with tap' the 180-degree rotation of tap."""
+    co, ci = w.shape[:2]
+    m = torch.zeros((ci, 9, cout_pad), dtype=torch.float32, device=w.device)
+    m[:, :, :co].copy_(w.flip(2, 3).permute(1, 2, 3, 0).reshape(ci, 9, co))
+    return m.reshape(ci, 9 * cout_pad)
+
+
+class Conv3x3(torch.autograd.Function):
+    """3x3 / pad 1 conv on rows ((f h w), Cin), stride 1 or 2; optional per-row-group bias (the ResBlock's embedding term) and
+    residual.  geo = (frames, h, w, stride)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, gbias, residual, geo, rows_per_group):
+        frames, h, wd, stride = geo
+        co, ci = w.shape[:2]
+        cpad = _pad8(ci)
+        ctx.save_for_backward(x, w)
+        ctx.geo, ctx.rpg, ctx.flags = geo, rows_per_group, (b is not None, gbias is not None, residual is not None)
+        return ops.conv3x3(op(_pad_cols(x, cpad)), op(_conv_weight(w, cpad)), frames=frames, hin=h, win=wd, cin=cpad, stride=stride,
+                           bias=None if b is None else b.float().contiguous(), gbias=gbias, rows_per_group=rows_per_group or 0,
+                           residual=residual, out_fp32=True)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        frames, h, wd, stride = ctx.geo
+        has_b, has_g, has_r = ctx.flags
+        co, ci = w.shape[:2]
+        ho, wo = (h - 1) // stride + 1, (wd - 1) // stride + 1
+        dy = dy.contiguous()
+        dx = dw = db = dg = None
+        if _need(ctx, 0):
+            copad = _pad8(co)
+            src = dy if stride == 1 else K.dilate2x(dy, frames, ho, wo, h, wd)
+            dx = ops.conv3x3(op(_pad_cols(src, copad)), op(_conv_weight_flipped(w, copad)), frames=frames, hin=h, win=wd, cin=copad,
+                             out_fp32=True)
+        if _need(ctx, 1):
+            p = frames * ho * wo
+            dyt = K.transpose_gather(dy)                                 # [Cout][P padded]
+            dw = torch.empty((co, ci, 3, 3), dtype=torch.float32, device=w.device)
+            g = dict(Hin=h, Win=wd, Hout=ho, Wout=wo, stride=stride, pad=1)
+            for ky in range(3):
+                for kx in range(3):
+                    xt = K.transpose_gather(x, P=p, mode=1, geo=dict(g, dy=ky, dx=kx))      # [Cin][P padded]: what tap (ky, kx) read
+                    dw[:, :, ky, kx].copy_(ops.gemm(dyt, xt, out_fp32=True))
+        if has_b and _need(ctx, 2):
+            db = K.group_colsum(dy)[0]
+        if has_g and _need(ctx, 3):
+            dg = K.group_colsum(dy, rows_per_group=ctx.rpg)
+        return dx, dw, db, dg, (dy if has_r else None), None, None
+
+
+class TConv3(torch.autograd.Function):
+    """(3,1,1) temporal conv, pad (1,0,0), on rows ((b t) hw); w (Cout, Cin, 3, 1, 1).  geo = (clips, t, hw)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, residual, geo):
+        clips, t, hw = geo
+        co, ci = w.shape[:2]
+        ctx.save_for_backward(x, w)
+        ctx.geo, ctx.flags = geo, (b is not None, residual is not None)
+        wm = w[:, :, :, 0, 0].permute(0, 2, 1).reshape(co, 3 * ci).contiguous()
+        return ops.tconv3(op(x), op(wm), clips=clips, t=t, hw=hw, cin=ci, bias=None if b is None else b.float().contiguous(),
+                          residual=residual, out_fp32=True)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        clips, t, hw = ctx.geo
+        has_b, has_r = ctx.flags
+        co, ci = w.shape[:2]
+        dy = dy.contiguous()
+        dx = dw = db = None
+        if _need(ctx, 0):
+            wf = w[:, :, :, 0, 0].flip(2).permute(1, 2, 0).reshape(ci, 3 * co).contiguous()        # [Cin][tap'][Cout]
+            dx = ops.tconv3(op(dy), op(wf), clips=clips, t=t, hw=hw, cin=co, out_fp32=True)
+        if _need(ctx, 1):
+            dyt = K.transpose_gather(dy)
+            dw = torch.empty((co, ci, 3, 1, 1), dtype=torch.float32, device=w.device)
+            for dt in range(3):
+                xt = K.transpose_gather(x, mode=2, geo=dict(T=t, HW=hw, dt=dt))
+                dw[:, :, dt, 0, 0].copy_(ops.gemm(dyt, xt, out_fp32=True))
+        if has_b and _need(ctx, 2):
+            db = K.group_colsum(dy)[0]
+        return dx, dw, db, (dy if has_r else None), None
+
+
+# ------------------------------------------------------------------------------------------------ normalisations, activations
+class GroupNorm(torch.autograd.Function):
+    """GroupNorm(32) (+ SiLU) over `rows` rows per sample (a frame, or a clip for the temporal blocks)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, samples, rows, eps, silu, groups):
+        g, b = gamma.float().contiguous(), beta.float().contiguous()
+        ctx.save_for_backward(x, g, b)
+        ctx.args = (samples, rows, eps, silu, groups)
+        return ops.to_f32(ops.groupnorm(x, g, b, samples=samples, rows=rows, eps=eps, silu=silu, groups=groups))
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g, b = ctx.saved_tensors
+        samples, rows, eps, silu, groups = ctx.args
+        stat = K.groupnorm_stats(x, samples, rows, groups, eps)
+        dx, dgamma, dbeta = K.groupnorm_bwd(x, dy.contiguous(), g, b, stat, samples, rows, groups, silu)
+        return dx, dgamma, dbeta, None, None, None, None, None
+
+
+class LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        g, b = gamma.float().contiguous(), beta.float().contiguous()
+        ctx.save_for_backward(x, g)
+        ctx.eps = eps
+        return ops.to_f32(ops.layernorm(x, g, b, eps=eps))
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g = ctx.saved_tensors
+        dx, dg, db = K.layernorm_bwd(x, dy.contiguous(), g, ctx.eps)
+        return dx, dg, db, None
+
+
+class Geglu(torch.autograd.Function):
+    """[value | gate] rows -> value * gelu(gate) (attention.py:579-586)."""
+
+    @staticmethod
+    def forward(ctx, h):
+        ctx.save_for_backward(h)
+        return K.geglu(h)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (h,) = ctx.saved_tensors
+        return K.geglu(h, dy.contiguous())
+
+
+class Silu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return K.silu(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return K.silu(x, dy)
+
+
+class Dropout(torch.autograd.Function):
+    """nn.Dropout(p) in training mode; the mask is a function of (seed, element index) and is regenerated in backward."""
+
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        ctx.p, ctx.seed = p, seed
+        return K.dropout(x, p, seed)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return K.dropout(dy, ctx.p, ctx.seed), None, None
+
+
+def dropout(mod, x):
+    """Apply an nn.Dropout module the way it would act now (identity in eval mode or at p = 0); the seed comes from torch's
+    CPU generator, so torch.manual_seed makes a training run reproducible."""
+    if mod is None or not mod.training or mod.p <= 0.0:
+        return x
+    return Dropout.apply(x, float(mod.p), int(torch.randint(0, 2 ** 62, (1,)).item()))
+
+
+class Add(torch.autograd.Function):
+    """a + b on fp32 rows (mudg_axpy_f32) for the places where a residual cannot ride in a GEMM epilogue."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        return ops.add_(a.contiguous().clone(), b.contiguous())
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
+
+
+class Upsample2x(torch.autograd.Function):
+    """Nearest-2x on rows (openaimodel3d.py:98-103); geo = (frames, h, w)."""
+
+    @staticmethod
+    def forward(ctx, x, geo):
+        ctx.geo = geo
+        return K.upsample2x(x, *geo)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return K.upsample2x(dy.contiguous(), *ctx.geo, adjoint=True), None
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def _vt(v, batches, nk):
+    """V^T per key / value batch as the flash kernels read it: [batches * C][nk padded] operand rows."""
+    c = v.shape[1]
+    ld = _pad8(nk)
+    out = ops.empty_rows(batches * c, ld, ops.H16(), v.device)
+    for b in range(batches):
+        K.transpose_gather(v[b * nk:(b + 1) * nk], out=out[b * c:(b + 1) * c])
+    return out, out.stride(0)
+
+
+def _attn_backward_set(q, k, v, do, groups, nqg, nk, heads, scale):
+    """Gradients of softmax(scale q k^T) v for one key / value set: `groups` key / value batches, each serving nqg query rows."""
+    c = q.shape[1]
+    dq, dk, dv = torch.zeros_like(q), torch.zeros_like(k), torch.zeros_like(v)
+    lds, ldq = _pad8(nk), _pad8(nqg)
+    dev = q.device
+    for h in range(heads):
+        hs = slice(h * 64, (h + 1) * 64)
+        qh, kh, vh, doh = op(q[:, hs]), op(k[:, hs]), op(v[:, hs]), op(do[:, hs])
+        s = torch.zeros((groups * nqg, lds), dtype=torch.float32, device=dev)
+        bat = dict(batch=groups, sx=nqg * qh.stride(0), sw=nk * kh.stride(0), sy=nqg * lds, M=nqg, N=nk, K=64)
+        ops.gemm(qh, kh, out=s, alpha=scale, **bat)
+        K.softmax_f32(s, nk)                                             # s now holds P (the padding columns stay 0)
+        dp = torch.zeros_like(s)
+        ops.gemm(doh, vh, out=dp, **dict(bat, sx=nqg * doh.stride(0), sw=nk * vh.stride(0)))
+        ds = torch.zeros_like(s)
+        K.softmax_bwd(s, dp, ds, nk, scale)
+        # transposed copies, one block of rows per group
+        kt = ops.empty_rows(groups * 64, lds, ops.H16(), dev)            # K^T   [64][nk]
+        qt = ops.empty_rows(groups * 64, ldq, ops.H16(), dev)            # Q^T   [64][nqg]
+        dot = ops.empty_rows(groups * 64, ldq, ops.H16(), dev)           # dO^T  [64][nqg]
+        dst = ops.empty_rows(groups * nk, ldq, ops.H16(), dev)           # dS^T  [nk][nqg]
+        pt = ops.empty_rows(groups * nk, ldq, ops.H16(), dev)            # P^T   [nk][nqg]
+        for g in range(groups):
+            qr, kr = slice(g * nqg, (g + 1) * nqg), slice(g * nk, (g + 1) * nk)
+            K.transpose_gather(k[kr, hs], out=kt[g * 64:(g + 1) * 64])
+            K.transpose_gather(q[qr, hs], out=qt[g * 64:(g + 1) * 64])
+            K.transpose_gather(do[qr, hs], out=dot[g * 64:(g + 1) * 64])
+            K.transpose_gather(ds[qr, :nk], out=dst[g * nk:(g + 1) * nk])
+            K.transpose_gather(s[qr, :nk], out=pt[g * nk:(g + 1) * nk])
+        dso = op(ds)
+        dqh = ops.gemm(dso, kt, out_fp32=True, batch=groups, sx=nqg * dso.stride(0), sw=64 * kt.stride(0), sy=nqg * 64, M=nqg, N=64, K=lds,
+                       out=torch.empty((groups * nqg, 64), dtype=torch.float32, device=dev))
+        dkh = ops.gemm(dst, qt, batch=groups, sx=nk * dst.stride(0), sw=64 * qt.stride(0), sy=nk * 64, M=nk, N=64, K=ldq,
+                       out=torch.empty((groups * nk, 64), dtype=torch.float32, device=dev))
+        dvh = ops.gemm(pt, dot, batch=groups, sx=nk * pt.stride(0), sw=64 * dot.stride(0), sy=nk * 64, M=nk, N=64, K=ldq,
+                       out=torch.empty((groups * nk, 64), dtype=torch.float32, device=dev))
+        dq[:, hs].copy_(dqh); dk[:, hs].copy_(dkh); dv[:, hs].copy_(dvh)
+    return dq, dk, dv
+
+
+class Attention(torch.autograd.Function):
+    """softmax(scale q k^T) v per (frame, head) on the flash kernels (attention.py:81-144), optionally plus a second key /
+    value set with its own softmax (the image tokens of the cross-attention).  q [frames * nq][C]; k, v [(frames / kv_div) * nk][C].
+    The backward pass recomputes the probabilities (nothing of size nq x nk is kept from the forward)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, k2, v2, geo):
+        frames, heads, nq, nk, kv_div, nk2, kv_div2, scale = geo
+        c = q.shape[1]
+        ctx.save_for_backward(q, k, v, *( (k2, v2) if k2 is not None else ()))
+        ctx.geo = geo
+        vt, ldv = _vt(v, frames // kv_div, nk)
+        out = ops.empty_rows(frames * nq, c, ops.H16(), q.device)
+        kw = {}
+        if k2 is not None:
+            vt2, ldv2 = _vt(v2, frames // kv_div2, nk2)
+            kw = dict(k2=op(k2), vt2=vt2, nk2=nk2, ldvt2=ldv2, svt2=c * ldv2, kv_div2=kv_div2)
+        ops.attention(op(q), op(k), vt, out, frames=frames, heads=heads, nq=nq, nk=nk, ldvt=ldv, svt=c * ldv, kv_div=kv_div, scale=scale, **kw)
+        return ops.to_f32(out)
+
+    @staticmethod
+    def backward(ctx, do):
+        frames, heads, nq, nk, kv_div, nk2, kv_div2, scale = ctx.geo
+        saved = ctx.saved_tensors
+        q, k, v = saved[:3]
+        do = do.contiguous()
+        dq, dk, dv = _attn_backward_set(q, k, v, do, frames // kv_div, kv_div * nq, nk, heads, scale)
+        dk2 = dv2 = None
+        if len(saved) == 5:
+            dq2, dk2, dv2 = _attn_backward_set(q, saved[3], saved[4], do, frames // kv_div2, kv_div2 * nq, nk2, heads, scale)
+            ops.add_(dq, dq2)
+        return dq, dk, dv, dk2, dv2, None
+
+
+class TemporalAttention(torch.autograd.Function):
+    """Self-attention over the T frames of every pixel (attention.py:529-576); qkv rows ((b t) hw) x [q | k | v]."""
+
+    @staticmethod
+    def forward(ctx, qkv, geo):
+        clips, t, hw, heads, scale = geo
+        ctx.save_for_backward(qkv)
+        ctx.geo = geo
+        c = qkv.shape[1] // 3
+        out = ops.empty_rows(qkv.shape[0], c, ops.H16(), qkv.device)
+        ops.temporal_attention(op(qkv), out, clips=clips, t=t, hw=hw, heads=heads, scale=scale)
+        return ops.to_f32(out)
+
+    @staticmethod
+    def backward(ctx, do):
+        (qkv,) = ctx.saved_tensors
+        clips, t, hw, heads, scale = ctx.geo
+        return K.temporal_attention_bwd(qkv, do.contiguous(), clips, t, hw, heads, scale), None
+
+
+# ------------------------------------------------------------------------------------------------ layout at the API edge, loss
+class ToRows(torch.autograd.Function):
+    """(B, C, T, H, W) fp32 -> rows ((b t) h w) x C fp32 (layout only)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.shape = x.shape
+        b, c, t, h, w = x.shape
+        return x.permute(0, 2, 3, 4, 1).reshape(b * t * h * w, c).contiguous()
+
+    @staticmethod
+    def backward(ctx, dy):
+        b, c, t, h, w = ctx.shape
+        return dy.reshape(b, t, h, w, c).permute(0, 4, 1, 2, 3).contiguous()
+
+
+class FromRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, shape):
+        b, c, t, h, w = shape
+        return y.reshape(b, t, h, w, c).permute(0, 4, 1, 2, 3).contiguous()
+
+    @staticmethod
+    def backward(ctx, dy):
+        b, c, t, h, w = dy.shape
+        return dy.permute(0, 2, 3, 4, 1).reshape(b * t * h * w, c).contiguous(), None
+
+
+class WeightedMSE(torch.autograd.Function):
+    """sum_b w[b] * mean((pred_b - target_b)^2): the simple + vlb terms of p_losses (ddpm3d.py:766-787) with their per-sample
+    coefficients folded into w.  Returns (loss, per-sample mse)."""
+
+    @staticmethod
+    def forward(ctx, pred, target, w):
+        w = w.float().contiguous()
+        loss_b, grad = K.mse(pred, target, w, want_grad=True)
+        ctx.save_for_backward(grad)
+        ctx.mark_non_differentiable(loss_b)
+        total = K.group_colsum(loss_b.reshape(-1, 1), w.reshape(-1, 1))          # sum_b w[b] loss[b], on the device
+        return total.reshape(()), loss_b
+
+    @staticmethod
+    def backward(ctx, dloss, _):
+        (grad,) = ctx.saved_tensors
+        b = grad.shape[0]
+        scale = dloss.reshape(1).float().expand(b).contiguous()
+        return ops.lincomb(grad, grad, scale, torch.zeros(b, dtype=torch.float32, device=grad.device)), None, None

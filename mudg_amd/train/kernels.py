@@ -1,0 +1,164 @@
+"""Tensor-level wrappers over the training entries of the C-ABI (csrc/train.hip).  fp32 rows matrices in, fp32 rows (or MFMA
+operand matrices) out; nothing here computes."""
+import ctypes as C
+
+import torch
+
+from .. import hip, ops
+
+
+def _s():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _f32(t):
+    if t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1 or not t.is_cuda:
+        raise hip.MudgError(f"expected a cuda fp32 rows matrix, got {tuple(t.shape)} {t.dtype} {t.stride()} on {t.device}")
+    return t
+
+
+def transpose_gather(src, P=None, mode=0, geo=None, out=None):
+    """dst[c][p] = src[srcrow(p)][c] as an operand matrix [C][P rounded up to 8] (mudg_transpose_gather)."""
+    _f32(src)
+    P = src.shape[0] if P is None else P
+    Cc = src.shape[1]
+    Ppad = (P + 7) // 8 * 8
+    if out is None:
+        out = ops.empty_rows(Cc, Ppad, ops.H16(), src.device)
+    g = dict(Hin=0, Win=0, Hout=0, Wout=0, stride=1, pad=1, dy=0, dx=0, T=0, HW=0, dt=0)
+    g.update(geo or {})
+    hip.check(hip.lib().mudg_transpose_gather(src.data_ptr(), src.stride(0), out.data_ptr(), out.stride(0), P, Cc, mode, g["Hin"], g["Win"],
+                                              g["Hout"], g["Wout"], g["stride"], g["pad"], g["dy"], g["dx"], g["T"], g["HW"], g["dt"], _s()),
+              "mudg_transpose_gather")
+    return out
+
+
+def group_colsum(a, b=None, rows_per_group=None):
+    _f32(a)
+    rows, cols = a.shape
+    rpg = rows if rows_per_group is None else rows_per_group
+    out = torch.empty((rows // rpg, cols), dtype=torch.float32, device=a.device)
+    hip.check(hip.lib().mudg_group_colsum(a.data_ptr(), a.stride(0), None if b is None else _f32(b).data_ptr(), 0 if b is None else b.stride(0),
+                                          rows, cols, rpg, out.data_ptr(), _s()), "mudg_group_colsum")
+    return out
+
+
+def groupnorm_stats(x, samples, rows, groups, eps):
+    _f32(x)
+    stat = torch.empty((samples * groups, 2), dtype=torch.float32, device=x.device)
+    hip.check(hip.lib().mudg_groupnorm_stats(x.data_ptr(), x.stride(0), samples, rows, x.shape[1], groups, eps, stat.data_ptr(), _s()),
+              "mudg_groupnorm_stats")
+    return stat
+
+
+def groupnorm_bwd(x, dy, gamma, beta, stat, samples, rows, groups, silu):
+    _f32(x); _f32(dy)
+    c = x.shape[1]
+    dx = torch.empty((samples * rows, c), dtype=torch.float32, device=x.device)
+    ab = torch.empty((samples, 2 * c), dtype=torch.float32, device=x.device)
+    ws = torch.empty(hip.lib().mudg_groupnorm_bwd_ws_floats(samples, rows, c, groups), dtype=torch.float32, device=x.device)
+    hip.check(hip.lib().mudg_groupnorm_bwd(x.data_ptr(), x.stride(0), dy.data_ptr(), dy.stride(0), gamma.data_ptr(), beta.data_ptr(),
+                                           stat.data_ptr(), samples, rows, c, groups, int(silu), dx.data_ptr(), dx.stride(0), ab.data_ptr(),
+                                           ws.data_ptr(), _s()), "mudg_groupnorm_bwd")
+    tot = group_colsum(ab)[0]                       # sums over the samples: [(dbeta_c, dgamma_c) interleaved]
+    return dx, tot[1::2].contiguous(), tot[0::2].contiguous()
+
+
+def layernorm_bwd(x, dy, gamma, eps):
+    _f32(x); _f32(dy)
+    rows, c = x.shape
+    dx = torch.empty_like(x)
+    dg = torch.empty(c, dtype=torch.float32, device=x.device)
+    db = torch.empty(c, dtype=torch.float32, device=x.device)
+    rs = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
+    hip.check(hip.lib().mudg_layernorm_bwd(x.data_ptr(), x.stride(0), dy.data_ptr(), dy.stride(0), gamma.data_ptr(), dx.data_ptr(), dx.stride(0),
+                                           dg.data_ptr(), db.data_ptr(), rs.data_ptr(), rows, c, eps, _s()), "mudg_layernorm_bwd")
+    return dx, dg, db
+
+
+def geglu(h, dy=None):
+    _f32(h)
+    m, n2 = h.shape
+    n = n2 // 2
+    out = torch.empty((m, n if dy is None else n2), dtype=torch.float32, device=h.device)
+    hip.check(hip.lib().mudg_geglu(h.data_ptr(), h.stride(0), None if dy is None else _f32(dy).data_ptr(), 0 if dy is None else dy.stride(0),
+                                   out.data_ptr(), out.stride(0), m, n, _s()), "mudg_geglu")
+    return out
+
+
+def softmax_f32(s, cols):
+    """In place over the first `cols` columns of every row."""
+    hip.check(hip.lib().mudg_softmax_f32(s.data_ptr(), s.stride(0), s.data_ptr(), s.stride(0), s.shape[0], cols, _s()), "mudg_softmax_f32")
+    return s
+
+
+def softmax_bwd(p, dp, ds, cols, scale):
+    hip.check(hip.lib().mudg_softmax_bwd(p.data_ptr(), p.stride(0), dp.data_ptr(), dp.stride(0), ds.data_ptr(), ds.stride(0), p.shape[0], cols,
+                                         scale, _s()), "mudg_softmax_bwd")
+    return ds
+
+
+def temporal_attention_bwd(qkv, do, clips, t, hw, heads, scale):
+    _f32(qkv); _f32(do)
+    c = qkv.shape[1] // 3
+    dqkv = torch.empty_like(qkv)
+    esz = 4
+    q, k, v = qkv.data_ptr(), qkv.data_ptr() + c * esz, qkv.data_ptr() + 2 * c * esz
+    dq, dk, dv = dqkv.data_ptr(), dqkv.data_ptr() + c * esz, dqkv.data_ptr() + 2 * c * esz
+    hip.check(hip.lib().mudg_temporal_attention_bwd(q, k, v, do.data_ptr(), qkv.stride(0), do.stride(0), dq, dk, dv, dqkv.stride(0), clips, t, hw,
+                                                    heads, scale, _s()), "mudg_temporal_attention_bwd")
+    return dqkv
+
+
+def mse(pred, target, weights=None, want_grad=False):
+    """(loss per sample [B], gradient of sum_b w[b] loss[b] or None) for (B, ...) fp32 tensors."""
+    pred, target = pred.contiguous(), target.contiguous()
+    b = pred.shape[0]
+    n = pred.numel() // b
+    loss = torch.empty(b, dtype=torch.float32, device=pred.device)
+    grad = torch.empty_like(pred) if want_grad else None
+    ws = torch.empty(hip.lib().mudg_mse_ws_doubles(b), dtype=torch.float64, device=pred.device)
+    hip.check(hip.lib().mudg_mse(pred.data_ptr(), target.data_ptr(), None if weights is None else weights.data_ptr(), b, n, loss.data_ptr(),
+                                 None if grad is None else grad.data_ptr(), ws.data_ptr(), _s()), "mudg_mse")
+    return loss, grad
+
+
+def upsample2x(x, frames, h, w, adjoint=False):
+    _f32(x)
+    c = x.shape[1]
+    x = x.contiguous()
+    out = torch.empty((frames * h * w * (1 if adjoint else 4), c), dtype=torch.float32, device=x.device)
+    hip.check(hip.lib().mudg_upsample2x(x.data_ptr(), out.data_ptr(), frames, h, w, c, int(adjoint), _s()), "mudg_upsample2x")
+    return out
+
+
+def dilate2x(dy, frames, ho, wo, hi, wi):
+    _f32(dy)
+    c = dy.shape[1]
+    dy = dy.contiguous()
+    out = torch.empty((frames * hi * wi, c), dtype=torch.float32, device=dy.device)
+    hip.check(hip.lib().mudg_dilate2x(dy.data_ptr(), out.data_ptr(), frames, ho, wo, hi, wi, c, _s()), "mudg_dilate2x")
+    return out
+
+
+def silu(x, dy=None):
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    hip.check(hip.lib().mudg_silu(x.data_ptr(), None if dy is None else dy.contiguous().data_ptr(), out.data_ptr(), x.numel(), _s()), "mudg_silu")
+    return out
+
+
+def adamw_(p, g, m, v, *, lr, betas, eps, weight_decay, step):
+    """One torch.optim.AdamW step on flat fp32 buffers, in place."""
+    for t in (p, g, m, v):
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise hip.MudgError("adamw_ expects contiguous fp32 tensors")
+    hip.check(hip.lib().mudg_adamw(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), lr, betas[0], betas[1], eps, weight_decay,
+                                   step, _s()), "mudg_adamw")
+
+
+def dropout(x, p, seed):
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    hip.check(hip.lib().mudg_dropout(x.data_ptr(), out.data_ptr(), x.numel(), p, seed, _s()), "mudg_dropout")
+    return out

@@ -1,0 +1,138 @@
+"""The training step around the UNet: v-prediction loss (p_losses), AdamW on the HIP kernel, data-parallel gradient all-reduce.
+
+Reference: lvdm/models/ddpm3d.py:741-802 (p_losses), :1267-1300 (configure_optimizers -> torch.optim.AdamW(params, lr)),
+main/utils_train.py:126-137 (data-parallel strategy: one process per GPU, gradients averaged after backward)."""
+import torch
+
+from . import functions as F_
+from . import kernels as K
+
+
+def p_losses(model, x_start, cond, t, noise=None, **kwargs):
+    """LatentDiffusion.p_losses: q_sample -> UNet (with an autograd graph) -> target by parameterisation -> per-sample MSE ->
+    loss = l_simple_weight * mean(mse / exp(logvar_t) + logvar_t) + original_elbo_weight * mean(lvlb_weights[t] * mse).
+    Returns (loss, loss_dict) with the reference's dictionary keys."""
+    if getattr(model, "learn_logvar", False):
+        raise NotImplementedError("learn_logvar is off in every MuDG config")
+    if noise is None:
+        noise = torch.randn_like(x_start)
+        if model.noise_strength > 0:                  # offset noise (ddpm3d.py:742-745): random-number plumbing, as in the reference
+            b, c, f = x_start.shape[:3]
+            noise = noise + model.noise_strength * torch.randn(b, c, f, 1, 1, device=x_start.device)
+    x_start, noise = x_start.float().contiguous(), noise.float().contiguous()
+    x_noisy = model.q_sample(x_start=x_start, t=t, noise=noise)
+    model_output = model.apply_model(x_noisy, t, cond, **kwargs)
+    if model.parameterization == "x0":
+        target = x_start
+    elif model.parameterization == "eps":
+        target = noise
+    elif model.parameterization == "v":
+        target = model.get_v(x_start, noise, t)
+    else:
+        raise NotImplementedError(model.parameterization)
+    dev = x_start.device
+    b = x_start.shape[0]
+    logvar_t = model.logvar.to(dev)[t].float()
+    lvlb_t = model.lvlb_weights.to(dev)[t].float()
+    # per-sample coefficients of the mse (host-sized vectors of B numbers, like the DDIM step's coefficients)
+    w = (model.l_simple_weight / torch.exp(logvar_t) + model.original_elbo_weight * lvlb_t) / b
+    weighted, mse_b = F_.WeightedMSE.apply(model_output.float(), target, w)
+    const = model.l_simple_weight * logvar_t.mean()
+    loss = weighted + const if float(const) != 0.0 else weighted
+    prefix = "train" if model.training else "val"
+    loss_dict = {f"{prefix}/loss_simple": mse_b.mean(), f"{prefix}/loss_vlb": (lvlb_t * mse_b).mean(), f"{prefix}/loss": loss.detach()}
+    return loss, loss_dict
+
+
+class AdamW(torch.optim.Optimizer):
+    """torch.optim.AdamW semantics (decoupled weight decay, bias correction) with the update done by mudg_adamw: one launch
+    per parameter tensor, fp32 moments next to fp32 master weights."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                if not p.is_cuda or p.dtype != torch.float32:
+                    raise RuntimeError("mudg AdamW updates fp32 parameters on the GPU")
+                st = self.state[p]
+                if not st:
+                    st["step"], st["exp_avg"], st["exp_avg_sq"] = 0, torch.zeros_like(p), torch.zeros_like(p)
+                st["step"] += 1
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                K.adamw_(p.data, g.float(), st["exp_avg"], st["exp_avg_sq"], lr=group["lr"], betas=group["betas"], eps=group["eps"],
+                         weight_decay=group["weight_decay"], step=st["step"])
+        return loss
+
+
+class GradientAllReducer:
+    """Data-parallel gradient averaging: the gradients of `params` are packed into flat fp32 buckets of about `bucket_mb` MiB (one
+    collective per bucket instead of one per tensor: xGMI rings are per-link bound, large messages amortise their latency),
+    all-reduced over `group` (RCCL when the tensors are on GPUs, gloo on CPU) and unpacked.  The bucket layout is a function of
+    the parameter list only, so every rank issues the same collectives in the same order."""
+
+    def __init__(self, params, bucket_mb=64, group=None):
+        self.params = [p for p in params if p.requires_grad]
+        self.group = group
+        limit = int(bucket_mb * (1 << 20)) // 4
+        self.buckets, cur, n = [], [], 0
+        for p in self.params:
+            if cur and n + p.numel() > limit:
+                self.buckets.append(cur)
+                cur, n = [], 0
+            cur.append(p)
+            n += p.numel()
+        if cur:
+            self.buckets.append(cur)
+
+    def __call__(self):
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
+            return 0
+        world = dist.get_world_size(self.group)
+        backend = dist.get_backend(self.group)
+        works = []
+        for bucket in self.buckets:
+            dev = bucket[0].device
+            flat = torch.zeros(sum(p.numel() for p in bucket), dtype=torch.float32, device=dev)
+            off = 0
+            for p in bucket:                              # a parameter that received no gradient contributes zeros
+                if p.grad is not None:
+                    flat[off:off + p.numel()].copy_(p.grad.reshape(-1))
+                off += p.numel()
+            if backend == "nccl":                         # RCCL averages in the collective itself
+                works.append((dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True), flat, bucket, False))
+            else:                                         # gloo (CPU tests): sum, then scale
+                works.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True), flat, bucket, True))
+        for work, flat, bucket, scale in works:
+            work.wait()
+            if scale:
+                flat /= world
+            off = 0
+            for p in bucket:
+                g = flat[off:off + p.numel()].view_as(p)
+                if p.grad is None:
+                    p.grad = g.clone()
+                else:
+                    p.grad.copy_(g)
+                off += p.numel()
+        return len(self.buckets)
+
+
+def training_step(model, x_start, cond, t, optimizer, reducer=None, noise=None, **kwargs):
+    """One optimisation step: zero_grad -> p_losses -> backward -> (gradient all-reduce) -> AdamW.  Returns (loss, loss_dict)."""
+    optimizer.zero_grad(set_to_none=True)
+    loss, info = p_losses(model, x_start, cond, t, noise=noise, **kwargs)
+    loss.backward()
+    if reducer is not None:
+        reducer()
+    optimizer.step()
+    return loss.detach(), info

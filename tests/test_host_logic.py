@@ -154,8 +154,12 @@ def test_training_surgery_on_the_module_tree_still_works():
 def test_product_path_fails_loudly_without_gpu():
     from lvdm.modules.networks.openaimodel3d import UNetModel
     net = UNetModel(**cfgs.UNET_B)
-    with pytest.raises(RuntimeError, match="no CPU fallback"):
-        net(torch.zeros(1, 12, 4, 8, 8), torch.zeros(1), c_label=torch.zeros(1), context=torch.zeros(1, 141, 64))
+    args = (torch.zeros(1, 12, 4, 8, 8), torch.zeros(1))
+    kw = dict(c_label=torch.zeros(1), context=torch.zeros(1, 141, 64))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):          # a fresh module is in training mode: the training forward
+        net(*args, **kw)
+    with pytest.raises(RuntimeError, match="no CPU fallback"), torch.no_grad():      # and the inference executor
+        net.eval()(*args, **kw)
     with pytest.raises(RuntimeError, match="parameter container"):
         net.out[0](torch.zeros(1, 64, 8, 8))
 

@@ -1,0 +1,61 @@
+"""Host logic of the training step that needs no GPU: the data-parallel gradient all-reduce (bucket layout, averaging, parameters
+without gradients) over two gloo ranks — the N > 1 path of SURVEY §8 f4 (one process per GPU, gradients averaged after
+backward: main/utils_train.py:126-137), and the boundary methods that route into mudg_amd.train."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mudg_amd.train.step import GradientAllReducer
+    torch.manual_seed(0)
+    params = [torch.nn.Parameter(torch.zeros(n)) for n in (5, 300000, 7, 120000, 3)]
+    frozen = torch.nn.Parameter(torch.zeros(4), requires_grad=False)
+    for i, p in enumerate(params):
+        p.grad = torch.full_like(p, float(rank + 1) * (i + 1))
+    params[2].grad = None if rank == 0 else params[2].grad          # a parameter one rank did not touch
+    red = GradientAllReducer(params + [frozen], bucket_mb=1)         # 1 MiB buckets: 262144 floats -> several buckets
+    n = red()
+    ok = n == len(red.buckets) and len(red.buckets) >= 2 and frozen.grad is None
+    for i, p in enumerate(params):
+        want = (1 + 2) / 2 * (i + 1) if i != 2 else (0 + 2 * 3) / 2
+        ok = ok and torch.allclose(p.grad, torch.full_like(p, want))
+    q.put((rank, bool(ok), [len(b) for b in red.buckets]))
+    dist.destroy_process_group()
+
+
+def test_gradient_all_reduce_over_two_gloo_ranks():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert all(ok for _, ok, _ in res), res
+    assert res[0][2] == res[1][2]                 # both ranks built the same bucket layout
+
+
+def test_training_entry_points_exist_and_reject_what_is_not_built():
+    import pytest
+    from helpers import cfgs
+    from lvdm.models.ddpm3d import LatentVisualDiffusion
+    ident = {"target": "torch.nn.Identity"}
+    model = LatentVisualDiffusion(img_cond_stage_config=ident, image_proj_stage_config=ident, cond_stage_config=ident,
+                                  first_stage_config=ident, unet_config={"target": "lvdm.modules.networks.openaimodel3d.UNetModel",
+                                                                         "params": cfgs.UNET_B}, **cfgs.DIFFUSION)
+    assert torch.equal(model.lvlb_weights, torch.ones(1000)) and model.logvar.shape == (1000,)       # v-prediction: ones (ddpm3d.py:178-180)
+    assert "lvlb_weights" not in model.state_dict() and "logvar" not in model.state_dict()          # as in the reference
+    with pytest.raises(NotImplementedError, match="data"):
+        model.shared_step({})
+    with pytest.raises(RuntimeError, match="GPU"):
+        model.configure_optimizers().step() if False else model.p_losses(
+            torch.zeros(1, 4, 4, 8, 8), {"c_crossattn": [torch.zeros(1, 141, 64)], "c_concat": [torch.zeros(1, 8, 4, 8, 8)]},
+            torch.zeros(1, dtype=torch.long), class_label=torch.zeros(1, 1, dtype=torch.long))

@@ -1,0 +1,235 @@
+"""The training step on the GPU: every autograd Function of mudg_amd/train/functions.py — forward AND backward are
+HIP kernels — against torch autograd of the same op on the CPU in fp64, then the whole UNet: loss and the gradient of EVERY
+parameter of p_losses (v-prediction MSE, ddpm3d.py:741-802) against autograd of the CPU oracle (oracle/unet.py restates the
+reference's forward; its functions are plain differentiable torch), and one AdamW step against torch.optim.AdamW.
+
+Tolerances follow the operand mode: the forward and both backward contractions round their operands (2^-9 bf16 / 2^-12 fp16;
+16 / 24 bits in the precision modes), so a gradient carries a few operand roundings; bounds are printed with the measurement."""
+import copy
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import golden, rel_l2, seeded_sd, unet_inputs
+
+from mudg_amd import hip as _hip
+
+pytestmark = pytest.mark.gpu
+MODE = _hip.operand_name()
+TOL = {"bf16": 1.5e-2, "fp16": 2e-3, "bf16x3": 2e-4, "bf16x6": 2e-5}[MODE]          # one op, forward value or gradient
+TOL_NET = {"bf16": 8e-2, "fp16": 1e-2, "bf16x3": 1e-3, "bf16x6": 1e-4}[MODE]          # gradients through the whole UNet
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def check(name, got, want, tol=TOL):
+    err = rel_l2(got, want)
+    print(f"[{MODE}] {name}: rel-L2 {err:.3e} (bound {tol:g})")
+    assert err < tol, (name, err)
+
+
+def run_both(fn_hip, fn_ref, tensors, cuda, grad_seed=99):
+    """Forward + backward of `fn_hip` on GPU copies and of `fn_ref` on fp64 CPU copies of `tensors` (dict name -> tensor);
+    returns ((y, grads), (y_ref, grads_ref))."""
+    g = {k: v.to(cuda).requires_grad_(True) for k, v in tensors.items()}
+    r = {k: v.double().requires_grad_(True) for k, v in tensors.items()}
+    y, yr = fn_hip(**g), fn_ref(**r)
+    dy = rnd(*yr.shape, seed=grad_seed)
+    y.backward(dy.to(cuda))
+    yr.backward(dy.double())
+    return (y, {k: v.grad for k, v in g.items()}), (yr, {k: v.grad for k, v in r.items()})
+
+
+def compare(name, hip_out, ref_out, tol=TOL):
+    (y, gh), (yr, gr) = hip_out, ref_out
+    check(f"{name} forward", y, yr, tol)
+    for k in gr:
+        check(f"{name} d{k}", gh[k], gr[k], tol)
+
+
+def test_linear_conv_and_temporal_conv_gradients(cuda):
+    from mudg_amd.train import functions as Fn
+    M, Kd, N = 200, 96, 72
+    t = dict(x=rnd(M, Kd, seed=1), w=rnd(N, Kd, seed=2, scale=0.1), b=rnd(N, seed=3), r=rnd(M, N, seed=4))
+    compare("linear", *run_both(lambda x, w, b, r: Fn.Linear.apply(x, w, b, r), lambda x, w, b, r: F.linear(x, w, b) + r, t, cuda))
+    # 3x3 conv: stride 1 with the embedding (row-group) bias and a residual, then stride 2; Cin = 12 exercises the channel padding
+    for stride, ci, co in ((1, 64, 40), (2, 12, 24)):
+        frames, h, wd = 4, 6, 8
+        ho, wo = (h - 1) // stride + 1, (wd - 1) // stride + 1
+        t = dict(x=rnd(frames * h * wd, ci, seed=1), w=rnd(co, ci, 3, 3, seed=2, scale=0.1), b=rnd(co, seed=3),
+                 e=rnd(2, co, seed=4), r=rnd(frames * ho * wo, co, seed=5))
+
+        def ref(x, w, b, e, r):
+            y = F.conv2d(x.reshape(frames, h, wd, ci).permute(0, 3, 1, 2), w, b, stride=stride, padding=1)
+            y = y + e.repeat_interleave(frames // 2, 0)[:, :, None, None]
+            return y.permute(0, 2, 3, 1).reshape(-1, co) + r
+        compare(f"conv3x3 stride {stride}", *run_both(
+            lambda x, w, b, e, r: Fn.Conv3x3.apply(x, w, b, e, r, (frames, h, wd, stride), (frames // 2) * ho * wo), ref, t, cuda))
+    clips, tt, hw, c = 2, 5, 12, 64
+    t = dict(x=rnd(clips * tt * hw, c, seed=1), w=rnd(c, c, 3, 1, 1, seed=2, scale=0.1), b=rnd(c, seed=3))
+
+    def tref(x, w, b):
+        y = F.conv3d(x.reshape(clips, tt, hw, 1, c).permute(0, 4, 1, 2, 3), w, b, padding=(1, 0, 0))
+        return y.permute(0, 2, 3, 4, 1).reshape(-1, c) + x
+    compare("tconv3", *run_both(lambda x, w, b: Fn.TConv3.apply(x, w, b, x, (clips, tt, hw)), tref, t, cuda))
+
+
+def test_norm_geglu_resampling_and_loss_gradients(cuda):
+    from mudg_amd.train import functions as Fn
+    samples, rows, c = 3, 50, 64
+    t = dict(x=rnd(samples * rows, c, seed=1) * 2 + 0.5, g=1 + 0.2 * rnd(c, seed=2), b=0.2 * rnd(c, seed=3))
+    for silu in (True, False):
+        def ref(x, g, b):
+            y = F.group_norm(x.reshape(samples, rows, c).transpose(1, 2), 32, g, b, 1e-5)
+            return (F.silu(y) if silu else y).transpose(1, 2).reshape(-1, c)
+        compare(f"groupnorm silu={silu}", *run_both(lambda x, g, b: Fn.GroupNorm.apply(x, g, b, samples, rows, 1e-5, silu, 32), ref, t, cuda))
+    t = dict(x=rnd(77, 320, seed=1) * 3, g=1 + 0.2 * rnd(320, seed=2), b=0.2 * rnd(320, seed=3))
+    compare("layernorm", *run_both(lambda x, g, b: Fn.LayerNorm.apply(x, g, b, 1e-5), lambda x, g, b: F.layer_norm(x, (320,), g, b, 1e-5), t, cuda))
+    t = dict(h=rnd(60, 256, seed=1))
+    compare("geglu", *run_both(lambda h: Fn.Geglu.apply(h), lambda h: h[:, :128] * F.gelu(h[:, 128:]), t, cuda), tol=1e-5)
+    t = dict(x=rnd(2 * 3 * 5, 16, seed=1))
+    compare("upsample2x", *run_both(lambda x: Fn.Upsample2x.apply(x, (2, 3, 5)),
+                                    lambda x: F.interpolate(x.reshape(2, 3, 5, 16).permute(0, 3, 1, 2), scale_factor=2, mode="nearest")
+                                    .permute(0, 2, 3, 1).reshape(-1, 16), t, cuda), tol=1e-6)
+    t = dict(x=rnd(40, 8, seed=1))
+    compare("silu", *run_both(lambda x: Fn.Silu.apply(x), lambda x: F.silu(x), t, cuda), tol=1e-5)
+    # weighted MSE: loss = sum_b w_b mean_b((p - t)^2)
+    p, tg, w = rnd(3, 4, 2, 5, 5, seed=1), rnd(3, 4, 2, 5, 5, seed=2), torch.tensor([0.5, 0.2, 0.3])
+    ph = p.to(cuda).requires_grad_(True)
+    loss, per = Fn.WeightedMSE.apply(ph, tg.to(cuda), w.to(cuda))
+    (loss * 2.0).backward()
+    pr = p.double().requires_grad_(True)
+    lr = (w.double() * ((pr - tg.double()) ** 2).mean(dim=(1, 2, 3, 4))).sum()
+    (lr * 2.0).backward()
+    check("mse loss", loss, lr, 1e-6); check("mse per sample", per, ((p - tg) ** 2).mean(dim=(1, 2, 3, 4)), 1e-6); check("mse grad", ph.grad, pr.grad, 1e-6)
+    # dropout: inverted scaling, the same mask forward and backward, and a sensible keep rate
+    x = torch.ones(4096, 64, device=cuda, requires_grad=True)
+    y = Fn.Dropout.apply(x, 0.25, 1234)
+    y.backward(torch.ones_like(y))
+    keep = (y != 0).float().mean().item()
+    assert torch.equal(y.detach(), x.grad) and abs(keep - 0.75) < 0.01 and torch.allclose(y[y != 0], torch.tensor(1 / 0.75, device=cuda))
+
+
+def _attn_ref(q, k, v, frames, heads, nq, nk, kv_div, scale):
+    c = q.shape[1]
+    qh = q.reshape(frames, nq, heads, 64).transpose(1, 2)
+    kh = k.reshape(frames // kv_div, nk, heads, 64).transpose(1, 2).repeat_interleave(kv_div, 0)
+    vh = v.reshape(frames // kv_div, nk, heads, 64).transpose(1, 2).repeat_interleave(kv_div, 0)
+    return (torch.softmax(qh @ kh.transpose(-1, -2) * scale, -1) @ vh).transpose(1, 2).reshape(frames * nq, c)
+
+
+def test_attention_gradients_self_cross_two_sets_and_temporal(cuda):
+    from mudg_amd.train import functions as Fn
+    frames, heads, n = 4, 2, 40
+    c = heads * 64
+    t = dict(q=rnd(frames * n, c, seed=1), k=rnd(frames * n, c, seed=2), v=rnd(frames * n, c, seed=3))
+    compare("self-attention", *run_both(lambda q, k, v: Fn.Attention.apply(q, k, v, None, None, (frames, heads, n, n, 1, 0, 1, 0.125)),
+                                        lambda q, k, v: _attn_ref(q, k, v, frames, heads, n, n, 1, 0.125), t, cuda))
+    T = 2      # text keys shared by the T frames of a clip (77 tokens, not a multiple of 8) + per-frame image keys, summed
+    t = dict(q=rnd(frames * n, c, seed=1), k=rnd(frames // T * 77, c, seed=2), v=rnd(frames // T * 77, c, seed=3),
+             k2=rnd(frames * 16, c, seed=4), v2=rnd(frames * 16, c, seed=5))
+    compare("text + image cross-attention", *run_both(
+        lambda q, k, v, k2, v2: Fn.Attention.apply(q, k, v, k2, v2, (frames, heads, n, 77, T, 16, 1, 0.125)),
+        lambda q, k, v, k2, v2: _attn_ref(q, k, v, frames, heads, n, 77, T, 0.125) + _attn_ref(q, k2, v2, frames, heads, n, 16, 1, 0.125), t, cuda))
+    clips, tt, hw = 2, 6, 10
+    t = dict(qkv=rnd(clips * tt * hw, 3 * c, seed=1))
+
+    def tref(qkv):
+        x = qkv.reshape(clips, tt, hw, 3, heads, 64).permute(3, 0, 2, 4, 1, 5)            # (3, b, s, h, t, d)
+        o = torch.softmax(x[0] @ x[1].transpose(-1, -2) * 0.125, -1) @ x[2]               # (b, s, h, t, d)
+        return o.permute(0, 3, 1, 2, 4).reshape(clips * tt * hw, c)
+    compare("temporal attention", *run_both(lambda qkv: Fn.TemporalAttention.apply(qkv, (clips, tt, hw, heads, 0.125)), tref, t, cuda))
+
+
+def _tiny_model(cuda):
+    from helpers import cfgs
+    from lvdm.models.ddpm3d import LatentVisualDiffusion
+    g = golden("unet_b.pt")
+    ident = {"target": "torch.nn.Identity"}
+    model = LatentVisualDiffusion(
+        img_cond_stage_config=ident, image_proj_stage_config=ident, cond_stage_config=ident,
+        first_stage_config={"target": "torch.nn.Identity"},
+        unet_config={"target": "lvdm.modules.networks.openaimodel3d.UNetModel", "params": g["cfg"]}, **cfgs.DIFFUSION)
+    sd = seeded_sd(g["param_shapes"], g["seed"], g["checksum"])
+    model.model.diffusion_model.load_state_dict(sd, strict=True)
+    model = model.to(cuda).train()
+    for m in model.modules():                 # parity needs the same function on both sides: no random masks
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    return model, g, sd
+
+
+def test_p_losses_loss_and_every_parameter_gradient_match_autograd_of_the_cpu_oracle(cuda):
+    from oracle import unet as o_unet
+    model, g, sd = _tiny_model(cuda)
+    shp = g["shape"]
+    x, ctx = unet_inputs(g["cfg"], shp, g["seed"])                        # x: (B, 12, T, H, W) = latents + c_concat
+    x_start, concat = x[:, :4].contiguous(), x[:, 4:].contiguous()
+    noise = rnd(*x_start.shape, seed=7)
+    t = torch.tensor([999, 420, 17])[:shp["B"]]
+    label = torch.tensor([0, 500, 1])[:shp["B"], None]
+    fs = torch.full((shp["B"],), 10)
+    cond = {"c_crossattn": [ctx.to(cuda)], "c_concat": [concat.to(cuda)]}
+    loss, info = model.p_losses(x_start.to(cuda), cond, t.to(cuda), noise=noise.to(cuda), class_label=label.to(cuda), fs=fs.to(cuda))
+    loss.backward()
+    unet = model.model.diffusion_model
+    # ---- the same step on the CPU oracle, differentiated by torch.autograd
+    ref_sd = {k: v.clone().double().requires_grad_(True) for k, v in sd.items()}
+    sac, s1m = model.sqrt_alphas_cumprod.cpu().double()[t], model.sqrt_one_minus_alphas_cumprod.cpu().double()[t]
+    bc = lambda v: v[:, None, None, None, None]
+    x_noisy = bc(sac) * x_start.double() + bc(s1m) * noise.double()
+    target = bc(sac) * noise.double() - bc(s1m) * x_start.double()
+    forward = o_unet.unet_forward.__wrapped__                               # the restatement without its no_grad wrapper
+    pred = forward(ref_sd, g["cfg"], torch.cat([x_noisy, concat.double()], 1).float().double(), t, label[:, 0], ctx.double(), fs)
+    want = ((pred - target) ** 2).mean()
+    want.backward()
+    check("p_losses loss", loss, want, TOL_NET)
+    assert abs(float(info["train/loss_simple"]) - float(want)) < TOL_NET * float(want)
+    worst, missing = 0.0, []
+    num = den = 0.0
+    for name, p in unet.named_parameters():
+        gr = ref_sd[name].grad
+        if p.grad is None:
+            missing.append(name)
+            continue
+        d = (p.grad.double().cpu() - gr).norm().item()
+        num += d * d; den += gr.norm().item() ** 2
+        if gr.norm() > 0:
+            worst = max(worst, d / gr.norm().item())
+    assert not missing, missing[:5]
+    total = (num / den) ** 0.5
+    print(f"[{MODE}] UNet parameter gradients vs oracle autograd: {len(list(unet.parameters()))} tensors, overall rel-L2 {total:.3e}, "
+          f"worst single tensor {worst:.3e} (bound {TOL_NET:g} overall)")
+    assert total < TOL_NET and worst < 10 * TOL_NET
+
+
+def test_adamw_step_matches_torch_and_training_reduces_the_loss(cuda):
+    from mudg_amd.train import step
+    p = torch.nn.Parameter(rnd(300, 7, seed=1).to(cuda))
+    q = torch.nn.Parameter(p.detach().clone())
+    mine, ref = step.AdamW([p], lr=1e-2, weight_decay=0.05), torch.optim.AdamW([q], lr=1e-2, weight_decay=0.05)
+    for i in range(3):
+        gr = rnd(300, 7, seed=10 + i).to(cuda)
+        p.grad, q.grad = gr.clone(), gr.clone()
+        mine.step(); ref.step()
+    check("AdamW 3 steps", p, q, 1e-6)
+    model, g, _ = _tiny_model(cuda)
+    model.learning_rate = 2e-4
+    opt = model.configure_optimizers()
+    shp = g["shape"]
+    x, ctx = unet_inputs(g["cfg"], shp, g["seed"])
+    batch = dict(x_start=x[:, :4].contiguous().to(cuda), cond={"c_crossattn": [ctx.to(cuda)], "c_concat": [x[:, 4:].contiguous().to(cuda)]},
+                 t=torch.tensor([700, 420, 100])[:shp["B"]].to(cuda), noise=rnd(shp["B"], 4, shp["T"], shp["H"], shp["W"], seed=3).to(cuda),
+                 class_label=torch.tensor([0, 500, 1])[:shp["B"], None].to(cuda), fs=torch.full((shp["B"],), 10).to(cuda))
+    losses = []
+    for _ in range(6):                                     # the same batch: the loss must go down
+        opt.zero_grad(set_to_none=True)
+        loss = model.training_step(batch)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    print(f"[{MODE}] six AdamW steps on one batch: loss {losses[0]:.5f} -> {losses[-1]:.5f}")
+    assert all(torch.isfinite(torch.tensor(losses))) and losses[-1] < losses[0]
