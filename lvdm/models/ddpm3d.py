@@ -93,7 +93,8 @@ class DDPM(nn.Module):
         self.learn_logvar = learn_logvar
         if learn_logvar:
             raise NotImplementedError("learn_logvar is off in every MuDG config and not implemented")
-        self.logvar = torch.full(fill_value=float(logvar_init), size=(self.num_timesteps,))
+        with torch.device("cpu"):       # a plain attribute, as in the reference: real memory even under torch.device("meta")
+            self.logvar = torch.full(fill_value=float(logvar_init), size=(self.num_timesteps,))
         if ckpt_path is not None:
             self.init_from_ckpt(ckpt_path, ignore_keys=ignore_keys, only_model=load_only_unet)
 

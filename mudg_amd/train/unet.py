@@ -32,6 +32,16 @@ class _Ctx:
     __slots__ = ("B", "T", "emb", "text", "img", "n_img", "img_div")
 
 
+def _ckpt(flag, fn, *args):
+    """lvdm/common.py:81-93 `checkpoint(func, inputs, params, flag)`: with the flag set (use_checkpoint of the UNet config) the
+    block's activations are not kept — its forward is replayed during backward.  torch.utils.checkpoint restores the RNG state
+    for the replay, so dropout masks (seeded from the CPU generator) come out the same."""
+    if not flag:
+        return fn(*args)
+    from torch.utils.checkpoint import checkpoint
+    return checkpoint(fn, *args, use_reentrant=False)
+
+
 def temporal_conv_block(mod, x, ctx, hw):
     y = x
     stages = (mod.conv1, mod.conv2, mod.conv3, mod.conv4)
@@ -95,7 +105,7 @@ def spatial_transformer(mod, x, h, w, ctx):
     hw, frames = h * w, ctx.B * ctx.T
     cur = _lin(mod.proj_in, _gn(mod.norm, x, frames, hw, False))
     for blk in mod.transformer_blocks:
-        cur = spatial_block(blk, cur, frames, hw, ctx)
+        cur = _ckpt(blk.checkpoint, spatial_block, blk, cur, frames, hw, ctx)
     return _lin(mod.proj_out, cur, residual=x)
 
 
@@ -112,7 +122,7 @@ def temporal_transformer(mod, x, h, w, ctx):
     hw = h * w
     cur = _lin(mod.proj_in, _gn(mod.norm, x, ctx.B, ctx.T * hw, False))
     for blk in mod.transformer_blocks:
-        cur = temporal_block(blk, cur, hw, ctx)
+        cur = _ckpt(blk.checkpoint, temporal_block, blk, cur, hw, ctx)
     return _lin(mod.proj_out, cur, residual=x)
 
 
@@ -121,7 +131,7 @@ def run_stage(seq, x, h, w, ctx):
         name = type(m).__name__
         frames = ctx.B * ctx.T
         if name == "ResBlock":
-            x = res_block(m, x, h, w, ctx)
+            x = _ckpt(m.use_checkpoint, res_block, m, x, h, w, ctx)
         elif name == "SpatialTransformer":
             x = spatial_transformer(m, x, h, w, ctx)
         elif name == "TemporalTransformer":

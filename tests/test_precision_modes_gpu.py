@@ -20,12 +20,13 @@ FWD512 = "tests/test_fullsize_gpu.py::test_mdm512_unet_forward_matches_the_cpu_o
 MODES = {
     "fp16": ({"MUDG_OPERAND": "fp16"},
              ["tests/test_kernels_gpu.py", "tests/test_operand_modes_gpu.py", "tests/test_unet_gpu.py",
-              "tests/test_pipeline_gpu.py", "tests/test_sampler_options_gpu.py", "tests/test_fullsize_gpu.py"]),
+              "tests/test_pipeline_gpu.py", "tests/test_sampler_options_gpu.py", "tests/test_fullsize_gpu.py",
+              "tests/test_training_gpu.py"]),
     # test_kernels_gpu.py builds its inputs as plain 16-bit tensors; the split modes run the mode-agnostic kernel suite.
     # bf16x3 is the mode that carries the contract: the full-size config-0 cut asserts the literal 1e-3 there
     "bf16x3": ({"MUDG_OPERAND": "bf16x3"},
                ["tests/test_operand_modes_gpu.py", "tests/test_unet_gpu.py", "tests/test_pipeline_gpu.py",
-                "tests/test_sampler_options_gpu.py", CUT, FWD512]),
+                "tests/test_sampler_options_gpu.py", "tests/test_training_gpu.py", CUT, FWD512]),
     "bf16x6": ({"MUDG_OPERAND": "bf16x6"},
                ["tests/test_operand_modes_gpu.py", "tests/test_unet_gpu.py", "tests/test_pipeline_gpu.py"]),
     # BASELINE.json configs[4]: MX-fp8 scores in the long self-attention (>= 512 tokens of head width 64: the full-size
