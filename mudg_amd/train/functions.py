@@ -43,6 +43,39 @@ def _need(ctx, i):
     return ctx.needs_input_grad[i]
 
 
+def _splits(m, n, k):
+    """K-slices for a weight-gradient GEMM: its output is only (channels x channels) — 9 to 100 tiles for 256 CUs — while the
+    contraction runs over every pixel, so the K axis is cut into slices that run as batch entries of the same launch; the
+    slices' fp32 results are then summed in a fixed order (group_colsum).  A function of the problem shape only."""
+    tiles = ((m + 127) // 128) * ((n + 127) // 128)
+    want = max(1, min(64, 1024 // max(tiles, 1)))
+    return max(1, min(want, k // 512))
+
+
+def wgrad_gemm(at, bt, m, n, p):
+    """sum_p at[m][p] * bt[n][p] -> fp32 [m][n], with the contraction cut into K-slices (see _splits).  at / bt: operand matrices
+    [m][ld], [n][ld] whose columns beyond p are zero and whose ld covers slices * chunk."""
+    s = _splits(m, n, p)
+    if s == 1:
+        return ops.gemm(at, bt, out_fp32=True, M=m, N=n, K=at.shape[1])
+    chunk = at.shape[1] // s
+    slabs = torch.empty((s * m, n), dtype=torch.float32, device=at.device)
+    ops.gemm(at, bt, out=slabs, batch=s, sx=chunk, sw=chunk, sy=m * n, M=m, N=n, K=chunk)
+    return K.group_colsum(slabs.reshape(s, m * n)).reshape(m, n)
+
+
+def transposed(src, m, n, **kw):
+    """transpose_gather into a zero-initialised operand matrix wide enough for the K-slices of the [m][n] weight gradient that
+    contracts over it."""
+    p = kw.pop("P", None) or src.shape[0]
+    s = _splits(m, n, p)
+    width = _pad8(p) if s == 1 else s * ((p + s * 64 - 1) // (s * 64)) * 64
+    out = ops.empty_rows(src.shape[1], width, ops.H16(), src.device)
+    ops_base = out if out._base is None else out._base
+    ops_base.zero_()
+    return K.transpose_gather(src, P=p, out=out, **kw)
+
+
 # ------------------------------------------------------------------------------------------------ linear
 class Linear(torch.autograd.Function):
     """y = x W^T (+ b) (+ residual); x [M][K], W [N][K] (nn.Linear / 1x1 conv weight), fp32 in and out."""
@@ -66,8 +99,9 @@ class Linear(torch.autograd.Function):
             wt = K.transpose_gather(w2)                                  # [K][N padded]
             dx = ops.gemm(dyo, wt, out_fp32=True)
         if _need(ctx, 1):
-            dyt, xt = K.transpose_gather(dy), K.transpose_gather(x)      # [N][M padded], [K][M padded]
-            dw = ops.gemm(dyt, xt, out_fp32=True).reshape(ctx.wshape)
+            m = x.shape[0]
+            dyt, xt = transposed(dy, n, k), transposed(x, n, k)          # [N][M padded], [K][M padded]
+            dw = wgrad_gemm(dyt, xt, n, k, m).reshape(ctx.wshape)
         if ctx.has_b and _need(ctx, 2):
             db = K.group_colsum(dy)[0]
         return dx, dw, db, (dy if ctx.has_r else None)
@@ -121,13 +155,13 @@ class Conv3x3(torch.autograd.Function):
                              out_fp32=True)
         if _need(ctx, 1):
             p = frames * ho * wo
-            dyt = K.transpose_gather(dy)                                 # [Cout][P padded]
+            dyt = transposed(dy, co, ci)                                 # [Cout][P padded]
             dw = torch.empty((co, ci, 3, 3), dtype=torch.float32, device=w.device)
             g = dict(Hin=h, Win=wd, Hout=ho, Wout=wo, stride=stride, pad=1)
             for ky in range(3):
                 for kx in range(3):
-                    xt = K.transpose_gather(x, P=p, mode=1, geo=dict(g, dy=ky, dx=kx))      # [Cin][P padded]: what tap (ky, kx) read
-                    dw[:, :, ky, kx].copy_(ops.gemm(dyt, xt, out_fp32=True))
+                    xt = transposed(x, co, ci, P=p, mode=1, geo=dict(g, dy=ky, dx=kx))      # [Cin][P padded]: what tap (ky, kx) read
+                    dw[:, :, ky, kx].copy_(wgrad_gemm(dyt, xt, co, ci, p))
         if has_b and _need(ctx, 2):
             db = K.group_colsum(dy)[0]
         if has_g and _need(ctx, 3):
@@ -160,11 +194,12 @@ class TConv3(torch.autograd.Function):
             wf = w[:, :, :, 0, 0].flip(2).permute(1, 2, 0).reshape(ci, 3 * co).contiguous()        # [Cin][tap'][Cout]
             dx = ops.tconv3(op(dy), op(wf), clips=clips, t=t, hw=hw, cin=co, out_fp32=True)
         if _need(ctx, 1):
-            dyt = K.transpose_gather(dy)
+            p = x.shape[0]
+            dyt = transposed(dy, co, ci)
             dw = torch.empty((co, ci, 3, 1, 1), dtype=torch.float32, device=w.device)
             for dt in range(3):
-                xt = K.transpose_gather(x, mode=2, geo=dict(T=t, HW=hw, dt=dt))
-                dw[:, :, dt, 0, 0].copy_(ops.gemm(dyt, xt, out_fp32=True))
+                xt = transposed(x, co, ci, mode=2, geo=dict(T=t, HW=hw, dt=dt))
+                dw[:, :, dt, 0, 0].copy_(wgrad_gemm(dyt, xt, co, ci, p))
         if has_b and _need(ctx, 2):
             db = K.group_colsum(dy)[0]
         return dx, dw, db, (dy if has_r else None), None

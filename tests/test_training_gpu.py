@@ -55,9 +55,14 @@ def test_linear_conv_and_temporal_conv_gradients(cuda):
     M, Kd, N = 200, 96, 72
     t = dict(x=rnd(M, Kd, seed=1), w=rnd(N, Kd, seed=2, scale=0.1), b=rnd(N, seed=3), r=rnd(M, N, seed=4))
     compare("linear", *run_both(lambda x, w, b, r: Fn.Linear.apply(x, w, b, r), lambda x, w, b, r: F.linear(x, w, b) + r, t, cuda))
+    # many rows: the weight-gradient contraction is cut into K-slices (functions._splits) summed in a fixed order
+    M = 4100
+    t = dict(x=rnd(M, Kd, seed=1), w=rnd(N, Kd, seed=2, scale=0.1), b=rnd(N, seed=3))
+    assert Fn._splits(N, Kd, M) > 1
+    compare("linear (K-sliced dW)", *run_both(lambda x, w, b: Fn.Linear.apply(x, w, b, None), lambda x, w, b: F.linear(x, w, b), t, cuda))
     # 3x3 conv: stride 1 with the embedding (row-group) bias and a residual, then stride 2; Cin = 12 exercises the channel padding
-    for stride, ci, co in ((1, 64, 40), (2, 12, 24)):
-        frames, h, wd = 4, 6, 8
+    for stride, ci, co, h, wd in ((1, 64, 40, 6, 8), (2, 12, 24, 6, 8), (1, 64, 64, 24, 32)):
+        frames = 4
         ho, wo = (h - 1) // stride + 1, (wd - 1) // stride + 1
         t = dict(x=rnd(frames * h * wd, ci, seed=1), w=rnd(co, ci, 3, 3, seed=2, scale=0.1), b=rnd(co, seed=3),
                  e=rnd(2, co, seed=4), r=rnd(frames * ho * wo, co, seed=5))

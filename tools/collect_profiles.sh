@@ -31,5 +31,8 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pw -- python bench.py --steps 
 python tools/rocprof_summary.py pmc $(find /tmp/pw -name "*.db" | head -1) > $OUT/pmc_write.md
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d /tmp/pm -- python bench.py --steps 1 --warmup 0 --no-graph --no-cpu-baseline --no-profile --no-decode > /tmp/pm.log 2>&1
 python tools/rocprof_summary.py mfma $(find /tmp/pm -name "*.db" | head -1) > $OUT/pmc_mfma.md
+# the training step of the full UNet at MDM512: seconds per step, peak memory (untuned baseline)
+timeout 900 python tools/train_bench.py 512 2 2>/dev/null | tail -4 > $OUT/train_bench512.log
+timeout 900 python tools/train_bench.py 512 2 ckpt 2>/dev/null | tail -1 >> $OUT/train_bench512.log
 rm -f $OUT/bench_n1.raw
 ls -la $OUT

@@ -13,7 +13,8 @@ FAM = {"0": "gemm", "1": "conv3x3", "2": "tconv3"}
 def table(path, counter):
     out = {}
     for line in open(path):
-        m = re.match(r"\| `(gemm\w*_kernel)<(\d)[^`]*` \| " + counter + r" \| (\d+) \| ([0-9.e+]+) \|", line)
+        # kernel names: gemm_kernel<Geo<4, 2>, MODE, FAST, SB> (round 3 on; the tile geometry comes first) or gemm_kernel<MODE, ...>
+        m = re.match(r"\| `(gemm\w*_kernel)<(?:\(anonymous namespace\)::)?(?:Geo<\d+, \d+>, )?(\d)[^`]*` \| " + counter + r" \| (\d+) \| ([0-9.e+]+) \|", line)
         if m:
             fam = FAM[m.group(2)]
             e = out.setdefault(fam, {"kernels": [], "launches": 0, "kib": 0.0})
