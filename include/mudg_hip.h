@@ -276,7 +276,10 @@ int mudg_semantic_nearest(const uint8_t* img, uint8_t* vis, int64_t* labels, int
  * (oy stride - pad + dy, ox stride - pad + dx) of the Hin x Win image, zero outside.  mode 2 (temporal tap dt): p = ((b T + t) HW + s)
  * reads row p + (dt - 1) HW while 0 <= t + dt - 1 < T. */
 int mudg_transpose_gather(const float* src, int64_t lds, void* dst, int64_t ldd, int64_t P, int C, int mode, int Hin, int Win,
-                          int Hout, int Wout, int stride, int pad, int dy, int dx, int T, int HW, int dt, void* stream);
+                          int Hout, int Wout, int stride, int pad, int dy, int dx, int T, int HW, int dt, int batch,
+                          int64_t src_batch_stride, int64_t dst_batch_stride, void* stream);
+/* batch > 1: entry z reads src + z * src_batch_stride and writes dst + z * dst_batch_stride (elements): the per-(frame, head)
+ * transposes of the attention backward pass in one launch. */
 /* out[g][c] = sum over the rows of group g (rows_per_group consecutive rows) of A[r][c] * (B ? B[r][c] : 1): bias gradients
  * (one group), the timestep-embedding gradient of a ResBlock (one group per clip). */
 int mudg_group_colsum(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t rows, int cols, int64_t rows_per_group,

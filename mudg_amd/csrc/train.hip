@@ -44,8 +44,10 @@ __device__ __forceinline__ int64_t gather_row(const GatherGeo& g, int64_t p) {
 }
 
 __global__ __launch_bounds__(256) void transpose_gather_kernel(const float* __restrict__ src, int64_t lds, h16* __restrict__ dst, int64_t ldd,
-                                                                int64_t P, int64_t Ppad, int C, GatherGeo g) {
+                                                                int64_t P, int64_t Ppad, int C, GatherGeo g, int64_t sbs, int64_t dbs) {
     __shared__ float tile[32][33];
+    src += (int64_t)blockIdx.z * sbs;               // batch entry z: its own source rows and destination block
+    dst += (int64_t)blockIdx.z * dbs;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
     const int64_t p0 = (int64_t)blockIdx.x * 32;
     const int c0 = blockIdx.y * 32;
@@ -457,16 +459,17 @@ inline unsigned blocks_for(int64_t n) { return (unsigned)((n + 255) / 256); }
 extern "C" {
 
 int mudg_transpose_gather(const float* src, int64_t lds, void* dst, int64_t ldd, int64_t P, int C, int mode, int Hin, int Win,
-                          int Hout, int Wout, int stride, int pad, int dy, int dx, int T, int HW, int dt, void* stream) {
-    MUDG_REQUIRE(src && dst && P > 0 && C > 0, "mudg_transpose_gather: bad arguments");
+                          int Hout, int Wout, int stride, int pad, int dy, int dx, int T, int HW, int dt, int batch, int64_t src_batch_stride,
+                          int64_t dst_batch_stride, void* stream) {
+    MUDG_REQUIRE(src && dst && P > 0 && C > 0 && batch >= 1 && batch <= 65535, "mudg_transpose_gather: bad arguments");
     MUDG_REQUIRE(mode >= 0 && mode <= 2, "mudg_transpose_gather: mode %d", mode);
     const int64_t Ppad = (P + 7) / 8 * 8;
     MUDG_REQUIRE(ldd % PLANES == 0 && ldd / PLANES >= Ppad, "mudg_transpose_gather: ldd=%lld too small for %lld columns", (long long)ldd, (long long)Ppad);
     if (mode == 1) MUDG_REQUIRE(Hin > 0 && Win > 0 && Hout > 0 && Wout > 0 && stride > 0 && P % ((int64_t)Hout * Wout) == 0, "mudg_transpose_gather: conv geometry");
     if (mode == 2) MUDG_REQUIRE(T > 0 && HW > 0 && P % ((int64_t)T * HW) == 0, "mudg_transpose_gather: temporal geometry");
     GatherGeo g{mode, Hin, Win, Hout, Wout, stride, pad, dy, dx, T, HW, dt};
-    hipLaunchKernelGGL(transpose_gather_kernel, dim3((unsigned)((Ppad + 31) / 32), (unsigned)((C + 31) / 32)), dim3(256), 0,
-                       reinterpret_cast<hipStream_t>(stream), src, lds, (h16*)dst, ldd, P, Ppad, C, g);
+    hipLaunchKernelGGL(transpose_gather_kernel, dim3((unsigned)((Ppad + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)batch), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), src, lds, (h16*)dst, ldd, P, Ppad, C, g, src_batch_stride, dst_batch_stride);
     return mudg_check_launch("mudg_transpose_gather");
 }
 

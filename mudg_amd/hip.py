@@ -120,7 +120,7 @@ SIGNATURES = {
     "mudg_semantic_nearest": (_I, [_P, _P, _P, _L, _P]),
     "mudg_ddim_step": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _L, C.POINTER(C.c_float), _P, _P]),
     "mudg_gaussian_sample": (_I, [_P, _P, _P, _I, _I, _I, _F, _P]),
-    "mudg_transpose_gather": (_I, [_P, _L, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "mudg_transpose_gather": (_I, [_P, _L, _P, _L, _L, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _I, _L, _L, _P]),
     "mudg_group_colsum": (_I, [_P, _L, _P, _L, _L, _I, _L, _P, _P]),
     "mudg_groupnorm_bwd_ws_floats": (_L, [_I, _I, _I, _I]),
     "mudg_groupnorm_stats": (_I, [_P, _L, _I, _I, _I, _I, _F, _P, _P]),

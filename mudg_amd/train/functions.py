@@ -64,16 +64,33 @@ def wgrad_gemm(at, bt, m, n, p):
     return K.group_colsum(slabs.reshape(s, m * n)).reshape(m, n)
 
 
+def _width(m, n, p):
+    """Columns of the transposed operands of an [m][n] weight gradient contracting over p rows: p rounded to 8, or a whole number
+    of 64-wide K tiles per slice when the contraction is cut (see _splits)."""
+    s = _splits(m, n, p)
+    return _pad8(p) if s == 1 else s * ((p + s * 64 - 1) // (s * 64)) * 64
+
+
+def _zeros_operand(rows, width, device):
+    out = ops.empty_rows(rows, width, ops.H16(), device)
+    (out if out._base is None else out._base).zero_()
+    return out
+
+
 def transposed(src, m, n, **kw):
     """transpose_gather into a zero-initialised operand matrix wide enough for the K-slices of the [m][n] weight gradient that
     contracts over it."""
     p = kw.pop("P", None) or src.shape[0]
-    s = _splits(m, n, p)
-    width = _pad8(p) if s == 1 else s * ((p + s * 64 - 1) // (s * 64)) * 64
-    out = ops.empty_rows(src.shape[1], width, ops.H16(), src.device)
-    ops_base = out if out._base is None else out._base
-    ops_base.zero_()
-    return K.transpose_gather(src, P=p, out=out, **kw)
+    return K.transpose_gather(src, P=p, out=_zeros_operand(src.shape[1], _width(m, n, p), src.device), **kw)
+
+
+def transposed_taps(x, m, ci, p, taps, mode, geo):
+    """[len(taps) * ci][width]: for every tap the transposed copy of the input pixels it read — the right-hand operand of ONE
+    weight-gradient GEMM over all taps (N = taps * Cin: more tiles, one launch)."""
+    out = _zeros_operand(len(taps) * ci, _width(m, len(taps) * ci, p), x.device)
+    for i, tap in enumerate(taps):
+        K.transpose_gather(x, P=p, mode=mode, geo=dict(geo, **tap), out=out[i * ci:(i + 1) * ci])
+    return out
 
 
 # ------------------------------------------------------------------------------------------------ linear
@@ -155,13 +172,11 @@ class Conv3x3(torch.autograd.Function):
                              out_fp32=True)
         if _need(ctx, 1):
             p = frames * ho * wo
-            dyt = transposed(dy, co, ci)                                 # [Cout][P padded]
-            dw = torch.empty((co, ci, 3, 3), dtype=torch.float32, device=w.device)
+            dyt = transposed(dy, co, 9 * ci)                             # [Cout][P padded]
             g = dict(Hin=h, Win=wd, Hout=ho, Wout=wo, stride=stride, pad=1)
-            for ky in range(3):
-                for kx in range(3):
-                    xt = transposed(x, co, ci, P=p, mode=1, geo=dict(g, dy=ky, dx=kx))      # [Cin][P padded]: what tap (ky, kx) read
-                    dw[:, :, ky, kx].copy_(wgrad_gemm(dyt, xt, co, ci, p))
+            taps = [dict(dy=ky, dx=kx) for ky in range(3) for kx in range(3)]
+            xt = transposed_taps(x, co, ci, p, taps, 1, g)               # [9 Cin][P padded]: what each tap read
+            dw = wgrad_gemm(dyt, xt, co, 9 * ci, p).reshape(co, 3, 3, ci).permute(0, 3, 1, 2).contiguous()
         if has_b and _need(ctx, 2):
             db = K.group_colsum(dy)[0]
         if has_g and _need(ctx, 3):
@@ -195,11 +210,9 @@ class TConv3(torch.autograd.Function):
             dx = ops.tconv3(op(dy), op(wf), clips=clips, t=t, hw=hw, cin=co, out_fp32=True)
         if _need(ctx, 1):
             p = x.shape[0]
-            dyt = transposed(dy, co, ci)
-            dw = torch.empty((co, ci, 3, 1, 1), dtype=torch.float32, device=w.device)
-            for dt in range(3):
-                xt = transposed(x, co, ci, mode=2, geo=dict(T=t, HW=hw, dt=dt))
-                dw[:, :, dt, 0, 0].copy_(wgrad_gemm(dyt, xt, co, ci, p))
+            dyt = transposed(dy, co, 3 * ci)
+            xt = transposed_taps(x, co, ci, p, [dict(dt=d) for d in range(3)], 2, dict(T=t, HW=hw))
+            dw = wgrad_gemm(dyt, xt, co, 3 * ci, p).reshape(co, 3, ci).permute(0, 2, 1).reshape(co, ci, 3, 1, 1).contiguous()
         if has_b and _need(ctx, 2):
             db = K.group_colsum(dy)[0]
         return dx, dw, db, (dy if has_r else None), None
@@ -318,8 +331,7 @@ def _vt(v, batches, nk):
     c = v.shape[1]
     ld = _pad8(nk)
     out = ops.empty_rows(batches * c, ld, ops.H16(), v.device)
-    for b in range(batches):
-        K.transpose_gather(v[b * nk:(b + 1) * nk], out=out[b * c:(b + 1) * c])
+    K.transpose_gather(v, P=nk, out=out, batch=batches, src_batch_rows=nk, dst_batch_rows=c)
     return out, out.stride(0)
 
 
@@ -346,13 +358,12 @@ def _attn_backward_set(q, k, v, do, groups, nqg, nk, heads, scale):
         dot = ops.empty_rows(groups * 64, ldq, ops.H16(), dev)           # dO^T  [64][nqg]
         dst = ops.empty_rows(groups * nk, ldq, ops.H16(), dev)           # dS^T  [nk][nqg]
         pt = ops.empty_rows(groups * nk, ldq, ops.H16(), dev)            # P^T   [nk][nqg]
-        for g in range(groups):
-            qr, kr = slice(g * nqg, (g + 1) * nqg), slice(g * nk, (g + 1) * nk)
-            K.transpose_gather(k[kr, hs], out=kt[g * 64:(g + 1) * 64])
-            K.transpose_gather(q[qr, hs], out=qt[g * 64:(g + 1) * 64])
-            K.transpose_gather(do[qr, hs], out=dot[g * 64:(g + 1) * 64])
-            K.transpose_gather(ds[qr, :nk], out=dst[g * nk:(g + 1) * nk])
-            K.transpose_gather(s[qr, :nk], out=pt[g * nk:(g + 1) * nk])
+        bt = lambda src, p, out, rows_out: K.transpose_gather(src, P=p, out=out, batch=groups, src_batch_rows=p, dst_batch_rows=rows_out)
+        bt(k[:, hs], nk, kt, 64)
+        bt(q[:, hs], nqg, qt, 64)
+        bt(do[:, hs], nqg, dot, 64)
+        bt(ds[:, :nk], nqg, dst, nk)
+        bt(s[:, :nk], nqg, pt, nk)
         dso = op(ds)
         dqh = ops.gemm(dso, kt, out_fp32=True, batch=groups, sx=nqg * dso.stride(0), sw=64 * kt.stride(0), sy=nqg * 64, M=nqg, N=64, K=lds,
                        out=torch.empty((groups * nqg, 64), dtype=torch.float32, device=dev))

@@ -17,8 +17,9 @@ def _f32(t):
     return t
 
 
-def transpose_gather(src, P=None, mode=0, geo=None, out=None):
-    """dst[c][p] = src[srcrow(p)][c] as an operand matrix [C][P rounded up to 8] (mudg_transpose_gather)."""
+def transpose_gather(src, P=None, mode=0, geo=None, out=None, batch=1, src_batch_rows=0, dst_batch_rows=0):
+    """dst[c][p] = src[srcrow(p)][c] as an operand matrix [C][P rounded up to 8] (mudg_transpose_gather).  batch > 1: entry z
+    transposes the P rows starting at row z * src_batch_rows of `src` into the C rows starting at row z * dst_batch_rows of `out`."""
     _f32(src)
     P = src.shape[0] if P is None else P
     Cc = src.shape[1]
@@ -28,7 +29,8 @@ def transpose_gather(src, P=None, mode=0, geo=None, out=None):
     g = dict(Hin=0, Win=0, Hout=0, Wout=0, stride=1, pad=1, dy=0, dx=0, T=0, HW=0, dt=0)
     g.update(geo or {})
     hip.check(hip.lib().mudg_transpose_gather(src.data_ptr(), src.stride(0), out.data_ptr(), out.stride(0), P, Cc, mode, g["Hin"], g["Win"],
-                                              g["Hout"], g["Wout"], g["stride"], g["pad"], g["dy"], g["dx"], g["T"], g["HW"], g["dt"], _s()),
+                                              g["Hout"], g["Wout"], g["stride"], g["pad"], g["dy"], g["dx"], g["T"], g["HW"], g["dt"], batch,
+                                              src_batch_rows * src.stride(0), dst_batch_rows * out.stride(0), _s()),
               "mudg_transpose_gather")
     return out
 

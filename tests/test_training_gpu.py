@@ -192,7 +192,7 @@ def test_p_losses_loss_and_every_parameter_gradient_match_autograd_of_the_cpu_or
     want = ((pred - target) ** 2).mean()
     want.backward()
     check("p_losses loss", loss, want, TOL_NET)
-    assert abs(float(info["train/loss_simple"]) - float(want)) < TOL_NET * float(want)
+    assert abs(float(info["train/loss_simple"]) - float(want.detach())) < TOL_NET * float(want.detach())
     worst, missing = 0.0, []
     num = den = 0.0
     for name, p in unet.named_parameters():

@@ -138,6 +138,19 @@ def test_prepared_context_equals_raw_context_and_graphs_are_shared_across_contex
                 m.transformer_blocks[0].attn2.to_k.weight.mul_(1.5)
     changed = net(*args, context=p1, **kw)
     assert torch.equal(changed, net(*args, context=ctx.to(cuda), **kw)) and not torch.equal(changed, raw1)
+    # the same on the hipGraph path with a prepared context that still holds the OLD projections (the sampler's cached one
+    # after a load_state_dict / LoRA swap): it must be re-projected at the source, never copied stale into the graph
+    p3 = net.prepare_context(ctx.to(cuda), T)
+    with torch.no_grad():
+        for m in net.modules():
+            if type(m).__name__ == "SpatialTransformer":
+                m.transformer_blocks[0].attn2.to_v.weight.mul_(0.7)
+    want = net(*args, context=ctx.to(cuda), **kw)
+    net.use_hip_graph = True
+    got1 = net(*args, context=p3, **kw)        # re-captures (parameters changed), p3 re-projected first
+    got2 = net(*args, context=p3, **kw)        # replay
+    net.use_hip_graph = False
+    assert torch.equal(got1, want) and torch.equal(got2, want)
 
 
 def test_guidance_replicas_share_the_context_free_prefix_bit_exactly(cuda):
