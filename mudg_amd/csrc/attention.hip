@@ -859,7 +859,7 @@ __global__ __launch_bounds__(256, TP == 16 ? 3 : 1) void tattn_kernel(const h16*
 // partial products — NSEG MFMAs where the 16-bit kernel issues one.  Exponentials and the output normalisation are the
 // same fp32 arithmetic.  One K / V^T tile per piece in LDS; precision first: 32 queries per wave, no 64-query variant.
 template <bool TWO>
-__global__ __launch_bounds__(256, 1) void attn_split_kernel(const MudgAttnDesc p, const int nqt, const int total) {
+__global__ __launch_bounds__(256, 2) void attn_split_kernel(const MudgAttnDesc p, const int nqt, const int total) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     h16* Ks = reinterpret_cast<h16*>(smem_raw);                   // [2 buffers][PLANES][ATILE]
     h16* Vs = Ks + 2 * PLANES * ATILE;
@@ -981,8 +981,12 @@ __global__ __launch_bounds__(256, 1) void attn_split_kernel(const MudgAttnDesc p
 #pragma unroll
         for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = exp2f((m_run - m_new) * c);
+        // The softmax of this kernel was its bottleneck (rocprofv3: twice as many VALU issue cycles as MFMA cycles per key tile): the
+        // exponentials run on v_exp_f32 directly (1 ulp — fp32-class, as the split products around them) instead of the library
+        // exp2f with its range handling, and O is rescaled only when some row's maximum actually grew (wave-uniform test).
+        const bool grew = !__all(mx <= m_run);
+        const float m_new = grew ? fmaxf(m_run, mx) : m_run;
+        const float alpha = grew ? __builtin_amdgcn_exp2f((m_run - m_new) * c) : 1.0f;
         const float mc = m_new * c;
         m_run = m_new;
         float ps = 0.f;
@@ -991,7 +995,7 @@ __global__ __launch_bounds__(256, 1) void attn_split_kernel(const MudgAttnDesc p
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float e = exp2f(fmaf(s[sub][r], c, -mc));
+                const float e = __builtin_amdgcn_exp2f(fmaf(s[sub][r], c, -mc));
                 ps += e;
                 h16 piece[PLANES];
                 split_operand(e, piece);
@@ -999,8 +1003,10 @@ __global__ __launch_bounds__(256, 1) void attn_split_kernel(const MudgAttnDesc p
                 for (int pl = 0; pl < PLANES; ++pl) pk[pl][sub][r >> 3][r & 7] = piece[pl];
             }
         l_run = l_run * alpha + ps;
+        if (grew) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+            for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+        }
 
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)

@@ -82,6 +82,8 @@ constexpr int VF_Y = 1, VF_R = 2;               // 16-byte access allowed on Y /
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+// Used by the 16-bit builds where the table is off and by the bf16x3 build (whose operands carry 16 significand bits: the
+// polynomial's 1.5e-7 is two orders below their representation error); bf16x6 evaluates erff exactly.
 __device__ __forceinline__ float gelu_fast(float x) {
     // 0.5 x (1 + erf(x / sqrt 2)) with Abramowitz-Stegun 7.1.26 for erf (|abs err| < 1.5e-7): the exact erff
     // costs about as much as the whole K loop of a K = 320 tile; the result is rounded to h16 anyway.
@@ -720,7 +722,7 @@ __global__ __launch_bounds__(G::NTH, G::WIDE ? 2 : ((SB && !fused_planes(FAST)) 
                     for (int j = 0; j < 4; ++j) v[j] = alpha * acc[ni][mi][4 * g + j] + sbias[nl + j];
                     if (p.act) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = PLANES > 1 ? gelu_erf_f(v[j]) : gelu_fast(v[j]);
+                        for (int j = 0; j < 4; ++j) v[j] = PLANES > 2 ? gelu_erf_f(v[j]) : gelu_fast(v[j]);
                     }
                     *reinterpret_cast<f32x4*>(&stg[ml * STGLD + nl]) = v;
                 }
@@ -735,7 +737,7 @@ __global__ __launch_bounds__(G::NTH, G::WIDE ? 2 : ((SB && !fused_planes(FAST)) 
                 for (int j = 0; j < 4; ++j) {
                     const float val = alpha * acc[2 * q][mi][4 * g + j] + sbias[nl + j];
                     const float gate = alpha * acc[2 * q + 1][mi][4 * g + j] + sbias[nl + 32 + j];
-                    v[j] = val * (PLANES > 1 ? gelu_erf_f(gate) : (phi ? gelu_lut(gate, phis) : gelu_fast(gate)));
+                    v[j] = val * (PLANES > 2 ? gelu_erf_f(gate) : (phi ? gelu_lut(gate, phis) : gelu_fast(gate)));
                 }
                 *reinterpret_cast<f32x4*>(&stg[ml * STGLD + wn * (16 * NI) + q * 32 + 8 * g + 4 * hi]) = v;
             }
