@@ -291,9 +291,10 @@ int mudg_groupnorm_stats(const float* X, int64_t ldx, int samples, int rows, int
 int mudg_groupnorm_bwd(const float* X, int64_t ldx, const float* dY, int64_t ldy, const float* gamma, const float* beta,
                        const float* stat, int samples, int rows, int C, int groups, int silu, float* dX, int64_t lddx, float* AB,
                        float* ws, void* stream);
-/* LayerNorm backward: dX, dgamma[C], dbeta[C]; rowstat: fp32 scratch [rows][2]. */
+/* LayerNorm backward: dX, and prod[rows][C] = dY * xhat — dgamma is the column sum of prod, dbeta that of dY
+ * (mudg_group_colsum; the caller chunks the rows so that the sums run on many workgroups). */
 int mudg_layernorm_bwd(const float* X, int64_t ldx, const float* dY, int64_t ldy, const float* gamma, float* dX, int64_t lddx,
-                       float* dgamma, float* dbeta, float* rowstat, int64_t rows, int C, float eps, void* stream);
+                       float* prod, int64_t rows, int C, float eps, void* stream);
 /* GEGLU on H = [value | gate] rows [M][2 N] (attention.py:579-586): dY NULL -> out[M][N] = value * gelu(gate);
  * else out = dH [M][2 N]. */
 int mudg_geglu(const float* H, int64_t ldh, const float* dY, int64_t lddy, float* out, int64_t ldo, int64_t M, int N, void* stream);

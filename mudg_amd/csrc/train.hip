@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
 // One wave per row: recomputes mean / rstd, writes dx and the row's (mean, rstd) for the parameter-gradient pass.
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ X, int64_t ldx, const float* __restrict__ dY, int64_t ldy,
                                                       const float* __restrict__ gamma, float* __restrict__ dX, int64_t lddx,
-                                                      float* __restrict__ rowstat, int64_t rows, int C, float eps) {
+                                                      float* __restrict__ prod, int64_t rows, int C, float eps) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -197,29 +197,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ X
     for (int c = lane; c < C; c += 64) {
         const float xh = (x[c] - mean) * rstd;
         dX[row * lddx + c] = rstd * (dy[c] * gamma[c] - m1 - xh * m2);
-    }
-    if (lane == 0) { rowstat[row * 2] = mean; rowstat[row * 2 + 1] = rstd; }
-}
-
-// dgamma[c] = sum_rows dy xhat, dbeta[c] = sum_rows dy: same walk as group_colsum_kernel (one group = all rows).
-__global__ __launch_bounds__(256) void ln_bwd_params_kernel(const float* __restrict__ X, int64_t ldx, const float* __restrict__ dY, int64_t ldy,
-                                                             const float* __restrict__ rowstat, int64_t rows, int C,
-                                                             float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    __shared__ double pg[4][64], pb[4][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + lane;
-    double g = 0.0, b = 0.0;
-    if (c < C)
-        for (int64_t r = wave; r < rows; r += 4) {
-            const float dy = dY[r * ldy + c];
-            g += (double)(dy * (X[r * ldx + c] - rowstat[r * 2]) * rowstat[r * 2 + 1]);
-            b += (double)dy;
-        }
-    pg[wave][lane] = g; pb[wave][lane] = b;
-    __syncthreads();
-    if (wave == 0 && c < C) {
-        dgamma[c] = (float)(((pg[0][lane] + pg[1][lane]) + pg[2][lane]) + pg[3][lane]);
-        dbeta[c] = (float)(((pb[0][lane] + pb[1][lane]) + pb[2][lane]) + pb[3][lane]);
+        prod[row * (int64_t)C + c] = dy[c] * xh;          // dgamma = its column sum (mudg_group_colsum, chunked by the caller)
     }
 }
 
@@ -513,12 +491,11 @@ int mudg_groupnorm_stats(const float* X, int64_t ldx, int samples, int rows, int
     return mudg_check_launch("mudg_groupnorm_stats");
 }
 
-int mudg_layernorm_bwd(const float* X, int64_t ldx, const float* dY, int64_t ldy, const float* gamma, float* dX, int64_t lddx, float* dgamma,
-                       float* dbeta, float* rowstat, int64_t rows, int C, float eps, void* stream) {
-    MUDG_REQUIRE(X && dY && gamma && dX && dgamma && dbeta && rowstat && rows > 0 && C > 0, "mudg_layernorm_bwd: bad arguments");
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, X, ldx, dY, ldy, gamma, dX, lddx, rowstat, rows, C, eps);
-    hipLaunchKernelGGL(ln_bwd_params_kernel, dim3((unsigned)((C + 63) / 64)), dim3(256), 0, s, X, ldx, dY, ldy, rowstat, rows, C, dgamma, dbeta);
+int mudg_layernorm_bwd(const float* X, int64_t ldx, const float* dY, int64_t ldy, const float* gamma, float* dX, int64_t lddx, float* prod,
+                       int64_t rows, int C, float eps, void* stream) {
+    MUDG_REQUIRE(X && dY && gamma && dX && prod && rows > 0 && C > 0, "mudg_layernorm_bwd: bad arguments");
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), X, ldx, dY, ldy, gamma,
+                       dX, lddx, prod, rows, C, eps);
     return mudg_check_launch("mudg_layernorm_bwd");
 }
 

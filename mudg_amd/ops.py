@@ -298,9 +298,11 @@ def _rows_any(t):
     return t
 
 
-def groupnorm(x, gamma, beta, *, samples, rows, eps, silu, groups=32, x2=None, out=None, fused=True):
+def groupnorm(x, gamma, beta, *, samples, rows, eps, silu, groups=32, x2=None, out=None, fused=True, return_stats=False):
     """GroupNorm(+SiLU).  When every source tensor still carries the partial sums its producing GEMM / conv wrote
-    (stats=True there) and a sample is a whole number of 128-row blocks, the statistics pass over x is skipped."""
+    (stats=True there) and a sample is a whole number of 128-row blocks, the statistics pass over x is skipped.
+    return_stats: also return the (mean, rstd) per (sample, group) the kernels computed, fp32 [samples * groups][2] (the
+    backward pass of the training step needs them)."""
     _rows_any(x)
     if x2 is not None and x2.dtype != x.dtype:
         raise hip.MudgError("groupnorm: both channel sources must share a dtype")
@@ -323,7 +325,7 @@ def groupnorm(x, gamma, beta, *, samples, rows, eps, silu, groups=32, x2=None, o
                                                  gamma.data_ptr(), beta.data_ptr(),
                                                  out.data_ptr(), out.stride(0), samples, rows, c, groups, eps, int(silu),
                                                  p1.data_ptr(), _ptr(p2), ws.data_ptr(), _stream()), "mudg_groupnorm_fused")
-        return out
+        return (out, ws.reshape(samples * groups, 2)) if return_stats else out
     n = hip.lib().mudg_groupnorm_ws_floats(samples, groups, rows)
     ws = torch.empty(n, dtype=torch.float32, device=x.device)
     hip.check(hip.lib().mudg_groupnorm(x.data_ptr(), _ptr(x2), x.shape[1], x.stride(0),
@@ -331,7 +333,8 @@ def groupnorm(x, gamma, beta, *, samples, rows, eps, silu, groups=32, x2=None, o
                                        gamma.data_ptr(), beta.data_ptr(),
                                        out.data_ptr(), out.stride(0), samples, rows, c, groups, eps, int(silu),
                                        ws.data_ptr(), _stream()), "mudg_groupnorm")
-    return out
+    # the statistics sit at the tail of the scratch (behind the chunk partials): see mudg_groupnorm
+    return (out, ws[-2 * samples * groups:].reshape(samples * groups, 2)) if return_stats else out
 
 
 def layernorm(x, gamma, beta, *, eps=1e-5, out=None):

@@ -225,15 +225,15 @@ class GroupNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, samples, rows, eps, silu, groups):
         g, b = gamma.float().contiguous(), beta.float().contiguous()
-        ctx.save_for_backward(x, g, b)
+        y, stat = ops.groupnorm(x, g, b, samples=samples, rows=rows, eps=eps, silu=silu, groups=groups, return_stats=True)
+        ctx.save_for_backward(x, g, b, stat)         # (mean, rstd) per (sample, group) as the forward kernels computed them
         ctx.args = (samples, rows, eps, silu, groups)
-        return ops.to_f32(ops.groupnorm(x, g, b, samples=samples, rows=rows, eps=eps, silu=silu, groups=groups))
+        return ops.to_f32(y)
 
     @staticmethod
     def backward(ctx, dy):
-        x, g, b = ctx.saved_tensors
+        x, g, b, stat = ctx.saved_tensors
         samples, rows, eps, silu, groups = ctx.args
-        stat = K.groupnorm_stats(x, samples, rows, groups, eps)
         dx, dgamma, dbeta = K.groupnorm_bwd(x, dy.contiguous(), g, b, stat, samples, rows, groups, silu)
         return dx, dgamma, dbeta, None, None, None, None, None
 

@@ -35,14 +35,26 @@ def transpose_gather(src, P=None, mode=0, geo=None, out=None, batch=1, src_batch
     return out
 
 
-def group_colsum(a, b=None, rows_per_group=None):
-    _f32(a)
+def _colsum_once(a, b, rpg):
     rows, cols = a.shape
-    rpg = rows if rows_per_group is None else rows_per_group
     out = torch.empty((rows // rpg, cols), dtype=torch.float32, device=a.device)
     hip.check(hip.lib().mudg_group_colsum(a.data_ptr(), a.stride(0), None if b is None else _f32(b).data_ptr(), 0 if b is None else b.stride(0),
                                           rows, cols, rpg, out.data_ptr(), _s()), "mudg_group_colsum")
     return out
+
+
+def group_colsum(a, b=None, rows_per_group=None):
+    """out[g][c] = sum over the rows of group g of a[r][c] (* b[r][c]).  One launch gives a workgroup per (64 columns, group): a
+    group of many rows is first cut into chunks (a divisor of its length, <= 1024 rows), whose partial sums are then summed —
+    two launches on many workgroups instead of one on a handful; the chunking depends on the shape only (fixed order)."""
+    _f32(a)
+    rows = a.shape[0]
+    rpg = rows if rows_per_group is None else rows_per_group
+    if rpg > 2048:
+        for chunk in (1024, 768, 640, 576, 512, 384, 320, 256, 192, 160, 128, 96, 64):
+            if rpg % chunk == 0:
+                return _colsum_once(_colsum_once(a, b, chunk), None, rpg // chunk)
+    return _colsum_once(a, b, rpg)
 
 
 def groupnorm_stats(x, samples, rows, groups, eps):
@@ -70,12 +82,10 @@ def layernorm_bwd(x, dy, gamma, eps):
     _f32(x); _f32(dy)
     rows, c = x.shape
     dx = torch.empty_like(x)
-    dg = torch.empty(c, dtype=torch.float32, device=x.device)
-    db = torch.empty(c, dtype=torch.float32, device=x.device)
-    rs = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
+    prod = torch.empty((rows, c), dtype=torch.float32, device=x.device)
     hip.check(hip.lib().mudg_layernorm_bwd(x.data_ptr(), x.stride(0), dy.data_ptr(), dy.stride(0), gamma.data_ptr(), dx.data_ptr(), dx.stride(0),
-                                           dg.data_ptr(), db.data_ptr(), rs.data_ptr(), rows, c, eps, _s()), "mudg_layernorm_bwd")
-    return dx, dg, db
+                                           prod.data_ptr(), rows, c, eps, _s()), "mudg_layernorm_bwd")
+    return dx, group_colsum(prod)[0], group_colsum(dy)[0]
 
 
 def geglu(h, dy=None):
