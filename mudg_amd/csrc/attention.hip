@@ -859,7 +859,7 @@ __global__ __launch_bounds__(256, TP == 16 ? 3 : 1) void tattn_kernel(const h16*
 // partial products — NSEG MFMAs where the 16-bit kernel issues one.  Exponentials and the output normalisation are the
 // same fp32 arithmetic.  One K / V^T tile per piece in LDS; precision first: 32 queries per wave, no 64-query variant.
 template <bool TWO>
-__global__ __launch_bounds__(256, 2) void attn_split_kernel(const MudgAttnDesc p, const int nqt, const int total) {
+__global__ __launch_bounds__(256, PLANES == 2 ? 2 : 1) void attn_split_kernel(const MudgAttnDesc p, const int nqt, const int total) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     h16* Ks = reinterpret_cast<h16*>(smem_raw);                   // [2 buffers][PLANES][ATILE]
     h16* Vs = Ks + 2 * PLANES * ATILE;

@@ -6,12 +6,14 @@ import os
 import torch
 
 
-def init_from_env(backend=None):
-    """Initialise torch.distributed from torchrun's environment.  Returns (rank, world, local_rank, dist or None)."""
+def init_from_env(backend=None, force=False):
+    """Initialise torch.distributed from torchrun's environment.  Returns (rank, world, local_rank, dist or None).  A
+    single process needs no process group (dist = None) unless `force` asks for one — a one-rank RCCL group, which is how the
+    collective code paths get exercised on a one-GPU box."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world == 1:
+    if world == 1 and not force:
         return rank, world, local, None
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -79,9 +79,9 @@ class GradientAllReducer:
     all-reduced over `group` (RCCL when the tensors are on GPUs, gloo on CPU) and unpacked.  The bucket layout is a function of
     the parameter list only, so every rank issues the same collectives in the same order."""
 
-    def __init__(self, params, bucket_mb=64, group=None):
+    def __init__(self, params, bucket_mb=64, group=None, always=False):
         self.params = [p for p in params if p.requires_grad]
-        self.group = group
+        self.group, self.always = group, always          # always: run the collectives even in a one-rank group (tests)
         limit = int(bucket_mb * (1 << 20)) // 4
         self.buckets, cur, n = [], [], 0
         for p in self.params:
@@ -95,7 +95,7 @@ class GradientAllReducer:
 
     def __call__(self):
         import torch.distributed as dist
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
+        if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(self.group) == 1 and not self.always):
             return 0
         world = dist.get_world_size(self.group)
         backend = dist.get_backend(self.group)
