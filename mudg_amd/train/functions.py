@@ -71,9 +71,15 @@ def _width(m, n, p):
     return _pad8(p) if s == 1 else s * ((p + s * 64 - 1) // (s * 64)) * 64
 
 
-def _zeros_operand(rows, width, device):
+def _zeros_operand(rows, width, device, written=0):
+    """Operand matrix whose columns [written, width) are zero (transpose_gather itself fills — and zero-pads to a multiple of 8 —
+    the first `written` columns of every piece)."""
     out = ops.empty_rows(rows, width, ops.H16(), device)
-    (out if out._base is None else out._base).zero_()
+    if written < width:
+        base = out if out._base is None else out._base
+        planes = base.shape[1] // width
+        for pl in range(planes):
+            base[:, pl * width + written:(pl + 1) * width].zero_()
     return out
 
 
@@ -81,13 +87,13 @@ def transposed(src, m, n, **kw):
     """transpose_gather into a zero-initialised operand matrix wide enough for the K-slices of the [m][n] weight gradient that
     contracts over it."""
     p = kw.pop("P", None) or src.shape[0]
-    return K.transpose_gather(src, P=p, out=_zeros_operand(src.shape[1], _width(m, n, p), src.device), **kw)
+    return K.transpose_gather(src, P=p, out=_zeros_operand(src.shape[1], _width(m, n, p), src.device, _pad8(p)), **kw)
 
 
 def transposed_taps(x, m, ci, p, taps, mode, geo):
     """[len(taps) * ci][width]: for every tap the transposed copy of the input pixels it read — the right-hand operand of ONE
     weight-gradient GEMM over all taps (N = taps * Cin: more tiles, one launch)."""
-    out = _zeros_operand(len(taps) * ci, _width(m, len(taps) * ci, p), x.device)
+    out = _zeros_operand(len(taps) * ci, _width(m, len(taps) * ci, p), x.device, _pad8(p))
     for i, tap in enumerate(taps):
         K.transpose_gather(x, P=p, mode=mode, geo=dict(geo, **tap), out=out[i * ci:(i + 1) * ci])
     return out
@@ -344,13 +350,14 @@ def _attn_backward_set(q, k, v, do, groups, nqg, nk, heads, scale):
     for h in range(heads):
         hs = slice(h * 64, (h + 1) * 64)
         qh, kh, vh, doh = op(q[:, hs]), op(k[:, hs]), op(v[:, hs]), op(do[:, hs])
-        s = torch.zeros((groups * nqg, lds), dtype=torch.float32, device=dev)
+        fresh = torch.empty if lds == nk else torch.zeros        # only padding columns need the zeros
+        s = fresh((groups * nqg, lds), dtype=torch.float32, device=dev)
         bat = dict(batch=groups, sx=nqg * qh.stride(0), sw=nk * kh.stride(0), sy=nqg * lds, M=nqg, N=nk, K=64)
         ops.gemm(qh, kh, out=s, alpha=scale, **bat)
         K.softmax_f32(s, nk)                                             # s now holds P (the padding columns stay 0)
-        dp = torch.zeros_like(s)
+        dp = fresh(s.shape, dtype=torch.float32, device=dev)
         ops.gemm(doh, vh, out=dp, **dict(bat, sx=nqg * doh.stride(0), sw=nk * vh.stride(0)))
-        ds = torch.zeros_like(s)
+        ds = fresh(s.shape, dtype=torch.float32, device=dev)
         K.softmax_bwd(s, dp, ds, nk, scale)
         # transposed copies, one block of rows per group
         kt = ops.empty_rows(groups * 64, lds, ops.H16(), dev)            # K^T   [64][nk]
