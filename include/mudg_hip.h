@@ -108,6 +108,11 @@ typedef struct MudgGemmDesc {
                              matrices sW apart, K ordered [Cin/64][tap 0..3][64] with tap = 2 a + b reading input pixel
                              (oy - 1 + py + a, ox - 1 + px + b); Y is the (2 Hin x 2 Win) image, row ((f 2Hin) + 2 oy + py) 2Win
                              + 2 ox + px.  Needs what mudg_conv_subpixel_ok checks. */
+    void* Y8; void* S8;   /* 16-bit builds, optional: also write the OCP MX-fp8 copy of Y (an operand-kind result of a plain or conv
+                             problem, N % 32 == 0, no GEGLU) — e4m3 bytes Y8[m][ldy8] and one E8M0 scale per 32 columns S8[m][lds8],
+                             bit-equal to mudg_quantize_mxfp8 of Y: the q | k projection of the long self-attention quantises its own
+                             output for the fp8 score path (BASELINE config 5) instead of two more passes over it */
+    int ldy8, lds8;
 } MudgGemmDesc;
 int mudg_gemm(const MudgGemmDesc* d, void* stream);
 /* 1 when `d` (mode 1, subpixel = 1) can run: batch 4, stride 1, pad 1, korder 1, Cin % 64 == 0, no X2 / R / gbias / stats /

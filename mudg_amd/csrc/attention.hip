@@ -1237,22 +1237,13 @@ __global__ __launch_bounds__(256) void quantize_mxfp8_kernel(const h16* __restri
 #pragma unroll
         for (int e = 0; e < 8; ++e) { v[q * 8 + e] = (float)t[e]; amax = fmaxf(amax, fabsf(v[q * 8 + e])); }
     }
-    int E = 0;                                   // shared exponent: floor(log2 amax) - emax(e4m3) = ... - 8
-    if (amax > 0.f) {
-        E = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 127 - 8;
-        E = E < -127 ? -127 : (E > 127 ? 127 : E);
-    }
+    const int E = mx_block_exponent(amax);       // shared exponent: floor(log2 amax) - emax(e4m3) = ... - 8
     const float inv = __uint_as_float((unsigned)(127 - E) << 23);           // 2^-E
     u32x4 lo, hi4;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-        float a[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) a[e] = fminf(fmaxf(v[q * 4 + e] * inv, -448.f), 448.f);
-        int w = 0;
-        w = __builtin_amdgcn_cvt_pk_fp8_f32(a[0], a[1], w, false);
-        w = __builtin_amdgcn_cvt_pk_fp8_f32(a[2], a[3], w, true);
-        if (q < 4) lo[q] = (unsigned)w; else hi4[q - 4] = (unsigned)w;
+        const unsigned w = mx_pack4_e4m3(v[q * 4], v[q * 4 + 1], v[q * 4 + 2], v[q * 4 + 3], inv);
+        if (q < 4) lo[q] = w; else hi4[q - 4] = w;
     }
     unsigned char* dst = Y + r * ldy + b * 32;
     st16(dst, lo);

@@ -130,6 +130,28 @@ __device__ __forceinline__ float operand_round(float v) {
     return acc;
 }
 
+// OCP MX-fp8 (e4m3 + E8M0 scale per 32 values): the shared exponent of a block with maximum magnitude amax and the e4m3 bytes
+// of four values scaled by 2^-E (saturating, round to nearest even in hardware).  Used by mudg_quantize_mxfp8 and by the GEMM
+// epilogue's fused fp8 copy: one definition, bit-equal results.
+#if MUDG_PLANES == 1
+__device__ __forceinline__ int mx_block_exponent(float amax) {
+    int E = 0;
+    if (amax > 0.f) {
+        E = (int)((__float_as_uint(amax) >> 23) & 0xffu) - 127 - 8;
+        E = E < -127 ? -127 : (E > 127 ? 127 : E);
+    }
+    return E;
+}
+__device__ __forceinline__ unsigned mx_pack4_e4m3(float a0, float a1, float a2, float a3, float inv) {
+    a0 = fminf(fmaxf(a0 * inv, -448.f), 448.f); a1 = fminf(fmaxf(a1 * inv, -448.f), 448.f);
+    a2 = fminf(fmaxf(a2 * inv, -448.f), 448.f); a3 = fminf(fmaxf(a3 * inv, -448.f), 448.f);
+    int w = 0;
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(a0, a1, w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(a2, a3, w, true);
+    return (unsigned)w;
+}
+#endif
+
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 

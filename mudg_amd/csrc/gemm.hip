@@ -863,6 +863,22 @@ __global__ __launch_bounds__(G::NTH, G::WIDE ? 2 : ((SB && !fused_planes(FAST)) 
 #pragma unroll
                 for (int j = 0; j < 8; ++j) if (j < nvalid) store1_operand(yp + j, p.ldy / PLANES, v[j]);
             }
+#if MUDG_PLANES == 1
+            if constexpr (!SB) if (p.Y8) {      // (the 4-per-CU variant has no registers to spare: Y8 problems run on this one) MX-fp8 copy of what was just stored: a 32-column block = the four adjacent lanes cc & ~3 .. + 3 of this row
+                float r8[8], amax = 0.f;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { r8[j] = (float)(h16)v[j]; amax = fmaxf(amax, fabsf(r8[j])); }
+                amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+                amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+                const int E = mx_block_exponent(amax);
+                const float inv = __uint_as_float((unsigned)(127 - E) << 23);
+                u32x2 w8;
+                w8[0] = mx_pack4_e4m3(r8[0], r8[1], r8[2], r8[3], inv);
+                w8[1] = mx_pack4_e4m3(r8[4], r8[5], r8[6], r8[7], inv);
+                *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned char*>(p.Y8) + (int64_t)m * p.ldy8 + n) = w8;
+                if ((cc & 3) == 0) reinterpret_cast<unsigned char*>(p.S8)[(int64_t)m * p.lds8 + (n >> 5)] = (unsigned char)(E + 127);
+            }
+#endif
         }
     }
     // GroupNorm partials are per 128-row block of Y (MudgGemmDesc.stats): flush whenever the passes done so far end one.
@@ -960,6 +976,7 @@ int launch(const MudgGemmDesc& d, int vflags, hipStream_t s) {
 // only FAST kernel, see fused_planes.)
 bool use_single_buffer(const MudgGemmDesc& d) {
     if (fused_planes(true)) return true;
+    if (d.Y8) return false;                   // the fused fp8 copy is compiled into the two-per-CU variant only
     static int mode = -1;
     if (mode < 0) mode = mudg_variant("GEMM_SB", 1);
     if (mode == 0) return false;
@@ -980,6 +997,7 @@ int use_wide(const MudgGemmDesc& d) {
     static int mode = -1;
     if (mode < 0) mode = mudg_variant("GEMM_WIDE", 2);
     if (mode == 0) return 0;
+    if (d.Y8) return 0;                       // the fused fp8 copy lives in the 128 x 128 kernels' epilogue
     int ni = 0;
     if (d.geglu) ni = (d.N % 256 == 0) ? 4 : 0;
     else if (d.N % 320 == 0) ni = 5;
@@ -1069,6 +1087,12 @@ extern "C" int mudg_gemm(const MudgGemmDesc* dp, void* stream) {
     if (d.gbias) MUDG_REQUIRE(d.rows_per_group > 0 && d.batch == 1, "mudg_gemm: gbias needs rows_per_group");
     if (d.stats) MUDG_REQUIRE(d.batch == 1 && !d.geglu, "mudg_gemm: stats needs batch == 1 and no GEGLU");
     if (d.alpha == 0.f) d.alpha = 1.f;
+    if (d.Y8) {
+        MUDG_REQUIRE(PLANES == 1, "mudg_gemm: the fused fp8 copy belongs to the 16-bit builds");
+        MUDG_REQUIRE(d.S8 && d.out_fp32 == KIND_OPERAND && !d.geglu && !d.subpixel && d.batch == 1 && (d.N & 31) == 0 && (d.ldy8 & 7) == 0 &&
+                     d.ldy8 >= d.N && d.lds8 >= d.N / 32 && (reinterpret_cast<uintptr_t>(d.Y8) & 7u) == 0,
+                     "mudg_gemm: Y8 needs S8, an operand-kind Y, N %% 32 == 0, no GEGLU / sub-pixel / batch, ldy8 %% 8 == 0");
+    }
     int vflags = 0;
     MUDG_REQUIRE(d.out_fp32 >= 0 && d.out_fp32 <= 2 && d.res_fp32 >= 0 && d.res_fp32 <= 2, "mudg_gemm: out_fp32 / res_fp32 are 0 (operand), 1 (fp32) or 2 (fp16)");
     const int ybytes = d.out_fp32 == KIND_F32 ? 4 : 2;

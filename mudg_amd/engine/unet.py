@@ -161,13 +161,15 @@ def spatial_block(blk, hcur, frames, hw, ctx, last):
     n1 = _ln(blk.norm1, hcur)
     lean = _LEAN_ATTENTION and ops.hip.planes() == 1     # 16-bit builds: scale * log2(e) rides in the packed q weights
     wqk = pk.qk_prescaled(a1, a1.to_q, a1.to_k, a1.scale) if lean else pk.linear_cat(a1, "qk", (a1.to_q, a1.to_k))
-    qk = ops.gemm(n1, wqk)
+    use_fp8 = lean and _FP8_ATTENTION and hw >= 512 and hw % 64 == 0      # BASELINE config 5: Q K^T on the MX-fp8 MFMA
+    fp8 = None
+    if use_fp8:         # the projection's own epilogue writes the MX-fp8 copy of q | k (no separate quantisation passes)
+        qk, q8, s8 = ops.gemm(n1, wqk, fp8=True)
+        fp8 = (q8[:, :c], s8[:, :c // 32], q8[:, c:], s8[:, c // 32:])
+    else:
+        qk = ops.gemm(n1, wqk)
     vt, ldv = _vt_projection(a1.to_v, n1, frames, hw)
     att = ops.empty_rows(frames * hw, c, ops.H16(), hcur.device)
-    fp8 = None
-    if lean and _FP8_ATTENTION and hw >= 512 and hw % 64 == 0:      # BASELINE config 5: Q K^T on the MX-fp8 MFMA
-        q8, s8 = ops.quantize_mxfp8(qk)
-        fp8 = (q8[:, :c], s8[:, :c // 32], q8[:, c:], s8[:, c // 32:])
     ops.attention(qk[:, :c], qk[:, c:], vt, att, frames=frames, heads=heads, nq=hw, nk=hw, ldvt=ldv, svt=c * ldv,
                   scale=a1.scale, q_prescaled=lean, fp8=fp8)
     hcur = _linear(a1.to_out[0], att, residual=hcur, stream=True)

@@ -71,6 +71,7 @@ class GemmDesc(C.Structure):
         ("T", C.c_int), ("HW", C.c_int),
         ("stats", C.c_void_p),
         ("subpixel", C.c_int),
+        ("Y8", C.c_void_p), ("S8", C.c_void_p), ("ldy8", C.c_int), ("lds8", C.c_int),
     ]
 
 

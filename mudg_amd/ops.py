@@ -124,9 +124,11 @@ def _attach_stats(d, out, M, nout):
 
 def gemm(x, w, *, out=None, bias=None, gbias=None, rows_per_group=0, residual=None, x2=None, geglu=False,
          out_fp32=False, alpha=1.0, batch=1, sx=0, sw=0, sy=0, sr=0, M=None, N=None, K=None, ldy=None, gelu=False,
-         stats=False, out_stream=False):
+         stats=False, out_stream=False, fp8=False):
     """out[m, n] = epilogue(alpha * sum_k x[m, k] w[n, k]); see MudgGemmDesc.  The result is an MFMA operand matrix by
-    default, fp32 with out_fp32, the residual-stream dtype (STREAM()) with out_stream; `out=` decides by its dtype."""
+    default, fp32 with out_fp32, the residual-stream dtype (STREAM()) with out_stream; `out=` decides by its dtype.
+    fp8=True (16-bit builds, operand result, N % 32 == 0): returns (out, e4m3 bytes [M, N] uint8, E8M0 scales [M, N / 32] uint8) —
+    the MX-fp8 copy of the result written by the same epilogue (MudgGemmDesc.Y8), bit-equal to quantize_mxfp8(out)."""
     _rows(x); _rows(w)
     if M is None:
         M = x.shape[0]
@@ -154,8 +156,12 @@ def gemm(x, w, *, out=None, bias=None, gbias=None, rows_per_group=0, residual=No
     d.act = int(gelu)
     if stats:
         _attach_stats(d, out, M, nout)
+    if fp8:
+        y8 = torch.empty((M, nout), dtype=torch.uint8, device=x.device)
+        s8 = torch.empty((M, nout // 32), dtype=torch.uint8, device=x.device)
+        d.Y8, d.S8, d.ldy8, d.lds8 = y8.data_ptr(), s8.data_ptr(), y8.stride(0), s8.stride(0)
     hip.check(hip.lib().mudg_gemm(C.byref(d), _stream()), "mudg_gemm")
-    return out
+    return (out, y8, s8) if fp8 else out
 
 
 def conv3x3(x, w, *, frames, hin, win, cin, stride=1, upsample=False, out=None, bias=None, gbias=None,

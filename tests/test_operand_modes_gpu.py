@@ -434,6 +434,12 @@ def test_mxfp8_quantiser_and_fp8_score_attention(cuda):
     want = (blocks / torch.pow(2.0, E)[..., None]).clamp(-448, 448).float().to(torch.float8_e4m3fn).float().reshape(frames * n, -1)
     got = y8.cpu().view(torch.float8_e4m3fn).float()
     assert torch.equal(got, want)
+    # the same copy written by a GEMM's own epilogue (MudgGemmDesc.Y8: how the engine makes it) equals the quantiser of its result
+    xg, _ = operand(f32(1000, 64, seed=7), cuda)
+    wg, _ = operand(f32(2 * c, 64, seed=8) * 0.2, cuda)
+    yg, yg8, sg8 = ops.gemm(xg, wg, fp8=True)
+    ref8, refs = ops.quantize_mxfp8(yg)
+    assert torch.equal(yg8, ref8) and torch.equal(sg8, refs)
     deq = (got.reshape(frames * n, -1, 32).double() * torch.pow(2.0, E)[..., None]).reshape(frames * n, -1)
     print(f"MX-fp8 quantisation error of q|k: rel-L2 {rel(deq, qkv):.3e}")
     _, vv = operand(f32(frames * n, c, seed=3), cuda)
