@@ -240,6 +240,47 @@ def test_activation_checkpointing_replays_blocks_and_gives_the_same_gradients(cu
     assert all(torch.equal(grads[0][n], grads[1][n]) for n in grads[0])
 
 
+def test_full_width_unet_gradients_match_autograd_of_the_cpu_oracle(cuda):
+    """The REAL topology — 1.44 B parameters, channels 320 / 640 / 1280, 4 levels, 16 spatial + 17 temporal transformers — on a small
+    clip (4 frames of 16 x 24 latents), so that autograd of the CPU oracle stays at tens of seconds: p_losses loss and the gradient
+    of all 1520-odd parameter tensors (K-sliced weight gradients, every conv / linear width of the production model)."""
+    from mudg_amd import configs, factory
+    from oracle import unet as o_unet
+    model = factory.build_synthetic_model("512", cuda, seed=9).train()
+    unet = model.model.diffusion_model
+    for m in unet.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    inp = factory.synthetic_inputs(model, "512", 1, cuda, seed=13, latent_shape=(4, 4, 16, 24))
+    t = torch.tensor([431], device=cuda)
+    noise = rnd(*inp["x_T"].shape, seed=5).to(cuda)
+    loss, _ = model.p_losses(inp["x_T"], inp["cond"], t, noise=noise, class_label=inp["class_label"], fs=inp["fs"])
+    loss.backward()
+    ref_sd = {k: v.detach().float().cpu().clone().requires_grad_(True) for k, v in unet.state_dict().items()}
+    x0, nz, concat = inp["x_T"].cpu(), noise.cpu(), inp["cond"]["c_concat"][0].cpu()
+    sac, s1m = model.sqrt_alphas_cumprod.cpu()[t.cpu()], model.sqrt_one_minus_alphas_cumprod.cpu()[t.cpu()]
+    x_noisy, target = sac * x0 + s1m * nz, sac * nz - s1m * x0
+    cfg = dict(configs.UNET_MDM)
+    pred = o_unet.unet_forward.__wrapped__(ref_sd, cfg, torch.cat([x_noisy, concat], 1), t.cpu(), inp["class_label"][:, 0].cpu(),
+                                           inp["cond"]["c_crossattn"][0].cpu(), inp["fs"].cpu())
+    want = ((pred - target) ** 2).mean()
+    want.backward()
+    check("full-width p_losses loss", loss, want.detach(), TOL_NET)
+    num = den = 0.0
+    worst, n = 0.0, 0
+    for name, p in unet.named_parameters():
+        gr = ref_sd[name].grad
+        assert p.grad is not None and gr is not None, name
+        d = (p.grad.float().cpu() - gr).norm().item()
+        num += d * d; den += gr.norm().item() ** 2
+        worst = max(worst, d / max(gr.norm().item(), 1e-30))
+        n += 1
+    total = (num / den) ** 0.5
+    print(f"[{MODE}] full-width UNet ({sum(p.numel() for p in unet.parameters()) / 1e9:.2f} B parameters, {n} tensors): gradients vs oracle autograd "
+          f"overall rel-L2 {total:.3e}, worst single tensor {worst:.3e} (bound {TOL_NET:g} overall)")
+    assert total < TOL_NET
+
+
 def test_adamw_step_matches_torch_and_training_reduces_the_loss(cuda):
     from mudg_amd.train import step
     p = torch.nn.Parameter(rnd(300, 7, seed=1).to(cuda))
