@@ -21,7 +21,7 @@ __device__ __forceinline__ float silu_grad(float z) {        // d/dz [z sigma(z)
 
 // ---------------------------------------------------------------------------------------------- transpose / gather
 // dst[c][p] = src[srcrow(p)][c] (or 0 where the source pixel of output position p does not exist), p < P; columns P .. Ppad
-// are zero.  dst is an MFMA operand matrix [C][ldd]; src fp32 rows [*][lds].  One 32 x 32 tile per 256-thread workgroup.
+// are zero.  dst is an MFMA operand matrix [C][ldd]; src fp32 rows [*][lds].  One 64 x 64 tile per 256-thread workgroup.
 //   mode 0: srcrow = p
 //   mode 1: p = (f, oy, ox) of an Hout x Wout grid, tap (dy, dx): source pixel (oy stride - pad + dy, ox stride - pad + dx)
 //   mode 2: p = ((b T + t) HW + s), tap dt: source row p + (dt - 1) HW while 0 <= t + dt - 1 < T
@@ -45,29 +45,29 @@ __device__ __forceinline__ int64_t gather_row(const GatherGeo& g, int64_t p) {
 
 __global__ __launch_bounds__(256) void transpose_gather_kernel(const float* __restrict__ src, int64_t lds, h16* __restrict__ dst, int64_t ldd,
                                                                 int64_t P, int64_t Ppad, int C, GatherGeo g, int64_t sbs, int64_t dbs) {
-    __shared__ float tile[32][33];
+    __shared__ float tile[64][65];
     src += (int64_t)blockIdx.z * sbs;               // batch entry z: its own source rows and destination block
     dst += (int64_t)blockIdx.z * dbs;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;          // 32 x 8
-    const int64_t p0 = (int64_t)blockIdx.x * 32;
-    const int c0 = blockIdx.y * 32;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int64_t p = p0 + ty + 8 * i;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;          // 64 x 4: a wave reads 256 B of a source row, writes 128 B of a destination row
+    const int64_t p0 = (int64_t)blockIdx.x * 64;
+    const int c0 = blockIdx.y * 64;
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+        const int64_t p = p0 + ty + 4 * i;
         const int c = c0 + tx;
         float v = 0.f;
         if (p < P && c < C) {
             const int64_t r = gather_row(g, p);
             if (r >= 0) v = src[r * lds + c];
         }
-        tile[ty + 8 * i][tx] = v;
+        tile[ty + 4 * i][tx] = v;
     }
     __syncthreads();
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = c0 + ty + 8 * i;
+#pragma unroll 4
+    for (int i = 0; i < 16; ++i) {
+        const int c = c0 + ty + 4 * i;
         const int64_t p = p0 + tx;
-        if (c < C && p < Ppad) store1_operand(dst + (int64_t)c * ldd + p, ldd / PLANES, tile[tx][ty + 8 * i]);
+        if (c < C && p < Ppad) store1_operand(dst + (int64_t)c * ldd + p, ldd / PLANES, tile[tx][ty + 4 * i]);
     }
 }
 
@@ -446,7 +446,7 @@ int mudg_transpose_gather(const float* src, int64_t lds, void* dst, int64_t ldd,
     if (mode == 1) MUDG_REQUIRE(Hin > 0 && Win > 0 && Hout > 0 && Wout > 0 && stride > 0 && P % ((int64_t)Hout * Wout) == 0, "mudg_transpose_gather: conv geometry");
     if (mode == 2) MUDG_REQUIRE(T > 0 && HW > 0 && P % ((int64_t)T * HW) == 0, "mudg_transpose_gather: temporal geometry");
     GatherGeo g{mode, Hin, Win, Hout, Wout, stride, pad, dy, dx, T, HW, dt};
-    hipLaunchKernelGGL(transpose_gather_kernel, dim3((unsigned)((Ppad + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)batch), dim3(256), 0,
+    hipLaunchKernelGGL(transpose_gather_kernel, dim3((unsigned)((Ppad + 63) / 64), (unsigned)((C + 63) / 64), (unsigned)batch), dim3(256), 0,
                        reinterpret_cast<hipStream_t>(stream), src, lds, (h16*)dst, ldd, P, Ppad, C, g, src_batch_stride, dst_batch_stride);
     return mudg_check_launch("mudg_transpose_gather");
 }
