@@ -493,7 +493,6 @@ __global__ __launch_bounds__(G::NTH, G::WIDE ? 2 : ((SB && !fused_planes(FAST)) 
                 if (!p.geglu) {
 #pragma unroll
                     for (int d = 0; d < 2; ++d) {
-                        constexpr int dummy = 0; (void)dummy;
                         const int ni = 2 * q + d;
                         if (ni < NI) {
 #pragma unroll
@@ -882,8 +881,7 @@ __global__ __launch_bounds__(G::NTH, G::WIDE ? 2 : ((SB && !fused_planes(FAST)) 
         }
     }
     // GroupNorm partials are per 128-row block of Y (MudgGemmDesc.stats): flush whenever the passes done so far end one.
-    constexpr bool STATS_FLUSH_EVERY_128 = true;
-    const bool flush = p.stats && STATS_FLUSH_EVERY_128 && (((pass + 1) * PROWS) % 128 == 0 || pass == NPASS - 1);
+    const bool flush = p.stats && (((pass + 1) * PROWS) % 128 == 0 || pass == NPASS - 1);
     if (NPASS > 1 || flush) __syncthreads();
     if (flush) {
         // thread t always handled channel chunk t % cpr: fold the threads of a chunk in a fixed order
