@@ -312,6 +312,24 @@ int mudg_softmax_bwd(const float* P, int64_t ldp, const float* dP, int64_t lddp,
 int mudg_temporal_attention_bwd(const float* Q, const float* K, const float* V, const float* dO, int64_t ldqkv, int64_t ldo,
                                 float* dQ, float* dK, float* dV, int64_t ldg, int B, int T, int HW, int heads, float scale,
                                 void* stream);
+/* Backward of softmax(scale Q K^T) V, head width 64, without materialising the scores (16-bit operand builds; the forward is
+ * mudg_attention, reference attention.py:81-144).  Q, dO: operand rows [F Nq][ld*]; K, V: operand rows [(F / kv_div) Nk][ld*]
+ * (kv_div frames share a key / value batch: the text tokens of a clip); head h at columns [64 h, 64 h + 64).  Qt, dOt
+ * [F / kv_div][heads 64][ld*t] and Kt [F / kv_div][heads 64][ldkt]: transposed copies (row = head channel, column = row of the
+ * batch; mudg_transpose_gather).  L, D: fp32 [F Nq][heads] scratch the call fills (log2-sum-exp of the scaled scores and
+ * sum_k P dP).  dQ [F Nq][ldgq], dK, dV [(F / kv_div) Nk][ldgk]: fp32, every element of the head columns written once. */
+typedef struct MudgAttnBwdDesc {
+    const void* Q; const void* K; const void* V; const void* dO;
+    const void* Qt; const void* dOt; const void* Kt;
+    float* L; float* D;
+    float* dQ; float* dK; float* dV;
+    int F, heads, Nq, Nk, kv_div;
+    int ldq, ldk, ldv, lddo;
+    int64_t ldqt, lddot, ldkt;
+    int64_t ldgq, ldgk;
+    float scale;
+} MudgAttnBwdDesc;
+int mudg_attention_bwd(const MudgAttnBwdDesc* d, void* stream);
 /* loss[b] = mean over the n elements of sample b of (pred - target)^2; grad (optional) = w[b] * 2 (pred - target) / n — the
  * gradient of sum_b w[b] loss[b] (ddpm3d.py:766-787 folds logvar, l_simple_weight and the vlb term into w). */
 int64_t mudg_mse_ws_doubles(int B);

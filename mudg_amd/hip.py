@@ -89,6 +89,20 @@ class AttnDesc(C.Structure):
     ]
 
 
+class AttnBwdDesc(C.Structure):
+    _fields_ = [
+        ("Q", C.c_void_p), ("K", C.c_void_p), ("V", C.c_void_p), ("dO", C.c_void_p),
+        ("Qt", C.c_void_p), ("dOt", C.c_void_p), ("Kt", C.c_void_p),
+        ("L", C.c_void_p), ("D", C.c_void_p),
+        ("dQ", C.c_void_p), ("dK", C.c_void_p), ("dV", C.c_void_p),
+        ("F", C.c_int), ("heads", C.c_int), ("Nq", C.c_int), ("Nk", C.c_int), ("kv_div", C.c_int),
+        ("ldq", C.c_int), ("ldk", C.c_int), ("ldv", C.c_int), ("lddo", C.c_int),
+        ("ldqt", C.c_int64), ("lddot", C.c_int64), ("ldkt", C.c_int64),
+        ("ldgq", C.c_int64), ("ldgk", C.c_int64),
+        ("scale", C.c_float),
+    ]
+
+
 # name -> (restype, argtypes); this table is also what tests check against include/mudg_hip.h
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 SIGNATURES = {
@@ -131,6 +145,7 @@ SIGNATURES = {
     "mudg_softmax_f32": (_I, [_P, _L, _P, _L, _L, _I, _P]),
     "mudg_softmax_bwd": (_I, [_P, _L, _P, _L, _P, _L, _L, _I, _F, _P]),
     "mudg_temporal_attention_bwd": (_I, [_P, _P, _P, _P, _L, _L, _P, _P, _P, _L, _I, _I, _I, _I, _F, _P]),
+    "mudg_attention_bwd": (_I, [C.POINTER(AttnBwdDesc), _P]),
     "mudg_mse_ws_doubles": (_L, [_I]),
     "mudg_mse": (_I, [_P, _P, _P, _I, _L, _P, _P, _P, _P]),
     "mudg_upsample2x": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),

@@ -10,14 +10,15 @@ contractions map onto the forward GEMM kernel (mudg_gemm: Y[m][n] = sum_k X[m][k
                                           stride 2: dY is first laid onto the input grid with zeros in between (dilate2x)
                 dW[tap] = dY^T X_tap      X_tap^T = transpose_gather(mode 1): the input pixels tap (dy, dx) reads, transposed
     temporal    the same with the three temporal taps (mode 2)
-    attention   recomputed: S = scale Q K^T, P = softmax(S) (fp32), dP = dO V^T, dS = P (dP - rowsum(dP P)) scale,
-                dQ = dS K, dK = dS^T Q, dV = P^T dO — per head, batched over the key / value batches
+    attention   recomputed: S = scale Q K^T, P = softmax(S), dP = dO V^T, dS = P (dP - rowsum(dP P)) scale,
+                dQ = dS K, dK = dS^T Q, dV = P^T dO.  16-bit builds: mudg_attention_bwd (csrc/attention_bwd.hip), the scores
+                never leave registers; split-operand builds: per head, fp32 scores in memory, batched GEMMs
 
 Reference semantics: lvdm/modules/attention.py, lvdm/modules/networks/openaimodel3d.py (forward), torch.autograd (backward);
 checked against autograd of the CPU oracle in tests/test_training_gpu.py."""
 import torch
 
-from .. import ops
+from .. import hip, ops
 from . import kernels as K
 
 
@@ -341,8 +342,19 @@ def _vt(v, batches, nk):
     return out, out.stride(0)
 
 
-def _attn_backward_set(q, k, v, do, groups, nqg, nk, heads, scale):
+def _attn_backward_fused(q, k, v, do, groups, nqg, nk, heads, scale, frames):
+    """The same gradients from mudg_attention_bwd (16-bit operand builds): no score matrix in memory — three transposed copies
+    (Q^T, dO^T per key / value batch, K^T) and one call."""
+    tr = lambda src, p: K.transpose_gather(src, P=p, batch=groups, src_batch_rows=p, dst_batch_rows=src.shape[1],
+                                           out=ops.empty_rows(groups * src.shape[1], _pad8(p), ops.H16(), src.device))
+    return K.attention_bwd(op(q), op(k), op(v), op(do), tr(q, nqg), tr(do, nqg), tr(k, nk), frames=frames, heads=heads,
+                           nq=nqg * groups // frames, nk=nk, kv_div=frames // groups, scale=scale)
+
+
+def _attn_backward_set(q, k, v, do, groups, nqg, nk, heads, scale, frames):
     """Gradients of softmax(scale q k^T) v for one key / value set: `groups` key / value batches, each serving nqg query rows."""
+    if hip.planes() == 1:
+        return _attn_backward_fused(q, k, v, do, groups, nqg, nk, heads, scale, frames)
     c = q.shape[1]
     dq, dk, dv = torch.zeros_like(q), torch.zeros_like(k), torch.zeros_like(v)
     lds, ldq = _pad8(nk), _pad8(nqg)
@@ -408,10 +420,10 @@ class Attention(torch.autograd.Function):
         saved = ctx.saved_tensors
         q, k, v = saved[:3]
         do = do.contiguous()
-        dq, dk, dv = _attn_backward_set(q, k, v, do, frames // kv_div, kv_div * nq, nk, heads, scale)
+        dq, dk, dv = _attn_backward_set(q, k, v, do, frames // kv_div, kv_div * nq, nk, heads, scale, frames)
         dk2 = dv2 = None
         if len(saved) == 5:
-            dq2, dk2, dv2 = _attn_backward_set(q, saved[3], saved[4], do, frames // kv_div2, kv_div2 * nq, nk2, heads, scale)
+            dq2, dk2, dv2 = _attn_backward_set(q, saved[3], saved[4], do, frames // kv_div2, kv_div2 * nq, nk2, heads, scale, frames)
             ops.add_(dq, dq2)
         return dq, dk, dv, dk2, dv2, None
 

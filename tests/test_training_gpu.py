@@ -133,6 +133,15 @@ def test_attention_gradients_self_cross_two_sets_and_temporal(cuda):
     t = dict(q=rnd(frames * n, c, seed=1), k=rnd(frames * n, c, seed=2), v=rnd(frames * n, c, seed=3))
     compare("self-attention", *run_both(lambda q, k, v: Fn.Attention.apply(q, k, v, None, None, (frames, heads, n, n, 1, 0, 1, 0.125)),
                                         lambda q, k, v: _attn_ref(q, k, v, frames, heads, n, n, 1, 0.125), t, cuda))
+    # several query and key tiles with ragged tails on both sides (the fused backward walks 64-row tiles under 128-row workgroups)
+    m = 333
+    t = dict(q=rnd(2 * m, c, seed=6), k=rnd(2 * m, c, seed=7), v=rnd(2 * m, c, seed=8))
+    compare("self-attention, 333 tokens", *run_both(lambda q, k, v: Fn.Attention.apply(q, k, v, None, None, (2, heads, m, m, 1, 0, 1, 0.125)),
+                                                    lambda q, k, v: _attn_ref(q, k, v, 2, heads, m, m, 1, 0.125), t, cuda))
+    t = dict(q=rnd(4 * 200, c, seed=9), k=rnd(2 * 150, c, seed=10), v=rnd(2 * 150, c, seed=11))
+    compare("two frames per key batch, 200 queries, 150 keys", *run_both(
+        lambda q, k, v: Fn.Attention.apply(q, k, v, None, None, (4, heads, 200, 150, 2, 0, 1, 0.125)),
+        lambda q, k, v: _attn_ref(q, k, v, 4, heads, 200, 150, 2, 0.125), t, cuda))
     T = 2      # text keys shared by the T frames of a clip (77 tokens, not a multiple of 8) + per-frame image keys, summed
     t = dict(q=rnd(frames * n, c, seed=1), k=rnd(frames // T * 77, c, seed=2), v=rnd(frames // T * 77, c, seed=3),
              k2=rnd(frames * 16, c, seed=4), v2=rnd(frames * 16, c, seed=5))
@@ -305,6 +314,6 @@ def test_adamw_step_matches_torch_and_training_reduces_the_loss(cuda):
         loss = model.training_step(batch)
         loss.backward()
         opt.step()
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
     print(f"[{MODE}] six AdamW steps on one batch: loss {losses[0]:.5f} -> {losses[-1]:.5f}")
     assert all(torch.isfinite(torch.tensor(losses))) and losses[-1] < losses[0]
