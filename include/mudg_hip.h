@@ -296,10 +296,16 @@ int mudg_groupnorm_stats(const float* X, int64_t ldx, int samples, int rows, int
 int mudg_groupnorm_bwd(const float* X, int64_t ldx, const float* dY, int64_t ldy, const float* gamma, const float* beta,
                        const float* stat, int samples, int rows, int C, int groups, int silu, float* dX, int64_t lddx, float* AB,
                        float* ws, void* stream);
-/* LayerNorm backward: dX, and prod[rows][C] = dY * xhat — dgamma is the column sum of prod, dbeta that of dY
- * (mudg_group_colsum; the caller chunks the rows so that the sums run on many workgroups). */
+/* LayerNorm backward: dX, and part[chunks][2][C] (chunks = mudg_layernorm_bwd_chunks(rows)): per chunk of rows the sums of
+ * dY * xhat (row 0) and dY (row 1) — dgamma / dbeta are their sums over the chunks (mudg_group_colsum).  C <= 1280. */
+int64_t mudg_layernorm_bwd_chunks(int64_t rows);
 int mudg_layernorm_bwd(const float* X, int64_t ldx, const float* dY, int64_t ldy, const float* gamma, float* dX, int64_t lddx,
-                       float* prod, int64_t rows, int C, float eps, void* stream);
+                       float* part, int64_t rows, int C, float eps, void* stream);
+/* One pass over fp32 rows src[P][C] (C % 4 == 0) for the three forms a layer's output gradient is needed in: dst[c][p] = src[p][c]
+ * as an operand matrix [C][ldd] (columns P .. P rounded up to 8 zero); rows (optional): the operand-row copy [P][ldr];
+ * part (optional): fp32 [ceil(P / 64)][C], the column sums of each 64-row tile (the bias gradient is their sum). */
+int mudg_transpose_cast_sum(const float* src, int64_t lds, void* dst, int64_t ldd, void* rows, int64_t ldr, float* part, int64_t P, int C,
+                            void* stream);
 /* GEGLU on H = [value | gate] rows [M][2 N] (attention.py:579-586): dY NULL -> out[M][N] = value * gelu(gate);
  * else out = dH [M][2 N]. */
 int mudg_geglu(const float* H, int64_t ldh, const float* dY, int64_t lddy, float* out, int64_t ldo, int64_t M, int N, void* stream);

@@ -71,6 +71,68 @@ __global__ __launch_bounds__(256) void transpose_gather_kernel(const float* __re
     }
 }
 
+// The gradient entering a linear / conv layer is needed three ways: transposed (left operand of the weight-gradient GEMM), as
+// operand rows (left operand of the input-gradient GEMM) and summed over the rows (bias gradient).  One pass over the fp32 rows
+// writes all three: a 64 x 64 tile per workgroup, 16-byte reads, 8-byte operand stores, and per tile the 64-row column sums
+// (fixed order) into part[tile][C] — mudg_group_colsum folds the tiles.  rows / part may be null.  C % 4 == 0.
+__global__ __launch_bounds__(256) void xpose_cast_sum_kernel(const float* __restrict__ src, int64_t lds, h16* __restrict__ dst, int64_t ldd,
+                                                              h16* __restrict__ rows, int64_t ldr, float* __restrict__ part, int64_t P,
+                                                              int64_t Ppad, int C) {
+    __shared__ float tile[64][65];
+    const int t = threadIdx.x;
+    const int64_t p0 = (int64_t)blockIdx.x * 64;
+    const int c0 = blockIdx.y * 64;
+    {
+        const int r = t >> 4, c = c0 + (t & 15) * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int64_t p = p0 + r + 16 * i;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (p < P && c < C) {
+                v = *reinterpret_cast<const f32x4*>(src + p * lds + c);
+                if (rows) {
+                    float w[4] = {v[0], v[1], v[2], v[3]};
+#pragma unroll
+                    for (int pl = 0; pl < PLANES; ++pl) {
+                        h16x4 o;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { o[e] = (h16)w[e]; w[e] -= (float)o[e]; }
+                        *reinterpret_cast<h16x4*>(rows + p * ldr + pl * (ldr / PLANES) + c) = o;
+                    }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tile[r + 16 * i][(t & 15) * 4 + e] = v[e];
+        }
+    }
+    __syncthreads();
+    {
+        const int cl = t >> 4, p4 = (t & 15) * 4;
+        if (p0 + p4 < Ppad)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = c0 + cl + 16 * i;
+                if (c >= C) continue;
+                float w[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w[e] = tile[p4 + e][cl + 16 * i];
+#pragma unroll
+                for (int pl = 0; pl < PLANES; ++pl) {
+                    h16x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { o[e] = (h16)w[e]; w[e] -= (float)o[e]; }
+                    *reinterpret_cast<h16x4*>(dst + (int64_t)c * ldd + pl * (ldd / PLANES) + p0 + p4) = o;
+                }
+            }
+    }
+    if (part && t < 64 && c0 + t < C) {
+        float sum = 0.f;
+#pragma unroll 8
+        for (int r = 0; r < 64; ++r) sum += tile[r][t];
+        part[(int64_t)blockIdx.x * C + c0 + t] = sum;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- column sums
 // out[g][c] = sum over the rows r of group g (rows_per_group consecutive rows) of a[r][c] * (b ? b[r][c] : 1).
 // One workgroup per (64 columns, group): four waves walk the rows 4 apart, their partials are folded in a fixed order.
@@ -173,32 +235,63 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
 }
 
 // ---------------------------------------------------------------------------------------------- LayerNorm backward
-// One wave per row: recomputes mean / rstd, writes dx and the row's (mean, rstd) for the parameter-gradient pass.
+// A workgroup owns LN_CHUNK consecutive rows, a wave every fourth of them: per row it recomputes mean / rstd and writes dx; the
+// parameter-gradient terms dy xhat (dgamma) and dy (dbeta) are summed per lane over the wave's rows, then over the four waves
+// in a fixed order, into part[chunk][2][C] — mudg_group_colsum folds the chunks.  Lane l owns columns l, l + 64, ... (C <= 64 LN_MAXC).
+constexpr int LN_CHUNK = 64, LN_MAXC = 20;
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ X, int64_t ldx, const float* __restrict__ dY, int64_t ldy,
                                                       const float* __restrict__ gamma, float* __restrict__ dX, int64_t lddx,
-                                                      float* __restrict__ prod, int64_t rows, int C, float eps) {
-    const int lane = threadIdx.x & 63;
-    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const float* x = X + row * ldx;
-    const float* dy = dY + row * ldy;
-    float s = 0.f;
-    for (int c = lane; c < C; c += 64) s += x[c];
-    const float mean = wave_sum(s) / (float)C;
-    float q = 0.f;
-    for (int c = lane; c < C; c += 64) { const float d = x[c] - mean; q = fmaf(d, d, q); }
-    const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
-    float m1 = 0.f, m2 = 0.f;
-    for (int c = lane; c < C; c += 64) {
-        const float dh = dy[c] * gamma[c], xh = (x[c] - mean) * rstd;
-        m1 += dh; m2 = fmaf(dh, xh, m2);
+                                                      float* __restrict__ part, int64_t rows, int C, float eps) {
+    __shared__ float red[3][2][LN_MAXC * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nc = (C + 63) / 64;
+    float ag[LN_MAXC], ab[LN_MAXC], ga[LN_MAXC];
+#pragma unroll
+    for (int j = 0; j < LN_MAXC; ++j) { ag[j] = 0.f; ab[j] = 0.f; ga[j] = (j < nc && lane + 64 * j < C) ? gamma[lane + 64 * j] : 0.f; }
+    const int64_t r0 = (int64_t)blockIdx.x * LN_CHUNK;
+    for (int64_t row = r0 + wave; row < r0 + LN_CHUNK && row < rows; row += 4) {
+        const float* x = X + row * ldx;
+        const float* dy = dY + row * ldy;
+        float xv[LN_MAXC], dv[LN_MAXC];
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < LN_MAXC; ++j) {
+            const bool ok = j < nc && lane + 64 * j < C;
+            xv[j] = ok ? x[lane + 64 * j] : 0.f;
+            dv[j] = ok ? dy[lane + 64 * j] : 0.f;
+            s += xv[j];
+        }
+        const float mean = wave_sum(s) / (float)C;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < LN_MAXC; ++j) if (j < nc && lane + 64 * j < C) { const float d = xv[j] - mean; q = fmaf(d, d, q); }
+        const float rstd = rsqrtf(wave_sum(q) / (float)C + eps);
+        float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < LN_MAXC; ++j) if (j < nc && lane + 64 * j < C) {
+            const float dh = dv[j] * ga[j], xh = (xv[j] - mean) * rstd;
+            m1 += dh; m2 = fmaf(dh, xh, m2);
+        }
+        m1 = wave_sum(m1) / (float)C; m2 = wave_sum(m2) / (float)C;
+#pragma unroll
+        for (int j = 0; j < LN_MAXC; ++j) if (j < nc && lane + 64 * j < C) {
+            const float xh = (xv[j] - mean) * rstd;
+            dX[row * lddx + lane + 64 * j] = rstd * (dv[j] * ga[j] - m1 - xh * m2);
+            ag[j] = fmaf(dv[j], xh, ag[j]);
+            ab[j] += dv[j];
+        }
     }
-    m1 = wave_sum(m1) / (float)C; m2 = wave_sum(m2) / (float)C;
-    for (int c = lane; c < C; c += 64) {
-        const float xh = (x[c] - mean) * rstd;
-        dX[row * lddx + c] = rstd * (dy[c] * gamma[c] - m1 - xh * m2);
-        prod[row * (int64_t)C + c] = dy[c] * xh;          // dgamma = its column sum (mudg_group_colsum, chunked by the caller)
-    }
+    if (wave > 0)
+#pragma unroll
+        for (int j = 0; j < LN_MAXC; ++j) if (j < nc) { red[wave - 1][0][j * 64 + lane] = ag[j]; red[wave - 1][1][j * 64 + lane] = ab[j]; }
+    __syncthreads();
+    if (wave == 0)
+#pragma unroll
+        for (int j = 0; j < LN_MAXC; ++j) if (j < nc && lane + 64 * j < C) {
+            const int i = j * 64 + lane;
+            part[((int64_t)blockIdx.x * 2 + 0) * C + lane + 64 * j] = ((ag[j] + red[0][0][i]) + red[1][0][i]) + red[2][0][i];
+            part[((int64_t)blockIdx.x * 2 + 1) * C + lane + 64 * j] = ((ab[j] + red[0][1][i]) + red[1][1][i]) + red[2][1][i];
+        }
 }
 
 // ---------------------------------------------------------------------------------------------- GEGLU (unfused, training)
@@ -491,12 +584,28 @@ int mudg_groupnorm_stats(const float* X, int64_t ldx, int samples, int rows, int
     return mudg_check_launch("mudg_groupnorm_stats");
 }
 
-int mudg_layernorm_bwd(const float* X, int64_t ldx, const float* dY, int64_t ldy, const float* gamma, float* dX, int64_t lddx, float* prod,
+int64_t mudg_layernorm_bwd_chunks(int64_t rows) { return (rows + LN_CHUNK - 1) / LN_CHUNK; }
+
+int mudg_layernorm_bwd(const float* X, int64_t ldx, const float* dY, int64_t ldy, const float* gamma, float* dX, int64_t lddx, float* part,
                        int64_t rows, int C, float eps, void* stream) {
-    MUDG_REQUIRE(X && dY && gamma && dX && prod && rows > 0 && C > 0, "mudg_layernorm_bwd: bad arguments");
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), X, ldx, dY, ldy, gamma,
-                       dX, lddx, prod, rows, C, eps);
+    MUDG_REQUIRE(X && dY && gamma && dX && part && rows > 0 && C > 0, "mudg_layernorm_bwd: bad arguments");
+    MUDG_REQUIRE(C <= 64 * LN_MAXC, "mudg_layernorm_bwd: C=%d above %d", C, 64 * LN_MAXC);
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3((unsigned)mudg_layernorm_bwd_chunks(rows)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), X, ldx,
+                       dY, ldy, gamma, dX, lddx, part, rows, C, eps);
     return mudg_check_launch("mudg_layernorm_bwd");
+}
+
+int mudg_transpose_cast_sum(const float* src, int64_t lds, void* dst, int64_t ldd, void* rows, int64_t ldr, float* part, int64_t P, int C,
+                            void* stream) {
+    MUDG_REQUIRE(src && dst && P > 0 && C > 0 && (C & 3) == 0 && (lds & 3) == 0, "mudg_transpose_cast_sum: bad arguments (C and the row stride must be multiples of 4)");
+    const int64_t Ppad = (P + 7) / 8 * 8;
+    MUDG_REQUIRE(ldd % PLANES == 0 && ldd / PLANES >= Ppad && ((ldd / PLANES) & 3) == 0, "mudg_transpose_cast_sum: ldd=%lld too small for %lld columns", (long long)ldd, (long long)Ppad);
+    MUDG_REQUIRE(!rows || (ldr % PLANES == 0 && ldr / PLANES >= C && ((ldr / PLANES) & 3) == 0), "mudg_transpose_cast_sum: ldr=%lld", (long long)ldr);
+    MUDG_REQUIRE((reinterpret_cast<uintptr_t>(src) & 15u) == 0 && (reinterpret_cast<uintptr_t>(dst) & 7u) == 0 && (reinterpret_cast<uintptr_t>(rows) & 7u) == 0,
+                 "mudg_transpose_cast_sum: alignment");
+    hipLaunchKernelGGL(xpose_cast_sum_kernel, dim3((unsigned)((Ppad + 63) / 64), (unsigned)((C + 63) / 64)), dim3(256), 0,
+                       reinterpret_cast<hipStream_t>(stream), src, lds, (h16*)dst, ldd, (h16*)rows, ldr, part, P, Ppad, C);
+    return mudg_check_launch("mudg_transpose_cast_sum");
 }
 
 int mudg_geglu(const float* H, int64_t ldh, const float* dY, int64_t lddy, float* out, int64_t ldo, int64_t M, int N, void* stream) {

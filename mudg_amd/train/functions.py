@@ -16,15 +16,35 @@ contractions map onto the forward GEMM kernel (mudg_gemm: Y[m][n] = sum_k X[m][k
 
 Reference semantics: lvdm/modules/attention.py, lvdm/modules/networks/openaimodel3d.py (forward), torch.autograd (backward);
 checked against autograd of the CPU oracle in tests/test_training_gpu.py."""
+import collections
+import weakref
+
 import torch
 
 from .. import hip, ops
 from . import kernels as K
 
 
+_recent_operands = collections.deque(maxlen=4)
+
+
 def op(t):
-    """fp32 rows (any row stride) -> MFMA operand rows."""
+    """fp32 rows (any row stride) -> MFMA operand rows.  A producer that computed the operand form anyway (the norms) leaves a
+    weak reference to it on its fp32 output; it is taken while it is still alive and the tensor unchanged."""
+    tag = getattr(t, "_mudg_operand", None)
+    if tag is not None and tag[0] == t._version:
+        cached = tag[1]()
+        if cached is not None:
+            return cached
     return ops.cast_bf16(t)
+
+
+def _with_operand(y32, y16):
+    """Attach the operand form a kernel produced to its fp32 copy; the last few stay alive (the consumers of a norm follow it
+    directly), older ones are freed — nothing is added to what the backward pass keeps."""
+    _recent_operands.append(y16)
+    y32._mudg_operand = (y32._version, weakref.ref(y16))
+    return y32
 
 
 def _pad8(n):
@@ -91,6 +111,17 @@ def transposed(src, m, n, **kw):
     return K.transpose_gather(src, P=p, out=_zeros_operand(src.shape[1], _width(m, n, p), src.device, _pad8(p)), **kw)
 
 
+def grad_forms(dy, m, n, rows, sums):
+    """The forms a layer's output gradient dy [P][m] is needed in for an [m][n] weight gradient: (dy^T wide enough for the K-slices,
+    operand rows or None, column sums or None) — one pass over dy when its width allows 16-byte accesses."""
+    p = dy.shape[0]
+    if dy.shape[1] % 8 or dy.stride(0) % 4:
+        return transposed(dy, m, n), (op(_pad_cols(dy, _pad8(dy.shape[1]))) if rows else None), (K.group_colsum(dy)[0] if sums else None)
+    out = _zeros_operand(dy.shape[1], _width(m, n, p), dy.device, _pad8(p))
+    r, s = K.transpose_cast_sum(dy, out, rows, sums)
+    return out, r, s
+
+
 def transposed_taps(x, m, ci, p, taps, mode, geo):
     """[len(taps) * ci][width]: for every tap the transposed copy of the input pixels it read — the right-hand operand of ONE
     weight-gradient GEMM over all taps (N = taps * Cin: more tiles, one launch)."""
@@ -117,17 +148,17 @@ class Linear(torch.autograd.Function):
         dy = dy.contiguous()
         n, k = w2.shape
         dx = dw = db = None
-        npad = _pad8(n)
-        dyo = op(_pad_cols(dy, npad))
+        want_b = ctx.has_b and _need(ctx, 2)
+        if _need(ctx, 1):
+            dyt, dyo, db = grad_forms(dy, n, k, _need(ctx, 0), want_b)
+        else:
+            dyo = op(_pad_cols(dy, _pad8(n))) if _need(ctx, 0) else None
+            db = K.group_colsum(dy)[0] if want_b else None
         if _need(ctx, 0):
             wt = K.transpose_gather(w2)                                  # [K][N padded]
             dx = ops.gemm(dyo, wt, out_fp32=True)
         if _need(ctx, 1):
-            m = x.shape[0]
-            dyt, xt = transposed(dy, n, k), transposed(x, n, k)          # [N][M padded], [K][M padded]
-            dw = wgrad_gemm(dyt, xt, n, k, m).reshape(ctx.wshape)
-        if ctx.has_b and _need(ctx, 2):
-            db = K.group_colsum(dy)[0]
+            dw = wgrad_gemm(dyt, transposed(x, n, k), n, k, x.shape[0]).reshape(ctx.wshape)
         return dx, dw, db, (dy if ctx.has_r else None)
 
 
@@ -172,20 +203,23 @@ class Conv3x3(torch.autograd.Function):
         ho, wo = (h - 1) // stride + 1, (wd - 1) // stride + 1
         dy = dy.contiguous()
         dx = dw = db = dg = None
+        want_b = has_b and _need(ctx, 2)
+        dyo = None
+        if _need(ctx, 1):
+            dyt, dyo, db = grad_forms(dy, co, 9 * ci, _need(ctx, 0) and stride == 1, want_b)       # [Cout][P padded], rows, sums
+        elif want_b:
+            db = K.group_colsum(dy)[0]
         if _need(ctx, 0):
             copad = _pad8(co)
-            src = dy if stride == 1 else K.dilate2x(dy, frames, ho, wo, h, wd)
-            dx = ops.conv3x3(op(_pad_cols(src, copad)), op(_conv_weight_flipped(w, copad)), frames=frames, hin=h, win=wd, cin=copad,
-                             out_fp32=True)
+            if dyo is None:
+                dyo = op(_pad_cols(dy if stride == 1 else K.dilate2x(dy, frames, ho, wo, h, wd), copad))
+            dx = ops.conv3x3(dyo, op(_conv_weight_flipped(w, copad)), frames=frames, hin=h, win=wd, cin=copad, out_fp32=True)
         if _need(ctx, 1):
             p = frames * ho * wo
-            dyt = transposed(dy, co, 9 * ci)                             # [Cout][P padded]
             g = dict(Hin=h, Win=wd, Hout=ho, Wout=wo, stride=stride, pad=1)
             taps = [dict(dy=ky, dx=kx) for ky in range(3) for kx in range(3)]
             xt = transposed_taps(x, co, ci, p, taps, 1, g)               # [9 Cin][P padded]: what each tap read
             dw = wgrad_gemm(dyt, xt, co, 9 * ci, p).reshape(co, 3, 3, ci).permute(0, 3, 1, 2).contiguous()
-        if has_b and _need(ctx, 2):
-            db = K.group_colsum(dy)[0]
         if has_g and _need(ctx, 3):
             dg = K.group_colsum(dy, rows_per_group=ctx.rpg)
         return dx, dw, db, dg, (dy if has_r else None), None, None
@@ -212,16 +246,19 @@ class TConv3(torch.autograd.Function):
         co, ci = w.shape[:2]
         dy = dy.contiguous()
         dx = dw = db = None
+        want_b = has_b and _need(ctx, 2)
+        if _need(ctx, 1):
+            dyt, dyo, db = grad_forms(dy, co, 3 * ci, _need(ctx, 0), want_b)
+        else:
+            dyo = op(dy) if _need(ctx, 0) else None
+            db = K.group_colsum(dy)[0] if want_b else None
         if _need(ctx, 0):
             wf = w[:, :, :, 0, 0].flip(2).permute(1, 2, 0).reshape(ci, 3 * co).contiguous()        # [Cin][tap'][Cout]
-            dx = ops.tconv3(op(dy), op(wf), clips=clips, t=t, hw=hw, cin=co, out_fp32=True)
+            dx = ops.tconv3(dyo, op(wf), clips=clips, t=t, hw=hw, cin=co, out_fp32=True)
         if _need(ctx, 1):
             p = x.shape[0]
-            dyt = transposed(dy, co, 3 * ci)
             xt = transposed_taps(x, co, ci, p, [dict(dt=d) for d in range(3)], 2, dict(T=t, HW=hw))
             dw = wgrad_gemm(dyt, xt, co, 3 * ci, p).reshape(co, 3, ci).permute(0, 2, 1).reshape(co, ci, 3, 1, 1).contiguous()
-        if has_b and _need(ctx, 2):
-            db = K.group_colsum(dy)[0]
         return dx, dw, db, (dy if has_r else None), None
 
 
@@ -235,7 +272,7 @@ class GroupNorm(torch.autograd.Function):
         y, stat = ops.groupnorm(x, g, b, samples=samples, rows=rows, eps=eps, silu=silu, groups=groups, return_stats=True)
         ctx.save_for_backward(x, g, b, stat)         # (mean, rstd) per (sample, group) as the forward kernels computed them
         ctx.args = (samples, rows, eps, silu, groups)
-        return ops.to_f32(y)
+        return _with_operand(ops.to_f32(y), y)
 
     @staticmethod
     def backward(ctx, dy):
@@ -251,7 +288,8 @@ class LayerNorm(torch.autograd.Function):
         g, b = gamma.float().contiguous(), beta.float().contiguous()
         ctx.save_for_backward(x, g)
         ctx.eps = eps
-        return ops.to_f32(ops.layernorm(x, g, b, eps=eps))
+        y = ops.layernorm(x, g, b, eps=eps)
+        return _with_operand(ops.to_f32(y), y)
 
     @staticmethod
     def backward(ctx, dy):

@@ -82,10 +82,25 @@ def layernorm_bwd(x, dy, gamma, eps):
     _f32(x); _f32(dy)
     rows, c = x.shape
     dx = torch.empty_like(x)
-    prod = torch.empty((rows, c), dtype=torch.float32, device=x.device)
+    chunks = hip.lib().mudg_layernorm_bwd_chunks(rows)
+    part = torch.empty((chunks, 2 * c), dtype=torch.float32, device=x.device)           # per chunk of rows: [sum dy xhat | sum dy]
     hip.check(hip.lib().mudg_layernorm_bwd(x.data_ptr(), x.stride(0), dy.data_ptr(), dy.stride(0), gamma.data_ptr(), dx.data_ptr(), dx.stride(0),
-                                           prod.data_ptr(), rows, c, eps, _s()), "mudg_layernorm_bwd")
-    return dx, group_colsum(prod)[0], group_colsum(dy)[0]
+                                           part.data_ptr(), rows, c, eps, _s()), "mudg_layernorm_bwd")
+    sums = group_colsum(part)[0]
+    return dx, sums[:c], sums[c:]
+
+
+def transpose_cast_sum(src, out, rows=False, sums=False):
+    """mudg_transpose_cast_sum: one pass over fp32 rows `src` [P][C] writing out[c][p] (operand matrix, the caller's), and on
+    request the operand-row copy and the column sums.  Returns (rows or None, sums or None)."""
+    _f32(src)
+    P, c = src.shape
+    r = ops.empty_rows(P, c, ops.H16(), src.device) if rows else None
+    part = torch.empty(((P + 63) // 64, c), dtype=torch.float32, device=src.device) if sums else None
+    hip.check(hip.lib().mudg_transpose_cast_sum(src.data_ptr(), src.stride(0), out.data_ptr(), out.stride(0), None if r is None else r.data_ptr(),
+                                                0 if r is None else r.stride(0), None if part is None else part.data_ptr(), P, c, _s()),
+              "mudg_transpose_cast_sum")
+    return r, (group_colsum(part)[0] if sums else None)
 
 
 def geglu(h, dy=None):
