@@ -104,11 +104,31 @@ def _zeros_operand(rows, width, device, written=0):
     return out
 
 
+_recent_transposes = collections.deque(maxlen=2)
+
+
 def transposed(src, m, n, **kw):
     """transpose_gather into a zero-initialised operand matrix wide enough for the K-slices of the [m][n] weight gradient that
-    contracts over it."""
+    contracts over it.  A plain transpose is remembered on `src` (weakly, the last two stay alive): the q / k / v projections of an
+    attention layer read the same input and run their backward passes one after the other."""
     p = kw.pop("P", None) or src.shape[0]
-    return K.transpose_gather(src, P=p, out=_zeros_operand(src.shape[1], _width(m, n, p), src.device, _pad8(p)), **kw)
+    width = _width(m, n, p)
+    plain = not kw and p == src.shape[0]
+    if plain:
+        tag = getattr(src, "_mudg_transposed", None)
+        if tag is not None and tag[0] == (src._version, width):
+            cached = tag[1]()
+            if cached is not None:
+                return cached
+    out = _zeros_operand(src.shape[1], width, src.device, _pad8(p))
+    if plain and src.shape[1] % 4 == 0 and src.stride(0) % 4 == 0 and src.data_ptr() % 16 == 0:
+        K.transpose_cast_sum(src, out)
+    else:
+        K.transpose_gather(src, P=p, out=out, **kw)
+    if plain:
+        _recent_transposes.append(out)
+        src._mudg_transposed = ((src._version, width), weakref.ref(out))
+    return out
 
 
 def grad_forms(dy, m, n, rows, sums):

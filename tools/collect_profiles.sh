@@ -32,8 +32,11 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pw -- python bench.py --steps 
 python tools/rocprof_summary.py pmc $(find /tmp/pw -name "*.db" | head -1) > $OUT/pmc_write.md
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d /tmp/pm -- python bench.py --steps 1 --warmup 0 --no-graph --no-cpu-baseline --no-profile --no-decode --no-at-tolerance > /tmp/pm.log 2>&1
 python tools/rocprof_summary.py mfma $(find /tmp/pm -name "*.db" | head -1) > $OUT/pmc_mfma.md
-# the training step of the full UNet at MDM512: seconds per step, peak memory (untuned baseline)
-timeout 900 python tools/train_bench.py 512 2 2>/dev/null | tail -4 > $OUT/train_bench512.log
-timeout 900 python tools/train_bench.py 512 2 ckpt 2>/dev/null | tail -1 >> $OUT/train_bench512.log
+# the training step of the full UNet: seconds per step, peak memory
+timeout 900 python tools/train_bench.py 512 3 2>/dev/null | tail -1 > $OUT/train_bench.log
+timeout 900 python tools/train_bench.py 1024 2 2>/dev/null | tail -1 >> $OUT/train_bench.log
+timeout 900 python tools/train_bench.py 1024 2 ckpt 2>/dev/null | tail -1 >> $OUT/train_bench.log
+rocprofv3 --kernel-trace --stats -d /tmp/ptr -- python tools/train_bench.py 1024 2 > /tmp/ptr.log 2>&1
+python tools/rocprof_summary.py trace $(find /tmp/ptr -name "*.db" | head -1) > $OUT/train1024_kernel_trace.md
 rm -f $OUT/bench_n1.raw
 ls -la $OUT
