@@ -349,6 +349,11 @@ int mudg_dilate2x(const float* src, float* dst, int F, int ho, int wo, int hi, i
 /* torch.optim.AdamW step (decoupled weight decay, bias correction with `step` >= 1), fp32, in place. */
 int mudg_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                float weight_decay, int step, void* stream);
+/* torch.nn.utils.clip_grad_norm_ over many fp32 tensors with no host round trip (the reference's trainer: gradient_clip_val 0.5,
+ * norm).  table: device int64 [nchunks][2] = (address, count <= mudg_clip_chunk()) covering every gradient; partial: fp64 [nchunks]
+ * scratch; out: float [2] = (total 2-norm, clip coefficient min(1, max_norm / (norm + 1e-6))); the gradients are scaled in place. */
+int mudg_clip_chunk(void);
+int mudg_clip_grad_norm(const int64_t* table, int nchunks, double* partial, float max_norm, float* out, void* stream);
 /* Inverted dropout out[i] = keep(seed, i) ? x[i] / (1 - p) : 0 with a counter-based mask (the backward pass applies the same
  * call to the gradient: nothing is stored). */
 int mudg_dropout(const float* x, float* out, int64_t n, float p, uint64_t seed, void* stream);

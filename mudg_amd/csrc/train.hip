@@ -480,6 +480,50 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
     p[i] = pi - (lr / bc1) * (mi / denom);
 }
 
+// Global gradient norm and clipping over many tensors without a host round trip (torch.nn.utils.clip_grad_norm_ semantics: the
+// reference's trainer clips to norm 0.5).  `table` lists chunks of at most CLIP_CHUNK fp32 values as (address, count) pairs; one
+// workgroup sums the squares of a chunk in fp64 (fixed order), one workgroup then folds the chunk sums in order and writes
+// out[0] = the norm, out[1] = min(1, max_norm / (norm + 1e-6)); the scale pass multiplies every chunk by out[1].
+constexpr int CLIP_CHUNK = 16384;
+__global__ __launch_bounds__(256) void chunk_sumsq_kernel(const int64_t* __restrict__ table, double* __restrict__ partial) {
+    __shared__ double red[256];
+    const float* x = reinterpret_cast<const float*>(table[2 * blockIdx.x]);
+    const int n = (int)table[2 * blockIdx.x + 1];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) { const double v = (double)x[i]; s += v * v; }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+__global__ __launch_bounds__(256) void norm_fold_kernel(const double* __restrict__ partial, int nchunks, float max_norm, float* __restrict__ out) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nchunks; i += 256) s += partial[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float norm = (float)sqrt(red[0]);
+        out[0] = norm;
+        const float coef = max_norm / (norm + 1e-6f);
+        out[1] = coef < 1.0f ? coef : 1.0f;
+    }
+}
+__global__ __launch_bounds__(256) void chunk_scale_kernel(const int64_t* __restrict__ table, const float* __restrict__ out) {
+    const float coef = out[1];
+    if (coef == 1.0f) return;
+    float* x = reinterpret_cast<float*>(table[2 * blockIdx.x]);
+    const int n = (int)table[2 * blockIdx.x + 1];
+    for (int i = threadIdx.x; i < n; i += 256) x[i] *= coef;
+}
+
 __global__ void silu_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ out, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -674,6 +718,17 @@ int mudg_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr
     hipLaunchKernelGGL(adamw_kernel, dim3(blocks_for(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), p, g, m, v, n, lr, beta1, beta2, eps,
                        weight_decay, bc1, bc2);
     return mudg_check_launch("mudg_adamw");
+}
+
+int mudg_clip_chunk(void) { return CLIP_CHUNK; }
+
+int mudg_clip_grad_norm(const int64_t* table, int nchunks, double* partial, float max_norm, float* out, void* stream) {
+    MUDG_REQUIRE(table && partial && out && nchunks > 0 && max_norm > 0.f, "mudg_clip_grad_norm: bad arguments");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(chunk_sumsq_kernel, dim3((unsigned)nchunks), dim3(256), 0, s, table, partial);
+    hipLaunchKernelGGL(norm_fold_kernel, dim3(1), dim3(256), 0, s, partial, nchunks, max_norm, out);
+    hipLaunchKernelGGL(chunk_scale_kernel, dim3((unsigned)nchunks), dim3(256), 0, s, table, out);
+    return mudg_check_launch("mudg_clip_grad_norm");
 }
 
 int mudg_dropout(const float* x, float* out, int64_t n, float p, uint64_t seed, void* stream) {

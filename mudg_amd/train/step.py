@@ -1,4 +1,5 @@
-"""The training step around the UNet: v-prediction loss (p_losses), AdamW on the HIP kernel, data-parallel gradient all-reduce.
+"""The training step around the UNet: v-prediction loss (p_losses), gradient-norm clipping and AdamW on HIP kernels, data-parallel
+gradient all-reduce.
 
 Reference: lvdm/models/ddpm3d.py:741-802 (p_losses), :1267-1300 (configure_optimizers -> torch.optim.AdamW(params, lr)),
 main/utils_train.py:126-137 (data-parallel strategy: one process per GPU, gradients averaged after backward)."""
@@ -73,6 +74,41 @@ class AdamW(torch.optim.Optimizer):
         return loss
 
 
+class GradientClipper:
+    """torch.nn.utils.clip_grad_norm_(params, max_norm) (2-norm) as the reference's trainer applies it between backward and the
+    optimiser step (configs/stage2-1024_mdm_waymo/config.yaml: gradient_clip_val 0.5, gradient_clip_algorithm norm), on HIP
+    kernels and without a host round trip: the norm and the clip coefficient stay on the device.  The chunk table is rebuilt
+    only when a gradient tensor moved."""
+
+    def __init__(self, params, max_norm):
+        self.params = [p for p in params if p.requires_grad]
+        self.max_norm = float(max_norm)
+        self._key, self._table, self._partial = None, None, None
+
+    @torch.no_grad()
+    def __call__(self):
+        """Scales the gradients in place; returns the device tensor [norm, coefficient]."""
+        from .. import hip
+        grads = [p.grad for p in self.params if p.grad is not None]
+        if not grads:
+            return None
+        for g in grads:
+            if not g.is_cuda or g.dtype != torch.float32 or not g.is_contiguous():
+                raise RuntimeError("GradientClipper works on contiguous fp32 gradients on the GPU")
+        key = tuple((g.data_ptr(), g.numel()) for g in grads)
+        dev = grads[0].device
+        if key != self._key:
+            chunk = hip.lib().mudg_clip_chunk()
+            rows = [(ptr + 4 * off, min(chunk, n - off)) for ptr, n in key for off in range(0, n, chunk)]
+            self._table = torch.tensor(rows, dtype=torch.int64).to(dev)
+            self._partial = torch.empty(len(rows), dtype=torch.float64, device=dev)
+            self._key = key
+        out = torch.empty(2, dtype=torch.float32, device=dev)
+        hip.check(hip.lib().mudg_clip_grad_norm(self._table.data_ptr(), self._table.shape[0], self._partial.data_ptr(), self.max_norm,
+                                                out.data_ptr(), torch.cuda.current_stream().cuda_stream), "mudg_clip_grad_norm")
+        return out
+
+
 class GradientAllReducer:
     """Data-parallel gradient averaging: the gradients of `params` are packed into flat fp32 buckets of about `bucket_mb` MiB (one
     collective per bucket instead of one per tensor: xGMI rings are per-link bound, large messages amortise their latency),
@@ -127,12 +163,17 @@ class GradientAllReducer:
         return len(self.buckets)
 
 
-def training_step(model, x_start, cond, t, optimizer, reducer=None, noise=None, **kwargs):
-    """One optimisation step: zero_grad -> p_losses -> backward -> (gradient all-reduce) -> AdamW.  Returns (loss, loss_dict)."""
+def training_step(model, x_start, cond, t, optimizer, reducer=None, noise=None, clipper=None, **kwargs):
+    """One optimisation step as the reference's trainer runs it: zero_grad -> p_losses -> backward -> (gradient all-reduce) ->
+    (gradient-norm clipping) -> AdamW.  Returns (loss, loss_dict); with a clipper, loss_dict["grad_norm"] is the device scalar."""
     optimizer.zero_grad(set_to_none=True)
     loss, info = p_losses(model, x_start, cond, t, noise=noise, **kwargs)
     loss.backward()
     if reducer is not None:
         reducer()
+    if clipper is not None:
+        stat = clipper()
+        if stat is not None:
+            info = dict(info, grad_norm=stat[0])
     optimizer.step()
     return loss.detach(), info

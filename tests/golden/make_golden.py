@@ -549,6 +549,13 @@ def golden_yaml():
     for tag, name in (("1024", "stage2-1024_mdm_waymo_infer.yaml"), ("512", "stage1-512_mdm_waymo_infer.yaml")):
         with open(os.path.join(REF, "configs", name)) as f:
             out[tag] = yaml.safe_load(f)["model"]
+    # the training configs: the model section and the trainer settings that shape one optimisation step
+    for tag, name in (("train1024", "stage2-1024_mdm_waymo/config.yaml"), ("train512", "stage1-512_mdm_waymo/config.yaml")):
+        with open(os.path.join(REF, "configs", name)) as f:
+            cfg = yaml.safe_load(f)
+        out[tag] = dict(cfg["model"], lightning={"precision": cfg["lightning"].get("precision"),
+                                                 "trainer": {k: cfg["lightning"]["trainer"].get(k) for k in
+                                                             ("accumulate_grad_batches", "gradient_clip_algorithm", "gradient_clip_val")}})
     path = os.path.join(HERE, "mdm_yaml.json")
     with open(path, "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)

@@ -297,6 +297,54 @@ def test_condition_shim_resolves_external_towers_or_explains(tmp_path, monkeypat
     sys.modules.pop("fake_condition", None)
 
 
+@pytest.mark.parametrize("tag", ["train1024", "train512"])
+def test_training_yaml_instantiates_unchanged_with_the_reference_trainable_set(tag, tmp_path, monkeypatch):
+    """configs/stage{2-1024,1-512}_mdm_waymo/config.yaml (the TRAINING configs): the model section instantiates through this
+    overlay as it stands, the temporal transformers come out frozen (temporal_frozen: true, attention.py:522-527), the Resampler
+    joins the optimiser (image_proj_model_trainable, ddpm3d.py:1276-1279), and the trainer settings that shape a step — clip the
+    gradient 2-norm to 0.5, AdamW at base_learning_rate — are what mudg_amd.train.step implements."""
+    import sys
+    import lvdm.modules.encoders.condition as cond
+    (tmp_path / "fake_condition_t.py").write_text(
+        "import torch.nn as nn\n"
+        "class FrozenOpenCLIPEmbedder(nn.Module):\n"
+        "    def __init__(self, freeze=True, layer='last'):\n"
+        "        super().__init__()\n"
+        "class FrozenOpenCLIPImageEmbedderV2(nn.Module):\n"
+        "    def __init__(self, freeze=True):\n"
+        "        super().__init__()\n")
+    monkeypatch.syspath_prepend(str(tmp_path))
+    monkeypatch.setenv("MUDG_CONDITION_MODULE", "fake_condition_t")
+    monkeypatch.setattr(cond, "_external", None)
+    from utils.utils import instantiate_from_config
+    cfg = _yaml_model(tag)
+    assert cfg["lightning"]["trainer"] == {"accumulate_grad_batches": 2, "gradient_clip_algorithm": "norm", "gradient_clip_val": 0.5}
+    frozen_flag = cfg["params"]["unet_config"]["params"].get("temporal_frozen", False)
+    assert frozen_flag is (tag == "train1024") and cfg["params"]["use_ema"] is False       # stage 2 freezes, stage 1 trains everything
+    with torch.device("meta"):
+        model = instantiate_from_config(cfg)
+    unet = model.model.diffusion_model
+    # stage 2: every TemporalTransformer of the stages is frozen; the one in init_attn is built without the flag
+    # (openaimodel3d.py:405-414) and stays trainable
+    first = unet.init_attn[0]
+    temporal = [m for m in unet.modules() if type(m).__name__ == "TemporalTransformer" and m is not first]
+    assert len(temporal) == 16 and all(p.requires_grad is not frozen_flag for m in temporal for p in m.parameters())
+    assert type(first).__name__ == "TemporalTransformer" and all(p.requires_grad for p in first.parameters())
+    frozen = sum(p.numel() for p in unet.parameters() if not p.requires_grad)
+    assert (frozen > 0) is frozen_flag and frozen < sum(p.numel() for p in unet.parameters())
+    assert all(p.requires_grad for m in unet.modules() if type(m).__name__ == "SpatialTransformer" for p in m.parameters())
+    model.learning_rate = cfg["base_learning_rate"]
+    opt = model.configure_optimizers()
+    from mudg_amd.train import step
+    assert isinstance(opt, step.AdamW) and opt.param_groups[0]["lr"] == cfg["base_learning_rate"]
+    ids = {id(p) for g in opt.param_groups for p in g["params"]}
+    assert all(id(p) in ids for p in model.image_proj_model.parameters())              # image_proj_model_trainable: True
+    assert all((id(p) in ids) == p.requires_grad for p in unet.parameters())
+    clip = step.GradientClipper([p for g in opt.param_groups for p in g["params"]], cfg["lightning"]["trainer"]["gradient_clip_val"])
+    assert clip.max_norm == 0.5 and len(clip.params) == len(ids)
+    sys.modules.pop("fake_condition_t", None)
+
+
 def test_reference_helper_names_exist_in_the_overlay():
     """Names MuDG modules import from the overlaid packages: lvdm.common and utils.utils."""
     import lvdm.common as c

@@ -142,6 +142,13 @@ def test_attention_gradients_self_cross_two_sets_and_temporal(cuda):
     compare("two frames per key batch, 200 queries, 150 keys", *run_both(
         lambda q, k, v: Fn.Attention.apply(q, k, v, None, None, (4, heads, 200, 150, 2, 0, 1, 0.125)),
         lambda q, k, v: _attn_ref(q, k, v, 4, heads, 200, 150, 2, 0.125), t, cuda))
+    # no atomics, fixed summation order: the same inputs give the same bits
+    q1, k1, v1 = (x.to(cuda).requires_grad_() for x in (t["q"], t["k"], t["v"]))
+    grads = []
+    for _ in range(2):
+        out = Fn.Attention.apply(q1, k1, v1, None, None, (4, heads, 200, 150, 2, 0, 1, 0.125))
+        grads.append(torch.autograd.grad(out.square().sum(), (q1, k1, v1)))
+    assert all(torch.equal(a, b) for a, b in zip(*grads)), "attention backward is not bit-reproducible"
     T = 2      # text keys shared by the T frames of a clip (77 tokens, not a multiple of 8) + per-frame image keys, summed
     t = dict(q=rnd(frames * n, c, seed=1), k=rnd(frames // T * 77, c, seed=2), v=rnd(frames // T * 77, c, seed=3),
              k2=rnd(frames * 16, c, seed=4), v2=rnd(frames * 16, c, seed=5))
@@ -288,6 +295,28 @@ def test_full_width_unet_gradients_match_autograd_of_the_cpu_oracle(cuda):
     print(f"[{MODE}] full-width UNet ({sum(p.numel() for p in unet.parameters()) / 1e9:.2f} B parameters, {n} tensors): gradients vs oracle autograd "
           f"overall rel-L2 {total:.3e}, worst single tensor {worst:.3e} (bound {TOL_NET:g} overall)")
     assert total < TOL_NET
+
+
+def test_gradient_clipping_equals_torch_clip_grad_norm(cuda):
+    """The reference's trainer clips the global gradient 2-norm to 0.5 (configs/stage2-1024_mdm_waymo/config.yaml); GradientClipper
+    does it on the device: same norm, same scaled gradients as torch.nn.utils.clip_grad_norm_, ragged tensor sizes included."""
+    from mudg_amd.train import step
+    shapes = [(5,), (300, 7), (16384,), (16385,), (3, 3, 64, 64), (1,)]
+    for scale, clipped in ((1.0, True), (1e-4, False)):               # above the bound (scaled down) and below it (untouched)
+        mine = [torch.nn.Parameter(torch.zeros(sh, device=cuda)) for sh in shapes]
+        ref = [torch.nn.Parameter(torch.zeros(sh, device=cuda)) for sh in shapes]
+        for i, (a, b) in enumerate(zip(mine, ref)):
+            g = (rnd(*shapes[i], seed=20 + i) * scale).to(cuda)
+            a.grad, b.grad = g.clone(), g.clone()
+        clip = step.GradientClipper(mine, 0.5)
+        stat = clip()
+        want = torch.nn.utils.clip_grad_norm_(ref, 0.5)
+        assert abs(float(stat[0]) - float(want)) <= 1e-6 * float(want)
+        assert (float(stat[1]) < 1.0) == clipped
+        for a, b in zip(mine, ref):
+            check(f"clipped gradient {tuple(a.shape)}", a.grad, b.grad, 1e-6)
+        again = clip()                                                 # the table is reused; the norm is now min(norm, 0.5)
+        assert float(again[0]) <= 0.5 * (1 + 1e-5) + 1e-12
 
 
 def test_adamw_step_matches_torch_and_training_reduces_the_loss(cuda):

@@ -36,6 +36,7 @@ python tools/rocprof_summary.py mfma $(find /tmp/pm -name "*.db" | head -1) > $O
 timeout 900 python tools/train_bench.py 512 3 2>/dev/null | tail -1 > $OUT/train_bench.log
 timeout 900 python tools/train_bench.py 1024 2 2>/dev/null | tail -1 >> $OUT/train_bench.log
 timeout 900 python tools/train_bench.py 1024 2 ckpt 2>/dev/null | tail -1 >> $OUT/train_bench.log
+timeout 900 python tools/train_bench.py 1024 2 stage2 2>/dev/null | tail -1 >> $OUT/train_bench.log
 rocprofv3 --kernel-trace --stats -d /tmp/ptr -- python tools/train_bench.py 1024 2 > /tmp/ptr.log 2>&1
 python tools/rocprof_summary.py trace $(find /tmp/ptr -name "*.db" | head -1) > $OUT/train1024_kernel_trace.md
 rm -f $OUT/bench_n1.raw

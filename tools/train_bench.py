@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """One training step (p_losses -> backward -> AdamW) of the full 1.44 B-parameter MDM UNet on ONE MI355X: seconds per step, peak
-memory.  `python tools/train_bench.py [512|1024] [steps] [ckpt]` — `ckpt` turns activation checkpointing on (use_checkpoint).
-The backward pass is built for correctness first (weight gradients as gather-transposes + GEMMs, attention backward
-by recomputation per head): this number is a baseline to improve, not a tuned figure."""
+memory.  `python tools/train_bench.py [512|1024] [steps] [ckpt] [stage2]` — `ckpt` turns activation checkpointing on
+(use_checkpoint); `stage2` applies what the reference's stage-2 training config adds to a step (configs/stage2-1024_mdm_waymo/
+config.yaml): the stages' temporal transformers frozen (temporal_frozen), the gradient 2-norm clipped to 0.5.  All parameters
+trainable and no clipping otherwise (the heavier step).  FLOP accounting: 3 x the forward, whatever is frozen."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -10,7 +11,8 @@ from mudg_amd import configs, factory
 
 res = sys.argv[1] if len(sys.argv) > 1 else "512"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-ckpt = len(sys.argv) > 3 and sys.argv[3] == "ckpt"
+ckpt = "ckpt" in sys.argv[3:]
+stage2 = "stage2" in sys.argv[3:]
 dev = torch.device("cuda:0")
 model = factory.build_synthetic_model(res, dev, seed=123).train()
 unet = model.model.diffusion_model
@@ -19,9 +21,15 @@ for m in unet.modules():
         m.use_checkpoint = ckpt
     if isinstance(getattr(m, "checkpoint", None), bool):
         m.checkpoint = ckpt
+if stage2:
+    for m in unet.modules():
+        if type(m).__name__ == "TemporalTransformer" and m is not unet.init_attn[0]:
+            m._frozen_model()
 inp = factory.synthetic_inputs(model, res, 1, dev, seed=123)
 model.learning_rate = 1e-5
 opt = model.configure_optimizers()
+from mudg_amd.train import step
+clip = step.GradientClipper([p for g in opt.param_groups for p in g["params"]], 0.5) if stage2 else None
 batch = dict(x_start=inp["x_T"], cond=inp["cond"], t=torch.tensor([500], device=dev), class_label=inp["class_label"], fs=inp["fs"])
 torch.cuda.reset_peak_memory_stats()
 times = []
@@ -30,11 +38,12 @@ for i in range(steps + 1):
     opt.zero_grad(set_to_none=True)
     loss = model.training_step(batch)
     loss.backward()
+    norm = clip() if clip is not None else None
     opt.step()
     torch.cuda.synchronize()
     times.append(time.perf_counter() - t0)
-    print(f"step {i}: loss {float(loss):.5f}  {times[-1]:.2f} s", flush=True)
+    print(f"step {i}: loss {float(loss):.5f}  {times[-1]:.2f} s" + (f"  grad norm {float(norm[0]):.3f}" if norm is not None else ""), flush=True)
 fl = 3 * configs.UNET_TFLOP[res]
 best = min(times[1:])
-print(f"MDM{res} training step (B = 1, 16 frames, checkpointing {'on' if ckpt else 'off'}): {best:.2f} s = {fl / best:.1f} TFLOP/s of the "
+print(f"MDM{res} training step (B = 1, 16 frames, checkpointing {'on' if ckpt else 'off'}{', stage-2 settings' if stage2 else ''}): {best:.2f} s = {fl / best:.1f} TFLOP/s of the "
       f"{fl:.1f} TFLOP a forward + backward costs (3 x forward); peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
