@@ -301,8 +301,21 @@ int mudg_groupnorm_bwd(const float* X, int64_t ldx, const float* dY, int64_t ldy
 int64_t mudg_layernorm_bwd_chunks(int64_t rows);
 int mudg_layernorm_bwd(const float* X, int64_t ldx, const float* dY, int64_t ldy, const float* gamma, float* dX, int64_t lddx,
                        float* part, int64_t rows, int C, float eps, void* stream);
+/* Weight gradient of a linear / 3x3 conv / temporal conv layer straight from the row-major operands of the forward pass (16-bit
+ * operand builds): out[slice][m][tap * C + c] = sum over the positions p of the slice of A[p][m] * B[src(p, tap)][c], with A = the
+ * output gradient as operand rows [P][lda], B = the layer input as operand rows [*][ldb], src as in mudg_transpose_gather (mode 0:
+ * identity, taps = 1; mode 1: 3x3 taps, tap = 3 dy + dx, taps = 9; mode 2: temporal taps, taps = 3).  M % 8 == 0, C % 64 == 0.
+ * The positions are cut into `slices` ranges of `chunk` (a multiple of 64) each; the caller adds the slabs (mudg_group_colsum). */
+typedef struct MudgWgradDesc {
+    const void* A; const void* B; float* out;
+    int64_t lda, ldb, P;
+    int M, C, taps, mode;
+    int Hin, Win, Hout, Wout, stride, pad, T, HW;
+    int slices; int64_t chunk;
+} MudgWgradDesc;
+int mudg_wgrad(const MudgWgradDesc* d, void* stream);
 /* One pass over fp32 rows src[P][C] (C % 4 == 0) for the three forms a layer's output gradient is needed in: dst[c][p] = src[p][c]
- * as an operand matrix [C][ldd] (columns P .. P rounded up to 8 zero); rows (optional): the operand-row copy [P][ldr];
+ * as an operand matrix [C][ldd] (columns P .. P rounded up to 8 zero; optional); rows (optional): the operand-row copy [P][ldr];
  * part (optional): fp32 [ceil(P / 64)][C], the column sums of each 64-row tile (the bias gradient is their sum). */
 int mudg_transpose_cast_sum(const float* src, int64_t lds, void* dst, int64_t ldd, void* rows, int64_t ldr, float* part, int64_t P, int C,
                             void* stream);

@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void transpose_gather_kernel(const float* __re
 // The gradient entering a linear / conv layer is needed three ways: transposed (left operand of the weight-gradient GEMM), as
 // operand rows (left operand of the input-gradient GEMM) and summed over the rows (bias gradient).  One pass over the fp32 rows
 // writes all three: a 64 x 64 tile per workgroup, 16-byte reads, 8-byte operand stores, and per tile the 64-row column sums
-// (fixed order) into part[tile][C] — mudg_group_colsum folds the tiles.  rows / part may be null.  C % 4 == 0.
+// (fixed order) into part[tile][C] — mudg_group_colsum folds the tiles.  dst / rows / part may each be null.  C % 4 == 0.
 __global__ __launch_bounds__(256) void xpose_cast_sum_kernel(const float* __restrict__ src, int64_t lds, h16* __restrict__ dst, int64_t ldd,
                                                               h16* __restrict__ rows, int64_t ldr, float* __restrict__ part, int64_t P,
                                                               int64_t Ppad, int C) {
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void xpose_cast_sum_kernel(const float* __rest
         }
     }
     __syncthreads();
-    {
+    if (dst) {
         const int cl = t >> 4, p4 = (t & 15) * 4;
         if (p0 + p4 < Ppad)
 #pragma unroll
@@ -641,9 +641,9 @@ int mudg_layernorm_bwd(const float* X, int64_t ldx, const float* dY, int64_t ldy
 
 int mudg_transpose_cast_sum(const float* src, int64_t lds, void* dst, int64_t ldd, void* rows, int64_t ldr, float* part, int64_t P, int C,
                             void* stream) {
-    MUDG_REQUIRE(src && dst && P > 0 && C > 0 && (C & 3) == 0 && (lds & 3) == 0, "mudg_transpose_cast_sum: bad arguments (C and the row stride must be multiples of 4)");
+    MUDG_REQUIRE(src && (dst || rows || part) && P > 0 && C > 0 && (C & 3) == 0 && (lds & 3) == 0, "mudg_transpose_cast_sum: bad arguments (C and the row stride must be multiples of 4)");
     const int64_t Ppad = (P + 7) / 8 * 8;
-    MUDG_REQUIRE(ldd % PLANES == 0 && ldd / PLANES >= Ppad && ((ldd / PLANES) & 3) == 0, "mudg_transpose_cast_sum: ldd=%lld too small for %lld columns", (long long)ldd, (long long)Ppad);
+    MUDG_REQUIRE(!dst || (ldd % PLANES == 0 && ldd / PLANES >= Ppad && ((ldd / PLANES) & 3) == 0), "mudg_transpose_cast_sum: ldd=%lld too small for %lld columns", (long long)ldd, (long long)Ppad);
     MUDG_REQUIRE(!rows || (ldr % PLANES == 0 && ldr / PLANES >= C && ((ldr / PLANES) & 3) == 0), "mudg_transpose_cast_sum: ldr=%lld", (long long)ldr);
     MUDG_REQUIRE((reinterpret_cast<uintptr_t>(src) & 15u) == 0 && (reinterpret_cast<uintptr_t>(dst) & 7u) == 0 && (reinterpret_cast<uintptr_t>(rows) & 7u) == 0,
                  "mudg_transpose_cast_sum: alignment");

@@ -103,6 +103,17 @@ class AttnBwdDesc(C.Structure):
     ]
 
 
+class WgradDesc(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("B", C.c_void_p), ("out", C.c_void_p),
+        ("lda", C.c_int64), ("ldb", C.c_int64), ("P", C.c_int64),
+        ("M", C.c_int), ("C", C.c_int), ("taps", C.c_int), ("mode", C.c_int),
+        ("Hin", C.c_int), ("Win", C.c_int), ("Hout", C.c_int), ("Wout", C.c_int), ("stride", C.c_int), ("pad", C.c_int),
+        ("T", C.c_int), ("HW", C.c_int),
+        ("slices", C.c_int), ("chunk", C.c_int64),
+    ]
+
+
 # name -> (restype, argtypes); this table is also what tests check against include/mudg_hip.h
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 SIGNATURES = {
@@ -148,6 +159,7 @@ SIGNATURES = {
     "mudg_softmax_bwd": (_I, [_P, _L, _P, _L, _P, _L, _L, _I, _F, _P]),
     "mudg_temporal_attention_bwd": (_I, [_P, _P, _P, _P, _L, _L, _P, _P, _P, _L, _I, _I, _I, _I, _F, _P]),
     "mudg_attention_bwd": (_I, [C.POINTER(AttnBwdDesc), _P]),
+    "mudg_wgrad": (_I, [C.POINTER(WgradDesc), _P]),
     "mudg_mse_ws_doubles": (_L, [_I]),
     "mudg_mse": (_I, [_P, _P, _P, _I, _L, _P, _P, _P, _P]),
     "mudg_upsample2x": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),

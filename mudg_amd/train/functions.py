@@ -131,6 +131,20 @@ def transposed(src, m, n, **kw):
     return out
 
 
+def rows_wgrad_ok(m, c):
+    """The row-contracting weight-gradient kernel (mudg_wgrad: no transposed copies) serves the 16-bit builds when the input
+    channels come in 64-wide blocks; everything else (the 12-channel input conv, the split-operand builds) takes the transposes."""
+    return hip.planes() == 1 and c % 64 == 0 and m % 8 == 0
+
+
+def grad_rows(dy, rows, sums):
+    """(operand rows or None, column sums or None) of an output gradient in one pass (no transposed copy is needed when the weight
+    gradient comes from mudg_wgrad)."""
+    if sums and dy.shape[1] % 8 == 0 and dy.stride(0) % 4 == 0 and dy.data_ptr() % 16 == 0:
+        return K.transpose_cast_sum(dy, None, rows, True)
+    return (op(dy) if rows else None), (K.group_colsum(dy)[0] if sums else None)
+
+
 def grad_forms(dy, m, n, rows, sums):
     """The forms a layer's output gradient dy [P][m] is needed in for an [m][n] weight gradient: (dy^T wide enough for the K-slices,
     operand rows or None, column sums or None) — one pass over dy when its width allows 16-byte accesses."""
@@ -158,9 +172,11 @@ class Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, residual):
         w2 = w.reshape(w.shape[0], -1)
-        ctx.save_for_backward(x, w2)
+        xo = op(x)
+        # what the weight gradient will read: the operand rows themselves (mudg_wgrad) or the fp32 rows (transposed copies)
+        ctx.save_for_backward(xo if rows_wgrad_ok(*w2.shape) else x, w2)
         ctx.wshape, ctx.has_b, ctx.has_r = w.shape, b is not None, residual is not None
-        return ops.gemm(op(x), op(w2), bias=None if b is None else b.float().contiguous(), residual=residual, out_fp32=True)
+        return ops.gemm(xo, op(w2), bias=None if b is None else b.float().contiguous(), residual=residual, out_fp32=True)
 
     @staticmethod
     def backward(ctx, dy):
@@ -169,7 +185,10 @@ class Linear(torch.autograd.Function):
         n, k = w2.shape
         dx = dw = db = None
         want_b = ctx.has_b and _need(ctx, 2)
-        if _need(ctx, 1):
+        direct = _need(ctx, 1) and rows_wgrad_ok(n, k)
+        if direct:
+            dyo, db = grad_rows(dy, True, want_b)
+        elif _need(ctx, 1):
             dyt, dyo, db = grad_forms(dy, n, k, _need(ctx, 0), want_b)
         else:
             dyo = op(_pad_cols(dy, _pad8(n))) if _need(ctx, 0) else None
@@ -177,7 +196,9 @@ class Linear(torch.autograd.Function):
         if _need(ctx, 0):
             wt = K.transpose_gather(w2)                                  # [K][N padded]
             dx = ops.gemm(dyo, wt, out_fp32=True)
-        if _need(ctx, 1):
+        if direct:
+            dw = K.wgrad(dyo, x, positions=x.shape[0], m=n, c=k).reshape(ctx.wshape)
+        elif _need(ctx, 1):
             dw = wgrad_gemm(dyt, transposed(x, n, k), n, k, x.shape[0]).reshape(ctx.wshape)
         return dx, dw, db, (dy if ctx.has_r else None)
 
@@ -208,9 +229,10 @@ class Conv3x3(torch.autograd.Function):
         frames, h, wd, stride = geo
         co, ci = w.shape[:2]
         cpad = _pad8(ci)
-        ctx.save_for_backward(x, w)
+        xo = op(_pad_cols(x, cpad))
+        ctx.save_for_backward(xo if rows_wgrad_ok(co, ci) else x, w)
         ctx.geo, ctx.rpg, ctx.flags = geo, rows_per_group, (b is not None, gbias is not None, residual is not None)
-        return ops.conv3x3(op(_pad_cols(x, cpad)), op(_conv_weight(w, cpad)), frames=frames, hin=h, win=wd, cin=cpad, stride=stride,
+        return ops.conv3x3(xo, op(_conv_weight(w, cpad)), frames=frames, hin=h, win=wd, cin=cpad, stride=stride,
                            bias=None if b is None else b.float().contiguous(), gbias=gbias, rows_per_group=rows_per_group or 0,
                            residual=residual, out_fp32=True)
 
@@ -225,16 +247,23 @@ class Conv3x3(torch.autograd.Function):
         dx = dw = db = dg = None
         want_b = has_b and _need(ctx, 2)
         dyo = None
-        if _need(ctx, 1):
+        direct = _need(ctx, 1) and rows_wgrad_ok(co, ci)
+        if direct:
+            dyo, db = grad_rows(dy, True, want_b)
+        elif _need(ctx, 1):
             dyt, dyo, db = grad_forms(dy, co, 9 * ci, _need(ctx, 0) and stride == 1, want_b)       # [Cout][P padded], rows, sums
         elif want_b:
             db = K.group_colsum(dy)[0]
         if _need(ctx, 0):
             copad = _pad8(co)
-            if dyo is None:
-                dyo = op(_pad_cols(dy if stride == 1 else K.dilate2x(dy, frames, ho, wo, h, wd), copad))
-            dx = ops.conv3x3(dyo, op(_conv_weight_flipped(w, copad)), frames=frames, hin=h, win=wd, cin=copad, out_fp32=True)
-        if _need(ctx, 1):
+            src = dyo
+            if src is None or stride != 1:
+                src = op(_pad_cols(dy if stride == 1 else K.dilate2x(dy, frames, ho, wo, h, wd), copad))
+            dx = ops.conv3x3(src, op(_conv_weight_flipped(w, copad)), frames=frames, hin=h, win=wd, cin=copad, out_fp32=True)
+        if direct:
+            dw = K.wgrad(dyo, x, positions=frames * ho * wo, m=co, c=ci, taps=9, mode=1,
+                         geo=dict(Hin=h, Win=wd, Hout=ho, Wout=wo, stride=stride, pad=1)).reshape(co, 3, 3, ci).permute(0, 3, 1, 2).contiguous()
+        elif _need(ctx, 1):
             p = frames * ho * wo
             g = dict(Hin=h, Win=wd, Hout=ho, Wout=wo, stride=stride, pad=1)
             taps = [dict(dy=ky, dx=kx) for ky in range(3) for kx in range(3)]
@@ -252,10 +281,11 @@ class TConv3(torch.autograd.Function):
     def forward(ctx, x, w, b, residual, geo):
         clips, t, hw = geo
         co, ci = w.shape[:2]
-        ctx.save_for_backward(x, w)
+        xo = op(x)
+        ctx.save_for_backward(xo if rows_wgrad_ok(co, ci) else x, w)
         ctx.geo, ctx.flags = geo, (b is not None, residual is not None)
         wm = w[:, :, :, 0, 0].permute(0, 2, 1).reshape(co, 3 * ci).contiguous()
-        return ops.tconv3(op(x), op(wm), clips=clips, t=t, hw=hw, cin=ci, bias=None if b is None else b.float().contiguous(),
+        return ops.tconv3(xo, op(wm), clips=clips, t=t, hw=hw, cin=ci, bias=None if b is None else b.float().contiguous(),
                           residual=residual, out_fp32=True)
 
     @staticmethod
@@ -267,7 +297,10 @@ class TConv3(torch.autograd.Function):
         dy = dy.contiguous()
         dx = dw = db = None
         want_b = has_b and _need(ctx, 2)
-        if _need(ctx, 1):
+        direct = _need(ctx, 1) and rows_wgrad_ok(co, ci)
+        if direct:
+            dyo, db = grad_rows(dy, True, want_b)
+        elif _need(ctx, 1):
             dyt, dyo, db = grad_forms(dy, co, 3 * ci, _need(ctx, 0), want_b)
         else:
             dyo = op(dy) if _need(ctx, 0) else None
@@ -275,7 +308,10 @@ class TConv3(torch.autograd.Function):
         if _need(ctx, 0):
             wf = w[:, :, :, 0, 0].flip(2).permute(1, 2, 0).reshape(ci, 3 * co).contiguous()        # [Cin][tap'][Cout]
             dx = ops.tconv3(dyo, op(wf), clips=clips, t=t, hw=hw, cin=co, out_fp32=True)
-        if _need(ctx, 1):
+        if direct:
+            dw = K.wgrad(dyo, x, positions=x.shape[0], m=co, c=ci, taps=3, mode=2,
+                         geo=dict(T=t, HW=hw)).reshape(co, 3, ci).permute(0, 2, 1).reshape(co, ci, 3, 1, 1).contiguous()
+        elif _need(ctx, 1):
             p = x.shape[0]
             xt = transposed_taps(x, co, ci, p, [dict(dt=d) for d in range(3)], 2, dict(T=t, HW=hw))
             dw = wgrad_gemm(dyt, xt, co, 3 * ci, p).reshape(co, 3, ci).permute(0, 2, 1).reshape(co, ci, 3, 1, 1).contiguous()

@@ -91,13 +91,14 @@ def layernorm_bwd(x, dy, gamma, eps):
 
 
 def transpose_cast_sum(src, out, rows=False, sums=False):
-    """mudg_transpose_cast_sum: one pass over fp32 rows `src` [P][C] writing out[c][p] (operand matrix, the caller's), and on
-    request the operand-row copy and the column sums.  Returns (rows or None, sums or None)."""
+    """mudg_transpose_cast_sum: one pass over fp32 rows `src` [P][C] writing out[c][p] (operand matrix, the caller's; None: no
+    transposed copy), and on request the operand-row copy and the column sums.  Returns (rows or None, sums or None)."""
     _f32(src)
     P, c = src.shape
     r = ops.empty_rows(P, c, ops.H16(), src.device) if rows else None
     part = torch.empty(((P + 63) // 64, c), dtype=torch.float32, device=src.device) if sums else None
-    hip.check(hip.lib().mudg_transpose_cast_sum(src.data_ptr(), src.stride(0), out.data_ptr(), out.stride(0), None if r is None else r.data_ptr(),
+    hip.check(hip.lib().mudg_transpose_cast_sum(src.data_ptr(), src.stride(0), None if out is None else out.data_ptr(),
+                                                0 if out is None else out.stride(0), None if r is None else r.data_ptr(),
                                                 0 if r is None else r.stride(0), None if part is None else part.data_ptr(), P, c, _s()),
               "mudg_transpose_cast_sum")
     return r, (group_colsum(part)[0] if sums else None)
@@ -146,6 +147,33 @@ def attention_bwd(q, k, v, do, qt, dot, kt, *, frames, heads, nq, nk, kv_div, sc
     d.scale = scale
     hip.check(hip.lib().mudg_attention_bwd(C.byref(d), _s()), "mudg_attention_bwd")
     return dq, dk, dv
+
+
+def wgrad(a, b, *, positions, m, c, taps=1, mode=0, geo=None):
+    """mudg_wgrad: out[m][tap * c + ch] = sum_p a[p][m] b[src(p, tap)][ch] from operand rows a [positions][>= m], b [*][>= c] (16-bit
+    operand builds; c % 64 == 0, m % 8 == 0) -> fp32 [m][taps * c].  The contraction is cut into slices sized from the problem
+    shape only (enough workgroups for the chip), whose slabs are added in a fixed order."""
+    n = taps * c
+    tiles = ((m + 127) // 128) * ((n + 127) // 128)
+    # 512 workgroups run at a time (2 per CU).  A slice count k costs rounds(k) / k passes over the positions at ~1 TFLOP/s per
+    # workgroup, plus writing and re-reading k fp32 slabs at ~4 TB/s: take the cheapest (a function of the shape only).
+    most = max(1, min(64, positions // 1024))
+    tile_us = 2.0 * 128 * 128 * positions / 1e6
+    slab_us = m * n * 8 / 4e6
+    slices = min(range(1, most + 1), key=lambda k: (-(-tiles * k // 512) / k * tile_us + (k * slab_us if k > 1 else 0.0), k))
+    chunk = ((positions + slices - 1) // slices + 63) // 64 * 64
+    slices = (positions + chunk - 1) // chunk
+    slabs = torch.empty((slices, m * n), dtype=torch.float32, device=a.device)
+    g = dict(Hin=0, Win=0, Hout=0, Wout=0, stride=1, pad=1, T=0, HW=0)
+    g.update(geo or {})
+    d = hip.WgradDesc()
+    d.A, d.B, d.out = a.data_ptr(), b.data_ptr(), slabs.data_ptr()
+    d.lda, d.ldb, d.P = a.stride(0), b.stride(0), positions
+    d.M, d.C, d.taps, d.mode = m, c, taps, mode
+    d.Hin, d.Win, d.Hout, d.Wout, d.stride, d.pad, d.T, d.HW = g["Hin"], g["Win"], g["Hout"], g["Wout"], g["stride"], g["pad"], g["T"], g["HW"]
+    d.slices, d.chunk = slices, chunk
+    hip.check(hip.lib().mudg_wgrad(C.byref(d), _s()), "mudg_wgrad")
+    return (slabs if slices == 1 else group_colsum(slabs)).reshape(m, n)
 
 
 def temporal_attention_bwd(qkv, do, clips, t, hw, heads, scale):

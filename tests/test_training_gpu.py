@@ -60,8 +60,14 @@ def test_linear_conv_and_temporal_conv_gradients(cuda):
     t = dict(x=rnd(M, Kd, seed=1), w=rnd(N, Kd, seed=2, scale=0.1), b=rnd(N, seed=3))
     assert Fn._splits(N, Kd, M) > 1
     compare("linear (K-sliced dW)", *run_both(lambda x, w, b: Fn.Linear.apply(x, w, b, None), lambda x, w, b: F.linear(x, w, b), t, cuda))
-    # 3x3 conv: stride 1 with the embedding (row-group) bias and a residual, then stride 2; Cin = 12 exercises the channel padding
-    for stride, ci, co, h, wd in ((1, 64, 40, 6, 8), (2, 12, 24, 6, 8), (1, 64, 64, 24, 32)):
+    # input widths in 64-channel blocks take the row-contracting weight-gradient kernel (mudg_wgrad) in the 16-bit builds: one
+    # slice, many slices with a ragged last K-step, an output narrower / wider than a tile
+    for M, Kd, N in ((200, 128, 72), (4100, 128, 72), (1000, 320, 328)):
+        t = dict(x=rnd(M, Kd, seed=1), w=rnd(N, Kd, seed=2, scale=0.1), b=rnd(N, seed=3))
+        compare(f"linear {M} x {Kd} -> {N}", *run_both(lambda x, w, b: Fn.Linear.apply(x, w, b, None), lambda x, w, b: F.linear(x, w, b), t, cuda))
+    # 3x3 conv: stride 1 with the embedding (row-group) bias and a residual, then stride 2; Cin = 12 exercises the channel padding;
+    # Cin = 192: an output tile of the weight gradient straddles two taps; odd sizes under stride 2
+    for stride, ci, co, h, wd in ((1, 64, 40, 6, 8), (2, 12, 24, 6, 8), (1, 64, 64, 24, 32), (1, 192, 136, 10, 12), (2, 64, 72, 9, 11)):
         frames = 4
         ho, wo = (h - 1) // stride + 1, (wd - 1) // stride + 1
         t = dict(x=rnd(frames * h * wd, ci, seed=1), w=rnd(co, ci, 3, 3, seed=2, scale=0.1), b=rnd(co, seed=3),
@@ -73,13 +79,13 @@ def test_linear_conv_and_temporal_conv_gradients(cuda):
             return y.permute(0, 2, 3, 1).reshape(-1, co) + r
         compare(f"conv3x3 stride {stride}", *run_both(
             lambda x, w, b, e, r: Fn.Conv3x3.apply(x, w, b, e, r, (frames, h, wd, stride), (frames // 2) * ho * wo), ref, t, cuda))
-    clips, tt, hw, c = 2, 5, 12, 64
-    t = dict(x=rnd(clips * tt * hw, c, seed=1), w=rnd(c, c, 3, 1, 1, seed=2, scale=0.1), b=rnd(c, seed=3))
+    for clips, tt, hw, c in ((2, 5, 12, 64), (2, 7, 50, 128), (1, 4, 9, 24)):
+        t = dict(x=rnd(clips * tt * hw, c, seed=1), w=rnd(c, c, 3, 1, 1, seed=2, scale=0.1), b=rnd(c, seed=3))
 
-    def tref(x, w, b):
-        y = F.conv3d(x.reshape(clips, tt, hw, 1, c).permute(0, 4, 1, 2, 3), w, b, padding=(1, 0, 0))
-        return y.permute(0, 2, 3, 4, 1).reshape(-1, c) + x
-    compare("tconv3", *run_both(lambda x, w, b: Fn.TConv3.apply(x, w, b, x, (clips, tt, hw)), tref, t, cuda))
+        def tref(x, w, b):
+            y = F.conv3d(x.reshape(clips, tt, hw, 1, c).permute(0, 4, 1, 2, 3), w, b, padding=(1, 0, 0))
+            return y.permute(0, 2, 3, 4, 1).reshape(-1, c) + x
+        compare(f"tconv3 {c} channels", *run_both(lambda x, w, b: Fn.TConv3.apply(x, w, b, x, (clips, tt, hw)), tref, t, cuda))
 
 
 def test_norm_geglu_resampling_and_loss_gradients(cuda):
