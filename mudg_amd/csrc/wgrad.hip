@@ -64,20 +64,22 @@ struct Walker {
     }
 };
 
-#ifdef MUDG_OPERAND_FP16
-typedef __attribute__((__vector_size__(4 * sizeof(__fp16)))) __fp16 tr_vec_t;
-#define TR_READ(ptr) __builtin_amdgcn_ds_read_tr16_b64_v4f16(ptr)
-#else
-typedef h16x4 tr_vec_t;
-#define TR_READ(ptr) __builtin_amdgcn_ds_read_tr16_b64_v4bf16(ptr)
-#endif
-typedef __attribute__((address_space(3))) tr_vec_t* lds_tr_ptr;
 typedef __attribute__((address_space(3))) void* lptr_t;
-__device__ __forceinline__ h16x4 tr_read(const h16* p) {
-    const tr_vec_t v = TR_READ((lds_tr_ptr)p);
-    h16x4 o;
-    __builtin_memcpy(&o, &v, sizeof(o));
-    return o;
+// The transposing reads are issued as inline assembly: behind the builtin the compiler cannot tell them from the LDS-DMA writes
+// of the OTHER stage and drains vmcnt before every group of reads, which serialises fetch and multiply.  In assembly the only
+// waits are the ones written here: lgkmcnt before a fragment is used (tr_wait ties the fragment registers to the wait), vmcnt(0)
+// + barrier once per K-step (__syncthreads).
+struct Frag { u32x2 lo, up; };
+__device__ __forceinline__ void tr_issue(Frag& f, unsigned addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:1024" : "=&v"(f.lo), "=&v"(f.up) : "v"(addr) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void tr_wait(Frag& a0, Frag& a1, Frag& b0, Frag& b1) {
+    asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(a0.lo), "+v"(a0.up), "+v"(a1.lo), "+v"(a1.up), "+v"(b0.lo), "+v"(b0.up), "+v"(b1.lo), "+v"(b1.up) : "n"(N) : "memory");
+}
+__device__ __forceinline__ h16x8 frag_value(const Frag& f) {
+    const u32x4 v = {f.lo[0], f.lo[1], f.up[0], f.up[1]};
+    return as_h16x8(v);
 }
 // LDS image of a K-step: 16 pieces of 1 KiB, piece t = positions 4 t .. 4 t + 3 of all 128 channels, written by ONE LDS-DMA
 // instruction (lane i delivers 16 bytes to piece + 16 i).  Lane i = 16 r + s fetches position 4 t + r and the 8-channel chunk
@@ -85,17 +87,13 @@ __device__ __forceinline__ h16x4 tr_read(const h16* p) {
 // bytes — what the memory pipeline coalesces), in an order that XORs the 32-byte chunk-pair index with 2 r.  A transposing read
 // of a 4-position x 16-channel block (one chunk pair, rows r = 0..3) then finds its four 32-byte row segments at four different
 // pair slots, and the two blocks a 32-lane half reads together cover all eight: every bank exactly once.
-// The 8-position fragment of channel cbase + (lane & 31) at positions kbase + 8 (lane >> 5) + 0..7:
-__device__ __forceinline__ h16x8 tr_fragment(const h16* img, int kbase, int cbase, int lane) {
+// Byte offset, inside an operand image, of the first of the two reads that give lane `lane` the 8-position fragment of channel
+// cbase + (lane & 31) at positions kbase + 8 (lane >> 5) + 0..7 (the second read is the next piece: + 1024 bytes):
+__device__ __forceinline__ unsigned tr_offset(int kbase, int cbase, int lane) {
     const int g = lane >> 4, q = lane & 15;
     const int piece = (kbase >> 2) + 2 * (g >> 1);
     const int pair = (cbase >> 4) + (g & 1), r = q >> 2;
-    const h16* p = img + piece * 512 + r * 128 + (((pair ^ (2 * r)) * 2 + ((q & 3) >> 1)) * 8) + (q & 1) * 4;
-    const h16x4 lo = tr_read(p), up = tr_read(p + 512);
-    h16x8 f;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { f[e] = lo[e]; f[4 + e] = up[e]; }
-    return f;
+    return (unsigned)(2 * (piece * 512 + r * 128 + (((pair ^ (2 * r)) * 2 + ((q & 3) >> 1)) * 8) + (q & 1) * 4));
 }
 
 constexpr unsigned OOB = 0x80000000u;            // a voffset at num_records: the buffer load returns 0 into the LDS
@@ -192,25 +190,37 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const MudgWgradDesc p, co
 #pragma unroll
     for (int i = 0; i < 16; ++i) { acc[0][0][i] = 0.f; acc[0][1][i] = 0.f; acc[1][0][i] = 0.f; acc[1][1][i] = 0.f; }
     const int wm = wave >> 1, wn = wave & 1;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned offa[2] = {tr_offset(0, wm * 64, lane), tr_offset(0, wm * 64 + 32, lane)};
+    const unsigned offb[2] = {tr_offset(0, wn * 64, lane), tr_offset(0, wn * 64 + 32, lane)};
     if (pbeg < pend) issue(pbeg, 0);
     int buf = 0;
     for (int64_t p0 = pbeg; p0 < pend; p0 += WK, buf ^= 1) {
         __syncthreads();                                   // vmcnt(0) + barrier: this step's images have landed, the other stage is free
         if (p0 + WK < pend) issue(p0 + WK, buf ^ 1);       // in flight under the MFMAs below
-        const h16* As = smem + buf * 2 * IMG;
-        const h16* Bs = As + IMG;
+        // fragment reads of k-step ks + 1 are in flight while the MFMAs of ks run (two register sets)
+        const unsigned abase = lds0 + (unsigned)(buf * 2 * IMG * 2), bbase = abase + IMG * 2;
+        Frag fa[2][2], fb[2][2];
+        auto reads = [&](int set, int ks) {
+            tr_issue(fa[set][0], abase + offa[0] + ks * 4096);           // 16 positions = 4 pieces = 4 KiB on
+            tr_issue(fa[set][1], abase + offa[1] + ks * 4096);
+            tr_issue(fb[set][0], bbase + offb[0] + ks * 4096);
+            tr_issue(fb[set][1], bbase + offb[1] + ks * 4096);
+        };
+        reads(0, 0);
 #pragma unroll
         for (int ks = 0; ks < WK / 16; ++ks) {
-            h16x8 af[2], bf[2];
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                af[b] = tr_fragment(As, ks * 16, wm * 64 + b * 32, lane);
-                bf[b] = tr_fragment(Bs, ks * 16, wn * 64 + b * 32, lane);
+            const int set = ks & 1;
+            if (ks + 1 < WK / 16) {
+                reads(set ^ 1, ks + 1);
+                tr_wait<8>(fa[set][0], fa[set][1], fb[set][0], fb[set][1]);
+            } else {
+                tr_wait<0>(fa[set][0], fa[set][1], fb[set][0], fb[set][1]);
             }
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-                for (int nb = 0; nb < 2; ++nb) acc[mb][nb] = MFMA_32x32x16(af[mb], bf[nb], acc[mb][nb]);
+                for (int nb = 0; nb < 2; ++nb) acc[mb][nb] = MFMA_32x32x16(frag_value(fa[set][mb]), frag_value(fb[set][nb]), acc[mb][nb]);
         }
     }
     // acc[mb][nb][i]: row m = (i & 3) + 8 (i >> 2) + 4 hi of the block, column n = lane & 31: 128-byte runs per register
