@@ -113,14 +113,25 @@ class GradientAllReducer:
     """Data-parallel gradient averaging: the gradients of `params` are packed into flat fp32 buckets of about `bucket_mb` MiB (one
     collective per bucket instead of one per tensor: xGMI rings are per-link bound, large messages amortise their latency),
     all-reduced over `group` (RCCL when the tensors are on GPUs, gloo on CPU) and unpacked.  The bucket layout is a function of
-    the parameter list only, so every rank issues the same collectives in the same order."""
+    the parameter list only, so every rank issues the same collectives in the same order.
 
-    def __init__(self, params, bucket_mb=64, group=None, always=False):
+    overlap=True: the collectives run UNDER the backward pass.  Buckets are filled in reverse parameter order (the order gradients
+    become final in); a post-accumulate-grad hook per parameter counts its bucket down and, when the bucket is complete and every
+    earlier-launched bucket has been launched (same order on every rank), packs it and starts its all-reduce asynchronously —
+    RCCL runs it on its own stream beside the remaining backward kernels.  Calling the reducer after backward() launches whatever
+    did not complete by itself (a parameter that received no gradient contributes zeros — and holds back its bucket and the ones
+    after it until then: the launch order is fixed), waits, and unpacks.  With gradient
+    accumulation (the reference's trainer: accumulate_grad_batches 2) set `.sync = False` for all but the last micro-batch: the
+    hooks then do nothing and the gradients keep accumulating locally, as under DDP's no_sync."""
+
+    def __init__(self, params, bucket_mb=64, group=None, always=False, overlap=False):
         self.params = [p for p in params if p.requires_grad]
         self.group, self.always = group, always          # always: run the collectives even in a one-rank group (tests)
+        self.overlap, self.sync = overlap, True
         limit = int(bucket_mb * (1 << 20)) // 4
+        order = list(reversed(self.params)) if overlap else self.params
         self.buckets, cur, n = [], [], 0
-        for p in self.params:
+        for p in order:
             if cur and n + p.numel() > limit:
                 self.buckets.append(cur)
                 cur, n = [], 0
@@ -128,39 +139,72 @@ class GradientAllReducer:
             n += p.numel()
         if cur:
             self.buckets.append(cur)
+        self._works = {}                                  # bucket index -> (work, flat, needs scaling)
+        self._pending = [len(b) for b in self.buckets]
+        self._next = 0                                    # buckets are launched strictly in index order
+        self._hooks = []
+        if overlap:
+            where = {id(p): i for i, b in enumerate(self.buckets) for p in b}
+            for p in self.params:
+                self._hooks.append(p.register_post_accumulate_grad_hook(lambda q, i=where[id(p)]: self._ready(i)))
+
+    def _active(self):
+        import torch.distributed as dist
+        return dist.is_available() and dist.is_initialized() and (dist.get_world_size(self.group) > 1 or self.always)
+
+    def _launch(self, i):
+        import torch.distributed as dist
+        bucket = self.buckets[i]
+        dev = bucket[0].device
+        flat = torch.zeros(sum(p.numel() for p in bucket), dtype=torch.float32, device=dev)
+        off = 0
+        for p in bucket:                                  # a parameter that received no gradient contributes zeros
+            if p.grad is not None:
+                flat[off:off + p.numel()].copy_(p.grad.reshape(-1))
+            off += p.numel()
+        if dist.get_backend(self.group) == "nccl":        # RCCL averages in the collective itself
+            self._works[i] = (dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True), flat, False)
+        else:                                             # gloo (CPU tests): sum, then scale
+            self._works[i] = (dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True), flat, True)
+
+    def _ready(self, i):
+        if not self.sync or not self._active():
+            return
+        self._pending[i] -= 1
+        while self._next < len(self.buckets) and self._pending[self._next] <= 0:
+            self._launch(self._next)
+            self._next += 1
 
     def __call__(self):
+        """After backward(): finish the gradient averaging.  Returns the number of collectives."""
         import torch.distributed as dist
-        if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(self.group) == 1 and not self.always):
+        if not self._active() or not self.sync:
             return 0
         world = dist.get_world_size(self.group)
-        backend = dist.get_backend(self.group)
-        works = []
-        for bucket in self.buckets:
-            dev = bucket[0].device
-            flat = torch.zeros(sum(p.numel() for p in bucket), dtype=torch.float32, device=dev)
-            off = 0
-            for p in bucket:                              # a parameter that received no gradient contributes zeros
-                if p.grad is not None:
-                    flat[off:off + p.numel()].copy_(p.grad.reshape(-1))
-                off += p.numel()
-            if backend == "nccl":                         # RCCL averages in the collective itself
-                works.append((dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True), flat, bucket, False))
-            else:                                         # gloo (CPU tests): sum, then scale
-                works.append((dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True), flat, bucket, True))
-        for work, flat, bucket, scale in works:
+        for i in range(self._next, len(self.buckets)):    # not launched under backward (or overlap off): now, in order
+            self._launch(i)
+        for i in range(len(self.buckets)):
+            work, flat, scale = self._works[i]
             work.wait()
             if scale:
                 flat /= world
             off = 0
-            for p in bucket:
+            for p in self.buckets[i]:
                 g = flat[off:off + p.numel()].view_as(p)
                 if p.grad is None:
                     p.grad = g.clone()
                 else:
                     p.grad.copy_(g)
                 off += p.numel()
+        self._works.clear()
+        self._pending = [len(b) for b in self.buckets]
+        self._next = 0
         return len(self.buckets)
+
+    def remove_hooks(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
 
 
 def training_step(model, x_start, cond, t, optimizer, reducer=None, noise=None, clipper=None, **kwargs):

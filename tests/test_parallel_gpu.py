@@ -27,6 +27,15 @@ for i, p in enumerate(params):
 red = GradientAllReducer(params, bucket_mb=1, always=True)
 assert red() == len(red.buckets) >= 2                      # one-rank group: the average of one value is the value
 assert all(torch.equal(p.grad, torch.full_like(p, float(i + 1))) for i, p in enumerate(params))
+# the same collectives launched from gradient hooks, under a backward pass on the GPU (RCCL on its own stream beside the kernels)
+net = torch.nn.Sequential(torch.nn.Linear(512, 512), torch.nn.Tanh(), torch.nn.Linear(512, 512)).to(dev)
+red = GradientAllReducer(list(net.parameters()), bucket_mb=0.5, always=True, overlap=True)
+x = torch.randn(64, 512, device=dev)
+net(x).square().mean().backward()
+launched = red._next
+want = [p.grad.clone() for p in net.parameters()]
+assert red() == len(red.buckets) >= 2 and launched == len(red.buckets)     # every bucket went out before backward() returned
+assert all(torch.allclose(p.grad, w) for p, w in zip(net.parameters(), want))
 dist.destroy_process_group()
 print("RCCL-OK")
 """

@@ -29,6 +29,57 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _worker_overlap(rank, world, port, q):
+    """The collectives launched from post-accumulate-grad hooks, under a real backward pass, must give what the after-backward
+    reducer gives; a micro-batch with .sync = False must leave the local gradients alone."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mudg_amd.train.step import GradientAllReducer
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(300, 400), torch.nn.Tanh(), torch.nn.Linear(400, 300), torch.nn.Tanh(), torch.nn.Linear(300, 5))
+    unused = torch.nn.Parameter(torch.ones(7))                       # never reaches the loss: its bucket (the last one) completes only at the end
+    params = [unused] + list(net.parameters())
+    red = GradientAllReducer(params, bucket_mb=0.25, overlap=True)    # 65536 floats per bucket: several buckets
+    launched = []
+    orig = red._launch
+    red._launch = lambda i: (launched.append((i, red._next)), orig(i))[1]
+    x = torch.randn(16, 300, generator=torch.Generator().manual_seed(10 + rank))
+    # micro-batch 1 of 2: local accumulation only
+    red.sync = False
+    net(x).square().mean().backward()
+    local = [p.grad.clone() for p in net.parameters()]
+    ok = red() == 0 and not launched
+    # micro-batch 2 of 2: the hooks launch the collectives while backward is still running
+    red.sync = True
+    net(2 * x).square().mean().backward()
+    under_backward = len(launched)
+    mine = [p.grad.clone() for p in net.parameters()]                # local sum of both micro-batches, before the averaging lands
+    n = red()
+    ok = ok and n == len(red.buckets) >= 3 and under_backward >= 1 and [i for i, _ in launched] == list(range(n))
+    # reference: gather every rank's local gradients and average
+    for p, g in zip(net.parameters(), mine):
+        both = [torch.zeros_like(g) for _ in range(world)]
+        dist.all_gather(both, g)
+        ok = ok and torch.allclose(p.grad, sum(both) / world, rtol=1e-6, atol=1e-7)
+    ok = ok and unused.grad is not None and float(unused.grad.abs().sum()) == 0.0 and all(not torch.equal(a, b) for a, b in zip(local, mine))
+    red.remove_hooks()
+    q.put((rank, bool(ok), under_backward))
+    dist.destroy_process_group()
+
+
+def test_overlapped_gradient_all_reduce_matches_and_respects_accumulation():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_overlap, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+    assert all(ok for _, ok, _ in res), res
+
+
 def test_gradient_all_reduce_over_two_gloo_ranks():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
