@@ -156,6 +156,9 @@ typedef struct MudgAttnDesc {
                             then runs its lean softmax: the running reference maximum enters as the score accumulator's
                             initial value, one v_exp + one add per score, and the rescale of O only happens when a row sum
                             outgrows 2^40 (never on real data after the first tile). */
+    float* Lse;          /* optional, fp32 [F Nq][heads]: the log2-sum-exp of the scaled scores of every (query, head) — what
+                            mudg_attention_bwd needs to rebuild P without a statistics pass (single key / value set, not
+                            prescaled, 16-bit builds) */
 } MudgAttnDesc;
 int mudg_attention(const MudgAttnDesc* d, void* stream);
 /* OCP microscaling quantisation of an operand matrix (16-bit builds): every 32 consecutive columns of a row share one
@@ -339,11 +342,13 @@ int mudg_temporal_attention_bwd(const float* Q, const float* K, const float* V, 
  * sum_k P dP).  dQ [F Nq][ldgq], dK, dV [(F / kv_div) Nk][ldgk]: fp32, every element of the head columns written once. */
 typedef struct MudgAttnBwdDesc {
     const void* Q; const void* K; const void* V; const void* dO;
+    const void* O;       /* optional: the forward output (operand rows, row stride ldo).  Not NULL: L holds what the forward pass
+                            wrote (MudgAttnDesc.Lse) and D = sum_d dO O is taken from O — the statistics pass is skipped */
     const void* Qt; const void* dOt; const void* Kt;
     float* L; float* D;
     float* dQ; float* dK; float* dV;
     int F, heads, Nq, Nk, kv_div;
-    int ldq, ldk, ldv, lddo;
+    int ldq, ldk, ldv, lddo, ldo;
     int64_t ldqt, lddot, ldkt;
     int64_t ldgq, ldgk;
     float scale;

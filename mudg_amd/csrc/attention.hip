@@ -201,6 +201,8 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const MudgAttnDesc p, cons
     // ---- normalise this set's result
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     inv = 1.f / l_tot;
+    if (!TWO && p.Lse && qok && hi == 0)               // log2-sum-exp of the scaled scores: P = 2^(c s - L) (mudg_attention_bwd)
+        p.Lse[((int64_t)f * p.Nq + q) * p.heads + h] = m_run * c + __log2f(l_tot);
     if (TWO) {
         if (set == 0) {
 #pragma unroll
@@ -401,6 +403,7 @@ __global__ __launch_bounds__(256, 2) void attn64q_kernel(const MudgAttnDesc p, c
     for (int qb = 0; qb < 2; ++qb) {
         const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
         const float inv = 1.f / l_tot;
+        if (p.Lse && qok[qb] && hi == 0) p.Lse[((int64_t)f * p.Nq + qrow[qb]) * p.heads + h] = m_run[qb] * c + __log2f(l_tot);
         if (qok[qb]) {
             h16* orow = Op + (int64_t)qrow[qb] * p.ldo;
 #pragma unroll
@@ -721,6 +724,7 @@ __global__ __launch_bounds__(256, 2) void attn64d_kernel(const MudgAttnDesc p, c
     for (int qb = 0; qb < 2; ++qb) {
         const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
         const float inv = 1.f / l_tot;
+        if (p.Lse && qok[qb] && hi == 0) p.Lse[((int64_t)f * p.Nq + qrow[qb]) * p.heads + h] = m_run[qb] * c + __log2f(l_tot);
         if (qok[qb]) {
             h16* orow = Op + (int64_t)qrow[qb] * p.ldo;
 #pragma unroll
@@ -1158,6 +1162,8 @@ extern "C" int mudg_attention(const MudgAttnDesc* dp, void* stream) {
                      d.ldk2 / PLANES >= d.heads * 64 && aligned16(d.K2) && aligned16(d.Vt2), "mudg_attention: second key/value set strides");
         MUDG_REQUIRE(!d.accumulate, "mudg_attention: accumulate and a second key/value set are exclusive");
     }
+    MUDG_REQUIRE(!d.Lse || (PLANES == 1 && !d.K2 && !d.q_prescaled && !d.Q8 && !d.accumulate),
+                 "mudg_attention: Lse (the softmax statistics for mudg_attention_bwd) comes from the plain single-set kernels of the 16-bit builds");
     const int nqt = (d.Nq + QB - 1) / QB;
     const int64_t total = (int64_t)nqt * d.F * d.heads;
     MUDG_REQUIRE(total < (1ll << 31), "mudg_attention: grid too large");

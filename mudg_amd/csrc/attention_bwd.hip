@@ -5,7 +5,7 @@
 //     dV = P^T dO,   dP = dO V^T,   dS = P (dP - D) scale,   dQ = dS K,   dK = dS^T Q.
 // Three passes, all in the forward kernel's idiom (32 rows per wave as MFMA B-operand fragments in registers, the other side
 // streamed through LDS in 64-row tiles, scores left in registers in the order the next MFMA contracts over):
-//   stats   per query: L = log2 sum_k 2^(c s_k) (so that P = 2^(c s - L), c = scale log2 e) and D = sum_k P_k dP_k (equal to
+//   stats   (skipped when the forward pass saved L and O: then D = sum_d dO O)  per query: L = log2 sum_k 2^(c s_k) (so that P = 2^(c s - L), c = scale log2 e) and D = sum_k P_k dP_k (equal to
 //           sum_d dO O of THIS key / value set — taken from P so that the two-set cross-attention needs no per-set output);
 //   Q side  a wave owns 32 QUERIES (fragments of q and dO): per key tile  S^T = K q^T, dP^T = V dO^T (lane = query, registers =
 //           keys), P, dS in registers, then dQ^T += K^T dS^T exactly as the forward accumulates O^T += V^T P^T;
@@ -193,7 +193,21 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(const MudgAttnBwdDes
     h16x8 qf[4], dof[4];
     own_fragments(reinterpret_cast<const h16*>(p.Q) + qrow * p.ldq + h * 64, qok, hi, qf);
     own_fragments(reinterpret_cast<const h16*>(p.dO) + qrow * p.lddo + h * 64, qok, hi, dof);
-    const float Lq = qok ? p.L[qrow * p.heads + h] : 0.f, Dq = qok ? p.D[qrow * p.heads + h] : 0.f;
+    const float Lq = qok ? p.L[qrow * p.heads + h] : 0.f;
+    float Dq;
+    if (p.O) {                                     // the forward pass left L and O: D = sum_d dO O, kept for the key side
+        h16x8 of[4];
+        own_fragments(reinterpret_cast<const h16*>(p.O) + qrow * p.ldo + h * 64, qok, hi, of);
+        float dsum = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) dsum = fmaf((float)dof[ks][e], (float)of[ks][e], dsum);
+        Dq = dsum + __shfl_xor(dsum, 32, 64);
+        if (qok && hi == 0) p.D[qrow * p.heads + h] = Dq;
+    } else {
+        Dq = qok ? p.D[qrow * p.heads + h] : 0.f;
+    }
     const float c = p.scale * 1.4426950408889634f;
     f32x16 dq[2];
 #pragma unroll
@@ -319,7 +333,8 @@ extern "C" int mudg_attention_bwd(const MudgAttnBwdDesc* dp, void* stream) {
     const int nkt = (d.Nk + BTQ - 1) / BTQ;
     const int64_t tk = (int64_t)nkt * (d.F / d.kv_div) * d.heads;
     MUDG_REQUIRE(tq < (1ll << 31) && tk < (1ll << 31), "mudg_attention_bwd: grid too large");
-    hipLaunchKernelGGL(attn_bwd_stats_kernel, dim3((unsigned)tq), dim3(256), 0, s, d, nqt, (int)tq);
+    if (d.O) MUDG_REQUIRE(d.ldo >= C && (d.ldo & 7) == 0 && aligned16(d.O), "mudg_attention_bwd: O stride / alignment");
+    else hipLaunchKernelGGL(attn_bwd_stats_kernel, dim3((unsigned)tq), dim3(256), 0, s, d, nqt, (int)tq);
     hipLaunchKernelGGL(attn_bwd_q_kernel, dim3((unsigned)tq), dim3(256), 0, s, d, nqt, (int)tq);
     hipLaunchKernelGGL(attn_bwd_k_kernel, dim3((unsigned)tk), dim3(256), 0, s, d, nkt, (int)tk);
     return mudg_check_launch("mudg_attention_bwd");

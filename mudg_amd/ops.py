@@ -248,7 +248,7 @@ def tconv3(x, w, *, clips, t, hw, cin, out=None, bias=None, residual=None, out_f
 
 # ------------------------------------------------------------------------------------------------ attention
 def attention(q, k, vt, out, *, frames, heads, nq, nk, ldvt=None, svt=None, kv_div=1, scale=0.125, accumulate=False,
-              k2=None, vt2=None, nk2=0, ldvt2=None, svt2=None, kv_div2=1, q_prescaled=False, fp8=None):
+              k2=None, vt2=None, nk2=0, ldvt2=None, svt2=None, kv_div2=1, q_prescaled=False, fp8=None, lse=None):
     """vt: V^T as [kv batches * heads * 64, keys] rows (row stride = ldvt, batch stride = heads * 64 rows by default).
     k2 / vt2 / nk2: an optional second key / value set with its own softmax whose output is added (the image tokens of
     the text + image cross-attention), in the same launch.  q_prescaled: q already carries scale * log2(e) (folded into
@@ -265,6 +265,10 @@ def attention(q, k, vt, out, *, frames, heads, nq, nk, ldvt=None, svt=None, kv_d
     d.ldq, d.ldk, d.ldvt, d.ldo = q.stride(0), k.stride(0), ldvt, out.stride(0)
     d.svt, d.kv_div, d.scale, d.accumulate = svt, kv_div, scale, int(accumulate)
     d.q_prescaled = int(q_prescaled)
+    if lse is not None:              # fp32 [frames * nq][heads]: the softmax statistics the training backward pass reuses
+        if lse.dtype != torch.float32 or tuple(lse.shape) != (frames * nq, heads) or not lse.is_contiguous():
+            raise hip.MudgError("attention: lse must be a contiguous fp32 [frames * nq][heads] tensor")
+        d.Lse = lse.data_ptr()
     if fp8 is not None:
         q8, qs, k8, ks = fp8
         d.Q8, d.Qs, d.K8, d.Ks = q8.data_ptr(), qs.data_ptr(), k8.data_ptr(), ks.data_ptr()

@@ -436,19 +436,20 @@ def _vt(v, batches, nk):
     return out, out.stride(0)
 
 
-def _attn_backward_fused(q, k, v, do, groups, nqg, nk, heads, scale, frames):
+def _attn_backward_fused(q, k, v, do, groups, nqg, nk, heads, scale, frames, o=None, lse=None):
     """The same gradients from mudg_attention_bwd (16-bit operand builds): no score matrix in memory — three transposed copies
     (Q^T, dO^T per key / value batch, K^T) and one call."""
     tr = lambda src, p: K.transpose_gather(src, P=p, batch=groups, src_batch_rows=p, dst_batch_rows=src.shape[1],
                                            out=ops.empty_rows(groups * src.shape[1], _pad8(p), ops.H16(), src.device))
     return K.attention_bwd(op(q), op(k), op(v), op(do), tr(q, nqg), tr(do, nqg), tr(k, nk), frames=frames, heads=heads,
-                           nq=nqg * groups // frames, nk=nk, kv_div=frames // groups, scale=scale)
+                           nq=nqg * groups // frames, nk=nk, kv_div=frames // groups, scale=scale, o=o, lse=lse)
 
 
-def _attn_backward_set(q, k, v, do, groups, nqg, nk, heads, scale, frames):
-    """Gradients of softmax(scale q k^T) v for one key / value set: `groups` key / value batches, each serving nqg query rows."""
+def _attn_backward_set(q, k, v, do, groups, nqg, nk, heads, scale, frames, o=None, lse=None):
+    """Gradients of softmax(scale q k^T) v for one key / value set: `groups` key / value batches, each serving nqg query rows.
+    o / lse: the forward output and softmax statistics when the forward pass kept them (single set, 16-bit builds)."""
     if hip.planes() == 1:
-        return _attn_backward_fused(q, k, v, do, groups, nqg, nk, heads, scale, frames)
+        return _attn_backward_fused(q, k, v, do, groups, nqg, nk, heads, scale, frames, o, lse)
     c = q.shape[1]
     dq, dk, dv = torch.zeros_like(q), torch.zeros_like(k), torch.zeros_like(v)
     lds, ldq = _pad8(nk), _pad8(nqg)
@@ -497,15 +498,20 @@ class Attention(torch.autograd.Function):
     def forward(ctx, q, k, v, k2, v2, geo):
         frames, heads, nq, nk, kv_div, nk2, kv_div2, scale = geo
         c = q.shape[1]
-        ctx.save_for_backward(q, k, v, *( (k2, v2) if k2 is not None else ()))
         ctx.geo = geo
         vt, ldv = _vt(v, frames // kv_div, nk)
         out = ops.empty_rows(frames * nq, c, ops.H16(), q.device)
         kw = {}
+        # one key / value set, 16-bit build: the forward kernel leaves its softmax statistics, and the backward pass reads them
+        # and the output instead of running a statistics pass over all keys
+        ctx.stats = k2 is None and hip.planes() == 1
         if k2 is not None:
             vt2, ldv2 = _vt(v2, frames // kv_div2, nk2)
             kw = dict(k2=op(k2), vt2=vt2, nk2=nk2, ldvt2=ldv2, svt2=c * ldv2, kv_div2=kv_div2)
+        elif ctx.stats:
+            kw = dict(lse=torch.empty((frames * nq, heads), dtype=torch.float32, device=q.device))
         ops.attention(op(q), op(k), vt, out, frames=frames, heads=heads, nq=nq, nk=nk, ldvt=ldv, svt=c * ldv, kv_div=kv_div, scale=scale, **kw)
+        ctx.save_for_backward(q, k, v, *((k2, v2) if k2 is not None else ()), *((out, kw["lse"]) if ctx.stats else ()))
         return ops.to_f32(out)
 
     @staticmethod
@@ -514,9 +520,10 @@ class Attention(torch.autograd.Function):
         saved = ctx.saved_tensors
         q, k, v = saved[:3]
         do = do.contiguous()
-        dq, dk, dv = _attn_backward_set(q, k, v, do, frames // kv_div, kv_div * nq, nk, heads, scale, frames)
+        o, lse = (saved[-2], saved[-1]) if ctx.stats else (None, None)
+        dq, dk, dv = _attn_backward_set(q, k, v, do, frames // kv_div, kv_div * nq, nk, heads, scale, frames, o, lse)
         dk2 = dv2 = None
-        if len(saved) == 5:
+        if not ctx.stats and len(saved) == 5:
             dq2, dk2, dv2 = _attn_backward_set(q, saved[3], saved[4], do, frames // kv_div2, kv_div2 * nq, nk2, heads, scale, frames)
             ops.add_(dq, dq2)
         return dq, dk, dv, dk2, dv2, None

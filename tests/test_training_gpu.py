@@ -144,6 +144,12 @@ def test_attention_gradients_self_cross_two_sets_and_temporal(cuda):
     t = dict(q=rnd(2 * m, c, seed=6), k=rnd(2 * m, c, seed=7), v=rnd(2 * m, c, seed=8))
     compare("self-attention, 333 tokens", *run_both(lambda q, k, v: Fn.Attention.apply(q, k, v, None, None, (2, heads, m, m, 1, 0, 1, 0.125)),
                                                     lambda q, k, v: _attn_ref(q, k, v, 2, heads, m, m, 1, 0.125), t, cuda))
+    # the long-sequence forward kernels (64 queries per wave: LDS-DMA staged when the keys come in whole 64-tiles, register-staged
+    # otherwise) hand their softmax statistics to the backward pass like the short one does
+    for m, mk in ((576, 576), (520, 300)):
+        t = dict(q=rnd(m, c, seed=12), k=rnd(mk, c, seed=13), v=rnd(mk, c, seed=14))
+        compare(f"attention {m} queries x {mk} keys", *run_both(lambda q, k, v: Fn.Attention.apply(q, k, v, None, None, (1, heads, m, mk, 1, 0, 1, 0.125)),
+                                                                lambda q, k, v: _attn_ref(q, k, v, 1, heads, m, mk, 1, 0.125), t, cuda))
     t = dict(q=rnd(4 * 200, c, seed=9), k=rnd(2 * 150, c, seed=10), v=rnd(2 * 150, c, seed=11))
     compare("two frames per key batch, 200 queries, 150 keys", *run_both(
         lambda q, k, v: Fn.Attention.apply(q, k, v, None, None, (4, heads, 200, 150, 2, 0, 1, 0.125)),
