@@ -336,20 +336,19 @@ int mudg_temporal_attention_bwd(const float* Q, const float* K, const float* V, 
                                 void* stream);
 /* Backward of softmax(scale Q K^T) V, head width 64, without materialising the scores (16-bit operand builds; the forward is
  * mudg_attention, reference attention.py:81-144).  Q, dO: operand rows [F Nq][ld*]; K, V: operand rows [(F / kv_div) Nk][ld*]
- * (kv_div frames share a key / value batch: the text tokens of a clip); head h at columns [64 h, 64 h + 64).  Qt, dOt
- * [F / kv_div][heads 64][ld*t] and Kt [F / kv_div][heads 64][ldkt]: transposed copies (row = head channel, column = row of the
- * batch; mudg_transpose_gather).  L, D: fp32 [F Nq][heads] scratch the call fills (log2-sum-exp of the scaled scores and
- * sum_k P dP).  dQ [F Nq][ldgq], dK, dV [(F / kv_div) Nk][ldgk]: fp32, every element of the head columns written once. */
+ * (kv_div frames share a key / value batch: the text tokens of a clip); head h at columns [64 h, 64 h + 64).  No transposed
+ * copies are needed (the kernels read K^T, Q^T, dO^T out of the row tiles with ds_read_b64_tr_b16).  L, D: fp32 [F Nq][heads]:
+ * the log2-sum-exp of the scaled scores and sum_k P dP — filled by the call, or, with O given, L read (MudgAttnDesc.Lse of the
+ * forward pass) and D taken from dO . O.  dQ [F Nq][ldgq], dK, dV [(F / kv_div) Nk][ldgk]: fp32, every element of the head
+ * columns written once. */
 typedef struct MudgAttnBwdDesc {
     const void* Q; const void* K; const void* V; const void* dO;
     const void* O;       /* optional: the forward output (operand rows, row stride ldo).  Not NULL: L holds what the forward pass
                             wrote (MudgAttnDesc.Lse) and D = sum_d dO O is taken from O — the statistics pass is skipped */
-    const void* Qt; const void* dOt; const void* Kt;
     float* L; float* D;
     float* dQ; float* dK; float* dV;
     int F, heads, Nq, Nk, kv_div;
     int ldq, ldk, ldv, lddo, ldo;
-    int64_t ldqt, lddot, ldkt;
     int64_t ldgq, ldgk;
     float scale;
 } MudgAttnBwdDesc;

@@ -11,8 +11,9 @@
 //           keys), P, dS in registers, then dQ^T += K^T dS^T exactly as the forward accumulates O^T += V^T P^T;
 //   K side  the mirror image — a wave owns 32 KEYS (fragments of k and v): per query tile  S = Q k^T, dP = dO v^T (lane = key,
 //           registers = queries), L and D of the tile's queries from LDS, then dV^T += dO^T P and dK^T += Q^T dS.
-// The transposed tiles (K^T for the Q side; Q^T, dO^T for the K side) come from transposed copies made once per call
-// (mudg_transpose_gather), like V^T in the forward.  Key / value batches shared by kv_div frames (the text tokens of the
+// The transposed operands (K^T for the Q side; dO^T, Q^T for the K side) are never made: the row-major tiles already in LDS for the
+// score products are read a second time through ds_read_b64_tr_b16 (accumulate_tr).  Each pass keeps the next tile's global loads in
+// flight in registers under the current tile's MFMAs.  Key / value batches shared by kv_div frames (the text tokens of the
 // cross-attention) are handled by the K side walking all kv_div * Nq query rows of its batch.  No atomics: every output
 // element is written by exactly one wave.
 #include "common.h"
@@ -34,25 +35,6 @@ __device__ __forceinline__ void load_rows(const h16* base, int64_t ld, int64_t r
         r[i] = row < nrows ? ld16(base + row * ld + kc * 8) : zero16();
     }
 }
-// 64 (d) x 64 (columns c0 .. c0 + 63) tile of a transposed copy [64][ld]; columns >= ncols contribute exactly zero
-__device__ __forceinline__ void load_cols(const h16* base, int64_t ld, int64_t c0, int64_t ncols, int tid, u32x4 (&r)[2]) {
-    const int lrow = tid >> 3, kc = tid & 7;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int64_t c = c0 + kc * 8;
-        u32x4 v = zero16();
-        if (c < ncols) {
-            v = ld16(base + (int64_t)(lrow + 32 * i) * ld + c);
-            if (c + 8 > ncols) {
-                h16x8 hv = as_h16x8(v);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) if (c + e >= ncols) hv[e] = (h16)0.f;
-                v = as_u32x4(hv);
-            }
-        }
-        r[i] = v;
-    }
-}
 __device__ __forceinline__ void stage(h16* tile, int tid, const u32x4 (&r)[2]) {
     const int lrow = tid >> 3, kc = tid & 7;
 #pragma unroll
@@ -64,24 +46,42 @@ __device__ __forceinline__ void scores(const h16* tile, int sub, int l31, int hi
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) acc = MFMA_32x32x16(*reinterpret_cast<const h16x8*>(p + ks * 16), own[ks], acc);
 }
-// out^T[d][own row] += T^T[d][streamed row] * packed[streamed row][own row] for both 32-wide halves of d
-__device__ __forceinline__ void accumulate(const h16* ttile, int l31, int hi, const h16x8 (&pk)[2][2], f32x16 (&out)[2]) {
+// out^T[d][own row] += T^T[d][streamed row] * packed[streamed row][own row] for both 32-wide halves of d, with T^T taken from
+// the ROW-major tile T[streamed row][d] through gfx950's transposing LDS read: a 16-lane
+// group reads a 4-row x 16-column block and each lane receives one column's 4 rows — here the four streamed rows
+// kk + 4 hi + 0..3 (then + 8) of head channel dt 32 + (lane & 31), exactly the operand order `packed` was built in.  No transposed
+// copy of the streamed matrix exists anywhere.  (With the 144-byte row stride the two 16-lane groups of a half wave collide on
+// half of their banks: 2 LDS cycles more per read, against 32 MFMA cycles per read.)
+#ifdef MUDG_OPERAND_FP16
+typedef __attribute__((__vector_size__(4 * sizeof(__fp16)))) __fp16 tr_vec_t;
+#define TR_READ(ptr) __builtin_amdgcn_ds_read_tr16_b64_v4f16(ptr)
+#else
+typedef h16x4 tr_vec_t;
+#define TR_READ(ptr) __builtin_amdgcn_ds_read_tr16_b64_v4bf16(ptr)
+#endif
+typedef __attribute__((address_space(3))) tr_vec_t* lds_tr_ptr;
+__device__ __forceinline__ h16x4 tr_read(const h16* p) {
+    const tr_vec_t v = TR_READ((lds_tr_ptr)p);
+    h16x4 o;
+    __builtin_memcpy(&o, &v, sizeof(o));
+    return o;
+}
+__device__ __forceinline__ void accumulate_tr(const h16* tile, int lane, const h16x8 (&pk)[2][2], f32x16 (&out)[2]) {
+    const int g = lane >> 4, q = lane & 15;
+    const h16* base = tile + (4 * (g >> 1) + (q >> 2)) * BLD + 16 * (g & 1) + 4 * (q & 3);
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt) {
-        const h16* vp = ttile + (dt * 32 + l31) * BLD + 4 * hi;
+    for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
-                const int kk = sub * 32 + jj * 16;
-                const h16x4 lo = *reinterpret_cast<const h16x4*>(vp + kk);
-                const h16x4 up = *reinterpret_cast<const h16x4*>(vp + kk + 8);
+                const h16* p = base + (sub * 32 + jj * 16) * BLD + dt * 32;
+                const h16x4 lo = tr_read(p), up = tr_read(p + 8 * BLD);
                 h16x8 f;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { f[e] = lo[e]; f[4 + e] = up[e]; }
                 out[dt] = MFMA_32x32x16(f, pk[sub][jj], out[dt]);
             }
-    }
 }
 // fp32 store of an accumulator pair: lane holds, for its row, columns dt*32 + 8g + 4 hi + {0..3}
 __device__ __forceinline__ void store_rows(float* row, int hi, const f32x16 (&o)[2]) {
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_stats_kernel(const MudgAttnBw
 
 // ---------------------------------------------------------------------------------------------- Q side: dQ
 __global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(const MudgAttnBwdDesc p, const int nqt, const int total) {
-    __shared__ __attribute__((aligned(16))) h16 Ks[BTILE], Vs[BTILE], Kts[BTILE];
+    __shared__ __attribute__((aligned(16))) h16 Ks[BTILE], Vs[BTILE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     const int w = xcd_item(total);
     const int pair = w / nqt, qt = w - pair * nqt;
@@ -189,7 +189,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(const MudgAttnBwdDes
     const int64_t qrow = (int64_t)f * p.Nq + q;
     const h16* Kp = reinterpret_cast<const h16*>(p.K) + (int64_t)g * p.Nk * p.ldk + h * 64;
     const h16* Vp = reinterpret_cast<const h16*>(p.V) + (int64_t)g * p.Nk * p.ldv + h * 64;
-    const h16* Ktp = reinterpret_cast<const h16*>(p.Kt) + ((int64_t)g * p.heads + h) * 64 * p.ldkt;
     h16x8 qf[4], dof[4];
     own_fragments(reinterpret_cast<const h16*>(p.Q) + qrow * p.ldq + h * 64, qok, hi, qf);
     own_fragments(reinterpret_cast<const h16*>(p.dO) + qrow * p.lddo + h * 64, qok, hi, dof);
@@ -213,14 +212,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(const MudgAttnBwdDes
 #pragma unroll
     for (int i = 0; i < 16; ++i) { dq[0][i] = 0.f; dq[1][i] = 0.f; }
     const int nkt = (p.Nk + BT - 1) / BT;
+    u32x4 rk[2], rv[2];
+    load_rows(Kp, p.ldk, 0, p.Nk, tid, rk);
+    load_rows(Vp, p.ldv, 0, p.Nk, tid, rv);
     for (int kt = 0; kt < nkt; ++kt) {
-        u32x4 rk[2], rv[2], rt[2];
-        load_rows(Kp, p.ldk, (int64_t)kt * BT, p.Nk, tid, rk);
-        load_rows(Vp, p.ldv, (int64_t)kt * BT, p.Nk, tid, rv);
-        load_cols(Ktp, p.ldkt, (int64_t)kt * BT, p.Nk, tid, rt);
         __syncthreads();                           // the previous tile's reads are done
-        stage(Ks, tid, rk); stage(Vs, tid, rv); stage(Kts, tid, rt);
+        stage(Ks, tid, rk); stage(Vs, tid, rv);
         __syncthreads();
+        if (kt + 1 < nkt) {                        // the next tile's rows travel while this one is multiplied
+            load_rows(Kp, p.ldk, (int64_t)(kt + 1) * BT, p.Nk, tid, rk);
+            load_rows(Vp, p.ldv, (int64_t)(kt + 1) * BT, p.Nk, tid, rv);
+        }
         h16x8 pk[2][2];
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
@@ -236,14 +238,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(const MudgAttnBwdDes
                 pk[sub][i >> 3][i & 7] = (h16)(pr * (dp[i] - Dq) * p.scale);
             }
         }
-        accumulate(Kts, l31, hi, pk, dq);          // dQ^T[d][query] += K^T[d][key] dS^T[key][query]
+        accumulate_tr(Ks, lane, pk, dq);           // dQ^T[d][query] += K^T[d][key] dS^T[key][query], K^T read out of the K rows
     }
     if (qok) store_rows(p.dQ + qrow * p.ldgq + h * 64, hi, dq);
 }
 
 // ---------------------------------------------------------------------------------------------- K side: dK, dV
 __global__ __launch_bounds__(256, 2) void attn_bwd_k_kernel(const MudgAttnBwdDesc p, const int nktile, const int total) {
-    __shared__ __attribute__((aligned(16))) h16 Qs[BTILE], dOs[BTILE], Qts[BTILE], dOts[BTILE];
+    __shared__ __attribute__((aligned(16))) h16 Qs[BTILE], dOs[BTILE];
     __shared__ __attribute__((aligned(16))) float Ls[BT], Ds[BT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     const int w = xcd_item(total);
@@ -256,8 +258,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_k_kernel(const MudgAttnBwdDes
     const int64_t q0 = (int64_t)g * NQ;
     const h16* Qp = reinterpret_cast<const h16*>(p.Q) + q0 * p.ldq + h * 64;
     const h16* dOp = reinterpret_cast<const h16*>(p.dO) + q0 * p.lddo + h * 64;
-    const h16* Qtp = reinterpret_cast<const h16*>(p.Qt) + ((int64_t)g * p.heads + h) * 64 * p.ldqt;
-    const h16* dOtp = reinterpret_cast<const h16*>(p.dOt) + ((int64_t)g * p.heads + h) * 64 * p.lddot;
     h16x8 kf[4], vf[4];
     own_fragments(reinterpret_cast<const h16*>(p.K) + krow * p.ldk + h * 64, kok, hi, kf);
     own_fragments(reinterpret_cast<const h16*>(p.V) + krow * p.ldv + h * 64, kok, hi, vf);
@@ -266,21 +266,24 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_k_kernel(const MudgAttnBwdDes
 #pragma unroll
     for (int i = 0; i < 16; ++i) { dk[0][i] = 0.f; dk[1][i] = 0.f; dv[0][i] = 0.f; dv[1][i] = 0.f; }
     const int64_t nqt = (NQ + BT - 1) / BT;
-    for (int64_t qt = 0; qt < nqt; ++qt) {
-        u32x4 rq[2], rd[2], rqt[2], rdt[2];
+    u32x4 rq[2], rd[2];
+    float lq = INFINITY, dq_ = 0.f;                                // a query row that does not exist: P = 2^(-inf) = 0
+    auto fetch = [&](int64_t qt) {
         load_rows(Qp, p.ldq, qt * BT, NQ, tid, rq);
         load_rows(dOp, p.lddo, qt * BT, NQ, tid, rd);
-        load_cols(Qtp, p.ldqt, qt * BT, NQ, tid, rqt);
-        load_cols(dOtp, p.lddot, qt * BT, NQ, tid, rdt);
-        float lq = INFINITY, dq_ = 0.f;                            // a query row that does not exist: P = 2^(-inf) = 0
+        lq = INFINITY; dq_ = 0.f;
         if (tid < BT && qt * BT + tid < NQ) {
             lq = p.L[(q0 + qt * BT + tid) * p.heads + h];
             dq_ = p.D[(q0 + qt * BT + tid) * p.heads + h];
         }
+    };
+    fetch(0);
+    for (int64_t qt = 0; qt < nqt; ++qt) {
         __syncthreads();
-        stage(Qs, tid, rq); stage(dOs, tid, rd); stage(Qts, tid, rqt); stage(dOts, tid, rdt);
+        stage(Qs, tid, rq); stage(dOs, tid, rd);
         if (tid < BT) { Ls[tid] = lq; Ds[tid] = dq_; }
         __syncthreads();
+        if (qt + 1 < nqt) fetch(qt + 1);                           // the next tile travels while this one is multiplied
         h16x8 pp[2][2], pds[2][2];
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {
@@ -302,8 +305,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_k_kernel(const MudgAttnBwdDes
                 }
             }
         }
-        accumulate(dOts, l31, hi, pp, dv);         // dV^T[d][key] += dO^T[d][query] P[query][key]
-        accumulate(Qts, l31, hi, pds, dk);         // dK^T[d][key] += Q^T[d][query] dS[query][key]
+        accumulate_tr(dOs, lane, pp, dv);          // dV^T[d][key] += dO^T[d][query] P[query][key], dO^T read out of the dO rows
+        accumulate_tr(Qs, lane, pds, dk);          // dK^T[d][key] += Q^T[d][query] dS[query][key]
     }
     if (kok) {
         store_rows(p.dK + krow * p.ldgk + h * 64, hi, dk);
@@ -318,15 +321,14 @@ extern "C" int mudg_attention_bwd(const MudgAttnBwdDesc* dp, void* stream) {
 #if MUDG_PLANES == 1
     MUDG_REQUIRE(dp, "mudg_attention_bwd: null descriptor");
     const MudgAttnBwdDesc d = *dp;
-    MUDG_REQUIRE(d.Q && d.K && d.V && d.dO && d.Qt && d.dOt && d.Kt && d.L && d.D && d.dQ && d.dK && d.dV, "mudg_attention_bwd: null pointer");
+    MUDG_REQUIRE(d.Q && d.K && d.V && d.dO && d.L && d.D && d.dQ && d.dK && d.dV, "mudg_attention_bwd: null pointer");
     MUDG_REQUIRE(d.F > 0 && d.heads > 0 && d.Nq > 0 && d.Nk > 0 && d.kv_div > 0 && d.F % d.kv_div == 0, "mudg_attention_bwd: geometry");
     const int C = d.heads * 64;
     MUDG_REQUIRE(d.ldq >= C && d.ldk >= C && d.ldv >= C && d.lddo >= C && d.ldgq >= C && d.ldgk >= C, "mudg_attention_bwd: row strides");
-    MUDG_REQUIRE((d.ldq & 7) == 0 && (d.ldk & 7) == 0 && (d.ldv & 7) == 0 && (d.lddo & 7) == 0 && (d.ldqt & 7) == 0 &&
-                 (d.lddot & 7) == 0 && (d.ldkt & 7) == 0 && (d.ldgq & 3) == 0 && (d.ldgk & 3) == 0, "mudg_attention_bwd: strides must keep 16-byte accesses aligned");
-    MUDG_REQUIRE(d.ldqt >= (int64_t)d.kv_div * d.Nq && d.lddot >= (int64_t)d.kv_div * d.Nq && d.ldkt >= d.Nk, "mudg_attention_bwd: transposed copies too narrow");
-    MUDG_REQUIRE(aligned16(d.Q) && aligned16(d.K) && aligned16(d.V) && aligned16(d.dO) && aligned16(d.Qt) && aligned16(d.dOt) &&
-                 aligned16(d.Kt) && aligned16(d.dQ) && aligned16(d.dK) && aligned16(d.dV), "mudg_attention_bwd: alignment");
+    MUDG_REQUIRE((d.ldq & 7) == 0 && (d.ldk & 7) == 0 && (d.ldv & 7) == 0 && (d.lddo & 7) == 0 &&
+                 (d.ldgq & 3) == 0 && (d.ldgk & 3) == 0, "mudg_attention_bwd: strides must keep 16-byte accesses aligned");
+    MUDG_REQUIRE(aligned16(d.Q) && aligned16(d.K) && aligned16(d.V) && aligned16(d.dO) &&
+                 aligned16(d.dQ) && aligned16(d.dK) && aligned16(d.dV), "mudg_attention_bwd: alignment");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int nqt = (d.Nq + BTQ - 1) / BTQ;
     const int64_t tq = (int64_t)nqt * d.F * d.heads;

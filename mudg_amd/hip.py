@@ -94,12 +94,10 @@ class AttnBwdDesc(C.Structure):
     _fields_ = [
         ("Q", C.c_void_p), ("K", C.c_void_p), ("V", C.c_void_p), ("dO", C.c_void_p),
         ("O", C.c_void_p),
-        ("Qt", C.c_void_p), ("dOt", C.c_void_p), ("Kt", C.c_void_p),
         ("L", C.c_void_p), ("D", C.c_void_p),
         ("dQ", C.c_void_p), ("dK", C.c_void_p), ("dV", C.c_void_p),
         ("F", C.c_int), ("heads", C.c_int), ("Nq", C.c_int), ("Nk", C.c_int), ("kv_div", C.c_int),
         ("ldq", C.c_int), ("ldk", C.c_int), ("ldv", C.c_int), ("lddo", C.c_int), ("ldo", C.c_int),
-        ("ldqt", C.c_int64), ("lddot", C.c_int64), ("ldkt", C.c_int64),
         ("ldgq", C.c_int64), ("ldgk", C.c_int64),
         ("scale", C.c_float),
     ]

@@ -437,12 +437,9 @@ def _vt(v, batches, nk):
 
 
 def _attn_backward_fused(q, k, v, do, groups, nqg, nk, heads, scale, frames, o=None, lse=None):
-    """The same gradients from mudg_attention_bwd (16-bit operand builds): no score matrix in memory — three transposed copies
-    (Q^T, dO^T per key / value batch, K^T) and one call."""
-    tr = lambda src, p: K.transpose_gather(src, P=p, batch=groups, src_batch_rows=p, dst_batch_rows=src.shape[1],
-                                           out=ops.empty_rows(groups * src.shape[1], _pad8(p), ops.H16(), src.device))
-    return K.attention_bwd(op(q), op(k), op(v), op(do), tr(q, nqg), tr(do, nqg), tr(k, nk), frames=frames, heads=heads,
-                           nq=nqg * groups // frames, nk=nk, kv_div=frames // groups, scale=scale, o=o, lse=lse)
+    """The same gradients from mudg_attention_bwd (16-bit operand builds): no score matrix and no transposed copy in memory."""
+    return K.attention_bwd(op(q), op(k), op(v), op(do), frames=frames, heads=heads, nq=nqg * groups // frames, nk=nk,
+                           kv_div=frames // groups, scale=scale, o=o, lse=lse)
 
 
 def _attn_backward_set(q, k, v, do, groups, nqg, nk, heads, scale, frames, o=None, lse=None):

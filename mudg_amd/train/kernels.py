@@ -126,9 +126,9 @@ def softmax_bwd(p, dp, ds, cols, scale):
     return ds
 
 
-def attention_bwd(q, k, v, do, qt, dot, kt, *, frames, heads, nq, nk, kv_div, scale, o=None, lse=None):
+def attention_bwd(q, k, v, do, *, frames, heads, nq, nk, kv_div, scale, o=None, lse=None):
     """mudg_attention_bwd: (dq, dk, dv) fp32 rows of softmax(scale q k^T) v from operand rows q, do [frames * nq][C], k, v
-    [(frames / kv_div) * nk][C] and the transposed copies qt, dot, kt [(frames / kv_div) * C][...] (16-bit operand builds)."""
+    [(frames / kv_div) * nk][C] (16-bit operand builds)."""
     dev = q.device
     c = heads * 64
     # o / lse: the forward output and the statistics it saved (ops.attention(lse=...)): no statistics pass
@@ -139,14 +139,12 @@ def attention_bwd(q, k, v, do, qt, dot, kt, *, frames, heads, nq, nk, kv_div, sc
     dv = torch.empty_like(dk)
     d = hip.AttnBwdDesc()
     d.Q, d.K, d.V, d.dO = q.data_ptr(), k.data_ptr(), v.data_ptr(), do.data_ptr()
-    d.Qt, d.dOt, d.Kt = qt.data_ptr(), dot.data_ptr(), kt.data_ptr()
     d.L, d.D = big_l.data_ptr(), stat[1].data_ptr()
     d.dQ, d.dK, d.dV = dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
     d.F, d.heads, d.Nq, d.Nk, d.kv_div = frames, heads, nq, nk, kv_div
     d.ldq, d.ldk, d.ldv, d.lddo = q.stride(0), k.stride(0), v.stride(0), do.stride(0)
     if o is not None and lse is not None:
         d.O, d.ldo = o.data_ptr(), o.stride(0)
-    d.ldqt, d.lddot, d.ldkt = qt.stride(0), dot.stride(0), kt.stride(0)
     d.ldgq, d.ldgk = c, c
     d.scale = scale
     hip.check(hip.lib().mudg_attention_bwd(C.byref(d), _s()), "mudg_attention_bwd")
