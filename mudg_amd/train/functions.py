@@ -509,7 +509,7 @@ class Attention(torch.autograd.Function):
             kw = dict(lse=torch.empty((frames * nq, heads), dtype=torch.float32, device=q.device))
         ops.attention(op(q), op(k), vt, out, frames=frames, heads=heads, nq=nq, nk=nk, ldvt=ldv, svt=c * ldv, kv_div=kv_div, scale=scale, **kw)
         ctx.save_for_backward(q, k, v, *((k2, v2) if k2 is not None else ()), *((out, kw["lse"]) if ctx.stats else ()))
-        return ops.to_f32(out)
+        return _with_operand(ops.to_f32(out), out)
 
     @staticmethod
     def backward(ctx, do):
@@ -537,7 +537,7 @@ class TemporalAttention(torch.autograd.Function):
         c = qkv.shape[1] // 3
         out = ops.empty_rows(qkv.shape[0], c, ops.H16(), qkv.device)
         ops.temporal_attention(op(qkv), out, clips=clips, t=t, hw=hw, heads=heads, scale=scale)
-        return ops.to_f32(out)
+        return _with_operand(ops.to_f32(out), out)
 
     @staticmethod
     def backward(ctx, do):
