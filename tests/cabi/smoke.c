@@ -20,7 +20,11 @@ int main(int argc, char** argv) {
         /* still reference every symbol so that the link step is the test */
         void* syms[] = {(void*)mudg_gemm, (void*)mudg_attention, (void*)mudg_temporal_attention, (void*)mudg_groupnorm,
                         (void*)mudg_groupnorm_fused, (void*)mudg_layernorm, (void*)mudg_softmax_rows, (void*)mudg_ddim_step,
-                        (void*)mudg_timestep_embedding, (void*)mudg_small_linear, (void*)mudg_last_error};
+                        (void*)mudg_timestep_embedding, (void*)mudg_small_linear, (void*)mudg_last_error,
+                        /* the training step */
+                        (void*)mudg_wgrad, (void*)mudg_attention_bwd, (void*)mudg_transpose_gather, (void*)mudg_transpose_cast_sum,
+                        (void*)mudg_group_colsum, (void*)mudg_groupnorm_bwd, (void*)mudg_layernorm_bwd, (void*)mudg_temporal_attention_bwd,
+                        (void*)mudg_geglu, (void*)mudg_mse, (void*)mudg_dropout, (void*)mudg_clip_grad_norm, (void*)mudg_adamw};
         printf("no GPU: %d symbols linked\n", (int)(sizeof(syms) / sizeof(syms[0])));
         return 0;
     }
