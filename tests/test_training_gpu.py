@@ -67,7 +67,10 @@ def test_linear_conv_and_temporal_conv_gradients(cuda):
         compare(f"linear {M} x {Kd} -> {N}", *run_both(lambda x, w, b: Fn.Linear.apply(x, w, b, None), lambda x, w, b: F.linear(x, w, b), t, cuda))
     # 3x3 conv: stride 1 with the embedding (row-group) bias and a residual, then stride 2; Cin = 12 exercises the channel padding;
     # Cin = 192: an output tile of the weight gradient straddles two taps; odd sizes under stride 2
-    for stride, ci, co, h, wd in ((1, 64, 40, 6, 8), (2, 12, 24, 6, 8), (1, 64, 64, 24, 32), (1, 192, 136, 10, 12), (2, 64, 72, 9, 11)):
+    # (the last three: image rows of 64 and 128 pixels and a 16-pixel one — the affine tap paths of mudg_wgrad, where a 64-position
+    # K-step is part of one image row or spans whole rows)
+    for stride, ci, co, h, wd in ((1, 64, 40, 6, 8), (2, 12, 24, 6, 8), (1, 64, 64, 24, 32), (1, 192, 136, 10, 12), (2, 64, 72, 9, 11),
+                                 (1, 64, 72, 5, 64), (1, 64, 40, 3, 128), (1, 128, 64, 8, 16), (1, 64, 72, 16, 64)):     # the last: several slices
         frames = 4
         ho, wo = (h - 1) // stride + 1, (wd - 1) // stride + 1
         t = dict(x=rnd(frames * h * wd, ci, seed=1), w=rnd(co, ci, 3, 3, seed=2, scale=0.1), b=rnd(co, seed=3),
@@ -79,7 +82,7 @@ def test_linear_conv_and_temporal_conv_gradients(cuda):
             return y.permute(0, 2, 3, 1).reshape(-1, co) + r
         compare(f"conv3x3 stride {stride}", *run_both(
             lambda x, w, b, e, r: Fn.Conv3x3.apply(x, w, b, e, r, (frames, h, wd, stride), (frames // 2) * ho * wo), ref, t, cuda))
-    for clips, tt, hw, c in ((2, 5, 12, 64), (2, 7, 50, 128), (1, 4, 9, 24)):
+    for clips, tt, hw, c in ((2, 5, 12, 64), (2, 7, 50, 128), (1, 4, 9, 24), (2, 5, 64, 64), (1, 3, 192, 128), (2, 8, 256, 64)):      # the last three: frames of whole K-steps, the last in several slices
         t = dict(x=rnd(clips * tt * hw, c, seed=1), w=rnd(c, c, 3, 1, 1, seed=2, scale=0.1), b=rnd(c, seed=3))
 
         def tref(x, w, b):
