@@ -526,6 +526,36 @@ class Attention(torch.autograd.Function):
         return dq, dk, dv, dk2, dv2, None
 
 
+class SelfAttention(torch.autograd.Function):
+    """Self-attention on the PACKED projection qkv [frames * n][q | k | v] (one GEMM made it, one GEMM takes its gradient back):
+    the 16-bit builds' route for attn1 of the spatial blocks.  Keeps the operand rows, the output and the softmax statistics; the
+    backward kernels write dq / dk / dv into the column blocks of one packed gradient."""
+
+    @staticmethod
+    def forward(ctx, qkv, geo):
+        frames, heads, n, scale = geo
+        c = heads * 64
+        qkv16 = op(qkv)
+        q16, k16 = qkv16[:, :c], qkv16[:, c:2 * c]
+        vt, ldv = _vt(qkv[:, 2 * c:], frames, n)
+        out = ops.empty_rows(frames * n, c, ops.H16(), qkv.device)
+        lse = torch.empty((frames * n, heads), dtype=torch.float32, device=qkv.device)
+        ops.attention(q16, k16, vt, out, frames=frames, heads=heads, nq=n, nk=n, ldvt=ldv, svt=c * ldv, kv_div=1, scale=scale, lse=lse)
+        ctx.save_for_backward(qkv16, out, lse)
+        ctx.geo = geo
+        return _with_operand(ops.to_f32(out), out)
+
+    @staticmethod
+    def backward(ctx, do):
+        frames, heads, n, scale = ctx.geo
+        qkv16, out, lse = ctx.saved_tensors
+        c = heads * 64
+        dqkv = torch.empty((frames * n, 3 * c), dtype=torch.float32, device=do.device)
+        K.attention_bwd(qkv16[:, :c], qkv16[:, c:2 * c], qkv16[:, 2 * c:], op(do.contiguous()), frames=frames, heads=heads, nq=n, nk=n, kv_div=1,
+                        scale=scale, o=out, lse=lse, out=(dqkv[:, :c], dqkv[:, c:2 * c], dqkv[:, 2 * c:]))
+        return dqkv, None
+
+
 class TemporalAttention(torch.autograd.Function):
     """Self-attention over the T frames of every pixel (attention.py:529-576); qkv rows ((b t) hw) x [q | k | v]."""
 

@@ -126,17 +126,23 @@ def softmax_bwd(p, dp, ds, cols, scale):
     return ds
 
 
-def attention_bwd(q, k, v, do, *, frames, heads, nq, nk, kv_div, scale, o=None, lse=None):
+def attention_bwd(q, k, v, do, *, frames, heads, nq, nk, kv_div, scale, o=None, lse=None, out=None):
     """mudg_attention_bwd: (dq, dk, dv) fp32 rows of softmax(scale q k^T) v from operand rows q, do [frames * nq][C], k, v
-    [(frames / kv_div) * nk][C] (16-bit operand builds)."""
+    [(frames / kv_div) * nk][C] (16-bit operand builds).  out: (dq, dk, dv) fp32 row views to write into (dk and dv with one row
+    stride), e.g. the column blocks of one packed gradient."""
     dev = q.device
     c = heads * 64
     # o / lse: the forward output and the statistics it saved (ops.attention(lse=...)): no statistics pass
     stat = torch.empty((2, frames * nq, heads), dtype=torch.float32, device=dev)
     big_l = stat[0] if lse is None else lse
-    dq = torch.empty((frames * nq, c), dtype=torch.float32, device=dev)
-    dk = torch.empty((frames // kv_div * nk, c), dtype=torch.float32, device=dev)
-    dv = torch.empty_like(dk)
+    if out is not None:
+        dq, dk, dv = out
+        if dk.stride(0) != dv.stride(0) or any(t.dtype != torch.float32 or t.stride(1) != 1 for t in out):
+            raise hip.MudgError("attention_bwd: out must be fp32 row views, dk and dv with the same row stride")
+    else:
+        dq = torch.empty((frames * nq, c), dtype=torch.float32, device=dev)
+        dk = torch.empty((frames // kv_div * nk, c), dtype=torch.float32, device=dev)
+        dv = torch.empty_like(dk)
     d = hip.AttnBwdDesc()
     d.Q, d.K, d.V, d.dO = q.data_ptr(), k.data_ptr(), v.data_ptr(), do.data_ptr()
     d.L, d.D = big_l.data_ptr(), stat[1].data_ptr()
@@ -145,7 +151,7 @@ def attention_bwd(q, k, v, do, *, frames, heads, nq, nk, kv_div, scale, o=None, 
     d.ldq, d.ldk, d.ldv, d.lddo = q.stride(0), k.stride(0), v.stride(0), do.stride(0)
     if o is not None and lse is not None:
         d.O, d.ldo = o.data_ptr(), o.stride(0)
-    d.ldgq, d.ldgk = c, c
+    d.ldgq, d.ldgk = dq.stride(0), dk.stride(0)
     d.scale = scale
     hip.check(hip.lib().mudg_attention_bwd(C.byref(d), _s()), "mudg_attention_bwd")
     return dq, dk, dv

@@ -8,12 +8,21 @@ its own kernel over the saved pre-activation, conditioning projected inside the 
 import torch
 import torch.nn as nn
 
-from .. import ops
+from .. import hip, ops
 from . import functions as F_
 
 
 def _lin(mod, x, residual=None):
     return F_.Linear.apply(x, mod.weight, mod.bias, residual)
+
+
+def _lin_packed(mods, x):
+    """The bias-free projections `mods` of one input as ONE GEMM: the weights are concatenated (autograd hands each its block
+    of the gradient), the input gradient comes back from one GEMM over the packed output gradient instead of a GEMM and an
+    accumulation per projection."""
+    if any(m.bias is not None for m in mods):
+        raise NotImplementedError("packed projections are bias-free (to_q / to_k / to_v)")
+    return F_.Linear.apply(x, torch.cat([m.weight for m in mods], dim=0), None, None)
 
 
 def _gn(mod, x, samples, rows, silu):
@@ -84,8 +93,11 @@ def _feed_forward(ff, x_norm, residual):
 def spatial_block(blk, cur, frames, hw, ctx):
     a1, a2 = blk.attn1, blk.attn2
     n1 = _ln(blk.norm1, cur)
-    att = F_.Attention.apply(_lin(a1.to_q, n1), _lin(a1.to_k, n1), _lin(a1.to_v, n1), None, None,
-                             (frames, a1.heads, hw, hw, 1, 0, 1, a1.scale))
+    if hip.planes() == 1:
+        att = F_.SelfAttention.apply(_lin_packed((a1.to_q, a1.to_k, a1.to_v), n1), (frames, a1.heads, hw, a1.scale))
+    else:
+        att = F_.Attention.apply(_lin(a1.to_q, n1), _lin(a1.to_k, n1), _lin(a1.to_v, n1), None, None,
+                                 (frames, a1.heads, hw, hw, 1, 0, 1, a1.scale))
     cur = _out_proj(a1, att, cur)
     n2 = _ln(blk.norm2, cur)
     q2 = _lin(a2.to_q, n2)
@@ -112,7 +124,7 @@ def spatial_transformer(mod, x, h, w, ctx):
 def temporal_block(blk, cur, hw, ctx):
     for attn, norm in ((blk.attn1, blk.norm1), (blk.attn2, blk.norm2)):
         n = _ln(norm, cur)
-        qkv = torch.cat([_lin(attn.to_q, n), _lin(attn.to_k, n), _lin(attn.to_v, n)], dim=1)        # layout: [q | k | v] columns
+        qkv = _lin_packed((attn.to_q, attn.to_k, attn.to_v), n)                                    # [q | k | v] columns
         att = F_.TemporalAttention.apply(qkv, (ctx.B, ctx.T, hw, attn.heads, attn.scale))
         cur = _out_proj(attn, att, cur)
     return _feed_forward(blk.ff, _ln(blk.norm3, cur), cur)

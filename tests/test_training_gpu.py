@@ -157,6 +157,12 @@ def test_attention_gradients_self_cross_two_sets_and_temporal(cuda):
     compare("two frames per key batch, 200 queries, 150 keys", *run_both(
         lambda q, k, v: Fn.Attention.apply(q, k, v, None, None, (4, heads, 200, 150, 2, 0, 1, 0.125)),
         lambda q, k, v: _attn_ref(q, k, v, 4, heads, 200, 150, 2, 0.125), t, cuda))
+    if MODE in ("bf16", "fp16"):      # the packed route of the 16-bit builds: q | k | v in one matrix, one packed gradient back
+        for fr, m in ((2, 40), (1, 576)):
+            packed = dict(qkv=rnd(fr * m, 3 * c, seed=15))
+            compare(f"packed self-attention {m} tokens", *run_both(
+                lambda qkv: Fn.SelfAttention.apply(qkv, (fr, heads, m, 0.125)),
+                lambda qkv: _attn_ref(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], fr, heads, m, m, 1, 0.125), packed, cuda))
     # no atomics, fixed summation order: the same inputs give the same bits
     q1, k1, v1 = (x.to(cuda).requires_grad_() for x in (t["q"], t["k"], t["v"]))
     grads = []
