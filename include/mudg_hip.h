@@ -300,10 +300,11 @@ int mudg_groupnorm_bwd(const float* X, int64_t ldx, const float* dY, int64_t ldy
                        const float* stat, int samples, int rows, int C, int groups, int silu, float* dX, int64_t lddx, float* AB,
                        float* ws, void* stream);
 /* LayerNorm backward: dX, and part[chunks][2][C] (chunks = mudg_layernorm_bwd_chunks(rows)): per chunk of rows the sums of
- * dY * xhat (row 0) and dY (row 1) — dgamma / dbeta are their sums over the chunks (mudg_group_colsum).  C <= 1280. */
+ * dY * xhat (row 0) and dY (row 1) — dgamma / dbeta are their sums over the chunks (mudg_group_colsum).  C <= 1280.  dres (optional,
+ * rows [rows][lddres]): added to dX — the gradient of the residual branch that bypassed the norm (x + f(LN(x))). */
 int64_t mudg_layernorm_bwd_chunks(int64_t rows);
 int mudg_layernorm_bwd(const float* X, int64_t ldx, const float* dY, int64_t ldy, const float* gamma, float* dX, int64_t lddx,
-                       float* part, int64_t rows, int C, float eps, void* stream);
+                       float* part, int64_t rows, int C, float eps, const float* dres, int64_t lddres, void* stream);
 /* Weight gradient of a linear / 3x3 conv / temporal conv layer straight from the row-major operands of the forward pass (16-bit
  * operand builds): out[slice][m][tap * C + c] = sum over the positions p of the slice of A[p][m] * B[src(p, tap)][c], with A = the
  * output gradient as operand rows [P][lda], B = the layer input as operand rows [*][ldb], src as in mudg_transpose_gather (mode 0:

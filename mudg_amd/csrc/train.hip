@@ -241,7 +241,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
 constexpr int LN_CHUNK = 64, LN_MAXC = 20;
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ X, int64_t ldx, const float* __restrict__ dY, int64_t ldy,
                                                       const float* __restrict__ gamma, float* __restrict__ dX, int64_t lddx,
-                                                      float* __restrict__ part, int64_t rows, int C, float eps) {
+                                                      float* __restrict__ part, int64_t rows, int C, float eps,
+                                                      const float* __restrict__ dRes, int64_t lddres) {
     __shared__ float red[3][2][LN_MAXC * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nc = (C + 63) / 64;
@@ -252,13 +253,14 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ X
     for (int64_t row = r0 + wave; row < r0 + LN_CHUNK && row < rows; row += 4) {
         const float* x = X + row * ldx;
         const float* dy = dY + row * ldy;
-        float xv[LN_MAXC], dv[LN_MAXC];
+        float xv[LN_MAXC], dv[LN_MAXC], rv[LN_MAXC];
         float s = 0.f;
 #pragma unroll
         for (int j = 0; j < LN_MAXC; ++j) {
             const bool ok = j < nc && lane + 64 * j < C;
             xv[j] = ok ? x[lane + 64 * j] : 0.f;
             dv[j] = ok ? dy[lane + 64 * j] : 0.f;
+            rv[j] = (ok && dRes) ? dRes[row * lddres + lane + 64 * j] : 0.f;      // fetched with the rest: its latency hides under the reductions
             s += xv[j];
         }
         const float mean = wave_sum(s) / (float)C;
@@ -276,7 +278,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ X
 #pragma unroll
         for (int j = 0; j < LN_MAXC; ++j) if (j < nc && lane + 64 * j < C) {
             const float xh = (xv[j] - mean) * rstd;
-            dX[row * lddx + lane + 64 * j] = rstd * (dv[j] * ga[j] - m1 - xh * m2);
+            dX[row * lddx + lane + 64 * j] = rstd * (dv[j] * ga[j] - m1 - xh * m2) + rv[j];     // + the gradient of the branch that bypassed the norm
             ag[j] = fmaf(dv[j], xh, ag[j]);
             ab[j] += dv[j];
         }
@@ -631,11 +633,11 @@ int mudg_groupnorm_stats(const float* X, int64_t ldx, int samples, int rows, int
 int64_t mudg_layernorm_bwd_chunks(int64_t rows) { return (rows + LN_CHUNK - 1) / LN_CHUNK; }
 
 int mudg_layernorm_bwd(const float* X, int64_t ldx, const float* dY, int64_t ldy, const float* gamma, float* dX, int64_t lddx, float* part,
-                       int64_t rows, int C, float eps, void* stream) {
+                       int64_t rows, int C, float eps, const float* dres, int64_t lddres, void* stream) {
     MUDG_REQUIRE(X && dY && gamma && dX && part && rows > 0 && C > 0, "mudg_layernorm_bwd: bad arguments");
     MUDG_REQUIRE(C <= 64 * LN_MAXC, "mudg_layernorm_bwd: C=%d above %d", C, 64 * LN_MAXC);
     hipLaunchKernelGGL(ln_bwd_kernel, dim3((unsigned)mudg_layernorm_bwd_chunks(rows)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), X, ldx,
-                       dY, ldy, gamma, dX, lddx, part, rows, C, eps);
+                       dY, ldy, gamma, dX, lddx, part, rows, C, eps, dres, lddres);
     return mudg_check_launch("mudg_layernorm_bwd");
 }
 

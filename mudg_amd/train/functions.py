@@ -354,6 +354,28 @@ class LayerNorm(torch.autograd.Function):
         return dx, dg, db, None
 
 
+class LayerNormSkip(torch.autograd.Function):
+    """x -> (LayerNorm(x), x): the second output is what the residual connection around the normalised branch adds back
+    (x + f(LN(x)), attention.py:392-400).  Routing the skip through this node lets the backward kernel add the skip's gradient to
+    the norm's input gradient as it writes it, instead of autograd accumulating two full-size tensors afterwards."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        g, b = gamma.float().contiguous(), beta.float().contiguous()
+        ctx.save_for_backward(x, g)
+        ctx.eps = eps
+        y = ops.layernorm(x, g, b, eps=eps)
+        return _with_operand(ops.to_f32(y), y), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dskip):
+        x, g = ctx.saved_tensors
+        if dy is None:
+            return dskip, None, None, None
+        dx, dg, db = K.layernorm_bwd(x, dy.contiguous(), g, ctx.eps, dres=None if dskip is None else dskip.contiguous())
+        return dx, dg, db, None
+
+
 class Geglu(torch.autograd.Function):
     """[value | gate] rows -> value * gelu(gate) (attention.py:579-586)."""
 

@@ -78,14 +78,16 @@ def groupnorm_bwd(x, dy, gamma, beta, stat, samples, rows, groups, silu):
     return dx, tot[1::2].contiguous(), tot[0::2].contiguous()
 
 
-def layernorm_bwd(x, dy, gamma, eps):
+def layernorm_bwd(x, dy, gamma, eps, dres=None):
+    """dres: fp32 rows added to dx (the gradient of the residual branch around the norm)."""
     _f32(x); _f32(dy)
     rows, c = x.shape
     dx = torch.empty_like(x)
     chunks = hip.lib().mudg_layernorm_bwd_chunks(rows)
     part = torch.empty((chunks, 2 * c), dtype=torch.float32, device=x.device)           # per chunk of rows: [sum dy xhat | sum dy]
     hip.check(hip.lib().mudg_layernorm_bwd(x.data_ptr(), x.stride(0), dy.data_ptr(), dy.stride(0), gamma.data_ptr(), dx.data_ptr(), dx.stride(0),
-                                           part.data_ptr(), rows, c, eps, _s()), "mudg_layernorm_bwd")
+                                           part.data_ptr(), rows, c, eps, None if dres is None else _f32(dres).data_ptr(),
+                                           0 if dres is None else dres.stride(0), _s()), "mudg_layernorm_bwd")
     sums = group_colsum(part)[0]
     return dx, sums[:c], sums[c:]
 

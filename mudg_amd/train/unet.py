@@ -33,6 +33,11 @@ def _ln(mod, x):
     return F_.LayerNorm.apply(x, mod.weight, mod.bias, mod.eps)
 
 
+def _ln_skip(mod, x):
+    """(LayerNorm(x), x) with the skip routed through the norm's node (functions.LayerNormSkip)."""
+    return F_.LayerNormSkip.apply(x, mod.weight, mod.bias, mod.eps)
+
+
 def _conv(mod, x, frames, h, w, stride=1, gbias=None, rows_per_group=None, residual=None):
     return F_.Conv3x3.apply(x, mod.weight, mod.bias, gbias, residual, (frames, h, w, stride), rows_per_group)
 
@@ -92,14 +97,14 @@ def _feed_forward(ff, x_norm, residual):
 
 def spatial_block(blk, cur, frames, hw, ctx):
     a1, a2 = blk.attn1, blk.attn2
-    n1 = _ln(blk.norm1, cur)
+    n1, cur = _ln_skip(blk.norm1, cur)
     if hip.planes() == 1:
         att = F_.SelfAttention.apply(_lin_packed((a1.to_q, a1.to_k, a1.to_v), n1), (frames, a1.heads, hw, a1.scale))
     else:
         att = F_.Attention.apply(_lin(a1.to_q, n1), _lin(a1.to_k, n1), _lin(a1.to_v, n1), None, None,
                                  (frames, a1.heads, hw, hw, 1, 0, 1, a1.scale))
     cur = _out_proj(a1, att, cur)
-    n2 = _ln(blk.norm2, cur)
+    n2, cur = _ln_skip(blk.norm2, cur)
     q2 = _lin(a2.to_q, n2)
     k_t, v_t = _lin(a2.to_k, ctx.text), _lin(a2.to_v, ctx.text)
     if ctx.img is not None and a2.image_cross_attention:
@@ -110,7 +115,8 @@ def spatial_block(blk, cur, frames, hw, ctx):
     else:
         att2 = F_.Attention.apply(q2, k_t, v_t, None, None, (frames, a2.heads, hw, 77, ctx.T, 0, 1, a2.scale))
     cur = _out_proj(a2, att2, cur)
-    return _feed_forward(blk.ff, _ln(blk.norm3, cur), cur)
+    n3, cur = _ln_skip(blk.norm3, cur)
+    return _feed_forward(blk.ff, n3, cur)
 
 
 def spatial_transformer(mod, x, h, w, ctx):
@@ -123,11 +129,12 @@ def spatial_transformer(mod, x, h, w, ctx):
 
 def temporal_block(blk, cur, hw, ctx):
     for attn, norm in ((blk.attn1, blk.norm1), (blk.attn2, blk.norm2)):
-        n = _ln(norm, cur)
+        n, cur = _ln_skip(norm, cur)
         qkv = _lin_packed((attn.to_q, attn.to_k, attn.to_v), n)                                    # [q | k | v] columns
         att = F_.TemporalAttention.apply(qkv, (ctx.B, ctx.T, hw, attn.heads, attn.scale))
         cur = _out_proj(attn, att, cur)
-    return _feed_forward(blk.ff, _ln(blk.norm3, cur), cur)
+    n3, cur = _ln_skip(blk.norm3, cur)
+    return _feed_forward(blk.ff, n3, cur)
 
 
 def temporal_transformer(mod, x, h, w, ctx):
