@@ -298,7 +298,7 @@ int64_t mudg_groupnorm_bwd_ws_floats(int samples, int rows, int C, int groups);
 int mudg_groupnorm_stats(const float* X, int64_t ldx, int samples, int rows, int C, int groups, float eps, float* stat, void* stream);
 int mudg_groupnorm_bwd(const float* X, int64_t ldx, const float* dY, int64_t ldy, const float* gamma, const float* beta,
                        const float* stat, int samples, int rows, int C, int groups, int silu, float* dX, int64_t lddx, float* AB,
-                       float* ws, void* stream);
+                       float* ws, const float* dres, int64_t lddres, void* stream);
 /* LayerNorm backward: dX, and part[chunks][2][C] (chunks = mudg_layernorm_bwd_chunks(rows)): per chunk of rows the sums of
  * dY * xhat (row 0) and dY (row 1) — dgamma / dbeta are their sums over the chunks (mudg_group_colsum).  C <= 1280.  dres (optional,
  * rows [rows][lddres]): added to dX — the gradient of the residual branch that bypassed the norm (x + f(LN(x))). */

@@ -221,17 +221,19 @@ __global__ __launch_bounds__(256) void gn_bwd_fold_kernel(const float* __restric
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ X, int64_t ldx, const float* __restrict__ dY, int64_t ldy,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             const float* __restrict__ stat, const float* __restrict__ m12, int rows, int C,
-                                                            int groups, int silu, float* __restrict__ dX, int64_t lddx, int64_t total) {
+                                                            int groups, int silu, float* __restrict__ dX, int64_t lddx, int64_t total,
+                                                            const float* __restrict__ dRes, int64_t lddres) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
     const int64_t row = i / C;
     const int c = (int)(i - row * C);
     const int smp = (int)(row / rows), g = c / (C / groups);
     const float mean = stat[(smp * groups + g) * 2], rstd = stat[(smp * groups + g) * 2 + 1];
+    const float res = dRes ? dRes[row * lddres + c] : 0.f;       // the gradient of the residual branch that bypassed the norm
     const float xh = (X[row * ldx + c] - mean) * rstd;
     float dz = dY[row * ldy + c];
     if (silu) dz *= silu_grad(fmaf(xh, gamma[c], beta[c]));
-    dX[row * lddx + c] = rstd * (dz * gamma[c] - m12[(smp * groups + g) * 2] - xh * m12[(smp * groups + g) * 2 + 1]);
+    dX[row * lddx + c] = rstd * (dz * gamma[c] - m12[(smp * groups + g) * 2] - xh * m12[(smp * groups + g) * 2 + 1]) + res;
 }
 
 // ---------------------------------------------------------------------------------------------- LayerNorm backward
@@ -606,7 +608,8 @@ int64_t mudg_groupnorm_bwd_ws_floats(int samples, int rows, int C, int groups) {
 /* stat: (mean, rstd) per (sample, group) as the forward pass left them; AB: fp32 [samples][C][2] out (dbeta / dgamma before the
  * sum over samples). */
 int mudg_groupnorm_bwd(const float* X, int64_t ldx, const float* dY, int64_t ldy, const float* gamma, const float* beta, const float* stat,
-                       int samples, int rows, int C, int groups, int silu, float* dX, int64_t lddx, float* AB, float* ws, void* stream) {
+                       int samples, int rows, int C, int groups, int silu, float* dX, int64_t lddx, float* AB, float* ws, const float* dres,
+                       int64_t lddres, void* stream) {
     MUDG_REQUIRE(X && dY && gamma && beta && stat && dX && AB && ws, "mudg_groupnorm_bwd: null pointer");
     MUDG_REQUIRE(samples > 0 && rows > 0 && C > 0 && groups > 0 && C % groups == 0 && C / groups <= 256 && samples <= 65535, "mudg_groupnorm_bwd: shape");
     int nch = rows / 256; if (nch < 1) nch = 1; if (nch > 256) nch = 256;
@@ -619,7 +622,7 @@ int mudg_groupnorm_bwd(const float* X, int64_t ldx, const float* dY, int64_t ldy
                        (double)rows * (C / groups), AB, m12);
     const int64_t total = (int64_t)samples * rows * C;
     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(blocks_for(total)), dim3(256), 0, s, X, ldx, dY, ldy, gamma, beta, stat, m12, rows, C, groups, silu,
-                       dX, lddx, total);
+                       dX, lddx, total, dres, lddres);
     return mudg_check_launch("mudg_groupnorm_bwd");
 }
 

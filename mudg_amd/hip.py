@@ -150,7 +150,7 @@ SIGNATURES = {
     "mudg_group_colsum": (_I, [_P, _L, _P, _L, _L, _I, _L, _P, _P]),
     "mudg_groupnorm_bwd_ws_floats": (_L, [_I, _I, _I, _I]),
     "mudg_groupnorm_stats": (_I, [_P, _L, _I, _I, _I, _I, _F, _P, _P]),
-    "mudg_groupnorm_bwd": (_I, [_P, _L, _P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _P, _L, _P, _P, _P]),
+    "mudg_groupnorm_bwd": (_I, [_P, _L, _P, _L, _P, _P, _P, _I, _I, _I, _I, _I, _P, _L, _P, _P, _P, _L, _P]),
     "mudg_layernorm_bwd": (_I, [_P, _L, _P, _L, _P, _P, _L, _P, _L, _I, _F, _P, _L, _P]),
     "mudg_layernorm_bwd_chunks": (_L, [_L]),
     "mudg_transpose_cast_sum": (_I, [_P, _L, _P, _L, _P, _L, _P, _L, _I, _P]),

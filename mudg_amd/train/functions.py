@@ -338,6 +338,29 @@ class GroupNorm(torch.autograd.Function):
         return dx, dgamma, dbeta, None, None, None, None, None
 
 
+class GroupNormSkip(torch.autograd.Function):
+    """x -> (GroupNorm(x) (+ SiLU), x): as LayerNormSkip, for the residual connections around a ResBlock, a temporal conv block and
+    a transformer (openaimodel3d.py:236, 279; attention.py:467)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, samples, rows, eps, silu, groups):
+        g, b = gamma.float().contiguous(), beta.float().contiguous()
+        y, stat = ops.groupnorm(x, g, b, samples=samples, rows=rows, eps=eps, silu=silu, groups=groups, return_stats=True)
+        ctx.save_for_backward(x, g, b, stat)
+        ctx.args = (samples, rows, eps, silu, groups)
+        return _with_operand(ops.to_f32(y), y), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dskip):
+        x, g, b, stat = ctx.saved_tensors
+        samples, rows, eps, silu, groups = ctx.args
+        if dy is None:
+            return dskip, None, None, None, None, None, None, None
+        dx, dgamma, dbeta = K.groupnorm_bwd(x, dy.contiguous(), g, b, stat, samples, rows, groups, silu,
+                                            dres=None if dskip is None else dskip.contiguous())
+        return dx, dgamma, dbeta, None, None, None, None, None
+
+
 class LayerNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, eps):

@@ -65,7 +65,8 @@ def groupnorm_stats(x, samples, rows, groups, eps):
     return stat
 
 
-def groupnorm_bwd(x, dy, gamma, beta, stat, samples, rows, groups, silu):
+def groupnorm_bwd(x, dy, gamma, beta, stat, samples, rows, groups, silu, dres=None):
+    """dres: fp32 rows added to dx (the gradient of the residual branch around the norm)."""
     _f32(x); _f32(dy)
     c = x.shape[1]
     dx = torch.empty((samples * rows, c), dtype=torch.float32, device=x.device)
@@ -73,7 +74,8 @@ def groupnorm_bwd(x, dy, gamma, beta, stat, samples, rows, groups, silu):
     ws = torch.empty(hip.lib().mudg_groupnorm_bwd_ws_floats(samples, rows, c, groups), dtype=torch.float32, device=x.device)
     hip.check(hip.lib().mudg_groupnorm_bwd(x.data_ptr(), x.stride(0), dy.data_ptr(), dy.stride(0), gamma.data_ptr(), beta.data_ptr(),
                                            stat.data_ptr(), samples, rows, c, groups, int(silu), dx.data_ptr(), dx.stride(0), ab.data_ptr(),
-                                           ws.data_ptr(), _s()), "mudg_groupnorm_bwd")
+                                           ws.data_ptr(), None if dres is None else _f32(dres).data_ptr(), 0 if dres is None else dres.stride(0),
+                                           _s()), "mudg_groupnorm_bwd")
     tot = group_colsum(ab)[0]                       # sums over the samples: [(dbeta_c, dgamma_c) interleaved]
     return dx, tot[1::2].contiguous(), tot[0::2].contiguous()
 

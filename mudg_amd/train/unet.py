@@ -29,6 +29,11 @@ def _gn(mod, x, samples, rows, silu):
     return F_.GroupNorm.apply(x, mod.weight, mod.bias, samples, rows, mod.eps, silu, mod.num_groups)
 
 
+def _gn_skip(mod, x, samples, rows, silu):
+    """(GroupNorm(x), x) with the skip routed through the norm's node (functions.GroupNormSkip)."""
+    return F_.GroupNormSkip.apply(x, mod.weight, mod.bias, samples, rows, mod.eps, silu, mod.num_groups)
+
+
 def _ln(mod, x):
     return F_.LayerNorm.apply(x, mod.weight, mod.bias, mod.eps)
 
@@ -61,7 +66,10 @@ def temporal_conv_block(mod, x, ctx, hw):
     stages = (mod.conv1, mod.conv2, mod.conv3, mod.conv4)
     for i, seq in enumerate(stages):
         norm, conv = seq[0], seq[-1]
-        y = _gn(norm, y, ctx.B, ctx.T * hw, True)
+        if i == 0:
+            y, x = _gn_skip(norm, y, ctx.B, ctx.T * hw, True)          # x: the identity the block adds back at its end
+        else:
+            y = _gn(norm, y, ctx.B, ctx.T * hw, True)
         if len(seq) == 4:                                   # GroupNorm, SiLU, Dropout, conv (openaimodel3d.py:256-266)
             y = F_.dropout(seq[2], y)
         y = F_.TConv3.apply(y, conv.weight, conv.bias, x if i == len(stages) - 1 else None, (ctx.B, ctx.T, hw))
@@ -70,11 +78,15 @@ def temporal_conv_block(mod, x, ctx, hw):
 
 def res_block(mod, x, h, w, ctx):
     frames, hw = ctx.B * ctx.T, h * w
-    a = _gn(mod.in_layers[0], x, frames, hw, True)
+    identity = isinstance(mod.skip_connection, nn.Identity)
+    if identity:
+        a, x = _gn_skip(mod.in_layers[0], x, frames, hw, True)         # x: the skip the block adds back
+    else:
+        a = _gn(mod.in_layers[0], x, frames, hw, True)
     emb_out = _lin(mod.emb_layers[1], F_.Silu.apply(ctx.emb))                          # (B, Cout): one row per clip
     a = _conv(mod.in_layers[2], a, frames, h, w, gbias=emb_out, rows_per_group=ctx.T * hw)
     a = F_.dropout(mod.out_layers[2], _gn(mod.out_layers[0], a, frames, hw, True))
-    skip = x if isinstance(mod.skip_connection, nn.Identity) else _lin(mod.skip_connection, x)
+    skip = x if identity else _lin(mod.skip_connection, x)
     out = _conv(mod.out_layers[3], a, frames, h, w, residual=skip)
     if mod.use_temporal_conv:
         out = temporal_conv_block(mod.temopral_conv, out, ctx, hw)
@@ -121,7 +133,8 @@ def spatial_block(blk, cur, frames, hw, ctx):
 
 def spatial_transformer(mod, x, h, w, ctx):
     hw, frames = h * w, ctx.B * ctx.T
-    cur = _lin(mod.proj_in, _gn(mod.norm, x, frames, hw, False))
+    n, x = _gn_skip(mod.norm, x, frames, hw, False)
+    cur = _lin(mod.proj_in, n)
     for blk in mod.transformer_blocks:
         cur = _ckpt(blk.checkpoint, spatial_block, blk, cur, frames, hw, ctx)
     return _lin(mod.proj_out, cur, residual=x)
@@ -139,7 +152,8 @@ def temporal_block(blk, cur, hw, ctx):
 
 def temporal_transformer(mod, x, h, w, ctx):
     hw = h * w
-    cur = _lin(mod.proj_in, _gn(mod.norm, x, ctx.B, ctx.T * hw, False))
+    n, x = _gn_skip(mod.norm, x, ctx.B, ctx.T * hw, False)
+    cur = _lin(mod.proj_in, n)
     for blk in mod.transformer_blocks:
         cur = _ckpt(blk.checkpoint, temporal_block, blk, cur, hw, ctx)
     return _lin(mod.proj_out, cur, residual=x)
