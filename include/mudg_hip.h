@@ -326,6 +326,11 @@ int mudg_transpose_cast_sum(const float* src, int64_t lds, void* dst, int64_t ld
 /* GEGLU on H = [value | gate] rows [M][2 N] (attention.py:579-586): dY NULL -> out[M][N] = value * gelu(gate);
  * else out = dH [M][2 N]. */
 int mudg_geglu(const float* H, int64_t ldh, const float* dY, int64_t lddy, float* out, int64_t ldo, int64_t M, int N, void* stream);
+/* GEGLU followed by the feed-forward's Dropout(p) in one pass (attention.py:579-606; N % 4 == 0).  dY NULL: out [M][N] = keep(value *
+ * gelu(gate)) / (1 - p) as fp32 rows and, when out16 is given, as operand rows [M][ldo16] for the next GEMM.  dY given: out = dH
+ * [M][2 N].  The keep mask depends on (seed, output element index) only and is regenerated in the backward pass; p = 0: no dropout. */
+int mudg_geglu_dropout(const float* H, int64_t ldh, const float* dY, int64_t lddy, float* out, int64_t ldo, void* out16, int64_t ldo16,
+                       int64_t M, int N, float p, uint64_t seed, void* stream);
 /* Row softmax in fp32 and its backward dS = scale * P (dP - sum_j dP_j P_j): the recomputed probabilities of the attention
  * backward pass. */
 int mudg_softmax_f32(const float* S, int64_t lds, float* P, int64_t ldp, int64_t rows, int cols, void* stream);

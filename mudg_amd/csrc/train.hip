@@ -318,6 +318,65 @@ __global__ void geglu_bwd_kernel(const float* __restrict__ H, int64_t ldh, const
     dH[m * lddh + N + n] = dy * v * gelu_grad(g);
 }
 
+// GEGLU followed by the feed-forward's Dropout (attention.py:579-606: GEGLU -> Dropout -> Linear), four output columns per thread:
+// forward  Y = keep(value * gelu(gate)) / (1 - p), written as fp32 rows and (optionally) as the operand rows the next GEMM reads;
+// backward dH = [dy' gelu(gate) | dy' value gelu'(gate)] with dy' = keep(dY) / (1 - p).  The keep mask is the counter-based one of
+// dropout_kernel on the output element index (regenerated, never stored); p = 0: plain GEGLU.
+__device__ __forceinline__ float keep_scale(uint64_t seed, int64_t i, float p, float inv) {
+    uint64_t z = seed + (uint64_t)i * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (float)(z >> 40) * (1.0f / 16777216.0f) >= p ? inv : 0.f;
+}
+__global__ __launch_bounds__(256) void geglu_drop_fwd_kernel(const float* __restrict__ H, int64_t ldh, float* __restrict__ Y, int64_t ldy,
+                                                              h16* __restrict__ Y16, int64_t ldy16, int64_t M, int N, float p, uint64_t seed) {
+    const int nv = N >> 2;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M * nv) return;
+    const int64_t m = i / nv;
+    const int n = (int)(i - m * nv) * 4;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(H + m * ldh + n), g = *reinterpret_cast<const f32x4*>(H + m * ldh + N + n);
+    const float inv = 1.0f / (1.0f - p);
+    f32x4 y;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        y[e] = v[e] * gelu_erf_f(g[e]);
+        if (p > 0.f) y[e] *= keep_scale(seed, m * N + n + e, p, inv);
+    }
+    *reinterpret_cast<f32x4*>(Y + m * ldy + n) = y;
+    if (Y16) {
+        float w[4] = {y[0], y[1], y[2], y[3]};
+#pragma unroll
+        for (int pl = 0; pl < PLANES; ++pl) {
+            h16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { o[e] = (h16)w[e]; w[e] -= (float)o[e]; }
+            *reinterpret_cast<h16x4*>(Y16 + m * ldy16 + pl * (ldy16 / PLANES) + n) = o;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void geglu_drop_bwd_kernel(const float* __restrict__ H, int64_t ldh, const float* __restrict__ dY, int64_t lddy,
+                                                              float* __restrict__ dH, int64_t lddh, int64_t M, int N, float p, uint64_t seed) {
+    const int nv = N >> 2;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M * nv) return;
+    const int64_t m = i / nv;
+    const int n = (int)(i - m * nv) * 4;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(H + m * ldh + n), g = *reinterpret_cast<const f32x4*>(H + m * ldh + N + n);
+    f32x4 dy = *reinterpret_cast<const f32x4*>(dY + m * lddy + n);
+    const float inv = 1.0f / (1.0f - p);
+    f32x4 dv, dg;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        if (p > 0.f) dy[e] *= keep_scale(seed, m * N + n + e, p, inv);
+        dv[e] = dy[e] * gelu_erf_f(g[e]);
+        dg[e] = dy[e] * v[e] * gelu_grad(g[e]);
+    }
+    *reinterpret_cast<f32x4*>(dH + m * lddh + n) = dv;
+    *reinterpret_cast<f32x4*>(dH + m * lddh + N + n) = dg;
+}
+
 // ---------------------------------------------------------------------------------------------- softmax (attention recompute)
 // P = softmax(S) row-wise, fp32 in place-capable; dS = scale * P (dP - sum_j dP_j P_j).  One workgroup per row.
 __global__ __launch_bounds__(256) void softmax_f32_kernel(const float* __restrict__ S, int64_t lds, float* __restrict__ P, int64_t ldp, int cols) {
@@ -663,6 +722,20 @@ int mudg_geglu(const float* H, int64_t ldh, const float* dY, int64_t lddy, float
     if (dY) hipLaunchKernelGGL(geglu_bwd_kernel, dim3(blocks_for(M * N)), dim3(256), 0, s, H, ldh, dY, lddy, out, ldo, M, N);
     else hipLaunchKernelGGL(geglu_fwd_kernel, dim3(blocks_for(M * N)), dim3(256), 0, s, H, ldh, out, ldo, M, N);
     return mudg_check_launch("mudg_geglu");
+}
+
+int mudg_geglu_dropout(const float* H, int64_t ldh, const float* dY, int64_t lddy, float* out, int64_t ldo, void* out16, int64_t ldo16,
+                       int64_t M, int N, float p, uint64_t seed, void* stream) {
+    MUDG_REQUIRE(H && out && M > 0 && N > 0 && (N & 3) == 0 && p >= 0.f && p < 1.f, "mudg_geglu_dropout: bad arguments (N must be a multiple of 4)");
+    MUDG_REQUIRE((ldh & 3) == 0 && (ldo & 3) == 0 && (!dY || (lddy & 3) == 0) && aligned16(H) && aligned16(out) && aligned16(dY),
+                 "mudg_geglu_dropout: row strides must be multiples of 4 floats and the bases 16-byte aligned");
+    MUDG_REQUIRE(!out16 || (!dY && ldo16 % PLANES == 0 && ldo16 / PLANES >= N && ((ldo16 / PLANES) & 3) == 0 && (reinterpret_cast<uintptr_t>(out16) & 7u) == 0),
+                 "mudg_geglu_dropout: operand output");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const unsigned blocks = blocks_for(M * (N / 4));
+    if (dY) hipLaunchKernelGGL(geglu_drop_bwd_kernel, dim3(blocks), dim3(256), 0, s, H, ldh, dY, lddy, out, ldo, M, N, p, seed);
+    else hipLaunchKernelGGL(geglu_drop_fwd_kernel, dim3(blocks), dim3(256), 0, s, H, ldh, out, ldo, (h16*)out16, ldo16, M, N, p, seed);
+    return mudg_check_launch("mudg_geglu_dropout");
 }
 
 int mudg_softmax_f32(const float* S, int64_t lds, float* P, int64_t ldp, int64_t rows, int cols, void* stream) {

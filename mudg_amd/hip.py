@@ -155,6 +155,7 @@ SIGNATURES = {
     "mudg_layernorm_bwd_chunks": (_L, [_L]),
     "mudg_transpose_cast_sum": (_I, [_P, _L, _P, _L, _P, _L, _P, _L, _I, _P]),
     "mudg_geglu": (_I, [_P, _L, _P, _L, _P, _L, _L, _I, _P]),
+    "mudg_geglu_dropout": (_I, [_P, _L, _P, _L, _P, _L, _P, _L, _L, _I, _F, C.c_uint64, _P]),
     "mudg_softmax_f32": (_I, [_P, _L, _P, _L, _L, _I, _P]),
     "mudg_softmax_bwd": (_I, [_P, _L, _P, _L, _P, _L, _L, _I, _F, _P]),
     "mudg_temporal_attention_bwd": (_I, [_P, _P, _P, _P, _L, _L, _P, _P, _P, _L, _I, _I, _I, _I, _F, _P]),

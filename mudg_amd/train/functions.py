@@ -413,6 +413,31 @@ class Geglu(torch.autograd.Function):
         return K.geglu(h, dy.contiguous())
 
 
+class GegluDropout(torch.autograd.Function):
+    """GEGLU and the Dropout that follows it in the feed-forward (attention.py:596-606) as one pass in each direction; the forward
+    also writes the operand rows the second projection reads.  p = 0: GEGLU alone."""
+
+    @staticmethod
+    def forward(ctx, h, p, seed):
+        ctx.save_for_backward(h)
+        ctx.p, ctx.seed = p, seed
+        y, y16 = K.geglu_dropout(h, p, seed, operand=True)
+        return _with_operand(y, y16)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (h,) = ctx.saved_tensors
+        return K.geglu_dropout(h, ctx.p, ctx.seed, dy=dy.contiguous()), None, None
+
+
+def geglu_dropout(mod, h):
+    """GEGLU, then the nn.Dropout module `mod` the way it would act now (see dropout())."""
+    active = mod is not None and mod.training and mod.p > 0.0
+    if h.shape[1] % 8 or h.stride(0) % 4:
+        return dropout(mod, Geglu.apply(h))
+    return GegluDropout.apply(h, float(mod.p) if active else 0.0, int(torch.randint(0, 2 ** 62, (1,)).item()) if active else 0)
+
+
 class Silu(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):

@@ -118,6 +118,19 @@ def geglu(h, dy=None):
     return out
 
 
+def geglu_dropout(h, p, seed, dy=None, operand=False):
+    """mudg_geglu_dropout: forward (dy None) -> (fp32 rows [M][N], operand rows or None); backward -> dH [M][2 N]."""
+    _f32(h)
+    m, n2 = h.shape
+    n = n2 // 2
+    out = torch.empty((m, n if dy is None else n2), dtype=torch.float32, device=h.device)
+    o16 = ops.empty_rows(m, n, ops.H16(), h.device) if (operand and dy is None) else None
+    hip.check(hip.lib().mudg_geglu_dropout(h.data_ptr(), h.stride(0), None if dy is None else _f32(dy).data_ptr(), 0 if dy is None else dy.stride(0),
+                                           out.data_ptr(), out.stride(0), None if o16 is None else o16.data_ptr(), 0 if o16 is None else o16.stride(0),
+                                           m, n, float(p), int(seed), _s()), "mudg_geglu_dropout")
+    return (out, o16) if dy is None else out
+
+
 def softmax_f32(s, cols):
     """In place over the first `cols` columns of every row."""
     hip.check(hip.lib().mudg_softmax_f32(s.data_ptr(), s.stride(0), s.data_ptr(), s.stride(0), s.shape[0], cols, _s()), "mudg_softmax_f32")

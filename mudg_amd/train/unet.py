@@ -103,7 +103,7 @@ def _out_proj(attn, att, residual):
 
 
 def _feed_forward(ff, x_norm, residual):
-    hidden = F_.dropout(ff.net[1], F_.Geglu.apply(_lin(ff.net[0].proj, x_norm)))
+    hidden = F_.geglu_dropout(ff.net[1], _lin(ff.net[0].proj, x_norm))
     return _lin(ff.net[2], hidden, residual=residual)
 
 

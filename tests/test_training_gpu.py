@@ -104,6 +104,24 @@ def test_norm_geglu_resampling_and_loss_gradients(cuda):
     compare("layernorm", *run_both(lambda x, g, b: Fn.LayerNorm.apply(x, g, b, 1e-5), lambda x, g, b: F.layer_norm(x, (320,), g, b, 1e-5), t, cuda))
     t = dict(h=rnd(60, 256, seed=1))
     compare("geglu", *run_both(lambda h: Fn.Geglu.apply(h), lambda h: h[:, :128] * F.gelu(h[:, 128:]), t, cuda), tol=1e-5)
+    # GEGLU + the feed-forward's Dropout as one pass each way: p = 0 is GEGLU; p > 0 keeps ~(1 - p) of the outputs, scaled, and the
+    # backward pass regenerates exactly the forward's mask
+    t = dict(h=rnd(60, 256, seed=1))
+    compare("geglu + dropout(0)", *run_both(lambda h: Fn.GegluDropout.apply(h, 0.0, 0), lambda h: h[:, :128] * F.gelu(h[:, 128:]), t, cuda), tol=1e-5)
+    hh = rnd(400, 512, seed=2).to(cuda).requires_grad_()
+    y = Fn.GegluDropout.apply(hh, 0.25, 1234)
+    keep = (y != 0).double().cpu()
+    assert abs(float(keep.mean()) - 0.75) < 0.02 and torch.equal(y, Fn.GegluDropout.apply(hh, 0.25, 1234)) and not torch.equal(y, Fn.GegluDropout.apply(hh, 0.25, 99))
+    dyy = rnd(400, 256, seed=3)
+    y.backward(dyy.to(cuda))
+    h64 = hh.detach().cpu().double().requires_grad_()
+    ref = h64[:, :256] * F.gelu(h64[:, 256:]) * keep / 0.75
+    ref.backward(dyy.double())
+    check("geglu + dropout(0.25) forward", y, ref, 1e-5)
+    check("geglu + dropout(0.25) dh", hh.grad, h64.grad, 1e-5)
+    if getattr(y, "_mudg_operand", None) is not None:                   # the operand rows handed to the second projection
+        from mudg_amd import ops as _ops
+        check("geglu + dropout operand rows", _ops.to_f32(Fn.op(y)), y, 5e-3 if MODE in ("bf16", "fp16") else 1e-5)
     t = dict(x=rnd(2 * 3 * 5, 16, seed=1))
     compare("upsample2x", *run_both(lambda x: Fn.Upsample2x.apply(x, (2, 3, 5)),
                                     lambda x: F.interpolate(x.reshape(2, 3, 5, 16).permute(0, 3, 1, 2), scale_factor=2, mode="nearest")
