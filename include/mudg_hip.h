@@ -380,6 +380,10 @@ int mudg_clip_grad_norm(const int64_t* table, int nchunks, double* partial, floa
 /* Inverted dropout out[i] = keep(seed, i) ? x[i] / (1 - p) : 0 with a counter-based mask (the backward pass applies the same
  * call to the gradient: nothing is stored). */
 int mudg_dropout(const float* x, float* out, int64_t n, float p, uint64_t seed, void* stream);
+/* The same mask (element index = m C + c) on fp32 rows [M][C] (C % 4 == 0) with any row strides, optionally also writing the
+ * operand rows of the result (what the conv / projection after the Dropout reads). */
+int mudg_dropout_rows(const float* X, int64_t ldx, float* Y, int64_t ldy, void* Y16, int64_t ldy16, int64_t M, int C, float p, uint64_t seed,
+                      void* stream);
 /* out = silu(x) (dy NULL) or dy * silu'(x). */
 int mudg_silu(const float* x, const float* dy, float* out, int64_t n, void* stream);
 

@@ -622,12 +622,33 @@ __global__ __launch_bounds__(256) void gn_stat_f32_kernel(const float* __restric
 __global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ out, int64_t n, float p, uint64_t seed) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    uint64_t z = seed + (uint64_t)i * 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z ^= z >> 31;
-    const float u = (float)(z >> 40) * (1.0f / 16777216.0f);
-    out[i] = u >= p ? x[i] / (1.0f - p) : 0.f;
+    out[i] = x[i] * keep_scale(seed, i, p, 1.0f / (1.0f - p));
+}
+// The same on rows [M][C] (C % 4 == 0), four columns per thread, with the operand rows of the result written alongside (the conv /
+// projection that follows reads those): element index = m C + c, as in dropout_kernel on the flattened contiguous rows.
+__global__ __launch_bounds__(256) void dropout_rows_kernel(const float* __restrict__ X, int64_t ldx, float* __restrict__ Y, int64_t ldy,
+                                                            h16* __restrict__ Y16, int64_t ldy16, int64_t M, int C, float p, uint64_t seed) {
+    const int cv = C >> 2;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= M * cv) return;
+    const int64_t m = i / cv;
+    const int c = (int)(i - m * cv) * 4;
+    const f32x4 x = *reinterpret_cast<const f32x4*>(X + m * ldx + c);
+    const float inv = 1.0f / (1.0f - p);
+    f32x4 y;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) y[e] = x[e] * keep_scale(seed, m * C + c + e, p, inv);
+    *reinterpret_cast<f32x4*>(Y + m * ldy + c) = y;
+    if (Y16) {
+        float w[4] = {y[0], y[1], y[2], y[3]};
+#pragma unroll
+        for (int pl = 0; pl < PLANES; ++pl) {
+            h16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { o[e] = (h16)w[e]; w[e] -= (float)o[e]; }
+            *reinterpret_cast<h16x4*>(Y16 + m * ldy16 + pl * (ldy16 / PLANES) + c) = o;
+        }
+    }
 }
 
 inline unsigned blocks_for(int64_t n) { return (unsigned)((n + 255) / 256); }
@@ -813,6 +834,17 @@ int mudg_dropout(const float* x, float* out, int64_t n, float p, uint64_t seed, 
     MUDG_REQUIRE(x && out && n > 0 && p >= 0.f && p < 1.f, "mudg_dropout: bad arguments");
     hipLaunchKernelGGL(dropout_kernel, dim3(blocks_for(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), x, out, n, p, seed);
     return mudg_check_launch("mudg_dropout");
+}
+
+int mudg_dropout_rows(const float* X, int64_t ldx, float* Y, int64_t ldy, void* Y16, int64_t ldy16, int64_t M, int C, float p, uint64_t seed,
+                      void* stream) {
+    MUDG_REQUIRE(X && Y && M > 0 && C > 0 && (C & 3) == 0 && (ldx & 3) == 0 && (ldy & 3) == 0 && p >= 0.f && p < 1.f && aligned16(X) && aligned16(Y),
+                 "mudg_dropout_rows: bad arguments (C and the row strides must be multiples of 4)");
+    MUDG_REQUIRE(!Y16 || (ldy16 % PLANES == 0 && ldy16 / PLANES >= C && ((ldy16 / PLANES) & 3) == 0 && (reinterpret_cast<uintptr_t>(Y16) & 7u) == 0),
+                 "mudg_dropout_rows: operand output");
+    hipLaunchKernelGGL(dropout_rows_kernel, dim3(blocks_for(M * (C / 4))), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), X, ldx, Y, ldy,
+                       (h16*)Y16, ldy16, M, C, p, seed);
+    return mudg_check_launch("mudg_dropout_rows");
 }
 
 int mudg_silu(const float* x, const float* dy, float* out, int64_t n, void* stream) {

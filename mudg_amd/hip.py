@@ -170,6 +170,7 @@ SIGNATURES = {
     "mudg_clip_grad_norm": (_I, [_P, _I, _P, _F, _P, _P]),
     "mudg_silu": (_I, [_P, _P, _P, _L, _P]),
     "mudg_dropout": (_I, [_P, _P, _L, _F, C.c_uint64, _P]),
+    "mudg_dropout_rows": (_I, [_P, _L, _P, _L, _P, _L, _L, _I, _F, C.c_uint64, _P]),
     "mudg_prof_enable": (_I, [_I]),
     "mudg_prof_collect": (_I, [_I, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double),
                                C.POINTER(C.c_double)]),

@@ -456,6 +456,9 @@ class Dropout(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, p, seed):
         ctx.p, ctx.seed = p, seed
+        if x.dim() == 2 and x.shape[1] % 8 == 0 and x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0:
+            y, y16 = K.dropout_rows(x, p, seed, operand=True)             # the layer after a Dropout is a conv / projection
+            return _with_operand(y, y16)
         return K.dropout(x, p, seed)
 
     @staticmethod

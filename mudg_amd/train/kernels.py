@@ -118,6 +118,17 @@ def geglu(h, dy=None):
     return out
 
 
+def dropout_rows(x, p, seed, operand=False):
+    """mudg_dropout_rows on fp32 rows (the mask of `dropout` on the same contiguous rows) -> (fp32 rows, operand rows or None)."""
+    _f32(x)
+    m, c = x.shape
+    y = torch.empty((m, c), dtype=torch.float32, device=x.device)
+    y16 = ops.empty_rows(m, c, ops.H16(), x.device) if operand else None
+    hip.check(hip.lib().mudg_dropout_rows(x.data_ptr(), x.stride(0), y.data_ptr(), y.stride(0), None if y16 is None else y16.data_ptr(),
+                                          0 if y16 is None else y16.stride(0), m, c, float(p), int(seed), _s()), "mudg_dropout_rows")
+    return y, y16
+
+
 def geglu_dropout(h, p, seed, dy=None, operand=False):
     """mudg_geglu_dropout: forward (dy None) -> (fp32 rows [M][N], operand rows or None); backward -> dH [M][2 N]."""
     _f32(h)
