@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--no-at-tolerance", action="store_true",
                     help="skip the bf16x3 child run (the operand mode that meets the 1e-3 decoded-frame tolerance) whose "
                          "steps/s is reported as `at_tolerance` next to the bf16 line")
+    ap.add_argument("--no-training", action="store_true",
+                    help="skip the training-step child run (SURVEY §8 f4: p_losses -> backward -> AdamW of the same UNet at the same "
+                         "resolution) whose seconds per step are reported as `training_step` next to the inference line")
     ap.add_argument("--operand", default=os.environ.get("MUDG_OPERAND", "bf16"), choices=["bf16", "fp16", "bf16x3", "bf16x6"],
                     help="MFMA operand type: bf16 (the BASELINE dtype), fp16 (the reference's autocast dtype), or the "
                          "split-operand precision modes bf16x3 / bf16x6 (2 / 3 bf16 pieces per value, 3 / 6 MFMAs per product "
@@ -179,6 +182,21 @@ def at_tolerance(args):
         except Exception:
             pass
     return out
+
+
+def training_step_record(args):
+    """One optimisation step of the same UNet at the same resolution, in a child process so that its 111 GiB of
+    activations never share the allocator with the inference replica: tools/train_bench.py, two timed steps after a warm-up."""
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "train_bench.py"), args.resolution, "2", "json"]
+    env = dict(os.environ, MUDG_OPERAND="bf16")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    try:
+        r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+        return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    except Exception as e:
+        return {"s_per_step": None, "error": f"{type(e).__name__}: {e}"}
 
 
 def main():
@@ -335,6 +353,8 @@ def main():
         out["kernel_time_ms_per_step"] = round(total_ms / prof_steps, 3)
     if world == 1 and args.operand == "bf16" and not args.no_at_tolerance:
         out["at_tolerance"] = at_tolerance(args)      # child process; this one idles meanwhile (288 GB hold both replicas)
+    if world == 1 and args.operand == "bf16" and not args.no_training and args.batch == 1:
+        out["training_step"] = training_step_record(args)
     if world == 1 and not args.no_cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(model, inp, args.resolution, args.cpu_baseline)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One training step (p_losses -> backward -> AdamW) of the full 1.44 B-parameter MDM UNet on ONE MI355X: seconds per step, peak
-memory.  `python tools/train_bench.py [512|1024] [steps] [ckpt] [stage2]` — `ckpt` turns activation checkpointing on
+memory.  `python tools/train_bench.py [512|1024] [steps] [ckpt] [stage2] [json]` — `ckpt` turns activation checkpointing on
 (use_checkpoint); `stage2` applies what the reference's stage-2 training config adds to a step (configs/stage2-1024_mdm_waymo/
 config.yaml): the stages' temporal transformers frozen (temporal_frozen), the gradient 2-norm clipped to 0.5.  All parameters
 trainable and no clipping otherwise (the heavier step).  FLOP accounting: 3 x the forward, whatever is frozen."""
@@ -32,7 +32,7 @@ from mudg_amd.train import step
 clip = step.GradientClipper([p for g in opt.param_groups for p in g["params"]], 0.5) if stage2 else None
 batch = dict(x_start=inp["x_T"], cond=inp["cond"], t=torch.tensor([500], device=dev), class_label=inp["class_label"], fs=inp["fs"])
 torch.cuda.reset_peak_memory_stats()
-times = []
+times, losses = [], []
 for i in range(steps + 1):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     opt.zero_grad(set_to_none=True)
@@ -42,8 +42,16 @@ for i in range(steps + 1):
     opt.step()
     torch.cuda.synchronize()
     times.append(time.perf_counter() - t0)
-    print(f"step {i}: loss {float(loss):.5f}  {times[-1]:.2f} s" + (f"  grad norm {float(norm[0]):.3f}" if norm is not None else ""), flush=True)
+    losses.append(float(loss))
+    print(f"step {i}: loss {losses[-1]:.5f}  {times[-1]:.2f} s" + (f"  grad norm {float(norm[0]):.3f}" if norm is not None else ""), flush=True)
 fl = 3 * configs.UNET_TFLOP[res]
 best = min(times[1:])
+if "json" in sys.argv[3:]:
+    import json
+    print(json.dumps({"workload": f"MDM{res} training step: p_losses -> backward -> AdamW, full 1.44 B-parameter UNet, B = 1, 16 frames",
+                      "s_per_step": round(best, 4), "steps": steps, "tflops_per_s": round(fl / best, 1), "tflop_per_step": round(fl, 1),
+                      "flop_accounting": "3 x the forward", "checkpointing": ckpt, "stage2_settings": stage2,
+                      "peak_memory_gib": round(torch.cuda.max_memory_allocated() / 2**30, 1), "loss_first_last": [round(losses[0], 5), round(losses[-1], 5)]}))
+    sys.exit(0)
 print(f"MDM{res} training step (B = 1, 16 frames, checkpointing {'on' if ckpt else 'off'}{', stage-2 settings' if stage2 else ''}): {best:.2f} s = {fl / best:.1f} TFLOP/s of the "
       f"{fl:.1f} TFLOP a forward + backward costs (3 x forward); peak memory {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB")
