@@ -79,10 +79,7 @@ def temporal_conv_block(mod, x, ctx, hw):
 def res_block(mod, x, h, w, ctx):
     frames, hw = ctx.B * ctx.T, h * w
     identity = isinstance(mod.skip_connection, nn.Identity)
-    if identity:
-        a, x = _gn_skip(mod.in_layers[0], x, frames, hw, True)         # x: the skip the block adds back
-    else:
-        a = _gn(mod.in_layers[0], x, frames, hw, True)
+    a, x = _gn_skip(mod.in_layers[0], x, frames, hw, True)             # x: what the skip branch (identity or 1x1 projection) reads
     emb_out = _lin(mod.emb_layers[1], F_.Silu.apply(ctx.emb))                          # (B, Cout): one row per clip
     a = _conv(mod.in_layers[2], a, frames, h, w, gbias=emb_out, rows_per_group=ctx.T * hw)
     a = F_.dropout(mod.out_layers[2], _gn(mod.out_layers[0], a, frames, hw, True))
