@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--no-at-tolerance", action="store_true",
                     help="skip the bf16x3 child run (the operand mode that meets the 1e-3 decoded-frame tolerance) whose "
                          "steps/s is reported as `at_tolerance` next to the bf16 line")
+    ap.add_argument("--no-children", action="store_true", help="no child runs at all (set by the children themselves)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the child runs of BASELINE configs[1] (MDM512) and configs[4] (MX-fp8 attention scores)")
     ap.add_argument("--no-training", action="store_true",
                     help="skip the training-step child run (SURVEY §8 f4: p_losses -> backward -> AdamW of the same UNet at the same "
                          "resolution) whose seconds per step are reported as `training_step` next to the inference line")
@@ -72,7 +75,8 @@ def cpu_baseline(model, inputs, resolution, mode):
     mode "full": ONE full MDM512 forward (BASELINE configs[0]'s model and shape: 16 frames, 12.6 TFLOP; minutes).
     Either way steps/s at the benchmarked configuration = measured TFLOP/s / algorithmic TFLOP per CFG step (MDM1024 is
     4.15x MDM512 by FLOPs); the einsum path's 27 GB score tensors rule out a direct MDM1024 run.
-    A recorded full-size measurement (profiles/r*/cpu_baseline_full.json), if committed, is quoted next to the live one."""
+    A recorded full-size measurement (profiles/r*/cpu_baseline_*.json), if committed, is quoted next to the live one; `value` is
+    always the live one."""
     from mudg_amd import configs
     from oracle import unet as o_unet
     threads = torch.get_num_threads()
@@ -116,15 +120,14 @@ def cpu_baseline(model, inputs, resolution, mode):
         except Exception:
             pass
     out["seconds"] = dt
-    out["live_sample_steps_per_s"] = out["value"]
+    # `value` is the sample timed on THIS box in THIS run (north_star: "timed on the same box's host cores in the same run").  A
+    # recorded whole forward at the benchmarked size on the same host class, when one is committed, rides along as an
+    # annotation: short clips use the cores worse, the two differ by 1.2-1.6x.
     key = "recorded_full_mdm1024_forward" if resolution == "1024" else "recorded_full_mdm512_forward"
     if key in out:
-        # a whole forward at the benchmarked size on the same host class is the better estimate of the CPU path than the
-        # 4-frame sample extrapolated by FLOPs (the two differ by 1.6x: short clips use the cores worse); the live sample stays
-        # in the record as `live_sample_steps_per_s`
-        out["value"] = out[key]["steps_per_s_at_this_config"]
-        out["sample"] += f"; value = the recorded full {key[14:-8].upper()} oracle forward ({out[key]['file']}: " \
-                         f"{out[key]['tflops']:.3f} TFLOP/s on {out[key]['cores']} threads), live sample kept beside it"
+        out["sample"] += (f"; for reference, the recorded full {key[14:-8].upper()} oracle forward ({out[key]['file']}: "
+                          f"{out[key]['tflops']:.3f} TFLOP/s on {out[key]['cores']} threads) = "
+                          f"{out[key]['steps_per_s_at_this_config']:.5f} steps/s")
     return out
 
 
@@ -150,30 +153,37 @@ def pmc_traffic(family, args, launches_per_step=None):
         return {}
 
 
-def at_tolerance(args):
-    """The same workload in the operand mode that meets north_star's tolerance (decoded frames within 1e-3 rel-L2 of the
-    reference): bf16x3, in a child process (the operand type is a property of the loaded library, one per process).  A few
-    steps after one warm-up; its own roofline record rides along.  The parity figures quoted are the last measured ones of
-    that mode (profiles/rN/parity_modes.json, written from the `-m gpu` run of tests/test_pipeline_gpu.py and
-    tests/test_fullsize_gpu.py, which assert the literal 1e-3 in that mode)."""
+def child_bench(args, what, flags=(), env_extra=None, steps=4, warmup=1):
+    """The same bench in a child process with a different operand mode / resolution / switch (the operand type is a property of
+    the loaded library and the switches are read at import: one configuration per process).  A few steps after one warm-up; the
+    child's own roofline record rides along.  Children run no children, no CPU baseline and no decode."""
     import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), "--operand", "bf16x3", "--steps", "4", "--warmup", "1", "--resolution", args.resolution,
-           "--batch", str(args.batch), "--no-cpu-baseline", "--no-decode", "--no-at-tolerance", "--profile-steps", "1"]
+    cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(steps), "--warmup", str(warmup), "--batch", str(args.batch),
+           "--no-cpu-baseline", "--no-decode", "--no-children", "--profile-steps", "1", *flags]
     if args.no_graph:
         cmd.append("--no-graph")
-    env = dict(os.environ, MUDG_OPERAND="bf16x3")
+    env = dict(os.environ, **(env_extra or {}))
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     try:
         r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
-        line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
-        rec = json.loads(line)
+        rec = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     except Exception as e:
-        return {"operand": "bf16x3", "value": None, "error": f"{type(e).__name__}: {e}"}
-    out = {"operand": "bf16x3", "value": rec["value"], "unit": rec["unit"], "ms_per_step": rec["ms_per_step"], "steps": rec["steps"],
-           "warmup": rec["warmup"], "output_finite": rec.get("output_finite"), "roofline": rec.get("roofline"),
-           "kernels": [{k: f[k] for k in ("family", "ms_per_step", "achieved", "unit", "frac")} for f in rec.get("kernels", [])],
-           "tolerance": "decoded frames within 1e-3 rel-L2 of the reference (BASELINE.json north_star)"}
+        return {"config": what, "value": None, "error": f"{type(e).__name__}: {e}"}
+    return {"config": what, "value": rec["value"], "unit": rec["unit"], "ms_per_step": rec["ms_per_step"], "steps": rec["steps"],
+            "warmup": rec["warmup"], "dtype": rec["dtype"], "output_finite": rec.get("output_finite"), "roofline": rec.get("roofline"),
+            "kernels": [{k: f[k] for k in ("family", "ms_per_step", "achieved", "unit", "frac")} for f in rec.get("kernels", [])]}
+
+
+def at_tolerance(args):
+    """The same workload in the operand mode that meets north_star's tolerance (decoded frames within 1e-3 rel-L2 of the
+    reference): bf16x3.  The parity figures quoted are the last measured ones of that mode (profiles/rN/parity_modes.json,
+    written from the `-m gpu` run of tests/test_pipeline_gpu.py and tests/test_fullsize_gpu.py, which assert the literal 1e-3
+    in that mode)."""
+    out = child_bench(args, "BASELINE configs[2] in the bf16x3 operand mode", ["--operand", "bf16x3", "--resolution", args.resolution],
+                      {"MUDG_OPERAND": "bf16x3"})
+    out["operand"] = "bf16x3"
+    out["tolerance"] = "decoded frames within 1e-3 rel-L2 of the reference (BASELINE.json north_star)"
     recs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "parity_modes.json")))
     if recs:
         try:
@@ -182,6 +192,15 @@ def at_tolerance(args):
         except Exception:
             pass
     return out
+
+
+def other_configs(args):
+    """BASELINE.json's other single-GPU configurations on the driver's clock: configs[1] (MDM512, bf16) and configs[4] (MDM1024
+    with MX-fp8 attention scores; GroupNorm-SiLU is fused and the decode frame-batched in every configuration)."""
+    return {"mdm512": child_bench(args, "BASELINE configs[1]: MDM512 320x512x16f, 50 DDIM steps, bf16", ["--operand", "bf16", "--resolution", "512"],
+                                  {"MUDG_OPERAND": "bf16"}, steps=8, warmup=2),
+            "fp8_scores": child_bench(args, "BASELINE configs[4]: MDM1024 with MX-fp8 scores in the long self-attention (MUDG_ATTN_FP8=1)",
+                                      ["--operand", "bf16", "--resolution", "1024"], {"MUDG_OPERAND": "bf16", "MUDG_ATTN_FP8": "1"})}
 
 
 def training_step_record(args):
@@ -199,29 +218,29 @@ def training_step_record(args):
         return {"s_per_step": None, "error": f"{type(e).__name__}: {e}"}
 
 
-def main():
-    args = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit(f"--gpus {args.gpus} needs torchrun with --nproc-per-node {args.gpus}")
+def setup(args, local):
+    """Device and collective backend of this rank (the plumbing test swaps in cpu / gloo)."""
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local)
-    device = torch.device("cuda", local)
-    from mudg_amd import parallel
-    dist = parallel.init_from_env("nccl")[3]
+    return torch.device("cuda", local), "nccl"
 
-    from mudg_amd import build as mbuild, configs, factory, hip
+
+def sync(device):
+    if device.type == "cuda":
+        torch.cuda.synchronize()
+
+
+def make_workload(args, device, rank, dist):
+    """Build the library (rank 0 only, the others wait), the synthetic model replica and this rank's clip; returns the pieces the
+    timed loop needs.  Rank r denoises clip r: its own seeded inputs, a full weight replica, no collective inside a step."""
+    from mudg_amd import build as mbuild, factory, hip, parallel
     if rank == 0:
         mbuild.build(verbose=False)          # no-op when the in-tree .so files are current; one rank only (no races)
     parallel.barrier(dist)
     hip.set_operand(args.operand)
     hip.lib()
     from lvdm.models.samplers.ddim import DDIMSampler
-
     torch.manual_seed(parallel.clip_seed(123, rank) % (2 ** 31))   # rank r denoises clip r (one clip per GPU per step)
     with contextlib.redirect_stdout(sys.stderr):       # the boundary modules print like the reference's; keep stdout = ONE JSON line
         model = factory.build_synthetic_model(args.resolution, device, seed=123)
@@ -240,19 +259,35 @@ def main():
             x, _ = sampler.p_sample_ddim(x, inp["cond"], ts, index=index, **kw)
         return x
 
+    model.model.diffusion_model.use_hip_graph = not args.no_graph
+    return {"run": run, "x0": inp["x_T"], "S": S, "model": model, "inp": inp, "hip": hip}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs torchrun with --nproc-per-node {args.gpus}")
+    device, backend = setup(args, local)
+    from mudg_amd import parallel
+    dist = parallel.init_from_env(backend)[3]
+    wl = make_workload(args, device, rank, dist)
+    run, S, model, hip = wl["run"], wl["S"], wl["model"], wl["hip"]
     use_graph = not args.no_graph
-    model.model.diffusion_model.use_hip_graph = use_graph
-    x = run(args.warmup, inp["x_T"], S - 1)
-    profile = not args.no_profile
+    x = run(args.warmup, wl["x0"], S - 1)
+    profile = not args.no_profile and hip is not None
     if profile and not use_graph:            # eager mode: the timed region itself is bracketed with hipEvents
         hip.prof_reset()
         hip.prof_enable((1 << len(hip.FAM_NAMES)) - 1)
-    torch.cuda.synchronize()
+    sync(device)
     if dist is not None:
         dist.barrier()
     t0 = time.perf_counter()
     x = run(args.steps, x, S - 1 - args.warmup)
-    torch.cuda.synchronize()
+    sync(device)
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
@@ -262,13 +297,13 @@ def main():
     # One clip = 50 such steps + one AutoencoderKL decode of its 16 frames (outside the timed region; reported so that
     # clips/min is a measured figure, not steps/s divided by 50).
     decode_ms = None
-    if not args.no_decode:
+    if not args.no_decode and model is not None:
         z = x[:1].contiguous()
         model.decode_first_stage(z)                      # warm-up: weight packing, allocator
-        torch.cuda.synchronize()
+        sync(device)
         td = time.perf_counter()
         frames = model.decode_first_stage(z)
-        torch.cuda.synchronize()
+        sync(device)
         decode_ms = 1000.0 * (time.perf_counter() - td)
         finite = finite and bool(torch.isfinite(frames).all().item())
         del frames
@@ -281,7 +316,7 @@ def main():
         hip.prof_reset()
         hip.prof_enable((1 << len(hip.FAM_NAMES)) - 1)
         run(prof_steps, x, S - 1 - args.warmup)
-        torch.cuda.synchronize()
+        sync(device)
     if profile:
         fams = [hip.prof_collect(i) for i in range(len(hip.FAM_NAMES))]
         hip.prof_enable(0)
@@ -290,9 +325,12 @@ def main():
             dist.destroy_process_group()
         return
 
+    from mudg_amd import configs
     steps_per_s = world * args.batch * args.steps / elapsed
-    from mudg_amd import ops as _ops
-    stream_name = {torch.float16: "fp16", torch.float32: "fp32"}[_ops.STREAM()]
+    stream_name = "fp16"
+    if hip is not None:
+        from mudg_amd import ops as _ops
+        stream_name = {torch.float16: "fp16", torch.float32: "fp32"}[_ops.STREAM()]
     step_tflop = 2 * configs.UNET_TFLOP[args.resolution]
     out = {
         "metric": "DDIM denoise steps/sec, MDM1024 576x1024x16f (CFG: 2 UNet forwards + fused update per step, per clip)"
@@ -351,13 +389,17 @@ def main():
             out["roofline"]["frac_of_measured_peak"] = round(dom["achieved"] / MEASURED_MFMA_PEAK_TFLOPS, 4)
         out["kernels"] = kernels
         out["kernel_time_ms_per_step"] = round(total_ms / prof_steps, 3)
-    if world == 1 and args.operand == "bf16" and not args.no_at_tolerance:
+    children = world == 1 and args.operand == "bf16" and not args.no_children and not os.environ.get("MUDG_ATTN_FP8")
+    if children and not args.no_at_tolerance:
         out["at_tolerance"] = at_tolerance(args)      # child process; this one idles meanwhile (288 GB hold both replicas)
-    if world == 1 and args.operand == "bf16" and not args.no_training and args.batch == 1:
+        out["value_at_tolerance"] = out["at_tolerance"].get("value")      # steps/s of the mode that meets the stated 1e-3 tolerance
+    if children and not args.no_other_configs and args.resolution == "1024" and args.batch == 1:
+        out["other_configs"] = other_configs(args)
+    if children and not args.no_training and args.batch == 1:
         out["training_step"] = training_step_record(args)
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and model is not None:
         try:
-            out["cpu_baseline"] = cpu_baseline(model, inp, args.resolution, args.cpu_baseline)
+            out["cpu_baseline"] = cpu_baseline(model, wl["inp"], args.resolution, args.cpu_baseline)
         except Exception as e:          # the baseline is a report, never a reason to lose the GPU number
             out["cpu_baseline"] = {"value": None, "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
                                    "sample": f"failed: {type(e).__name__}: {e}"}

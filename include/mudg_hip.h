@@ -372,6 +372,10 @@ int mudg_dilate2x(const float* src, float* dst, int F, int ho, int wo, int hi, i
 /* torch.optim.AdamW step (decoupled weight decay, bias correction with `step` >= 1), fp32, in place. */
 int mudg_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                float weight_decay, int step, void* stream);
+/* The same step over many parameter tensors in ONE launch (the UNet has 1520): table = device int64 [nchunks][5] rows
+ * (p, g, m, v addresses, count <= mudg_clip_chunk()) covering every parameter; bit-identical to mudg_adamw per element. */
+int mudg_adamw_multi(const int64_t* table, int nchunks, float lr, float beta1, float beta2, float eps, float weight_decay, int step,
+                     void* stream);
 /* torch.nn.utils.clip_grad_norm_ over many fp32 tensors with no host round trip (the reference's trainer: gradient_clip_val 0.5,
  * norm).  table: device int64 [nchunks][2] = (address, count <= mudg_clip_chunk()) covering every gradient; partial: fp64 [nchunks]
  * scratch; out: float [2] = (total 2-norm, clip coefficient min(1, max_norm / (norm + 1e-6))); the gradients are scaled in place. */
@@ -384,6 +388,8 @@ int mudg_dropout(const float* x, float* out, int64_t n, float p, uint64_t seed, 
  * operand rows of the result (what the conv / projection after the Dropout reads). */
 int mudg_dropout_rows(const float* X, int64_t ldx, float* Y, int64_t ldy, void* Y16, int64_t ldy16, int64_t M, int C, float p, uint64_t seed,
                       void* stream);
+/* out = gelu_erf(x) (dy NULL) or dy * gelu_erf'(x): the Perceiver Resampler's feed-forward activation (resampler.py:27-34). */
+int mudg_gelu(const float* x, const float* dy, float* out, int64_t n, void* stream);
 /* out = silu(x) (dy NULL) or dy * silu'(x). */
 int mudg_silu(const float* x, const float* dy, float* out, int64_t n, void* stream);
 

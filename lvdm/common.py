@@ -27,8 +27,14 @@ def noise_like(shape, device, repeat=False):
 
 
 def checkpoint(func, inputs, params, flag):
-    """Activation checkpointing only matters for backward; the HIP path is inference-only, so this is a call-through
-    (the reference's driver forces use_checkpoint=False as well: virtual_pose_render.py:156)."""
+    """common.py:81-93: evaluate func(*inputs) without keeping its intermediate activations when `flag` is set — the forward is
+    replayed during backward.  Without gradients (sampling; the reference's driver forces use_checkpoint=False as well,
+    virtual_pose_render.py:156) or with the flag off this is a plain call.  With both, torch.utils.checkpoint does the replay (it
+    restores the RNG state, so dropout masks repeat); `params` needs no handling: the autograd Functions of mudg_amd.train hold
+    the parameters through their graph edges."""
+    if flag and torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in (*inputs, *params)):
+        from torch.utils.checkpoint import checkpoint as _ckpt
+        return _ckpt(func, *inputs, use_reentrant=False)
     return func(*inputs)
 
 

@@ -185,13 +185,21 @@ class DDPM(nn.Module):
         return step.p_losses(self, x_start, cond, t, noise=noise, **kwargs)
 
     def configure_optimizers(self):
-        """AdamW over the trainable UNet (+ image-projection) parameters at `self.learning_rate`, as ddpm3d.py:1267-1300; the
-        update runs on the HIP kernel (mudg_amd.train.step.AdamW has torch.optim.AdamW's semantics and defaults)."""
+        """AdamW over the trainable UNet (+ image-projection: the Resampler trains through mudg_amd.train.resampler) parameters at
+        `self.learning_rate`, as ddpm3d.py:1267-1300; the update runs on the HIP kernel (mudg_amd.train.step.AdamW has
+        torch.optim.AdamW's semantics and defaults).  What the reference can also put into the optimiser but this build does not
+        train raises instead of being dropped silently."""
         from mudg_amd.train import step
+        if getattr(self, "cond_stage_trainable", False):
+            raise NotImplementedError("cond_stage_trainable: the text tower has no HIP backward (frozen in every MuDG config)")
+        if getattr(self, "learn_logvar", False):
+            raise NotImplementedError("learn_logvar is off in every MuDG config")
+        if getattr(self, "use_scheduler", False):
+            raise NotImplementedError("use_scheduler: build the LambdaLR of configure_schedulers around the returned optimiser")
         params = [p for p in self.model.parameters() if p.requires_grad]
         proj = getattr(self, "image_proj_model", None)
         if getattr(self, "image_proj_model_trainable", False) and proj is not None:
-            params.extend(p for p in proj.parameters() if p.requires_grad)
+            params.extend(proj.parameters())
         return step.AdamW(params, lr=getattr(self, "learning_rate", 1e-4))
 
     def training_step(self, batch, batch_idx=0):
@@ -201,6 +209,15 @@ class DDPM(nn.Module):
         kw = {k: v for k, v in batch.items() if k not in ("x_start", "cond", "t", "noise")}
         loss, _ = self.p_losses(batch["x_start"], batch["cond"], batch["t"], noise=batch.get("noise"), **kw)
         return loss
+
+    def forward(self, x, c, **kwargs):
+        """The training entry (ddpm3d.py:711-715): draw one timestep per sample, apply the dynamic rescale of the latents when the
+        config enables it (`use_dynamic_rescale`: scale_arr[t], base_scale 0.3 / 0.7 in the MDM configs), then p_losses.
+        Returns (loss, loss_dict)."""
+        t = torch.randint(0, self.num_timesteps, (x.shape[0],), device=x.device).long()
+        if getattr(self, "use_dynamic_rescale", False):
+            x = x * extract_into_tensor(self.scale_arr.to(x.device), t, x.shape)
+        return self.p_losses(x, c, t, **kwargs)
 
     def shared_step(self, batch, **kwargs):
         raise NotImplementedError("get_batch_input (VAE-encoding Waymo items, CLIP towers, random conditioning dropout) is the data "

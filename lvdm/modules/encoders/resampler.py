@@ -41,6 +41,11 @@ class Resampler(nn.Module):
                                                     FeedForward(dim=dim, mult=ff_mult)]) for _ in range(depth)])
 
     def forward(self, x):
-        """x (B, n_tokens, embedding_dim) image tokens -> (B, total_queries, output_dim), fp32."""
+        """x (B, n_tokens, embedding_dim) image tokens -> (B, total_queries, output_dim), fp32.  With gradients enabled and a
+        parameter (or the input) that wants one, the forward runs on the autograd Functions of mudg_amd.train (the MuDG training
+        configs train this module: image_proj_model_trainable); otherwise on the fused inference executor."""
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())) and self.training:
+            from mudg_amd.train import resampler as train_resampler
+            return train_resampler.forward(self, x)
         from mudg_amd.engine import resampler
         return resampler.forward(self, x)

@@ -211,7 +211,7 @@ class UNetModel(nn.Module):
         c_label (B,) long, context (B, 77 + 16 T, context_dim), fs (B,) long.  Extra kwargs the reference's callers
         pass (sparse_x, class_label, cfg_img, ...) are accepted and ignored, as in the reference.  Returns
         (B, out_channels, T, H, W) in x's dtype."""
-        if self.training and torch.is_grad_enabled():
+        if self.training and torch.is_grad_enabled() and self._wants_grad(x, context):
             # training step (SURVEY §8 f4): the same network on autograd Functions whose forward and backward are HIP kernels
             if features_adapter is not None:
                 raise NotImplementedError("features_adapter is not used on the MuDG path")
@@ -220,6 +220,14 @@ class UNetModel(nn.Module):
         from mudg_amd.engine import unet as engine
         return engine.forward_entry(self, x, timesteps, c_label=c_label, context=context,
                                     features_adapter=features_adapter, fs=fs)
+
+    def _wants_grad(self, x, context):
+        """A module is in training mode by default: only a caller that can actually receive a gradient (a trainable parameter, or an
+        input / context that requires one) is sent down the training path; everybody else keeps the fused inference engine."""
+        xs = x if isinstance(x, (list, tuple)) else [x]
+        if any(isinstance(t, torch.Tensor) and t.requires_grad for t in (*xs, context)):
+            return True
+        return any(p.requires_grad for p in self.parameters())
 
     def prepare_context(self, context, temporal_length=None):
         """Not in the reference: make a (B, L, D) context ready once for many forward calls — operand rows plus every

@@ -20,9 +20,9 @@ OUT_FP16 = os.path.join(HERE, "libmudg_hip_fp16.so")
 OUT_X3 = os.path.join(HERE, "libmudg_hip_x3.so")
 OUT_X6 = os.path.join(HERE, "libmudg_hip_x6.so")
 OUT_DBG = os.path.join(HERE, "libmudg_hip_dbg.so")      # bf16 + kernel-variant switches (tests / tools only; hip.py loads it under MUDG_DEBUG_VARIANTS=1)
-SOURCES = ["capi.hip", "gemm.hip", "attention.hip", "norm.hip", "misc.hip", "post.hip", "train.hip", "attention_bwd.hip", "wgrad.hip"]
+SOURCES = ["capi.hip", "gemm.hip", "pgemm.hip", "attention.hip", "norm.hip", "misc.hip", "post.hip", "train.hip", "attention_bwd.hip", "wgrad.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-         "-ffp-contract=off"]
+         "-ffp-contract=off", *os.environ.get("MUDG_EXTRA_HIPCC_FLAGS", "").split()]      # extra flags: kernel experiments only
 
 
 def _hipcc() -> str:
@@ -73,18 +73,23 @@ def _build_one(out: str, extra, tag: str, force: bool, verbose: bool) -> str:
     return out
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, only=None) -> str:
     """Every operand-type build of the same sources: bf16 (default), fp16 (-DMUDG_OPERAND_FP16), the split-operand
     precision modes bf16x3 / bf16x6 (-DMUDG_PLANES=2 / 3; csrc/common.h), and the bf16 build with the kernel-variant
     switches compiled in (-DMUDG_DEBUG_VARIANTS: the only library in which an environment variable can change which
-    kernel runs; the variant tests and the A/B tools load it)."""
-    _build_one(OUT_FP16, ["-DMUDG_OPERAND_FP16"], "fp16", force, verbose)
-    _build_one(OUT_X3, ["-DMUDG_PLANES=2"], "x3", force, verbose)
-    _build_one(OUT_X6, ["-DMUDG_PLANES=3"], "x6", force, verbose)
-    _build_one(OUT_DBG, ["-DMUDG_DEBUG_VARIANTS"], "dbg", force, verbose)
-    return _build_one(OUT, [], "bf16", force, verbose)
+    kernel runs; the variant tests and the A/B tools load it).  The five libraries are built side by side;
+    `only` (or `--only dbg,bf16` on the command line) restricts the set while iterating on a kernel."""
+    jobs = {"fp16": (OUT_FP16, ["-DMUDG_OPERAND_FP16"]), "x3": (OUT_X3, ["-DMUDG_PLANES=2"]), "x6": (OUT_X6, ["-DMUDG_PLANES=3"]),
+            "dbg": (OUT_DBG, ["-DMUDG_DEBUG_VARIANTS"]), "bf16": (OUT, [])}
+    tags = [t for t in jobs if only is None or t in only]
+    with ThreadPoolExecutor(max_workers=len(tags)) as ex:
+        list(ex.map(lambda t: _build_one(jobs[t][0], jobs[t][1], t, force, verbose), tags))
+    return OUT
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    sel = None
+    if "--only" in sys.argv:
+        sel = sys.argv[sys.argv.index("--only") + 1].split(",")
+    build(force="--force" in sys.argv, only=sel)
     print(OUT)

@@ -19,7 +19,7 @@
 // Epilogue: accumulators (+bias, GEGLU through an LDS Phi table) -> fp32 LDS tile -> coalesced 16-B rows (+group bias,
 // +residual, optional GroupNorm partial sums of what was stored) -> HBM.
 // Workgroups are numbered so that each XCD gets a contiguous run of tiles, walked in 8-row groups (8 x 8 tile patches).
-#include "common.h"
+#include "gemm_shared.h"
 #include <cstdlib>
 #include <cmath>
 #include <type_traits>
@@ -28,8 +28,6 @@ bool mudg_gemm_fast_ok(const MudgGemmDesc& d);
 
 namespace {
 
-constexpr int BK = 64;
-constexpr int LDSLD = 64;                       // h16 elements per LDS row: unpadded, XOR-swizzled (see header)
 
 // Tile geometry.  Every variant is waves laid out WM (rows) x 2 (columns), a wave owning 64 rows x 32 NI columns as
 // 2 x NI v_mfma_f32_32x32x16 tiles:
@@ -65,7 +63,6 @@ using G256 = Geo<8, 4>;
 // and every fragment read feeds the three kept products x1 w0 + x0 w1 + x0 w0: each piece is fetched once per K-tile (4 tile
 // fetches instead of the 6 of three whole passes over K) and 12 MFMAs follow 8 fragment reads instead of 4 following 4.
 // Single K-buffer + two-pass epilogue = 64 KiB -> 2 workgroups per CU.
-constexpr bool fused_planes(bool fast) { return PLANES == 2 && fast; }
 // Stages: the single-buffer variant (SB, short K: one K-tile stage, the epilogue in 64-row passes -> 34 KiB, 4 workgroups per
 // CU) and the fused-piece variant hold one stage, everything else two.
 template <typename G> constexpr int stage_elems(bool fast) { return (fused_planes(fast) ? PLANES : 1) * (G::TILE_X + G::TILE_W); }
@@ -77,32 +74,6 @@ template <typename G> constexpr int smem_main(bool fast, bool sb) {
     return loop > stg ? loop : stg;
 }
 
-constexpr int VF_Y = 1, VF_R = 2;               // 16-byte access allowed on Y / R
-
-typedef const __attribute__((address_space(1))) void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
-
-// Used by the 16-bit builds where the table is off and by the bf16x3 build (whose operands carry 16 significand bits: the
-// polynomial's 1.5e-7 is two orders below their representation error); bf16x6 evaluates erff exactly.
-__device__ __forceinline__ float gelu_fast(float x) {
-    // 0.5 x (1 + erf(x / sqrt 2)) with Abramowitz-Stegun 7.1.26 for erf (|abs err| < 1.5e-7): the exact erff
-    // costs about as much as the whole K loop of a K = 320 tile; the result is rounded to h16 anyway.
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
-    float p = fmaf(1.061405429f, t, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
-    const float e = 1.0f - p * t * __expf(-z * z);          // erf(|x| / sqrt 2)
-    return 0.5f * x * (1.0f + copysignf(e, x));
-}
-
-// voffset of a lane whose source row / tap does not exist: at num_records, so the buffer load returns 0 into the LDS.
-constexpr unsigned OOB = 0x80000000u;
-
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const h16* base) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<h16*>(base), 0, (int)0x80000000u, 0x00020000);
-}
 
 // FAST (host-checked: K, Cin, csplit multiples of 64, no upsample, block-relative offsets < 2 GiB): operand tiles are
 // fetched with buffer_load_dwordx4 ... lds through block-relative buffer descriptors — the per-lane byte offset
@@ -117,17 +88,6 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const h16* base) {
 // (|error| <= h^2/8 max|Phi''| = 7.4e-6 at h = 1/64 — below the h16 rounding of the result by two orders): ten VALU
 // instructions and one ds_read2 instead of the ~21 issue slots of the erf polynomial + v_exp + v_rcp, which made the
 // K = 320 GEGLU tiles VALU-bound (GELU was 21 % of their time).
-constexpr int PHI_N = 1024;
-constexpr int PHI_BYTES = (PHI_N + 4) * 4;
-__device__ __forceinline__ float gelu_lut(float x, const float* __restrict__ T) {
-    float u = fmaf(x, 64.0f, 512.0f);
-    u = __builtin_amdgcn_fmed3f(u, 0.0f, 1023.99f);
-    const int i = (int)u;
-    const float f = u - (float)i;
-    const float a = T[i], b = T[i + 1];
-    return x * fmaf(f, b - a, a);
-}
-
 template <typename G, int MODE, bool FAST, bool SB>
 __global__ __launch_bounds__(G::NTH, G::WIDE ? 2 : ((SB && !fused_planes(FAST)) ? 4 : 2)) void gemm_kernel(const MudgGemmDesc p, const int vflags,
                                                                 const h16* __restrict__ zpage, const float* __restrict__ phi) {
@@ -904,12 +864,14 @@ __global__ __launch_bounds__(G::NTH, G::WIDE ? 2 : ((SB && !fused_planes(FAST)) 
 
 // Lazily created per-device state (a zero page, the Phi table, the kernels' LDS opt-in): keyed by the current device so
 // that one process may drive several GPUs.
-constexpr int MAX_DEVICES = 64;
-int current_device() {
+}  // namespace
+int mudg_current_device() {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return -1;
     return dev;
 }
+namespace {
+int current_device() { return mudg_current_device(); }
 
 const h16* zero_page() {
     static h16* page[MAX_DEVICES] = {};
@@ -925,7 +887,8 @@ const h16* zero_page() {
 
 // Phi(x) = 0.5 erfc(-x / sqrt 2) at x = -8 + i / 64, i = 0..1024, built once on the host in double precision.
 // Variant switch GELU_LUT=0 keeps the erf polynomial (A/B measurements).
-const float* phi_table() {
+}  // namespace
+const float* mudg_phi_table() {
     static float* tabs[MAX_DEVICES] = {};
     static int mode = -1;
     if (mode < 0) mode = mudg_variant("GELU_LUT", 1);
@@ -946,6 +909,8 @@ const float* phi_table() {
     }
     return tab;
 }
+namespace {
+const float* phi_table() { return mudg_phi_table(); }
 
 template <typename G, int MODE, bool FAST, bool SB = false>
 int launch(const MudgGemmDesc& d, int vflags, hipStream_t s) {
@@ -981,6 +946,51 @@ bool use_single_buffer(const MudgGemmDesc& d) {
     if (mode == 2) return true;
     const int64_t tiles = (int64_t)((d.M + G128::BM - 1) / G128::BM) * ((d.N + G128::BN - 1) / G128::BN) * d.batch;
     return tiles >= (d.mode == 1 ? 2048 : 768);
+}
+
+// Variant switch GEMM_PERSIST=0: the non-persistent 128 x 128 kernels (A/B measurements); 2 / 3 / 4: that many persistent
+// workgroups per CU for every problem.
+int persist_mode() {
+    static int mode = -1;
+    if (mode < 0) mode = mudg_variant("GEMM_PERSIST", 1);
+    return mode;
+}
+bool use_persistent() { return persist_mode() != 0; }
+// Workgroups per CU of the persistent kernel: one K-tile stage at 4 per CU where the one-tile-per-workgroup rule chose the
+// single-buffer variant, two stages at 2 per CU otherwise.
+// What the persistent kernel (pgemm.hip) takes, and where it is used.
+// Takes: whole 16-byte pieces everywhere (Nout % 8 == 0, aligned Y / R rows), a residual that may seed the accumulators (alpha 1),
+// a group bias constant over a 128-row tile, bias-only GEGLU, no plain activation; ragged widths, the Perceiver's GELU and odd
+// row groups stay on the one-tile-per-workgroup kernels.
+// Used (measured per shape on MI355X, tools/exp_tiles.py with MUDG_GEMM_PERSIST = 0 / 1 / 4 / 3 / 2, profiles/r4/tiles_*.txt):
+//   * every GEGLU problem: + 13 % / + 10 % / + 5 % at levels 0 / 1 / 2 (its epilogue is the longest of all and has no residual:
+//     the direct epilogue + the prefetch across it pay, and the kernel fits 128 registers);
+//   * the plain GEMMs of the 1280-wide levels (at most ~ 6 tiles per CU at one clip): + 4 ... + 16 % — no tail of one-tile
+//     workgroups, no first-fetch latency per tile;
+//   * NOT the long plain / conv problems: there four one-tile workgroups per CU with the staged epilogue are as fast or faster
+//     (- 5 ... - 13 % persistent).  Residual seeds and GroupNorm partials cost the persistent kernel its fourth workgroup
+//     (150-170 registers), and with its stores disabled the same kernel runs the level-0 shapes 1.5-2 x faster: what bounds
+//     these problems is the result stream slowing every fetch of a K loop that has one stage in flight per workgroup
+//     (DESIGN §6), which neither persistence nor the direct epilogue changes.
+// Variant switch GEMM_PERSIST: 0 = never, 1 = this rule, 2 / 3 / 4 = every eligible problem at that many workgroups per CU.
+bool persistent_ok(const MudgGemmDesc& d, int vflags) {
+    if (!use_persistent() || PLANES > 2) return false;
+    if (d.act || !(vflags & VF_Y) || (d.R && !(vflags & VF_R))) return false;
+    if ((d.geglu ? d.N / 2 : d.N) % 8 != 0) return false;
+    if (d.geglu && (d.mode != 0 || d.R || d.gbias || d.stats)) return false;
+    if (d.R && d.alpha != 1.f) return false;
+    if (d.gbias && d.rows_per_group % 128 != 0) return false;
+    if (persist_mode() != 1 || d.geglu) return true;
+    // The rule must not look at M: a residual enters the persistent kernel's sum first and the one-tile kernels' last, and a clip's
+    // result may not depend on the batch it travels in (tests/test_fullsize_gpu.py).  N, K >= 1280 = the plain GEMMs of the
+    // 1280-wide levels, whatever the number of clips.
+    return d.mode == 0 && d.N >= 1280 && d.K >= 1280;
+}
+bool use_single_buffer(const MudgGemmDesc& d);
+int persistent_wgs(const MudgGemmDesc& d) {
+    const int m = persist_mode();
+    if (m >= 2 && m <= 4) return m;
+    return use_single_buffer(d) ? 4 : 2;
 }
 
 #if MUDG_PLANES == 1
@@ -1112,6 +1122,11 @@ extern "C" int mudg_gemm(const MudgGemmDesc* dp, void* stream) {
         const int wide = use_wide(d);
         if (wide) rc = wide == 5 ? by_mode(G320{}, std::true_type{}, std::false_type{}) : by_mode(G256{}, std::true_type{}, std::false_type{});
         else
+#endif
+#if MUDG_PLANES <= 2
+        if (persistent_ok(d, vflags)) {
+            rc = mudg_pgemm_launch(d, vflags, persistent_wgs(d), s);
+        } else
 #endif
         if (use_single_buffer(d)) rc = by_mode(G128{}, std::true_type{}, std::true_type{});
 #if MUDG_PLANES != 2

@@ -166,8 +166,10 @@ SIGNATURES = {
     "mudg_upsample2x": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "mudg_dilate2x": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "mudg_adamw": (_I, [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P]),
+    "mudg_adamw_multi": (_I, [_P, _I, _F, _F, _F, _F, _F, _I, _P]),
     "mudg_clip_chunk": (_I, []),
     "mudg_clip_grad_norm": (_I, [_P, _I, _P, _F, _P, _P]),
+    "mudg_gelu": (_I, [_P, _P, _P, _L, _P]),
     "mudg_silu": (_I, [_P, _P, _P, _L, _P]),
     "mudg_dropout": (_I, [_P, _P, _L, _F, C.c_uint64, _P]),
     "mudg_dropout_rows": (_I, [_P, _L, _P, _L, _P, _L, _L, _I, _F, C.c_uint64, _P]),

@@ -262,6 +262,19 @@ def silu(x, dy=None):
     return out
 
 
+def gelu(x, dy=None):
+    """Exact (erf) GELU, or dy * gelu'(x) when dy is given."""
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    hip.check(hip.lib().mudg_gelu(x.data_ptr(), None if dy is None else dy.contiguous().data_ptr(), out.data_ptr(), x.numel(), _s()), "mudg_gelu")
+    return out
+
+
+def adamw_multi_(table, nchunks, *, lr, betas, eps, weight_decay, step):
+    """One torch.optim.AdamW step over every tensor listed in `table` (device int64 [nchunks][5]: p, g, m, v, count), one launch."""
+    hip.check(hip.lib().mudg_adamw_multi(table.data_ptr(), nchunks, lr, betas[0], betas[1], eps, weight_decay, step, _s()), "mudg_adamw_multi")
+
+
 def adamw_(p, g, m, v, *, lr, betas, eps, weight_decay, step):
     """One torch.optim.AdamW step on flat fp32 buffers, in place."""
     for t in (p, g, m, v):

@@ -16,10 +16,15 @@ def p_losses(model, x_start, cond, t, noise=None, **kwargs):
     if getattr(model, "learn_logvar", False):
         raise NotImplementedError("learn_logvar is off in every MuDG config")
     if noise is None:
-        noise = torch.randn_like(x_start)
-        if model.noise_strength > 0:                  # offset noise (ddpm3d.py:742-745): random-number plumbing, as in the reference
+        # offset noise (ddpm3d.py:742-747): the per-(sample, channel, frame) term is drawn FIRST, then the full-size noise — the
+        # reference's order, so that a seeded run draws the same numbers
+        offset = None
+        if model.noise_strength > 0:
             b, c, f = x_start.shape[:3]
-            noise = noise + model.noise_strength * torch.randn(b, c, f, 1, 1, device=x_start.device)
+            offset = torch.randn(b, c, f, 1, 1, device=x_start.device)
+        noise = torch.randn_like(x_start)
+        if offset is not None:
+            noise = noise + model.noise_strength * offset
     x_start, noise = x_start.float().contiguous(), noise.float().contiguous()
     x_noisy = model.q_sample(x_start=x_start, t=t, noise=noise)
     model_output = model.apply_model(x_noisy, t, cond, **kwargs)
@@ -38,19 +43,40 @@ def p_losses(model, x_start, cond, t, noise=None, **kwargs):
     # per-sample coefficients of the mse (host-sized vectors of B numbers, like the DDIM step's coefficients)
     w = (model.l_simple_weight / torch.exp(logvar_t) + model.original_elbo_weight * lvlb_t) / b
     weighted, mse_b = F_.WeightedMSE.apply(model_output.float(), target, w)
-    const = model.l_simple_weight * logvar_t.mean()
-    loss = weighted + const if float(const) != 0.0 else weighted
+    loss = weighted + model.l_simple_weight * logvar_t.mean()          # (a device scalar: no host round trip; 0 in every MuDG config)
     prefix = "train" if model.training else "val"
     loss_dict = {f"{prefix}/loss_simple": mse_b.mean(), f"{prefix}/loss_vlb": (lvlb_t * mse_b).mean(), f"{prefix}/loss": loss.detach()}
     return loss, loss_dict
 
 
 class AdamW(torch.optim.Optimizer):
-    """torch.optim.AdamW semantics (decoupled weight decay, bias correction) with the update done by mudg_adamw: one launch
-    per parameter tensor, fp32 moments next to fp32 master weights."""
+    """torch.optim.AdamW semantics (decoupled weight decay, bias correction) with the update done on the HIP kernel, fp32 moments
+    next to fp32 master weights.  All tensors of a parameter group are updated by ONE launch (mudg_adamw_multi over a device table
+    of (parameter, gradient, moment, moment, count) chunks; the table is rebuilt only when a tensor moved), instead of one launch
+    per tensor — 1520 for the UNet.  After the update every parameter's autograd version counter is bumped: the kernel writes
+    through raw pointers, and the inference side (packed operand weights, captured hipGraphs, cached K / V^T of a prepared
+    context) recognises changed weights by (data_ptr, _version)."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._tables = {}                                 # group index -> (key, device table, chunk count)
+
+    def _table(self, gi, ps):
+        from .. import hip
+        key = tuple((p.data_ptr(), p.grad.data_ptr(), p.numel()) for p in ps)
+        hit = self._tables.get(gi)
+        if hit is not None and hit[0] == key:
+            return hit[1], hit[2]
+        chunk = hip.lib().mudg_clip_chunk()
+        rows = []
+        for p in ps:
+            st = self.state[p]
+            base = (p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr())
+            n = p.numel()
+            rows.extend((*(a + 4 * off for a in base), min(chunk, n - off)) for off in range(0, n, chunk))
+        table = torch.tensor(rows, dtype=torch.int64).to(ps[0].device)
+        self._tables[gi] = (key, table, len(rows))
+        return table, len(rows)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -58,19 +84,31 @@ class AdamW(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        for group in self.param_groups:
-            for p in group["params"]:
-                if p.grad is None:
-                    continue
-                if not p.is_cuda or p.dtype != torch.float32:
-                    raise RuntimeError("mudg AdamW updates fp32 parameters on the GPU")
+        for gi, group in enumerate(self.param_groups):
+            ps = [p for p in group["params"] if p.grad is not None]
+            if not ps:
+                continue
+            steps = set()
+            for p in ps:
+                if not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous():
+                    raise RuntimeError("mudg AdamW updates contiguous fp32 parameters on the GPU")
+                if p.grad.dtype != torch.float32 or not p.grad.is_contiguous():
+                    p.grad = p.grad.float().contiguous()
                 st = self.state[p]
                 if not st:
                     st["step"], st["exp_avg"], st["exp_avg_sq"] = 0, torch.zeros_like(p), torch.zeros_like(p)
                 st["step"] += 1
-                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                K.adamw_(p.data, g.float(), st["exp_avg"], st["exp_avg_sq"], lr=group["lr"], betas=group["betas"], eps=group["eps"],
-                         weight_decay=group["weight_decay"], step=st["step"])
+                steps.add(st["step"])
+            hyper = dict(lr=group["lr"], betas=group["betas"], eps=group["eps"], weight_decay=group["weight_decay"])
+            if len(steps) == 1:
+                table, n = self._table(gi, ps)
+                K.adamw_multi_(table, n, step=steps.pop(), **hyper)
+            else:                                         # parameters that joined the group at different times: one launch each
+                for p in ps:
+                    st = self.state[p]
+                    K.adamw_(p.data, p.grad, st["exp_avg"], st["exp_avg_sq"], step=st["step"], **hyper)
+            for p in ps:
+                torch.autograd.graph.increment_version(p)
         return loss
 
 
@@ -139,7 +177,19 @@ class GradientAllReducer:
             n += p.numel()
         if cur:
             self.buckets.append(cur)
-        self._works = {}                                  # bucket index -> (work, flat, needs scaling)
+        # Persistent flat buckets; every parameter's .grad is a VIEW into its bucket (as DDP's gradient_as_bucket_view): backward
+        # accumulates straight into the bucket, the collective runs on it in place, nothing is packed, unpacked or allocated per
+        # step.  (Round 3 allocated 5.8 GB of zeros and issued 2 x 1520 copies per step.)  A parameter that receives no gradient
+        # keeps its zeros — it then sees weight decay only, as under DDP.
+        self.flats = [torch.zeros(sum(p.numel() for p in b), dtype=torch.float32, device=b[0].device) for b in self.buckets]
+        self._views = {}
+        for flat, bucket in zip(self.flats, self.buckets):
+            off = 0
+            for p in bucket:
+                self._views[id(p)] = flat[off:off + p.numel()].view_as(p)
+                off += p.numel()
+        self.attach()
+        self._works = {}                                  # bucket index -> (work, needs scaling)
         self._pending = [len(b) for b in self.buckets]
         self._next = 0                                    # buckets are launched strictly in index order
         self._hooks = []
@@ -148,24 +198,43 @@ class GradientAllReducer:
             for p in self.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(lambda q, i=where[id(p)]: self._ready(i)))
 
+    def attach(self):
+        """Point every parameter's .grad at its slice of the flat buckets (keeping a gradient that is already there)."""
+        with torch.no_grad():
+            for p in self.params:
+                v = self._views[id(p)]
+                if p.grad is None:
+                    p.grad = v
+                elif p.grad.data_ptr() != v.data_ptr():
+                    v.copy_(p.grad)
+                    p.grad = v
+
+    def zero_grad(self):
+        """One fill per bucket instead of one per tensor; use it instead of optimizer.zero_grad(set_to_none=True), which would
+        detach the gradients from the buckets (attach() repairs that at the cost of a copy per tensor)."""
+        for flat in self.flats:
+            flat.zero_()
+        self.attach()
+
     def _active(self):
         import torch.distributed as dist
         return dist.is_available() and dist.is_initialized() and (dist.get_world_size(self.group) > 1 or self.always)
 
     def _launch(self, i):
         import torch.distributed as dist
-        bucket = self.buckets[i]
-        dev = bucket[0].device
-        flat = torch.zeros(sum(p.numel() for p in bucket), dtype=torch.float32, device=dev)
-        off = 0
-        for p in bucket:                                  # a parameter that received no gradient contributes zeros
-            if p.grad is not None:
-                flat[off:off + p.numel()].copy_(p.grad.reshape(-1))
-            off += p.numel()
+        for p in self.buckets[i]:                         # a gradient replaced behind the reducer's back: bring it home first
+            g, v = p.grad, self._views[id(p)]
+            if g is None:
+                v.zero_()
+                p.grad = v
+            elif g.data_ptr() != v.data_ptr():
+                v.copy_(g)
+                p.grad = v
+        flat = self.flats[i]
         if dist.get_backend(self.group) == "nccl":        # RCCL averages in the collective itself
-            self._works[i] = (dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True), flat, False)
+            self._works[i] = (dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group, async_op=True), False)
         else:                                             # gloo (CPU tests): sum, then scale
-            self._works[i] = (dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True), flat, True)
+            self._works[i] = (dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True), True)
 
     def _ready(self, i):
         if not self.sync or not self._active():
@@ -176,7 +245,7 @@ class GradientAllReducer:
             self._next += 1
 
     def __call__(self):
-        """After backward(): finish the gradient averaging.  Returns the number of collectives."""
+        """After backward(): finish the gradient averaging (in place, in the buckets).  Returns the number of collectives."""
         import torch.distributed as dist
         if not self._active() or not self.sync:
             return 0
@@ -184,18 +253,10 @@ class GradientAllReducer:
         for i in range(self._next, len(self.buckets)):    # not launched under backward (or overlap off): now, in order
             self._launch(i)
         for i in range(len(self.buckets)):
-            work, flat, scale = self._works[i]
+            work, scale = self._works[i]
             work.wait()
             if scale:
-                flat /= world
-            off = 0
-            for p in self.buckets[i]:
-                g = flat[off:off + p.numel()].view_as(p)
-                if p.grad is None:
-                    p.grad = g.clone()
-                else:
-                    p.grad.copy_(g)
-                off += p.numel()
+                self.flats[i] /= world
         self._works.clear()
         self._pending = [len(b) for b in self.buckets]
         self._next = 0
@@ -210,7 +271,10 @@ class GradientAllReducer:
 def training_step(model, x_start, cond, t, optimizer, reducer=None, noise=None, clipper=None, **kwargs):
     """One optimisation step as the reference's trainer runs it: zero_grad -> p_losses -> backward -> (gradient all-reduce) ->
     (gradient-norm clipping) -> AdamW.  Returns (loss, loss_dict); with a clipper, loss_dict["grad_norm"] is the device scalar."""
-    optimizer.zero_grad(set_to_none=True)
+    if reducer is not None:
+        reducer.zero_grad()                               # one fill per bucket; the gradients stay views into the buckets
+    else:
+        optimizer.zero_grad(set_to_none=False)            # (multi-tensor fill; the clipper's and AdamW's pointer tables stay valid)
     loss, info = p_losses(model, x_start, cond, t, noise=noise, **kwargs)
     loss.backward()
     if reducer is not None:

@@ -24,7 +24,8 @@ int main(int argc, char** argv) {
                         /* the training step */
                         (void*)mudg_wgrad, (void*)mudg_attention_bwd, (void*)mudg_transpose_gather, (void*)mudg_transpose_cast_sum,
                         (void*)mudg_group_colsum, (void*)mudg_groupnorm_bwd, (void*)mudg_layernorm_bwd, (void*)mudg_temporal_attention_bwd,
-                        (void*)mudg_geglu, (void*)mudg_mse, (void*)mudg_dropout, (void*)mudg_clip_grad_norm, (void*)mudg_adamw};
+                        (void*)mudg_geglu, (void*)mudg_mse, (void*)mudg_dropout, (void*)mudg_clip_grad_norm, (void*)mudg_adamw,
+                        (void*)mudg_adamw_multi, (void*)mudg_gelu};
         printf("no GPU: %d symbols linked\n", (int)(sizeof(syms) / sizeof(syms[0])));
         return 0;
     }

@@ -540,6 +540,40 @@ def golden_sampler_options():
 
 
 # ---------------------------------------------------------------------------------------------- 11. the YAML configs
+def golden_training_forward():
+    """LatentDiffusion.forward — the training entry (ddpm3d.py:711-715: draw t, dynamic rescale of the latents, p_losses) — on
+    the tiny pipeline model with offset noise on: the timesteps and the noise the reference drew from the seeded CPU generator
+    are recorded next to the loss and its dictionary.  Evaluation mode (no dropout draw), so the value is a pure function of
+    what is stored."""
+    diff = dict(cfgs.DIFFUSION, noise_strength=0.1)
+    model = build_diffusion(cfgs.UNET_B, diff)
+    unet_shapes, unet_cks = reseed(model.model.diffusion_model, cfgs.SEED)
+    shp = cfgs.UNET_B_SHAPE
+    B, T, H, W = shp["B"], shp["T"], shp["H"], shp["W"]
+    seed = cfgs.SEED + 9
+    x = seeding.seeded_input("x_start", (B, 4, T, H, W), seed)
+    ctx = seeding.seeded_input("ctx_train", (B, 77 + 16 * T, cfgs.UNET_B["context_dim"]), seed)
+    concat = seeding.seeded_input("c_concat_train", (B, 8, T, H, W), seed, 0.18215 * 5)
+    fs = torch.full((B,), 10, dtype=torch.long)
+    class_label = torch.tensor([0, 500, 1], dtype=torch.long)[:B, None]
+    cond = {"c_crossattn": [ctx], "c_concat": [concat]}
+    seen = {}
+    orig_q = model.q_sample
+
+    def q_tapped(x_start, t, noise=None):
+        seen.update(x_rescaled=x_start.clone(), t=t.clone(), noise=noise.clone())
+        return orig_q(x_start=x_start, t=t, noise=noise)
+
+    model.q_sample = q_tapped
+    torch.manual_seed(4242)
+    loss, loss_dict = model(x, cond, fs=fs, class_label=class_label)
+    save("training_forward.pt", {"unet_cfg": cfgs.UNET_B, "diffusion_cfg": diff, "shape": shp, "seed": cfgs.SEED, "input_seed": seed,
+                                 "cpu_seed": 4242, "unet_checksum": unet_cks, "unet_param_shapes": unet_shapes,
+                                 "fs": fs, "class_label": class_label, "t": seen["t"], "noise": seen["noise"],
+                                 "x_rescaled": seen["x_rescaled"], "loss": loss.clone(),
+                                 "loss_dict": {k: v.clone() for k, v in loss_dict.items()}})
+
+
 def golden_yaml():
     """model.params of the reference's two inference YAMLs as JSON: mudg_amd/configs.py is asserted equal to it, and every
     `target:` in it must resolve against this repo's overlay (tests/test_host_logic.py)."""
@@ -575,6 +609,9 @@ if __name__ == "__main__":
     if "--only-options" in sys.argv:
         golden_sampler_options()
         sys.exit(0)
+    if "--only-training" in sys.argv:
+        golden_training_forward()
+        sys.exit(0)
     if "--only-round2" in sys.argv:
         golden_pipeline50()
         golden_threeway()
@@ -592,4 +629,5 @@ if __name__ == "__main__":
     golden_threeway()
     golden_driver()
     golden_sampler_options()
+    golden_training_forward()
     golden_yaml()

@@ -145,14 +145,18 @@ def _mode():
     return hip.operand_name() + ("+fp8scores" if os.environ.get("MUDG_ATTN_FP8") == "1" else "")
 
 
-def _forward_vs_oracle(model, res, seed):
+def _forward_vs_oracle(model, res, seed, frames=None):
     import time
     from helpers import cached_oracle, record_parity
     from mudg_amd import configs, factory, hip
     from oracle import unet as o_unet
     unet = model.model.diffusion_model
     dev = next(unet.parameters()).device
-    inp = factory.synthetic_inputs(model, res, 1, dev, seed=seed)
+    shape = None
+    if frames is not None:                        # a shorter clip at the same spatial size (77 + 16 x frames context tokens)
+        c, _, h, w = configs.LATENT_SHAPE[res]
+        shape = (c, frames, h, w)
+    inp = factory.synthetic_inputs(model, res, 1, dev, seed=seed, latent_shape=shape)
     x = torch.cat([inp["x_T"], inp["cond"]["c_concat"][0]], dim=1)
     ts = torch.full((1,), 499, device=dev, dtype=torch.long)
     lab, fs, ctx = inp["class_label"][:, 0], inp["fs"], inp["cond"]["c_crossattn"][0]
@@ -161,17 +165,21 @@ def _forward_vs_oracle(model, res, seed):
 
     def oracle():
         sd = {k: v.detach().float().cpu() for k, v in unet.state_dict().items()}
-        return o_unet.unet_forward(sd, dict(configs.UNET_MDM), x.cpu(), ts.cpu(), lab.cpu(), ctx.cpu(), fs.cpu(), head_chunk=8)
+        cfg = dict(configs.UNET_MDM) if frames is None else dict(configs.UNET_MDM, temporal_length=frames)
+        return o_unet.unet_forward(sd, cfg, x.cpu(), ts.cpu(), lab.cpu(), ctx.cpu(), fs.cpu(), head_chunk=8)
 
+    tag = "" if frames is None else f"_{frames}frames"
+    flop = configs.UNET_TFLOP[res] * (1.0 if frames is None else frames / 16.0)
     t0 = time.perf_counter()
-    want, hit = cached_oracle(f"unet_forward_mdm{res}_model7_seed{seed}_t499", oracle)
+    want, hit = cached_oracle(f"unet_forward_mdm{res}{tag}_model7_seed{seed}_t499", oracle)
     dt = time.perf_counter() - t0
     err = ((got - want).double().norm() / want.double().norm()).item()
     tol = {"bf16": 2.5e-2, "fp16": 4e-3, "bf16x3": 2e-4, "bf16x6": 2e-5}[hip.operand_name()]
     took = "cached from an earlier process of this test run" if hit else \
-        f"{dt:.1f} s on {torch.get_num_threads()} threads = {configs.UNET_TFLOP[res] / dt:.3f} TFLOP/s"
-    print(f"[{_mode()}] MDM{res} full-size UNet forward vs CPU oracle: rel-L2 {err:.3e} (bound {tol:g}); oracle {took}")
-    record_parity(_mode(), f"mdm{res}_unet_forward_vs_cpu_oracle", err)
+        f"{dt:.1f} s on {torch.get_num_threads()} threads = {flop / dt:.3f} TFLOP/s"
+    what = "full-size" if frames is None else f"{frames}-frame"
+    print(f"[{_mode()}] MDM{res} {what} UNet forward vs CPU oracle: rel-L2 {err:.3e} (bound {tol:g}); oracle {took}")
+    record_parity(_mode(), f"mdm{res}{tag}_unet_forward_vs_cpu_oracle", err)
     assert got.shape == want.shape and err < tol
 
 
@@ -184,6 +192,17 @@ def test_mdm512_unet_forward_matches_the_cpu_oracle_at_full_size(big):
     if os.environ.get("MUDG_SKIP_FULLSIZE_ORACLE") == "1":
         pytest.skip("MUDG_SKIP_FULLSIZE_ORACLE=1")
     _forward_vs_oracle(big[0], "512", 21)
+
+
+def test_mdm1024_4_frame_unet_forward_matches_the_cpu_oracle(big):
+    """NUMERICAL parity at the benchmarked spatial size, cheap enough to run by default: the real 1.44 B-parameter UNet on MDM1024
+    latents (1, 12, T = 4, 72, 128) — 9216-token spatial self-attention, every level-0 shape of the benchmark — with context
+    (1, 77 + 64, 1024): 13 TFLOP, about a minute of CPU oracle (memoised for the operand-mode children, where bf16x3 is held to
+    2e-4).  MUDG_SKIP_FULLSIZE_ORACLE=1 skips it.  The 16-frame forward below stays opt-in (four minutes)."""
+    import os
+    if os.environ.get("MUDG_SKIP_FULLSIZE_ORACLE") == "1":
+        pytest.skip("MUDG_SKIP_FULLSIZE_ORACLE=1")
+    _forward_vs_oracle(big[0], "1024", 27, frames=4)
 
 
 def test_mdm1024_unet_forward_matches_the_cpu_oracle_at_the_benchmark_size(big):

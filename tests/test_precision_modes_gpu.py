@@ -15,6 +15,12 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CUT = "tests/test_fullsize_gpu.py::test_config0_cut_one_ddim_step_and_4_frame_decode_at_mdm512_match_the_cpu_oracle"
 FWD512 = "tests/test_fullsize_gpu.py::test_mdm512_unet_forward_matches_the_cpu_oracle_at_full_size"
+FWD1024 = "tests/test_fullsize_gpu.py::test_mdm1024_4_frame_unet_forward_matches_the_cpu_oracle"
+# the MDM1024 property tests (clip independence, determinism, graph replay, guided steps per clip): BASELINE configs[4] is stated at
+# MDM1024, so its switch runs them too
+PROPS1024 = ["tests/test_fullsize_gpu.py::test_unet_clips_are_independent_and_runs_are_deterministic_at_mdm1024",
+             "tests/test_fullsize_gpu.py::test_hipgraph_replay_is_bit_identical_to_eager_at_mdm1024",
+             "tests/test_fullsize_gpu.py::test_guided_ddim_steps_are_clip_independent_at_mdm1024"]
 # mode -> (environment of the child, what it runs).  The full-size CPU-oracle results are memoised on disk by the default-mode
 # run of tests/test_fullsize_gpu.py (helpers.cached_oracle), so the children only pay for their own GPU work.
 MODES = {
@@ -26,14 +32,15 @@ MODES = {
     # bf16x3 is the mode that carries the contract: the full-size config-0 cut asserts the literal 1e-3 there
     "bf16x3": ({"MUDG_OPERAND": "bf16x3"},
                ["tests/test_operand_modes_gpu.py", "tests/test_unet_gpu.py", "tests/test_pipeline_gpu.py",
-                "tests/test_sampler_options_gpu.py", "tests/test_training_gpu.py", CUT, FWD512]),
+                "tests/test_sampler_options_gpu.py", "tests/test_training_gpu.py", CUT, FWD512, FWD1024]),
     "bf16x6": ({"MUDG_OPERAND": "bf16x6"},
                ["tests/test_operand_modes_gpu.py", "tests/test_unet_gpu.py", "tests/test_pipeline_gpu.py"]),
     # BASELINE.json configs[4]: MX-fp8 scores in the long self-attention (>= 512 tokens of head width 64: the full-size
-    # topology, not the small fixtures), END TO END: the full-size MDM512 UNet forward and the config-0 cut (guided DDIM step
-    # + decode) against the CPU oracle under the switch, next to the kernel-level test of the fp8 score path
+    # topology, not the small fixtures), END TO END: the full-size MDM512 UNet forward, the 4-frame MDM1024 forward and the config-0
+    # cut (guided DDIM step + decode) against the CPU oracle under the switch, the MDM1024 property tests, and the kernel-level
+    # test of the fp8 score path
     "bf16+fp8scores": ({"MUDG_OPERAND": "bf16", "MUDG_ATTN_FP8": "1"},
-                       [FWD512, CUT, "tests/test_operand_modes_gpu.py::test_mxfp8_quantiser_and_fp8_score_attention"]),
+                       [FWD512, FWD1024, CUT, *PROPS1024, "tests/test_operand_modes_gpu.py::test_mxfp8_quantiser_and_fp8_score_attention"]),
 }
 
 

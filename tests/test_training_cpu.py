@@ -40,28 +40,37 @@ def _worker_overlap(rank, world, port, q):
     unused = torch.nn.Parameter(torch.ones(7))                       # never reaches the loss: its bucket (the last one) completes only at the end
     params = [unused] + list(net.parameters())
     red = GradientAllReducer(params, bucket_mb=0.25, overlap=True)    # 65536 floats per bucket: several buckets
-    launched = []
+    launched, snap = [], {}
     orig = red._launch
-    red._launch = lambda i: (launched.append((i, red._next)), orig(i))[1]
+
+    def launch(i):                                                   # the bucket as this rank filled it, before the collective averages it in place
+        launched.append((i, red._next))
+        snap[i] = red.flats[i].clone()
+        return orig(i)
+    red._launch = launch
     x = torch.randn(16, 300, generator=torch.Generator().manual_seed(10 + rank))
     # micro-batch 1 of 2: local accumulation only
     red.sync = False
     net(x).square().mean().backward()
     local = [p.grad.clone() for p in net.parameters()]
     ok = red() == 0 and not launched
+    ok = ok and all(p.grad.data_ptr() == red._views[id(p)].data_ptr() for p in params)       # gradients live in the buckets
     # micro-batch 2 of 2: the hooks launch the collectives while backward is still running
     red.sync = True
     net(2 * x).square().mean().backward()
     under_backward = len(launched)
-    mine = [p.grad.clone() for p in net.parameters()]                # local sum of both micro-batches, before the averaging lands
     n = red()
     ok = ok and n == len(red.buckets) >= 3 and under_backward >= 1 and [i for i, _ in launched] == list(range(n))
-    # reference: gather every rank's local gradients and average
-    for p, g in zip(net.parameters(), mine):
-        both = [torch.zeros_like(g) for _ in range(world)]
-        dist.all_gather(both, g)
-        ok = ok and torch.allclose(p.grad, sum(both) / world, rtol=1e-6, atol=1e-7)
-    ok = ok and unused.grad is not None and float(unused.grad.abs().sum()) == 0.0 and all(not torch.equal(a, b) for a, b in zip(local, mine))
+    # reference: gather every rank's local bucket (both micro-batches accumulated) and average
+    for i in range(n):
+        both = [torch.zeros_like(snap[i]) for _ in range(world)]
+        dist.all_gather(both, snap[i])
+        ok = ok and torch.allclose(red.flats[i], sum(both) / world, rtol=1e-6, atol=1e-7)
+    ok = ok and unused.grad is not None and float(unused.grad.abs().sum()) == 0.0
+    ok = ok and all(not torch.equal(a, p.grad) for a, p in zip(local, net.parameters()))
+    # zero_grad keeps the views and clears them with one fill per bucket
+    red.zero_grad()
+    ok = ok and all(float(f.abs().sum()) == 0.0 for f in red.flats) and all(p.grad.data_ptr() == red._views[id(p)].data_ptr() for p in params)
     red.remove_hooks()
     q.put((rank, bool(ok), under_backward))
     dist.destroy_process_group()

@@ -9,14 +9,14 @@ cd /tmp && export TMPDIR=/tmp
 cd $REPO
 if [ "$2" = "proffix" ]; then SKIPBENCH=1; fi
 [ -z "$SKIPBENCH" ] && python bench.py > $OUT/bench_n1.raw 2> $OUT/bench_n1.err; tail -1 $OUT/bench_n1.raw > $OUT/bench_n1.json
-python bench.py --no-cpu-baseline --no-training --resolution 512 2>/dev/null | tail -1 > $OUT/bench_m512.json
-python bench.py --no-cpu-baseline --batch 3 --steps 4 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_b3.json
+python bench.py --no-cpu-baseline --no-children --resolution 512 2>/dev/null | tail -1 > $OUT/bench_m512.json
+python bench.py --no-cpu-baseline --no-children --batch 3 --steps 4 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_b3.json
 python bench.py --no-cpu-baseline --operand fp16 2>/dev/null | tail -1 > $OUT/bench_fp16.json
 # the cost of exactness: the split-operand precision modes (the ones that meet the 1e-3 decoded-frame tolerance)
 python bench.py --no-cpu-baseline --operand bf16x3 --steps 4 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_bf16x3.json
 python bench.py --no-cpu-baseline --operand bf16x6 --steps 3 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_bf16x6.json
 # BASELINE config 5: MX-fp8 scores in the long self-attention
-MUDG_ATTN_FP8=1 python bench.py --no-cpu-baseline --no-training 2>/dev/null | tail -1 > $OUT/bench_fp8attn.json
+MUDG_ATTN_FP8=1 python bench.py --no-cpu-baseline --no-children 2>/dev/null | tail -1 > $OUT/bench_fp8attn.json
 # the CPU baseline as a measurement: one full MDM512 oracle forward on this host
 if [ "$2" = "cpufull" ]; then
   python bench.py --steps 3 --warmup 1 --cpu-baseline full --no-decode 2>/dev/null | tail -1 | python -c "
@@ -24,19 +24,21 @@ import json, sys
 d = json.loads(sys.stdin.read())['cpu_baseline']
 json.dump({'tflops': d['tflops'], 'cores': d['cores'], 'seconds': d['seconds'], 'sample': d['sample']}, open('$OUT/cpu_baseline_full.json', 'w'), indent=1)"
 fi
-rocprofv3 --kernel-trace --stats -d /tmp/pt -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-at-tolerance --no-training > /tmp/pt.log 2>&1
+rocprofv3 --kernel-trace --stats -d /tmp/pt -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-children > /tmp/pt.log 2>&1
 python tools/rocprof_summary.py trace $(find /tmp/pt -name "*.db" | head -1) > $OUT/kernel_trace.md
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pf -- python bench.py --steps 1 --warmup 0 --no-graph --no-cpu-baseline --no-profile --no-decode --no-at-tolerance --no-training > /tmp/pf.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pf -- python bench.py --steps 1 --warmup 0 --no-graph --no-cpu-baseline --no-profile --no-decode --no-children > /tmp/pf.log 2>&1
 python tools/rocprof_summary.py pmc $(find /tmp/pf -name "*.db" | head -1) > $OUT/pmc_fetch.md
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pw -- python bench.py --steps 1 --warmup 0 --no-graph --no-cpu-baseline --no-profile --no-decode --no-at-tolerance --no-training > /tmp/pw.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pw -- python bench.py --steps 1 --warmup 0 --no-graph --no-cpu-baseline --no-profile --no-decode --no-children > /tmp/pw.log 2>&1
 python tools/rocprof_summary.py pmc $(find /tmp/pw -name "*.db" | head -1) > $OUT/pmc_write.md
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d /tmp/pm -- python bench.py --steps 1 --warmup 0 --no-graph --no-cpu-baseline --no-profile --no-decode --no-at-tolerance --no-training > /tmp/pm.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d /tmp/pm -- python bench.py --steps 1 --warmup 0 --no-graph --no-cpu-baseline --no-profile --no-decode --no-children > /tmp/pm.log 2>&1
 python tools/rocprof_summary.py mfma $(find /tmp/pm -name "*.db" | head -1) > $OUT/pmc_mfma.md
 # the training step of the full UNet: seconds per step, peak memory
 timeout 900 python tools/train_bench.py 512 3 2>/dev/null | tail -1 > $OUT/train_bench.log
 timeout 900 python tools/train_bench.py 1024 2 2>/dev/null | tail -1 >> $OUT/train_bench.log
 timeout 900 python tools/train_bench.py 1024 2 ckpt 2>/dev/null | tail -1 >> $OUT/train_bench.log
 timeout 900 python tools/train_bench.py 1024 2 stage2 2>/dev/null | tail -1 >> $OUT/train_bench.log
+# the reference's training batch: 4 clips per GPU, activation checkpointing, two micro-batches per optimiser step
+timeout 1500 python tools/train_bench.py 1024 1 ckpt b4 acc2 2>/dev/null | tail -1 >> $OUT/train_bench.log
 rocprofv3 --kernel-trace --stats -d /tmp/ptr -- python tools/train_bench.py 1024 2 > /tmp/ptr.log 2>&1
 python tools/rocprof_summary.py trace $(find /tmp/ptr -name "*.db" | head -1) > $OUT/train1024_kernel_trace.md
 rm -f $OUT/bench_n1.raw
