@@ -258,14 +258,20 @@ extern "C" int mudg_wgrad(const MudgWgradDesc* dp, void* stream) {
     if (d.mode == 2) MUDG_REQUIRE(d.taps == 3 && d.T > 0 && d.HW > 0 && d.P % ((int64_t)d.T * d.HW) == 0, "mudg_wgrad: temporal geometry");
     MUDG_REQUIRE(d.slices >= 1 && d.slices <= 65535 && d.chunk > 0 && d.chunk % WK == 0 && (int64_t)d.slices * d.chunk >= d.P, "mudg_wgrad: slices=%d chunk=%lld",
                  d.slices, (long long)d.chunk);
-    MUDG_REQUIRE((d.chunk + WK) * d.lda * 2 < (1ll << 31) && d.ldb * 2 * (d.mode == 1 ? (d.P / ((int64_t)d.Hout * d.Wout)) * d.Hin * d.Win : d.P) < (1ll << 31),
-                 "mudg_wgrad: an operand exceeds the 2 GiB window of its buffer descriptor");
     const int ntm = (d.M + WT - 1) / WT, ntn = (d.taps * d.C + WT - 1) / WT;
     int gm = 3;
     if (d.mode == 0) gm = 0;
     else if (d.mode == 1 && d.stride == 1 && d.pad == 1 && d.Hin == d.Hout && d.Win == d.Wout && ((int64_t)d.Hout * d.Wout) % WK == 0 &&
              (d.Wout % WK == 0 || WK % d.Wout == 0)) gm = 1;
     else if (d.mode == 2 && d.HW % WK == 0) gm = 2;
+    // 32-bit offsets from the descriptors' bases: A and (geometries 0-2) B are based at the slice's first row — B moved back by the
+    // most negative tap shift — so a slice must fit the window; the generic geometry addresses B from the operand's start.
+    {
+        const int64_t back = gm == 1 ? d.Wout + 1 : (gm == 2 ? d.HW : 0);
+        const int64_t brows = gm == 3 ? (d.mode == 1 ? (d.P / ((int64_t)d.Hout * d.Wout)) * d.Hin * d.Win : d.P) : d.chunk + WK + 2 * back;
+        MUDG_REQUIRE((d.chunk + WK) * d.lda * 2 < (1ll << 31) && brows * d.ldb * 2 < (1ll << 31),
+                     "mudg_wgrad: a slice exceeds the 2 GiB window of its buffer descriptor (more slices, or smaller operands)");
+    }
     const dim3 grid((unsigned)(ntm * ntn), (unsigned)d.slices);
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     if (gm == 0) hipLaunchKernelGGL(wgrad_kernel<0>, grid, dim3(256), 0, s, d, ntn);

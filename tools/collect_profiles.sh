@@ -17,6 +17,9 @@ python bench.py --no-cpu-baseline --operand bf16x3 --steps 4 --warmup 1 2>/dev/n
 python bench.py --no-cpu-baseline --operand bf16x6 --steps 3 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_bf16x6.json
 # BASELINE config 5: MX-fp8 scores in the long self-attention
 MUDG_ATTN_FP8=1 python bench.py --no-cpu-baseline --no-children 2>/dev/null | tail -1 > $OUT/bench_fp8attn.json
+# same box, same library (the debug-variants build): the one-tile contraction kernels only vs the shipped selection rule
+MUDG_DEBUG_VARIANTS=1 MUDG_GEMM_PERSIST=0 python bench.py --no-cpu-baseline --no-children --steps 10 --warmup 3 2>/dev/null | tail -1 > $OUT/bench_onetile_kernels.json
+MUDG_DEBUG_VARIANTS=1 MUDG_GEMM_PERSIST=1 python bench.py --no-cpu-baseline --no-children --steps 10 --warmup 3 2>/dev/null | tail -1 > $OUT/bench_persistent_rule.json
 # the CPU baseline as a measurement: one full MDM512 oracle forward on this host
 if [ "$2" = "cpufull" ]; then
   python bench.py --steps 3 --warmup 1 --cpu-baseline full --no-decode 2>/dev/null | tail -1 | python -c "

@@ -14,7 +14,7 @@ def table(path, counter):
     out = {}
     for line in open(path):
         # kernel names: gemm_kernel<Geo<4, 2>, MODE, FAST, SB> (round 3 on; the tile geometry comes first) or gemm_kernel<MODE, ...>
-        m = re.match(r"\| `(gemm\w*_kernel)<(?:\(anonymous namespace\)::)?(?:Geo<\d+, \d+>, )?(\d)[^`]*` \| " + counter + r" \| (\d+) \| ([0-9.e+]+) \|", line)
+        m = re.match(r"\| `(p?gemm\w*_kernel)<(?:\(anonymous namespace\)::)?(?:Geo<\d+, \d+>, )?(\d)[^`]*` \| " + counter + r" \| (\d+) \| ([0-9.e+]+) \|", line)
         if m:
             fam = FAM[m.group(2)]
             e = out.setdefault(fam, {"kernels": [], "launches": 0, "kib": 0.0})

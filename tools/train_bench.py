@@ -53,7 +53,7 @@ for i in range(steps + 1):
     loss, norm = one_step()
     torch.cuda.synchronize()
     times.append(time.perf_counter() - t0)
-    losses.append(float(loss))
+    losses.append(float(loss.detach()))
     print(f"step {i}: loss {losses[-1]:.5f}  {times[-1]:.2f} s" + (f"  grad norm {float(norm[0]):.3f}" if norm is not None else ""), flush=True)
 from mudg_amd import hip
 hip.prof_reset(); hip.prof_enable((1 << len(hip.FAM_NAMES)) - 1)
