@@ -1,7 +1,8 @@
 """Every contraction-kernel variant through the same kernel parity tests, in child processes on the debug-variants build
 (libmudg_hip_dbg.so, MUDG_DEBUG_VARIANTS=1: the only library that reads the MUDG_<switch> variables, once per process):
 the generic 64-bit-address path of all kernels with the buffer-descriptor (FAST) path disabled, the single-buffer
-short-K kernel forced on / off for every FAST problem, the phase-scheduled large-tile kernel forced on / off, both
+short-K kernel forced on / off for every FAST problem, the phase-scheduled large-tile kernel forced on / off, the persistent kernel
+off / forced at 4, 3 and 2 workgroups per CU for every problem it accepts (its residual-seed / GroupNorm-partial variants included), both
 flash-attention kernels (32 / 64 queries per wave) forced."""
 import os
 import subprocess
@@ -11,7 +12,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SELECT = "gemm or conv or tconv or resblock or transformer or geglu or fused or attention or attn or wide"
+SELECT = "gemm or conv or tconv or resblock or transformer or geglu or fused or attention or attn or wide or persistent"
 
 
 @pytest.mark.parametrize("env", [
@@ -20,6 +21,10 @@ SELECT = "gemm or conv or tconv or resblock or transformer or geglu or fused or 
     {"MUDG_GEMM_SB": "0"},
     {"MUDG_GEMM_WIDE": "1"},
     {"MUDG_GEMM_WIDE": "0"},
+    {"MUDG_GEMM_PERSIST": "0"},
+    {"MUDG_GEMM_PERSIST": "4"},
+    {"MUDG_GEMM_PERSIST": "3"},
+    {"MUDG_GEMM_PERSIST": "2"},
     {"MUDG_ATTN_Q": "32"},
     {"MUDG_ATTN_Q": "64"},
 ], ids=lambda e: ",".join(f"{k[5:]}={v}" for k, v in e.items()))

@@ -634,3 +634,61 @@ def test_wide_tile_is_selected_for_many_tile_problems_and_matches_the_small_tile
     parts = torch.cat([ops.gemm(xd[i * q:(i + 1) * q], wd, bias=bd) for i in range(4)], 0)
     assert torch.equal(whole, parts)
     assert rel_l2(whole[::97], x[::97].float() @ w.float().t() + b) < TOL_BF16
+
+
+# ---- the persistent kernel (pgemm.hip): every GEGLU problem and plain GEMMs with N, K >= 1280 under the library's rule; the
+# variant children GEMM_PERSIST=4 / 3 / 2 / 0 (tests/test_gemm_variants_gpu.py) force it on (or off for) every FAST problem of
+# this file.  These tests reach it through the rule, with more tiles than persistent workgroups (each walks several tiles).
+def test_persistent_geglu_walks_many_tiles_and_rows_do_not_depend_on_the_batch(cuda):
+    from mudg_amd import ops
+    M, C = 20000 + 40, 320                                # 157 row tiles (the last ragged) x 20 column tiles = 3140 tiles > 1024 workgroups
+    x, w = rnd(M, C, seed=1), rnd(8 * C, C, seed=2, scale=0.06)
+    b = torch.randn(8 * C, generator=torch.Generator().manual_seed(3)) * 0.1
+    val, gate = (x.float() @ w.float().t() + b).chunk(2, dim=-1)
+    wp, bp = pack_geglu(w, b)
+    xd, wd, bd = x.to(cuda), wp.to(cuda), bp.to(cuda)
+    y = ops.gemm(xd, wd, bias=bd, geglu=True)
+    assert tuple(y.shape) == (M, 4 * C) and rel_l2(y, val * F.gelu(gate)) < TOL_BF16
+    part = ops.gemm(xd[:4096 + 128], wd, bias=bd, geglu=True)          # fewer tiles: another walk, the same arithmetic per tile
+    assert torch.equal(part, y[:4096 + 128])
+    again = ops.gemm(xd, wd, bias=bd, geglu=True)
+    assert torch.equal(again, y)
+
+
+@pytest.mark.parametrize("kind", ["operand", "stream", "f32"])
+def test_persistent_plain_gemm_with_residual_seed_and_groupnorm_partials(cuda, kind):
+    """N, K >= 1280: the persistent kernel under the library's rule.  The residual seeds the accumulators (every storage kind
+    of it), the epilogue writes GroupNorm partials of what it stored, and a clip's rows do not depend on what else is in M."""
+    from mudg_amd import ops
+    M, N, K = 128 * 150 + 72, 1280, 1280                   # 151 x 10 = 1510 tiles on 768 (3 per CU) workgroups, ragged last row tile
+    x, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.03)
+    b = torch.randn(N, generator=torch.Generator().manual_seed(3)) * 0.1
+    r = torch.randn(M, N, generator=torch.Generator().manual_seed(4))
+    res = {"operand": r.to(BF), "stream": r.to(ops.STREAM()), "f32": r}[kind]
+    ref = x.float() @ w.float().t() + b + res.float()
+    kw = dict(out_stream=kind == "stream", out_fp32=kind == "f32")
+    y = ops.gemm(x.to(cuda), w.to(cuda), bias=b.to(cuda), residual=res.to(cuda), stats=True, **kw)
+    assert rel_l2(y, ref) < (TOL_F32 if kind == "f32" else TOL_BF16)
+    stats = getattr(y, ops.GN_ATTR)                        # [ceil(M / 128)][N][2]: sum and sum of squares of the stored values
+    assert tuple(stats.shape) == ((M + 127) // 128, N, 2)
+    yf = torch.nn.functional.pad(y.float().cpu(), (0, 0, 0, (-M) % 128)).reshape(-1, 128, N)
+    assert rel_l2(stats[..., 0], yf.sum(1)) < 1e-5 and rel_l2(stats[..., 1], (yf * yf).sum(1)) < 1e-5
+    sub = 128 * 37
+    part = ops.gemm(x[:sub].to(cuda), w.to(cuda), bias=b.to(cuda), residual=res[:sub].to(cuda), stats=True, **kw)
+    assert torch.equal(part, y[:sub]) and torch.equal(getattr(part, ops.GN_ATTR), stats[:37])
+
+
+def test_persistent_rule_takes_ragged_widths_and_scaled_residuals_elsewhere(cuda):
+    """What the persistent kernel does not take (a width that is not a multiple of 8, alpha != 1 with a residual, the plain GELU)
+    still runs — on the one-tile kernels — and stays correct at N, K >= 1280."""
+    from mudg_amd import ops
+    M, N, K = 1024, 1284, 1280
+    x, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.03)
+    r = torch.randn(M, N, generator=torch.Generator().manual_seed(4))
+    y = ops.gemm(x.to(cuda), w.to(cuda), residual=r.to(cuda), out_fp32=True)
+    assert rel_l2(y, x.float() @ w.float().t() + r) < TOL_F32
+    w8 = w[:1280].contiguous()
+    y2 = ops.gemm(x.to(cuda), w8.to(cuda), residual=r[:, :1280].contiguous().to(cuda), out_fp32=True, alpha=0.5)
+    assert rel_l2(y2, 0.5 * (x.float() @ w8.float().t()) + r[:, :1280]) < TOL_F32
+    y3 = ops.gemm(x.to(cuda), w8.to(cuda), gelu=True, out_fp32=True)
+    assert rel_l2(y3, F.gelu(x.float() @ w8.float().t())) < 1e-4
