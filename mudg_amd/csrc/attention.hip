@@ -1065,6 +1065,231 @@ __global__ __launch_bounds__(256, PLANES == 2 ? 2 : 1) void attn_split_kernel(co
     }
 }
 
+#if MUDG_PLANES == 2
+// The long self-attention of the bf16x3 build on the staging of attn64d_kernel (round 4; attn_split_kernel above was the
+// round-1 register-staged design: global loads -> registers -> ds_write -> 48 eight-byte V reads per key tile, 38 % MFMA-busy):
+//  * K and V^T tiles of BOTH pieces go HBM/L2 -> LDS by LDS-DMA (no register round trip, no ds_write pass), unpadded [64][64]
+//    tiles with the source-side XOR swizzle, K rows permuted at the source by the involution that swaps the middle 4-blocks of
+//    every 16, so that a P V fragment is one natural 16-byte chunk of V^T (see attn64d_kernel);
+//  * every fragment of piece 0 is read once and feeds two of the three kept products (k0 q1 + k0 q0, v0 p1 + v0 p0);
+//  * the lean softmax (q prescaled: the reference maximum of the first key tile is the score accumulators' initial value, one
+//    v_exp + one add + the split per score, no rescale of O), with the classic online softmax as the overflow fallback;
+//  * 32 queries per wave (q pieces 32 + scores 32 + P pieces 32 + O 32 registers): the 64-query form of the 16-bit kernel
+//    would need 256 registers for those alone.
+// Same arithmetic as attn_split_kernel per (query, key tile): x1 w0 + x0 w1 + x0 w0 for both contractions, fp32 softmax.
+constexpr int SDT = 64 * 64;             // h16 per unpadded tile
+constexpr int SPLIT_DMA_SMEM = 2 * 2 * 2 * SDT * (int)sizeof(h16);        // [buffer][K | V][piece] = 64 KiB
+template <bool LEAN>
+__global__ __launch_bounds__(256, 2) void attn_split_dma_kernel(const MudgAttnDesc p, const int nqt, const int total) {
+    extern __shared__ __attribute__((aligned(1024))) char smem_dma[];
+    h16* Ks = reinterpret_cast<h16*>(smem_dma);                   // [2 buffers][2 pieces][SDT]
+    h16* Vs = Ks + 4 * SDT;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    int w;
+    {
+        const int q8 = total >> 3, r8 = total & 7;
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        w = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    }
+    const int pair = w / nqt, qt = w - pair * nqt;
+    const int f = pair / p.heads, h = pair - f * p.heads;
+    const int kvb = f / p.kv_div;
+    const int psq = p.ldq / 2, psk = p.ldk / 2, psv = p.ldvt / 2, pso = p.ldo / 2;
+
+    const h16* Qp = reinterpret_cast<const h16*>(p.Q) + (int64_t)f * p.Nq * p.ldq + h * 64;
+    const h16* Kp = reinterpret_cast<const h16*>(p.K) + (int64_t)kvb * p.Nk * p.ldk + h * 64;
+    const h16* Vp = reinterpret_cast<const h16*>(p.Vt) + (int64_t)kvb * p.svt + (int64_t)(h * 64) * p.ldvt;
+    h16* Op = reinterpret_cast<h16*>(p.O) + (int64_t)f * p.Nq * p.ldo + h * 64;
+
+    const int q = qt * QB + wave * 32 + l31;
+    const bool qok = q < p.Nq;
+    h16x8 qf[2][4];
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            qf[pl][ks] = as_h16x8(qok ? ld16(Qp + (int64_t)q * p.ldq + pl * psq + ks * 16 + hi * 8) : zero16());
+
+    // DMA geometry: wave w stages rows [16w, 16w + 16) of the four tiles, two 1-KiB instructions each
+    const __amdgpu_buffer_rsrc_t rK = attn_rsrc(Kp), rV = attn_rsrc(Vp);
+    unsigned vk[2], vv[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = 16 * wave + 8 * i + (lane >> 3), slot = lane & 7;
+        const int chunk = slot ^ ((row >> 1) & 7);
+        const int i16 = row & 15;
+        const int key = (row & ~15) | (i16 & 3) | ((i16 & 8) >> 1) | ((i16 & 4) << 1);     // swap the middle 4-blocks
+        vk[i] = (unsigned)key * (unsigned)p.ldk * 2u + (unsigned)chunk * 16u;
+        vv[i] = (unsigned)row * (unsigned)p.ldvt * 2u + (unsigned)chunk * 16u;
+    }
+    auto request = [&](int kt, int buf) {
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rK, (attn_lptr_t)(Ks + (buf * 2 + pl) * SDT + (16 * wave + 8 * i) * 64), 16, (int)vk[i],
+                                                         (kt * 64 * p.ldk + pl * psk) * 2, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rV, (attn_lptr_t)(Vs + (buf * 2 + pl) * SDT + (16 * wave + 8 * i) * 64), 16, (int)vv[i],
+                                                         (kt * 64 + pl * psv) * 2, 0, 0);
+            }
+    };
+    const int sw = (l31 >> 1) & 7;
+    // scores of 32 keys (sub-tile `sub` of K tile `buf`) x this wave's 32 queries: k1 q0 + k0 q1 + k0 q0, small terms first
+    auto score_block = [&](int buf, int sub, f32x16& sc) {
+        const h16* k0 = Ks + (buf * 2) * SDT + (sub * 32 + l31) * 64;
+        const h16* k1 = k0 + SDT;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int off = ((ks * 2 + hi) ^ sw) << 3;
+            const h16x8 f1 = *reinterpret_cast<const h16x8*>(k1 + off), f0 = *reinterpret_cast<const h16x8*>(k0 + off);
+            sc = MFMA_32x32x16(f1, qf[0][ks], sc);
+            sc = MFMA_32x32x16(f0, qf[1][ks], sc);
+            sc = MFMA_32x32x16(f0, qf[0][ks], sc);
+        }
+    };
+
+    f32x16 o[2];
+    float m_run, l_run;
+    const float c = p.q_prescaled ? 1.0f : p.scale * 1.4426950408889634f;
+    const int nkt = p.Nk / KB;
+    bool overflow = false;
+
+    auto key_loop = [&](auto lean_tag) {
+        constexpr bool LN = decltype(lean_tag)::value;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
+        m_run = LN ? 0.f : -INFINITY;
+        l_run = 0.f;
+        request(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if constexpr (LN) {      // reference maximum = the first tile's row maximum (one extra set of score MFMAs)
+            f32x16 s0[2];
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s0[sub][r] = 0.f;
+                score_block(0, sub, s0[sub]);
+            }
+            float mx = s0[0][0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s0[0][r]);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s0[1][r]);
+            m_run = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        }
+        for (int kt = 0; kt < nkt; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < nkt) request(kt + 1, cur ^ 1);
+            f32x16 sc[2];
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+                const float init = LN ? -m_run : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sc[sub][r] = init;
+                score_block(cur, sub, sc[sub]);
+            }
+            h16x8 pk[2][2][2];        // [piece][sub][jj]
+            float ps = 0.f;
+            if constexpr (LN) {
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float e = __builtin_amdgcn_exp2f(sc[sub][r]);
+                        ps += e;
+                        const h16 p0 = (h16)e;
+                        pk[0][sub][r >> 3][r & 7] = p0;
+                        pk[1][sub][r >> 3][r & 7] = (h16)(e - (float)p0);
+                    }
+                l_run += ps;
+                overflow = overflow || !(ps <= LEAN_LIMIT);
+            } else {
+                float mx = sc[0][0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sc[0][r]);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[1][r]);
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                const bool grew = !__all(mx <= m_run);
+                const float m_new = grew ? fmaxf(m_run, mx) : m_run;
+                const float alpha = grew ? __builtin_amdgcn_exp2f((m_run - m_new) * c) : 1.0f;
+                const float mc = m_new * c;
+                m_run = m_new;
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float e = __builtin_amdgcn_exp2f(fmaf(sc[sub][r], c, -mc));
+                        ps += e;
+                        const h16 p0 = (h16)e;
+                        pk[0][sub][r >> 3][r & 7] = p0;
+                        pk[1][sub][r >> 3][r & 7] = (h16)(e - (float)p0);
+                    }
+                l_run = l_run * alpha + ps;
+                if (grew) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+                }
+            }
+            // P V: v1 p0 + v0 p1 + v0 p0; register group (sub, jj) of half hi holds keys 32 sub + 16 jj + 8 hi .. + 7
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const h16* v0 = Vs + (cur * 2) * SDT + (dt * 32 + l31) * 64;
+                const h16* v1 = v0 + SDT;
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        const int off = ((4 * sub + 2 * jj + hi) ^ sw) << 3;
+                        const h16x8 f1 = *reinterpret_cast<const h16x8*>(v1 + off), f0 = *reinterpret_cast<const h16x8*>(v0 + off);
+                        o[dt] = MFMA_32x32x16(f1, pk[0][sub][jj], o[dt]);
+                        o[dt] = MFMA_32x32x16(f0, pk[1][sub][jj], o[dt]);
+                        o[dt] = MFMA_32x32x16(f0, pk[0][sub][jj], o[dt]);
+                    }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of tile kt + 1
+            __syncthreads();                                      // every wave's; everyone is done reading tile kt
+        }
+    };
+
+    if constexpr (LEAN) {
+        key_loop(std::true_type{});
+        if (__syncthreads_or(overflow ? 1 : 0)) key_loop(std::false_type{});      // cold: exact, merely slower
+    } else {
+        key_loop(std::false_type{});
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.f / l_tot;
+    if (qok) {
+        h16* orow = Op + (int64_t)q * p.ldo;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                h16* dst = orow + dt * 32 + 8 * g + 4 * hi;
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = o[dt][4 * g + j] * inv;
+                if (p.accumulate) {
+                    Pack8 a, b; a.u = *reinterpret_cast<const u32x2*>(dst); b.u = *reinterpret_cast<const u32x2*>(dst + pso);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] += (float)a.h[j] + (float)b.h[j];
+                }
+                Pack8 n0, n1;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { n0.h[j] = (h16)v[j]; n1.h[j] = (h16)(v[j] - (float)n0.h[j]); }
+                *reinterpret_cast<u32x2*>(dst) = n0.u;
+                *reinterpret_cast<u32x2*>(dst + pso) = n1.u;
+            }
+    }
+}
+#endif
+
 // Temporal attention of the split builds: q / k / v pieces are summed to fp32 on load and the T x T problem runs on
 // fp32 FMAs (this kernel is bandwidth-bound in every build).  One wave per (pixel, head), K / V of the item in LDS.
 template <int TP>
@@ -1186,8 +1411,25 @@ extern "C" int mudg_attention(const MudgAttnDesc* dp, void* stream) {
             if (e != hipSuccess) MUDG_FAIL(MUDG_ELAUNCH, "mudg_attention: hipFuncSetAttribute: %s", hipGetErrorString(e));
             attr_done[dev] = true;
         }
+        bool dma_ok = false;
+#if MUDG_PLANES == 2
+        // the long self-attention on LDS-DMA staged tiles (whole key tiles inside the 2-GiB window of a buffer descriptor)
+        dma_ok = wide && d.Nk % 64 == 0 && (int64_t)d.Nk * d.ldk * 2 < (1ll << 31) && (int64_t)64 * d.ldvt * 2 + (int64_t)d.Nk * 2 + d.ldvt < (1ll << 31);
+        if (dma_ok) {
+            static bool attr2[64] = {};
+            if (!attr2[dev]) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_split_dma_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, SPLIT_DMA_SMEM);
+                if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_split_dma_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, SPLIT_DMA_SMEM);
+                if (e != hipSuccess) MUDG_FAIL(MUDG_ELAUNCH, "mudg_attention: hipFuncSetAttribute: %s", hipGetErrorString(e));
+                attr2[dev] = true;
+            }
+            if (d.q_prescaled) hipLaunchKernelGGL(attn_split_dma_kernel<true>, dim3((unsigned)total), dim3(256), SPLIT_DMA_SMEM, s, d, nqt, (int)total);
+            else hipLaunchKernelGGL(attn_split_dma_kernel<false>, dim3((unsigned)total), dim3(256), SPLIT_DMA_SMEM, s, d, nqt, (int)total);
+        }
+#endif
         (void)wide;
-        if (d.K2) hipLaunchKernelGGL(attn_split_kernel<true>, dim3((unsigned)total), dim3(256), smem, s, d, nqt, (int)total);
+        if (dma_ok) {}
+        else if (d.K2) hipLaunchKernelGGL(attn_split_kernel<true>, dim3((unsigned)total), dim3(256), smem, s, d, nqt, (int)total);
         else hipLaunchKernelGGL(attn_split_kernel<false>, dim3((unsigned)total), dim3(256), smem, s, d, nqt, (int)total);
     }
 #else

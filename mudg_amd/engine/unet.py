@@ -159,9 +159,10 @@ def spatial_block(blk, hcur, frames, hw, ctx, last):
     c, heads = hcur.shape[1], a1.heads
     # self-attention over the hw tokens of each frame
     n1 = _ln(blk.norm1, hcur)
-    lean = _LEAN_ATTENTION and ops.hip.planes() == 1     # 16-bit builds: scale * log2(e) rides in the packed q weights
+    # 16-bit builds and bf16x3: scale * log2(e) rides in the packed q weights (folded in fp32 before the one cast / split)
+    lean = _LEAN_ATTENTION and ops.hip.planes() <= 2
     wqk = pk.qk_prescaled(a1, a1.to_q, a1.to_k, a1.scale) if lean else pk.linear_cat(a1, "qk", (a1.to_q, a1.to_k))
-    use_fp8 = lean and _FP8_ATTENTION and hw >= 512 and hw % 64 == 0      # BASELINE config 5: Q K^T on the MX-fp8 MFMA
+    use_fp8 = lean and ops.hip.planes() == 1 and _FP8_ATTENTION and hw >= 512 and hw % 64 == 0      # BASELINE config 5: Q K^T on the MX-fp8 MFMA
     fp8 = None
     if use_fp8:         # the projection's own epilogue writes the MX-fp8 copy of q | k (no separate quantisation passes)
         qk, q8, s8 = ops.gemm(n1, wqk, fp8=True)
