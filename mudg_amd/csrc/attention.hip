@@ -856,6 +856,125 @@ __global__ __launch_bounds__(256, TP == 16 ? 3 : 1) void tattn_kernel(const h16*
 }
 
 
+#if MUDG_PLANES == 1
+// The same problem on the matrix cores (T <= 16).  The VALU kernel above spends ~800 instructions per (pixel, head) item — at the
+// UNet's level 0 that is ~120 us of pure VALU time for a pass whose 755 MB take ~135 us at the rate the norms reach — so it was
+// compute-bound on the wrong unit.  Here an item is 2 + 4 MFMAs:
+//   S^T = K Q^T   two v_mfma_f32_16x16x32: lane (c = l % 16, g = l / 16) feeds row c of K as A and row c of Q as B, dims 8g + 32s ..
+//                 + 7 — exactly one 16-byte global load each, no staging; the result lands as S^T[tk = 4g + i][tq = c], i = 0..3,
+//                 so the softmax over tk is 4 in-lane values and two cross-lane steps (xor 16, xor 32);
+//   O^T = V^T P^T four v_mfma_f32_16x16x16 (k = tk): P^T is already the B fragment (lane (c, g) holds tk = 4g + i of column tq = c);
+//                 V^T[d][tk = 4g + j] is the one transposed read — V goes through a per-wave 2-KiB LDS tile (8-byte writes, 2-byte
+//                 reads, the 8-byte units of a row XOR-swizzled by row / 4 so the 64 lanes of a read meet 32 distinct banks).  Row
+//                 r of output block m stands for dim 32 (m / 2) + 8 (r / 4) + 4 (m % 2) + r % 4, so lane (c, g) ends up with dims
+//                 8g .. 8g + 7 and 32 + 8g .. 32 + 8g + 7 of query c: two 16-byte stores, each instruction 64 contiguous bytes per row.
+// P is rounded to the operand type before the second contraction, as in the flash kernels.
+#ifdef MUDG_OPERAND_FP16
+typedef __attribute__((ext_vector_type(4))) _Float16 mf4;
+#define MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
+#define MFMA_16x16x16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0)
+#else
+typedef __attribute__((ext_vector_type(4))) short mf4;
+#define MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+#define MFMA_16x16x16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0)
+#endif
+
+__global__ __launch_bounds__(256) void tattn_mfma_kernel(const h16* __restrict__ QKV, h16* __restrict__ O,
+                                                          int B, int T, int HW, int heads, int ldqkv, int ldo,
+                                                          float scale, int total) {
+    __shared__ __attribute__((aligned(16))) h16 Vs[4][16 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int C = heads * 64;
+    const int w0 = (blockIdx.x * 4 + wave) * TATTN_ITEMS;
+    char* vs = reinterpret_cast<char*>(&Vs[wave][0]);
+
+    auto fz = [](int rg) { return (rg & 1) | ((rg >> 1) << 3); };     // the swizzle of row group rg: bits 0 and 3 of the unit index
+    u32x4 qn[2], kn[2], vn[2];                       // the item being fetched
+    int64_t rown = 0; int hn = 0; bool okn = false;
+    auto fetch = [&](int w) {
+        okn = w < total && c < T;
+        const int bp = w < total ? w / heads : 0;
+        hn = w < total ? w - bp * heads : 0;
+        const int b = bp / HW, px = bp - b * HW;
+        rown = ((int64_t)(b * T + (c < T ? c : 0)) * HW + px);
+        const h16* src = QKV + rown * ldqkv + hn * 64 + g * 8;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            qn[s] = okn ? ld16(src + s * 32) : zero16();
+            kn[s] = okn ? ld16(src + C + s * 32) : zero16();
+            vn[s] = okn ? ld16(src + 2 * C + s * 32) : zero16();
+        }
+    };
+    fetch(w0);
+
+    for (int it = 0; it < TATTN_ITEMS; ++it) {
+        if (w0 + it >= total) break;                 // wave-uniform
+        const int64_t row = rown; const int h = hn; const bool rok = okn;
+        f32x4 st = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 2; ++s) st = MFMA_16x16x32(as_h16x8(kn[s]), as_h16x8(qn[s]), st);
+        __builtin_amdgcn_wave_barrier();             // the previous item's LDS reads are issued before these writes
+        // V row c, dims 8g + 32s .. + 7 = the 8-byte units 2g + 8s, 2g + 8s + 1; unit u of row r sits at unit u ^ fz(r / 4)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int u0 = 2 * g + 8 * s, z = fz(c >> 2);
+            u32x2 lo = {vn[s][0], vn[s][1]}, hi = {vn[s][2], vn[s][3]};
+            *reinterpret_cast<u32x2*>(vs + c * 128 + ((u0 ^ z) << 3)) = lo;
+            *reinterpret_cast<u32x2*>(vs + c * 128 + (((u0 + 1) ^ z) << 3)) = hi;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (it + 1 < TATTN_ITEMS) fetch(w0 + it + 1);
+
+        // softmax over tk = 4g + i: in-lane over i, then across the four lane groups
+        float sc[4];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { sc[i] = (4 * g + i < T) ? st[i] * scale : -INFINITY; mx = fmaxf(mx, sc[i]); }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+        union { mf4 m; h16 e[4]; } pt;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const h16 ph = (h16)__expf(sc[i] - mx);
+            pt.e[i] = ph;
+            sum += (float)ph;                        // the denominator of the probabilities the contraction really uses
+        }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.f / sum;
+
+        float ov[16];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            union { mf4 m4; unsigned short e[4]; } vt;
+            // row c of block m stands for dim 32 (m / 2) + 8 (c / 4) + 4 (m % 2) + c % 4 = unit 8 (m / 2) + 2 (c / 4) + m % 2, element c % 4
+            const int u = (8 * (m >> 1) + 2 * (c >> 2) + (m & 1)) ^ fz(g);    // row 4g + j has r / 4 = g
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                vt.e[j] = *reinterpret_cast<const unsigned short*>(vs + (4 * g + j) * 128 + (u << 3) + 2 * (c & 3));
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            acc = MFMA_16x16x16(vt.m4, pt.m, acc);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ov[4 * m + i] = acc[i] * inv;
+        }
+        if (rok) {
+            // ov[4m + i] is dim 32 (m / 2) + 8g + 4 (m % 2) + i: blocks 0, 1 are dims 8g .. 8g + 7, blocks 2, 3 the same + 32 — a store
+            // instruction covers 64 contiguous bytes per query row
+            h16* dst = O + row * ldo + h * 64 + g * 8;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                h16x8 t;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) t[e] = (h16)ov[half * 8 + e];
+                st16(dst + half * 32, as_u32x4(t));
+            }
+        }
+    }
+}
+#endif
+
 #if MUDG_PLANES > 1
 // ------------------------------------------------------------------------------------------------ split-operand builds
 // attn_kernel with every operand carried as PLANES bf16 pieces (common.h): Q / K / V^T pieces come from planes of the
@@ -1542,7 +1661,12 @@ extern "C" int mudg_temporal_attention(const void* QKV, void* O, int B, int T, i
                            ldqkv, ldo, scale, (int)total);
 #else
     const unsigned grid = (unsigned)((total + 4 * TATTN_ITEMS - 1) / (4 * TATTN_ITEMS));
-    if (T <= 16)
+    static int use_mfma = -1;               // MUDG_TATTN_MFMA=0: the VALU kernel for every length (A/B, tests)
+    if (use_mfma < 0) use_mfma = mudg_variant("TATTN_MFMA", 1);
+    if (T <= 16 && use_mfma)
+        hipLaunchKernelGGL(tattn_mfma_kernel, dim3(grid), dim3(256), 0, s, (const h16*)QKV, (h16*)O, B, T, HW, heads,
+                           ldqkv, ldo, scale, (int)total);
+    else if (T <= 16)
         hipLaunchKernelGGL(tattn_kernel<16>, dim3(grid), dim3(256), 0, s, (const h16*)QKV, (h16*)O, B, T, HW, heads,
                            ldqkv, ldo, scale, (int)total);
     else

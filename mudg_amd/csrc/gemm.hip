@@ -430,8 +430,8 @@ __global__ __launch_bounds__(G::NTH, G::WIDE ? 2 : ((SB && !fused_planes(FAST)) 
                 }
             }
         }
-        if (gbias_rows || !p.gbias || p.geglu) {
-            for (int t = tid; t < BN; t += NTH) sbias[t] = (p.bias && n0 + t < p.N) ? p.bias[n0 + t] : 0.f;
+        if (gbias_rows || !p.gbias || p.geglu) {     // straddling tile: bias + group bias go row by row as one pre-summed constant (see below)
+            for (int t = tid; t < BN; t += NTH) sbias[t] = (!(gbias_rows && !p.geglu) && p.bias && n0 + t < p.N) ? p.bias[n0 + t] : 0.f;
         }
         __syncthreads();
 
@@ -529,8 +529,9 @@ __global__ __launch_bounds__(G::NTH, G::WIDE ? 2 : ((SB && !fused_planes(FAST)) 
                     const int64_t m = mrow[u];
                     if (gbias_rows) {
                         const float* gb = p.gbias + (int64_t)(m / p.rows_per_group) * Nout + n;
+                        const bool withb = p.bias && !p.geglu;
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) if (j < nvalid) v[u][j] += gb[j];
+                        for (int j = 0; j < 8; ++j) if (j < nvalid) v[u][j] += withb ? p.bias[n + j] + gb[j] : gb[j];
                     }
                     if (RK != 3) {
                         if (wideR) {
@@ -637,8 +638,10 @@ __global__ __launch_bounds__(G::NTH, G::WIDE ? 2 : ((SB && !fused_planes(FAST)) 
             }
         }
     }
+    // (a straddling tile adds bias + group bias row by row, as ONE pre-summed constant like the staged one: a row's bits must not
+    // depend on which of the two paths its tile took — that changes with M, i.e. with how many clips share the launch)
     if (gbias_rows || !p.gbias || p.geglu) {
-        for (int t = tid; t < BN; t += NTH) sbias[t] = (p.bias && n0 + t < p.N) ? p.bias[n0 + t] : 0.f;
+        for (int t = tid; t < BN; t += NTH) sbias[t] = (!(gbias_rows && !p.geglu) && p.bias && n0 + t < p.N) ? p.bias[n0 + t] : 0.f;
     }
     __syncthreads();
 
@@ -748,8 +751,9 @@ __global__ __launch_bounds__(G::NTH, G::WIDE ? 2 : ((SB && !fused_planes(FAST)) 
         }
         if (gbias_rows) {
             const float* gb = p.gbias + (int64_t)(m / p.rows_per_group) * Nout + n;
+            const bool withb = p.bias && !p.geglu;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) if (j < nvalid) v[j] += gb[j];
+            for (int j = 0; j < 8; ++j) if (j < nvalid) v[j] += withb ? p.bias[n + j] + gb[j] : gb[j];
         }
         if (R) {
             const h16* rp = R + (int64_t)m * p.ldr + n;
@@ -1093,6 +1097,8 @@ extern "C" int mudg_gemm(const MudgGemmDesc* dp, void* stream) {
     }
     if (d.geglu) MUDG_REQUIRE((d.N & 63) == 0, "mudg_gemm: geglu needs N %% 64 == 0");
     if (d.gbias) MUDG_REQUIRE(d.rows_per_group > 0 && d.batch == 1, "mudg_gemm: gbias needs rows_per_group");
+    // the group bias is a second bias (added with it, before nothing): an activation or a GEGLU gate between them is not defined
+    MUDG_REQUIRE(!(d.gbias && (d.act || d.geglu)), "mudg_gemm: gbias combines with neither act nor geglu");
     if (d.stats) MUDG_REQUIRE(d.batch == 1 && !d.geglu, "mudg_gemm: stats needs batch == 1 and no GEGLU");
     if (d.alpha == 0.f) d.alpha = 1.f;
     if (d.Y8) {

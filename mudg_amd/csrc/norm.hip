@@ -8,19 +8,47 @@ namespace {
 constexpr int GN_CMAX = 4096;
 
 // Eight consecutive channels of one pixel as fp32, from operand (h16, PLANES pieces `ld / PLANES` apart) or fp32 storage.
+// `raw` only issues the 16-byte requests and `decode` turns them into values, so a kernel can put several vectors' requests in
+// flight before it touches any of them.
 template <typename T> struct Load8;
 template <> struct Load8<h16> {
+    static constexpr int NR = PLANES;
     static __device__ __forceinline__ void get(const h16* p, int ld, float (&x)[8]) { load8_operand(p, ld / PLANES, x); }
+    static __device__ __forceinline__ void raw(const h16* p, int ld, u32x4 (&r)[NR]) {
+#pragma unroll
+        for (int k = 0; k < PLANES; ++k) r[k] = ld16(p + (int64_t)k * (ld / PLANES));
+    }
+    static __device__ __forceinline__ void decode(const u32x4 (&r)[NR], float (&x)[8]) {
+#pragma unroll
+        for (int k = 0; k < PLANES; ++k) {
+            const h16x8 t = as_h16x8(r[k]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = k ? x[e] + (float)t[e] : (float)t[e];
+        }
+    }
 };
 struct StreamH { _Float16 v; };       // fp16 residual-stream storage (KIND_F16): a type of its own, h16 may be _Float16 too
 template <> struct Load8<StreamH> {
+    static constexpr int NR = 1;
     static __device__ __forceinline__ void get(const StreamH* p, int, float (&x)[8]) { load8_f16(reinterpret_cast<const _Float16*>(p), x); }
+    static __device__ __forceinline__ void raw(const StreamH* p, int, u32x4 (&r)[NR]) { r[0] = ld16(p); }
+    static __device__ __forceinline__ void decode(const u32x4 (&r)[NR], float (&x)[8]) {
+        union { u32x4 u; f16x8 h; } t; t.u = r[0];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = (float)t.h[e];
+    }
 };
 template <> struct Load8<float> {
+    static constexpr int NR = 2;
     static __device__ __forceinline__ void get(const float* p, int, float (&x)[8]) {
         const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) { x[e] = a[e]; x[4 + e] = b[e]; }
+    }
+    static __device__ __forceinline__ void raw(const float* p, int, u32x4 (&r)[NR]) { r[0] = ld16(p); r[1] = ld16(p + 4); }
+    static __device__ __forceinline__ void decode(const u32x4 (&r)[NR], float (&x)[8]) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { x[e] = __uint_as_float(r[0][e]); x[4 + e] = __uint_as_float(r[1][e]); }
     }
 };
 
@@ -30,16 +58,6 @@ template <> struct Load8<float> {
 __host__ __device__ inline int gn_chunks(int samples, int rows) {
     (void)samples;
     int want = rows / 64;
-    if (want > 1024) want = 1024;
-    return want < 1 ? 1 : want;
-}
-
-// Workgroups per sample of the apply pass (no effect on the arithmetic): enough of them to fill the chip.
-__host__ __device__ inline int gn_apply_blocks(int samples, int rows) {
-    int want = 2048 / (samples > 0 ? samples : 1);
-    if (want < 1) want = 1;
-    const int most = (rows + 15) / 16;
-    if (want > most) want = most;
     if (want > 1024) want = 1024;
     return want < 1 ? 1 : want;
 }
@@ -67,11 +85,30 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ X, 
             const int c0 = v * 8;
             const T* base = X; int cc = c0, ld = ldx;
             if (c0 >= csplit) { base = X2; cc = c0 - csplit; ld = ldx2; }
-            for (int r = r0 + wave; r < r1; r += 4) {
-                float xv[8];
-                Load8<T>::get(base + (srow + r) * ld + cc, ld, xv);
+            // four rows' requests in flight per lane (pinned before any is decoded, as in gn_apply_kernel); the rows are still
+            // accumulated in ascending order
+            for (int r = r0 + wave; r < r1; r += 16) {
+                constexpr int NR = Load8<T>::NR;
+                u32x4 raw[4][NR];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { s[e] += xv[e]; q[e] = fmaf(xv[e], xv[e], q[e]); }
+                for (int u = 0; u < 4; ++u) {
+                    const int rr = (r + 4 * u < r1) ? r + 4 * u : r;
+                    Load8<T>::raw(base + (srow + rr) * ld + cc, ld, raw[u]);
+                }
+                if constexpr (NR == 1) asm volatile("" : "+v"(raw[0][0]), "+v"(raw[1][0]), "+v"(raw[2][0]), "+v"(raw[3][0]));
+                else if constexpr (NR == 2) asm volatile("" : "+v"(raw[0][0]), "+v"(raw[0][1]), "+v"(raw[1][0]), "+v"(raw[1][1]), "+v"(raw[2][0]),
+                                                         "+v"(raw[2][1]), "+v"(raw[3][0]), "+v"(raw[3][1]));
+                else asm volatile("" : "+v"(raw[0][0]), "+v"(raw[0][1]), "+v"(raw[0][2]), "+v"(raw[1][0]), "+v"(raw[1][1]), "+v"(raw[1][2]),
+                                  "+v"(raw[2][0]), "+v"(raw[2][1]), "+v"(raw[2][2]), "+v"(raw[3][0]), "+v"(raw[3][1]), "+v"(raw[3][2]));
+                static_assert(NR <= 3, "the pin above lists its operands");
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (r + 4 * u >= r1) break;
+                    float xv[8];
+                    Load8<T>::decode(raw[u], xv);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { s[e] += xv[e]; q[e] = fmaf(xv[e], xv[e], q[e]); }
+                }
             }
         }
 #pragma unroll
@@ -158,47 +195,206 @@ __global__ __launch_bounds__(256) void gn_finalize_ch_kernel(const float* __rest
     }
 }
 
-// Pass 3: y = (x - mean) * rstd * gamma + beta, optional SiLU.
+// Pass 3: y = (x - mean) * rstd * gamma + beta, optional SiLU.  HBM-bound (2 B in + 2 B out per element on the 16-bit builds).
+// One-shot workgroups, as ln_rows_kernel: a workgroup owns RB rows x one slab of CS channels (<= 640, so its scale / shift table
+// is a few KiB of dynamic LDS and costs fewer requests than the payload), every lane puts its GN_UNROLL 16-byte requests in
+// flight first, builds the table while they travel, applies, stores and ENDS.  A looping workgroup (rounds 1-3: 2048 resident
+// workgroups walking 144 rows each) issues its next loads behind its own stores — vmcnt retires in order, so every iteration pays
+// a load AND a store round trip — and measured 3.6-4.3 TB/s whatever the unroll; short-lived workgroups let the dispatcher
+// overlap one workgroup's stores with the next one's loads.
+constexpr int GN_UNROLL = 4;
 template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ X, const T* __restrict__ X2,
                                                         int csplit, int ldx, int ldx2, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, h16* __restrict__ Y, int ldy,
-                                                        int rows, int C, int groups, int nblk, int silu,
+                                                        int rows, int C, int groups, int CS, int RB, int silu,
                                                         const float* __restrict__ stat) {
-    __shared__ float sc[GN_CMAX], sh[GN_CMAX];
+    extern __shared__ float gn_tab[];
+    float* sc = gn_tab;
+    float* sh = gn_tab + CS;
     const int tid = threadIdx.x;
     const int smp = blockIdx.y;
+    const int cbase = blockIdx.z * CS;
+    const int nvec = CS >> 3;
+    const int r0 = blockIdx.x * RB, r1 = (r0 + RB < rows) ? r0 + RB : rows;
+    const int64_t srow = (int64_t)smp * rows;
+    const int n = (r1 - r0) * nvec;                        // <= 256 * GN_UNROLL (the host sizes RB)
+    const int dr = 256 / nvec, dv = 256 - dr * nvec;       // entry i + 256 is dr rows and dv vectors further (with carry)
+    int r = r0 + tid / nvec, v = tid - (tid / nvec) * nvec;
+    constexpr int NR = Load8<T>::NR;
+    u32x4 raw[GN_UNROLL][NR];
+    int64_t yoff[GN_UNROLL];
+    int c0s[GN_UNROLL];
+#pragma unroll
+    for (int u = 0; u < GN_UNROLL; ++u) {
+        const bool live = tid + 256 * u < n;               // past the end: re-read the workgroup's first vector, store nothing
+        const int cl = live ? v * 8 : 0;                   // (unconditional loads: the GN_UNROLL requests leave back to back)
+        const int rr = live ? r : r0;
+        const int c0 = cbase + cl;
+        c0s[u] = cl;
+        yoff[u] = (srow + rr) * ldy + c0;
+        const T* base = X; int cc = c0, ld = ldx;
+        if (c0 >= csplit) { base = X2; cc = c0 - csplit; ld = ldx2; }
+        Load8<T>::raw(base + (srow + rr) * ld + cc, ld, raw[u]);
+        r += dr; v += dv;
+        if (v >= nvec) { v -= nvec; ++r; }
+    }
     const int cpg = C / groups;
-    for (int c = tid; c < C; c += 256) {
+    for (int cl = tid; cl < CS; cl += 256) {
+        const int c = cbase + cl;
         const int g = c / cpg;
         const float mean = stat[(smp * groups + g) * 2], rstd = stat[(smp * groups + g) * 2 + 1];
         const float a = rstd * gamma[c];
-        sc[c] = a;
-        sh[c] = beta[c] - mean * a;
+        sc[cl] = a;
+        sh[cl] = beta[c] - mean * a;
     }
     __syncthreads();
-    const int nvec = C >> 3;
-    const int rpb = (rows + nblk - 1) / nblk;
-    const int r0 = blockIdx.x * rpb, r1 = (r0 + rpb < rows) ? r0 + rpb : rows;
-    const int64_t srow = (int64_t)smp * rows;
-    const int n = (r1 - r0) * nvec;
-    for (int i = tid; i < n; i += 256) {
-        const int r = r0 + i / nvec, v = i % nvec;
-        const int c0 = v * 8;
-        const T* base = X; int cc = c0, ld = ldx;
-        if (c0 >= csplit) { base = X2; cc = c0 - csplit; ld = ldx2; }
+    // every request is pinned here, in straight-line code, before any value is decoded: without it the compiler sinks each
+    // load into the conditional block that stores its result, and the requests go out one at a time
+    if constexpr (NR == 1) asm volatile("" : "+v"(raw[0][0]), "+v"(raw[1][0]), "+v"(raw[2][0]), "+v"(raw[3][0]));
+    else if constexpr (NR == 2) asm volatile("" : "+v"(raw[0][0]), "+v"(raw[0][1]), "+v"(raw[1][0]), "+v"(raw[1][1]), "+v"(raw[2][0]),
+                                             "+v"(raw[2][1]), "+v"(raw[3][0]), "+v"(raw[3][1]));
+    else asm volatile("" : "+v"(raw[0][0]), "+v"(raw[0][1]), "+v"(raw[0][2]), "+v"(raw[1][0]), "+v"(raw[1][1]), "+v"(raw[1][2]),
+                      "+v"(raw[2][0]), "+v"(raw[2][1]), "+v"(raw[2][2]), "+v"(raw[3][0]), "+v"(raw[3][1]), "+v"(raw[3][2]));
+    static_assert(GN_UNROLL == 4 && NR <= 3, "the pin above lists its operands");
+#pragma unroll
+    for (int u = 0; u < GN_UNROLL; ++u) {
+        if (tid + 256 * u >= n) break;
         float xv[8];
-        Load8<T>::get(base + (srow + r) * ld + cc, ld, xv);
+        Load8<T>::decode(raw[u], xv);
+        const int cl = c0s[u];
         float o[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            float y = fmaf(xv[e], sc[c0 + e], sh[c0 + e]);
+            float y = fmaf(xv[e], sc[cl + e], sh[cl + e]);
             if (silu) y = PLANES > 1 ? y / (1.0f + expf(-y))                   // split builds: IEEE division, full-precision exp
                                      : y * __builtin_amdgcn_rcpf(1.0f + __expf(-y));      // 1-ulp reciprocal: the result is rounded to h16
             o[e] = y;
         }
+        store8_operand(Y + yoff[u], ldy / PLANES, o);
+    }
+}
+
+// The same pass with the scale / shift of a lane's eight channels in REGISTERS: a lane keeps one channel vector and takes it from
+// GN_UNROLL rows (256 / nvec rows per pass, so 240 of 256 lanes work at nvec = 40 / 80), gamma / beta / the statistics come straight
+// from global memory (L1 / L2 hits) while the payload requests travel — no LDS table, no barrier, no bank conflicts (the table's
+// 16-byte reads at a 32-byte lane stride were two-way conflicted).  Needs nvec <= 256.
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_reg_kernel(const T* __restrict__ X, const T* __restrict__ X2,
+                                                            int csplit, int ldx, int ldx2, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, h16* __restrict__ Y, int ldy,
+                                                            int rows, int C, int groups, int CS, int silu,
+                                                            const float* __restrict__ stat) {
+    const int tid = threadIdx.x;
+    const int nvec = CS >> 3;
+    const int RP = 256 / nvec;                             // rows per pass
+    const int rsub = tid / nvec, v = tid - rsub * nvec;
+    const int r0 = blockIdx.x * (RP * GN_UNROLL) + rsub;
+    if (rsub >= RP || r0 >= rows) return;
+    const int smp = blockIdx.y;
+    const int c0 = blockIdx.z * CS + v * 8;
+    const int64_t srow = (int64_t)smp * rows;
+    const T* base = X; int cc = c0, ld = ldx;
+    if (c0 >= csplit) { base = X2; cc = c0 - csplit; ld = ldx2; }
+    constexpr int NR = Load8<T>::NR;
+    u32x4 raw[GN_UNROLL][NR];
+#pragma unroll
+    for (int u = 0; u < GN_UNROLL; ++u) {
+        const int r = r0 + RP * u;
+        Load8<T>::raw(base + (srow + (r < rows ? r : rows - 1)) * ld + cc, ld, raw[u]);
+    }
+    const int cpg = C / groups;
+    const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + c0), g1 = *reinterpret_cast<const f32x4*>(gamma + c0 + 4);
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + c0), b1 = *reinterpret_cast<const f32x4*>(beta + c0 + 4);
+    const f32x2* st = reinterpret_cast<const f32x2*>(stat) + smp * groups;
+    f32x2 mr[8];
+    const int gq = c0 / cpg, rem = c0 - gq * cpg;
+    if (cpg >= 8) {                                        // eight channels meet at most two groups: two requests, one division
+        const f32x2 ma = st[gq], mb = st[gq + 1 < groups ? gq + 1 : gq];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) mr[e] = (rem + e >= cpg) ? mb : ma;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) mr[e] = st[(c0 + e) / cpg];
+    }
+    // Everything above is requests only; nothing below may be scheduled above this line (left alone, the scheduler spreads the
+    // requests between the uses to save registers: three round trips).  The pin keeps the payload loads out of the conditional
+    // blocks that consume them (the IR-level sinking the scheduling barrier does not see).
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (NR == 1) asm volatile("" : "+v"(raw[0][0]), "+v"(raw[1][0]), "+v"(raw[2][0]), "+v"(raw[3][0]));
+    else if constexpr (NR == 2) asm volatile("" : "+v"(raw[0][0]), "+v"(raw[0][1]), "+v"(raw[1][0]), "+v"(raw[1][1]), "+v"(raw[2][0]),
+                                             "+v"(raw[2][1]), "+v"(raw[3][0]), "+v"(raw[3][1]));
+    else asm volatile("" : "+v"(raw[0][0]), "+v"(raw[0][1]), "+v"(raw[0][2]), "+v"(raw[1][0]), "+v"(raw[1][1]), "+v"(raw[1][2]),
+                      "+v"(raw[2][0]), "+v"(raw[2][1]), "+v"(raw[2][2]), "+v"(raw[3][0]), "+v"(raw[3][1]), "+v"(raw[3][2]));
+    static_assert(GN_UNROLL == 4 && NR <= 3, "the pin above lists its operands");
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float a = mr[e][1] * (e < 4 ? g0[e & 3] : g1[e & 3]);
+        sc[e] = a;
+        sh[e] = (e < 4 ? b0[e & 3] : b1[e & 3]) - mr[e][0] * a;
+    }
+#pragma unroll
+    for (int u = 0; u < GN_UNROLL; ++u) {
+        const int r = r0 + RP * u;
+        if (u > 0 && r >= rows) break;
+        float xv[8];
+        Load8<T>::decode(raw[u], xv);
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float y = fmaf(xv[e], sc[e], sh[e]);
+            if (silu) y = PLANES > 1 ? y / (1.0f + expf(-y))
+                                     : y * __builtin_amdgcn_rcpf(1.0f + __expf(-y));
+            o[e] = y;
+        }
         store8_operand(Y + (srow + r) * ldy + c0, ldy / PLANES, o);
     }
+}
+
+// The apply pass's geometry: the channel slab CS = the largest divisor of C that is <= 640 and a multiple of 64 (of 8 if there is
+// none; C itself when C <= 640 or when it has no such divisor >= 128); a workgroup takes GN_UNROLL passes of 256 / nvec rows.
+void launch_gn_apply(int x_fp32, const void* X, const void* X2, int csplit, int ldx, int ldx2, const float* gamma, const float* beta,
+                     void* Y, int ldy, int samples, int rows, int C, int groups, int silu, const float* stat, hipStream_t s) {
+    int CS = C;
+    if (C > 640) {
+        int best = 0;
+        for (int d = 640; d >= 128 && !best; d -= 64)      // whole 128-byte lines per row segment first (960 -> 3 x 320, not 2 x 480)
+            if (C % d == 0) best = d;
+        for (int d = 640; d >= 128 && !best; d -= 8)
+            if (C % d == 0) best = d;
+        if (best) CS = best;
+    }
+    static int reg_table = -1;              // MUDG_GN_REG=0: the LDS-table kernel for every width (A/B, tests)
+    if (reg_table < 0) reg_table = mudg_variant("GN_REG", 1);
+    const int nvec = CS >> 3;
+    if (reg_table && nvec <= 256 && aligned16(gamma) && aligned16(beta)) {
+        const int RB = (256 / nvec) * GN_UNROLL;
+        const dim3 grid((rows + RB - 1) / RB, samples, C / CS);
+        if (x_fp32 == KIND_F16)
+            hipLaunchKernelGGL(gn_apply_reg_kernel<StreamH>, grid, dim3(256), 0, s, (const StreamH*)X, (const StreamH*)X2,
+                               csplit, ldx, ldx2, gamma, beta, (h16*)Y, ldy, rows, C, groups, CS, silu, stat);
+        else if (x_fp32)
+            hipLaunchKernelGGL(gn_apply_reg_kernel<float>, grid, dim3(256), 0, s, (const float*)X, (const float*)X2,
+                               csplit, ldx, ldx2, gamma, beta, (h16*)Y, ldy, rows, C, groups, CS, silu, stat);
+        else
+            hipLaunchKernelGGL(gn_apply_reg_kernel<h16>, grid, dim3(256), 0, s, (const h16*)X, (const h16*)X2,
+                               csplit, ldx, ldx2, gamma, beta, (h16*)Y, ldy, rows, C, groups, CS, silu, stat);
+        return;
+    }
+    int RB = (256 * GN_UNROLL) / nvec;
+    if (RB < 1) RB = 1;
+    const dim3 grid((rows + RB - 1) / RB, samples, C / CS);
+    const size_t lds = 2 * (size_t)CS * sizeof(float);
+    if (x_fp32 == KIND_F16)
+        hipLaunchKernelGGL(gn_apply_kernel<StreamH>, grid, dim3(256), lds, s, (const StreamH*)X, (const StreamH*)X2,
+                           csplit, ldx, ldx2, gamma, beta, (h16*)Y, ldy, rows, C, groups, CS, RB, silu, stat);
+    else if (x_fp32)
+        hipLaunchKernelGGL(gn_apply_kernel<float>, grid, dim3(256), lds, s, (const float*)X, (const float*)X2,
+                           csplit, ldx, ldx2, gamma, beta, (h16*)Y, ldy, rows, C, groups, CS, RB, silu, stat);
+    else
+        hipLaunchKernelGGL(gn_apply_kernel<h16>, grid, dim3(256), lds, s, (const h16*)X, (const h16*)X2,
+                           csplit, ldx, ldx2, gamma, beta, (h16*)Y, ldy, rows, C, groups, CS, RB, silu, stat);
 }
 
 // LayerNorm: one wave per row, up to VMAX 16-byte vectors per lane kept in registers (C <= 512 * VMAX).
@@ -378,16 +574,7 @@ extern "C" int mudg_groupnorm(const void* X, const void* X2, int csplit, int ldx
     const int ng = samples * groups;
     hipLaunchKernelGGL(gn_finalize_kernel, dim3((ng + 3) / 4), dim3(256), 0, s, part, stat, samples, groups, nchunks,
                        (double)rows * (C / groups), eps);
-    const int nblk = gn_apply_blocks(samples, rows);
-    if (x_fp32 == KIND_F16)
-        hipLaunchKernelGGL(gn_apply_kernel<StreamH>, dim3(nblk, samples), dim3(256), 0, s, (const StreamH*)X, (const StreamH*)X2,
-                           csplit, ldx, ldx2, gamma, beta, (h16*)Y, ldy, rows, C, groups, nblk, silu, stat);
-    else if (x_fp32)
-        hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(nblk, samples), dim3(256), 0, s, (const float*)X, (const float*)X2,
-                           csplit, ldx, ldx2, gamma, beta, (h16*)Y, ldy, rows, C, groups, nblk, silu, stat);
-    else
-        hipLaunchKernelGGL(gn_apply_kernel<h16>, dim3(nblk, samples), dim3(256), 0, s, (const h16*)X, (const h16*)X2,
-                           csplit, ldx, ldx2, gamma, beta, (h16*)Y, ldy, rows, C, groups, nblk, silu, stat);
+    launch_gn_apply(x_fp32, X, X2, csplit, ldx, ldx2, gamma, beta, Y, ldy, samples, rows, C, groups, silu, stat, s);
     const int rc = mudg_check_launch("mudg_groupnorm");
     mudg_prof_end(slot, s, 0.0, (double)samples * rows * C * (x_fp32 == KIND_F32 ? 10.0 : 6.0));
     return rc;
@@ -413,16 +600,7 @@ extern "C" int mudg_groupnorm_fused(const void* X, const void* X2, int csplit, i
     const int ng = samples * groups;
     hipLaunchKernelGGL(gn_finalize_ch_kernel, dim3(ng), dim3(256), 0, s, P1, P2, csplit, C, stat, samples, groups,
                        rows / 128, (double)rows * (C / groups), eps);
-    const int nblk = gn_apply_blocks(samples, rows);
-    if (x_fp32 == KIND_F16)
-        hipLaunchKernelGGL(gn_apply_kernel<StreamH>, dim3(nblk, samples), dim3(256), 0, s, (const StreamH*)X, (const StreamH*)X2,
-                           csplit, ldx, ldx2, gamma, beta, (h16*)Y, ldy, rows, C, groups, nblk, silu, stat);
-    else if (x_fp32)
-        hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(nblk, samples), dim3(256), 0, s, (const float*)X, (const float*)X2,
-                           csplit, ldx, ldx2, gamma, beta, (h16*)Y, ldy, rows, C, groups, nblk, silu, stat);
-    else
-        hipLaunchKernelGGL(gn_apply_kernel<h16>, dim3(nblk, samples), dim3(256), 0, s, (const h16*)X, (const h16*)X2,
-                           csplit, ldx, ldx2, gamma, beta, (h16*)Y, ldy, rows, C, groups, nblk, silu, stat);
+    launch_gn_apply(x_fp32, X, X2, csplit, ldx, ldx2, gamma, beta, Y, ldy, samples, rows, C, groups, silu, stat, s);
     const int rc = mudg_check_launch("mudg_groupnorm_fused");
     mudg_prof_end(slot, s, 0.0, (double)samples * rows * C * (x_fp32 == KIND_F32 ? 6.0 : 4.0));
     return rc;

@@ -251,6 +251,48 @@ def test_temporal_attention(cuda, clips, t, hw, heads):
     assert rel_l2(out, ref) < TOL_BF16
 
 
+@pytest.mark.parametrize("out_fp32", [False, True])
+def test_conv_with_a_group_bias_does_not_depend_on_the_batch(cuda, out_fp32):
+    """A ResBlock's conv adds bias + embedding term.  A 128-row tile inside one group adds them as one staged column constant, a tile
+    that straddles groups adds them row by row — as the SAME pre-summed constant, so a row's bits do not depend on which tile it fell
+    into (that changes with the number of clips in the launch: 36 frames of 4 x 4 pixels = 4.5 tiles against 12 frames = 1.5 tiles;
+    seen as a one-ulp drift between stacked and back-to-back guidance passes before the two paths were aligned)."""
+    from mudg_amd import ops
+    cin, cout, h, w = 64, 128, 4, 4
+    g = torch.Generator().manual_seed(21)
+    for trial in range(4):
+        x = rnd(36 * h * w, cin, seed=30 + trial).to(cuda)
+        wt = rnd(cout, 9 * cin, seed=40 + trial, scale=0.05).to(cuda)
+        bias, gb = torch.randn(cout, generator=g).to(cuda), torch.randn(9, cout, generator=g).to(cuda)
+        ya = ops.conv3x3(x, wt, frames=36, hin=h, win=w, cin=cin, bias=bias, gbias=gb, rows_per_group=64, korder=1, out_fp32=out_fp32)
+        yb = ops.conv3x3(x[:192].contiguous(), wt, frames=12, hin=h, win=w, cin=cin, bias=bias, gbias=gb[:3].contiguous(),
+                         rows_per_group=64, korder=1, out_fp32=out_fp32)
+        assert torch.equal(ya[:192], yb)
+
+
+@pytest.mark.parametrize("t,hw,heads", [(16, 36, 5), (4, 64, 2), (5, 7, 3), (20, 9, 1)])
+def test_temporal_attention_and_groupnorm_do_not_depend_on_the_batch(cuda, t, hw, heads):
+    """A clip's result must carry the same bits whether its pass runs alone or stacked with other clips (the samplers stack the guidance
+    passes; clip-level data parallelism splits them): the MFMA temporal attention and the register-table GroupNorm, stacked vs one by one."""
+    from mudg_amd import ops
+    c = heads * 64
+    qkv = rnd(3 * t * hw, 3 * c, seed=5).to(cuda)
+    out = torch.zeros(3 * t * hw, c, dtype=BF, device=cuda)
+    ops.temporal_attention(qkv, out, clips=3, t=t, hw=hw, heads=heads)
+    for b in range(3):
+        one = torch.zeros(t * hw, c, dtype=BF, device=cuda)
+        ops.temporal_attention(qkv[b * t * hw:(b + 1) * t * hw].contiguous(), one, clips=1, t=t, hw=hw, heads=heads)
+        assert torch.equal(one, out[b * t * hw:(b + 1) * t * hw])
+    rows, cg = 150, 960
+    x = (rnd(3 * rows, cg, seed=6).float() * 2 + 0.3).to(BF).to(cuda)
+    g = (1 + 0.1 * torch.randn(cg, generator=torch.Generator().manual_seed(2))).to(cuda)
+    bb = (0.1 * torch.randn(cg, generator=torch.Generator().manual_seed(3))).to(cuda)
+    y = ops.groupnorm(x, g, bb, samples=3, rows=rows, eps=1e-5, silu=True)
+    for b in range(3):
+        one = ops.groupnorm(x[b * rows:(b + 1) * rows].contiguous(), g, bb, samples=1, rows=rows, eps=1e-5, silu=True)
+        assert torch.equal(one, y[b * rows:(b + 1) * rows])
+
+
 @pytest.mark.parametrize("samples,rows,c,silu,eps", [(2, 50, 64, True, 1e-5), (3, 144, 320, True, 1e-5),
                                                      (1, 700, 960, False, 1e-6), (2, 33, 2560, True, 1e-5),
                                                      (1, 5000, 128, True, 1e-6), (2, 20, 32, True, 1e-5)])

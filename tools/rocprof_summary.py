@@ -4,6 +4,7 @@ into the small markdown tables committed under profiles/.
 
   python tools/rocprof_summary.py trace  <results.db>            per-kernel calls / total / avg / min / max / share
   python tools/rocprof_summary.py mfma   <results.db>            MFMA utilisation per kernel from SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE
+  python tools/rocprof_summary.py grids  <results.db> <substr>   per (kernel, grid) calls / total / avg of the kernels whose name contains <substr>
   python tools/rocprof_summary.py pmc    <results.db> [scale]    per-kernel sum and per-launch mean of each collected counter
                                                                   (scale multiplies the values, e.g. 2 for FETCH_SIZE on gfx950)
 """
@@ -27,6 +28,26 @@ def trace(path, top=40):
     print("|---|---:|---:|---:|---:|---:|---:|")
     for name, n, tot, avg, mn, mx in rows[:top]:
         print(f"| `{short(name)}` | {n} | {tot / 1e6:.3f} | {avg / 1e3:.2f} | {mn / 1e3:.2f} | {mx / 1e3:.2f} | {100 * tot / total:.2f} |")
+
+
+def grids(path, flt):
+    """The launches of one kernel family split by launch geometry (= by problem shape)."""
+    cur = sqlite3.connect(path).cursor()
+    cols = [r[1] for r in cur.execute("pragma table_info(kernels)").fetchall()]
+    g = [c for c in ("grid_x", "grid_y", "grid_z", "grid_size_x", "grid_size_y", "grid_size_z") if c in cols]
+    if not g:
+        print("no grid columns in the kernels view:", cols)
+        return
+    gs = ", ".join(g)
+    rows = cur.execute(f"select name, {gs}, count(*), sum(end - start), avg(end - start), min(end - start) from kernels "
+                       f"where name like ? group by name, {gs} order by {len(g) + 3} desc", (f"%{flt}%",)).fetchall()
+    total = sum(r[len(g) + 2] for r in rows) or 1
+    print(f"# launches of kernels matching '{flt}' by grid ({path.split('/')[-1]}): {total / 1e6:.3f} ms\n")
+    print("| kernel | grid (work-items) | calls | total ms | avg us | min us |")
+    print("|---|---|---:|---:|---:|---:|")
+    for r in rows:
+        print(f"| `{short(r[0], 48)}` | {' x '.join(str(x) for x in r[1:1 + len(g)])} | {r[len(g) + 1]} | {r[len(g) + 2] / 1e6:.3f} | "
+              f"{r[len(g) + 3] / 1e3:.1f} | {r[len(g) + 4] / 1e3:.1f} |")
 
 
 def pmc(path, scale=1.0, top=25):
@@ -89,6 +110,8 @@ if __name__ == "__main__":
         trace(path)
     elif mode == "mfma":
         mfma(path)
+    elif mode == "grids":
+        grids(path, sys.argv[3])
     elif mode == "pmcd":
         pmc_dispatches(path, sys.argv[3] if len(sys.argv) > 3 else "")
     else:
