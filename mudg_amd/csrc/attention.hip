@@ -861,14 +861,16 @@ __global__ __launch_bounds__(256, TP == 16 ? 3 : 1) void tattn_kernel(const h16*
 // UNet's level 0 that is ~120 us of pure VALU time for a pass whose 755 MB take ~135 us at the rate the norms reach — so it was
 // compute-bound on the wrong unit.  Here an item is 2 + 4 MFMAs:
 //   S^T = K Q^T   two v_mfma_f32_16x16x32: lane (c = l % 16, g = l / 16) feeds row c of K as A and row c of Q as B, dims 8g + 32s ..
-//                 + 7 — exactly one 16-byte global load each, no staging; the result lands as S^T[tk = 4g + i][tq = c], i = 0..3,
-//                 so the softmax over tk is 4 in-lane values and two cross-lane steps (xor 16, xor 32);
-//   O^T = V^T P^T four v_mfma_f32_16x16x16 (k = tk): P^T is already the B fragment (lane (c, g) holds tk = 4g + i of column tq = c);
+//                 + 7; the result lands as S^T[tk = 4g + i][tq = c], i = 0..3, so the softmax over tk is 4 in-lane values and two
+//                 cross-lane steps (xor 16, xor 32).  The fragments could come straight from global memory (one 16-byte load per lane),
+//                 but then adjacent lanes ask for different frames' rows, 17 MB apart: q, k, v are fetched eight lanes per row — a
+//                 request is whole 128-byte head slices — and pass through a per-wave LDS tile (chunk-swizzled, 16-byte reads);
+//   O^T = V^T P^T 2 x four v_mfma_f32_16x16x16 (k = tk): P^T is already the B fragment (lane (c, g) holds tk = 4g + i of column tq = c);
 //                 V^T[d][tk = 4g + j] is the one transposed read — V goes through a per-wave 2-KiB LDS tile (8-byte writes, 2-byte
 //                 reads, the 8-byte units of a row XOR-swizzled by row / 4 so the 64 lanes of a read meet 32 distinct banks).  Row
 //                 r of output block m stands for dim 32 (m / 2) + 8 (r / 4) + 4 (m % 2) + r % 4, so lane (c, g) ends up with dims
 //                 8g .. 8g + 7 and 32 + 8g .. 32 + 8g + 7 of query c: two 16-byte stores, each instruction 64 contiguous bytes per row.
-// P is rounded to the operand type before the second contraction, as in the flash kernels.
+// P enters the second contraction as two 16-bit pieces (eight MFMAs instead of four): fp32-class probabilities, as in the VALU kernel.
 #ifdef MUDG_OPERAND_FP16
 typedef __attribute__((ext_vector_type(4))) _Float16 mf4;
 #define MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
@@ -882,49 +884,63 @@ typedef __attribute__((ext_vector_type(4))) short mf4;
 __global__ __launch_bounds__(256) void tattn_mfma_kernel(const h16* __restrict__ QKV, h16* __restrict__ O,
                                                           int B, int T, int HW, int heads, int ldqkv, int ldo,
                                                           float scale, int total) {
-    __shared__ __attribute__((aligned(16))) h16 Vs[4][16 * 64];
+    // per wave: Q, K, V tiles of one item, 16 rows x 128 B each
+    __shared__ __attribute__((aligned(16))) h16 Ts[4][3][16 * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int c = lane & 15, g = lane >> 4;
-    const int C = heads * 64;
+    const int c = lane & 15, g = lane >> 4;          // MFMA coordinates: row / column c, k-group g
+    const int lr = lane >> 3, lj = lane & 7;         // fetch coordinates: rows lr and lr + 8, 16-byte chunk lj — a request covers
+    const int C = heads * 64;                        //   whole 128-byte head slices, eight lanes per row
     const int w0 = (blockIdx.x * 4 + wave) * TATTN_ITEMS;
-    char* vs = reinterpret_cast<char*>(&Vs[wave][0]);
+    char* qs = reinterpret_cast<char*>(&Ts[wave][0][0]);
+    char* ks = reinterpret_cast<char*>(&Ts[wave][1][0]);
+    char* vs = reinterpret_cast<char*>(&Ts[wave][2][0]);
+    auto fz = [](int rg) { return (rg & 1) | ((rg >> 1) << 3); };     // V's swizzle of row group rg: bits 0 and 3 of the 8-byte unit index
 
-    auto fz = [](int rg) { return (rg & 1) | ((rg >> 1) << 3); };     // the swizzle of row group rg: bits 0 and 3 of the unit index
-    u32x4 qn[2], kn[2], vn[2];                       // the item being fetched
-    int64_t rown = 0; int hn = 0; bool okn = false;
+    u32x4 qn[2], kn[2], vn[2];                       // the item being fetched: [row half]
+    int64_t pixn = 0; int hn = 0; bool itemn = false;
     auto fetch = [&](int w) {
-        okn = w < total && c < T;
-        const int bp = w < total ? w / heads : 0;
-        hn = w < total ? w - bp * heads : 0;
+        itemn = w < total;
+        const int bp = itemn ? w / heads : 0;
+        hn = itemn ? w - bp * heads : 0;
         const int b = bp / HW, px = bp - b * HW;
-        rown = ((int64_t)(b * T + (c < T ? c : 0)) * HW + px);
-        const h16* src = QKV + rown * ldqkv + hn * 64 + g * 8;
+        pixn = (int64_t)b * T * HW + px;             // row of frame t: pixn + t * HW
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            qn[s] = okn ? ld16(src + s * 32) : zero16();
-            kn[s] = okn ? ld16(src + C + s * 32) : zero16();
-            vn[s] = okn ? ld16(src + 2 * C + s * 32) : zero16();
+            const int t = lr + 8 * s;
+            const bool ok = itemn && t < T;
+            const h16* src = QKV + (pixn + (int64_t)(ok ? t : 0) * HW) * ldqkv + hn * 64 + lj * 8;
+            qn[s] = ok ? ld16(src) : zero16();
+            kn[s] = ok ? ld16(src + C) : zero16();
+            vn[s] = ok ? ld16(src + 2 * C) : zero16();
         }
     };
     fetch(w0);
 
     for (int it = 0; it < TATTN_ITEMS; ++it) {
         if (w0 + it >= total) break;                 // wave-uniform
-        const int64_t row = rown; const int h = hn; const bool rok = okn;
-        f32x4 st = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int s = 0; s < 2; ++s) st = MFMA_16x16x32(as_h16x8(kn[s]), as_h16x8(qn[s]), st);
+        const int64_t pix = pixn; const int h = hn;
         __builtin_amdgcn_wave_barrier();             // the previous item's LDS reads are issued before these writes
-        // V row c, dims 8g + 32s .. + 7 = the 8-byte units 2g + 8s, 2g + 8s + 1; unit u of row r sits at unit u ^ fz(r / 4)
+        // Q / K: chunk j of row r at chunk j ^ (r & 7) (fragment reads of one chunk column by 16 rows: two rows per bank group);
+        // V: the two 8-byte units of chunk j at units (2j, 2j + 1) ^ fz(r / 4) (2-byte transposed reads, see the header)
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            const int u0 = 2 * g + 8 * s, z = fz(c >> 2);
+            const int r = lr + 8 * s;
+            st16(qs + r * 128 + ((lj ^ (r & 7)) << 4), qn[s]);
+            st16(ks + r * 128 + ((lj ^ (r & 7)) << 4), kn[s]);
+            const int z = fz(r >> 2);
             u32x2 lo = {vn[s][0], vn[s][1]}, hi = {vn[s][2], vn[s][3]};
-            *reinterpret_cast<u32x2*>(vs + c * 128 + ((u0 ^ z) << 3)) = lo;
-            *reinterpret_cast<u32x2*>(vs + c * 128 + (((u0 + 1) ^ z) << 3)) = hi;
+            *reinterpret_cast<u32x2*>(vs + r * 128 + (((2 * lj) ^ z) << 3)) = lo;
+            *reinterpret_cast<u32x2*>(vs + r * 128 + (((2 * lj + 1) ^ z) << 3)) = hi;
         }
         __builtin_amdgcn_wave_barrier();
         if (it + 1 < TATTN_ITEMS) fetch(w0 + it + 1);
+
+        f32x4 st = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {                // dims 8g + 32s .. + 7 = chunk g + 4s of row c
+            const int off = c * 128 + (((g + 4 * s) ^ (c & 7)) << 4);
+            st = MFMA_16x16x32(as_h16x8(ld16(ks + off)), as_h16x8(ld16(qs + off)), st);
+        }
 
         // softmax over tk = 4g + i: in-lane over i, then across the four lane groups
         float sc[4];
@@ -933,13 +949,16 @@ __global__ __launch_bounds__(256) void tattn_mfma_kernel(const h16* __restrict__
         for (int i = 0; i < 4; ++i) { sc[i] = (4 * g + i < T) ? st[i] * scale : -INFINITY; mx = fmaxf(mx, sc[i]); }
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        // the probabilities enter the second contraction as TWO 16-bit pieces (p = p0 + p1, four more MFMAs on a kernel that waits
+        // for memory): the fp32-probability arithmetic of the VALU kernel it replaces, not one more 16-bit rounding per layer
         float sum = 0.f;
-        union { mf4 m; h16 e[4]; } pt;
+        union { mf4 m; h16 e[4]; } pt, pr;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const h16 ph = (h16)__expf(sc[i] - mx);
-            pt.e[i] = ph;
-            sum += (float)ph;                        // the denominator of the probabilities the contraction really uses
+            const float pv = __expf(sc[i] - mx);
+            sum += pv;
+            pt.e[i] = (h16)pv;
+            pr.e[i] = (h16)(pv - (float)pt.e[i]);
         }
         sum += __shfl_xor(sum, 16, 64);
         sum += __shfl_xor(sum, 32, 64);
@@ -955,14 +974,15 @@ __global__ __launch_bounds__(256) void tattn_mfma_kernel(const h16* __restrict__
             for (int j = 0; j < 4; ++j)
                 vt.e[j] = *reinterpret_cast<const unsigned short*>(vs + (4 * g + j) * 128 + (u << 3) + 2 * (c & 3));
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            acc = MFMA_16x16x16(vt.m4, pr.m, acc);
             acc = MFMA_16x16x16(vt.m4, pt.m, acc);
 #pragma unroll
             for (int i = 0; i < 4; ++i) ov[4 * m + i] = acc[i] * inv;
         }
-        if (rok) {
+        if (c < T) {
             // ov[4m + i] is dim 32 (m / 2) + 8g + 4 (m % 2) + i: blocks 0, 1 are dims 8g .. 8g + 7, blocks 2, 3 the same + 32 — a store
             // instruction covers 64 contiguous bytes per query row
-            h16* dst = O + row * ldo + h * 64 + g * 8;
+            h16* dst = O + (pix + (int64_t)c * HW) * ldo + h * 64 + g * 8;
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 h16x8 t;
@@ -1484,6 +1504,127 @@ __global__ __launch_bounds__(256, 1) void tattn_split_kernel(const h16* __restri
         }
     }
 }
+
+#if MUDG_PLANES == 2
+// tattn_mfma_kernel (above, 16-bit builds) for the bf16x3 build: q, k, v arrive as two bf16 pieces each, every contraction keeps
+// the three partial products of the fused-piece GEMMs — S^T = k0 q1 + k1 q0 + k0 q0 (six v_mfma_f32_16x16x32), the probabilities are
+// split in registers (p = p0 + p1), O^T = v0 p1 + v1 p0 + v0 p0 (twelve v_mfma_f32_16x16x16) — small terms first; exponentials and the
+// normalisation are full-precision fp32 as everywhere in this build.  One wave per item at a time, TATTN_SPLIT_ITEMS items per wave
+// with the next item's twelve requests in flight; six 2-KiB LDS tiles per wave.
+constexpr int TATTN_SPLIT_ITEMS = 4;
+typedef __attribute__((ext_vector_type(4))) short mf4s;
+__global__ __launch_bounds__(256) void tattn_split_mfma_kernel(const h16* __restrict__ QKV, h16* __restrict__ O,
+                                                                int B, int T, int HW, int heads, int ldqkv, int ldo,
+                                                                float scale, int total) {
+    __shared__ __attribute__((aligned(16))) h16 Ts[4][3][2][16 * 64];          // [wave][q | k | v][piece][16 rows x 64 dims]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane & 15, g = lane >> 4;          // MFMA coordinates
+    const int lr = lane >> 3, lj = lane & 7;         // fetch coordinates: rows lr and lr + 8, 16-byte chunk lj
+    const int C = heads * 64;
+    const int64_t ps = ldqkv / PLANES;
+    const int w0 = (blockIdx.x * 4 + wave) * TATTN_SPLIT_ITEMS;
+    auto tile = [&](int which, int piece) { return reinterpret_cast<char*>(&Ts[wave][which][piece][0]); };
+    auto fz = [](int rg) { return (rg & 1) | ((rg >> 1) << 3); };
+
+    u32x4 nx[3][2][2];                               // the item being fetched: [q | k | v][piece][row half]
+    int64_t pixn = 0; int hn = 0;
+    auto fetch = [&](int w) {
+        const bool item = w < total;
+        const int bp = item ? w / heads : 0;
+        hn = item ? w - bp * heads : 0;
+        const int b = bp / HW, px = bp - b * HW;
+        pixn = (int64_t)b * T * HW + px;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int t = lr + 8 * s;
+            const bool ok = item && t < T;
+            const h16* src = QKV + (pixn + (int64_t)(ok ? t : 0) * HW) * ldqkv + hn * 64 + lj * 8;
+#pragma unroll
+            for (int x = 0; x < 3; ++x)
+#pragma unroll
+                for (int pc = 0; pc < 2; ++pc) nx[x][pc][s] = ok ? ld16(src + x * C + pc * ps) : zero16();
+        }
+    };
+    fetch(w0);
+
+    for (int it = 0; it < TATTN_SPLIT_ITEMS; ++it) {
+        if (w0 + it >= total) break;                 // wave-uniform
+        const int64_t pix = pixn; const int h = hn;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int r = lr + 8 * s, z = fz(r >> 2);
+#pragma unroll
+            for (int pc = 0; pc < 2; ++pc) {
+                st16(tile(0, pc) + r * 128 + ((lj ^ (r & 7)) << 4), nx[0][pc][s]);
+                st16(tile(1, pc) + r * 128 + ((lj ^ (r & 7)) << 4), nx[1][pc][s]);
+                u32x2 lo = {nx[2][pc][s][0], nx[2][pc][s][1]}, hi = {nx[2][pc][s][2], nx[2][pc][s][3]};
+                *reinterpret_cast<u32x2*>(tile(2, pc) + r * 128 + (((2 * lj) ^ z) << 3)) = lo;
+                *reinterpret_cast<u32x2*>(tile(2, pc) + r * 128 + (((2 * lj + 1) ^ z) << 3)) = hi;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (it + 1 < TATTN_SPLIT_ITEMS) fetch(w0 + it + 1);
+
+        f32x4 st = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int term = 0; term < 3; ++term) {       // (k piece, q piece): (0,1) (1,0) (0,0)
+            const int kp = term == 1 ? 1 : 0, qp = term == 0 ? 1 : 0;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int off = c * 128 + (((g + 4 * s) ^ (c & 7)) << 4);
+                st = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_h16x8(ld16(tile(1, kp) + off)), as_h16x8(ld16(tile(0, qp) + off)), st, 0, 0, 0);
+            }
+        }
+        float sc[4];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { sc[i] = (4 * g + i < T) ? st[i] * scale : -INFINITY; mx = fmaxf(mx, sc[i]); }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+        union { mf4s m; h16 e[4]; } p0, p1;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float pv = expf(sc[i] - mx);
+            sum += pv;
+            p0.e[i] = (h16)pv;
+            p1.e[i] = (h16)(pv - (float)p0.e[i]);
+        }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+
+        float ov[16];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            union { mf4s m4; unsigned short e[4]; } v0, v1;
+            const int u = (8 * (m >> 1) + 2 * (c >> 2) + (m & 1)) ^ fz(g);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int off = (4 * g + j) * 128 + (u << 3) + 2 * (c & 3);
+                v0.e[j] = *reinterpret_cast<const unsigned short*>(tile(2, 0) + off);
+                v1.e[j] = *reinterpret_cast<const unsigned short*>(tile(2, 1) + off);
+            }
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(v0.m4, p1.m, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(v1.m4, p0.m, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(v0.m4, p0.m, acc, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ov[4 * m + i] = acc[i] / sum;
+        }
+        if (c < T) {
+            h16* dst = O + (pix + (int64_t)c * HW) * ldo + h * 64 + g * 8;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                float o8[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o8[e] = ov[half * 8 + e];
+                store8_operand(dst + half * 32, ldo / PLANES, o8);
+            }
+        }
+    }
+}
+#endif
 #endif  // MUDG_PLANES > 1
 
 }  // namespace
@@ -1653,6 +1794,14 @@ extern "C" int mudg_temporal_attention(const void* QKV, void* O, int B, int T, i
     const int slot = mudg_prof_begin(MUDG_FAM_TATTN, s);
 #if MUDG_PLANES > 1
     const unsigned grid = (unsigned)((total + 3) / 4);
+#if MUDG_PLANES == 2
+    static int use_mfma = -1;               // MUDG_TATTN_MFMA=0: the fp32 FMA kernel for every length (A/B, tests)
+    if (use_mfma < 0) use_mfma = mudg_variant("TATTN_MFMA", 1);
+    if (T <= 16 && use_mfma)
+        hipLaunchKernelGGL(tattn_split_mfma_kernel, dim3((unsigned)((total + 4 * TATTN_SPLIT_ITEMS - 1) / (4 * TATTN_SPLIT_ITEMS))), dim3(256), 0, s,
+                           (const h16*)QKV, (h16*)O, B, T, HW, heads, ldqkv, ldo, scale, (int)total);
+    else
+#endif
     if (T <= 16)
         hipLaunchKernelGGL(tattn_split_kernel<16>, dim3(grid), dim3(256), 0, s, (const h16*)QKV, (h16*)O, B, T, HW, heads,
                            ldqkv, ldo, scale, (int)total);

@@ -57,8 +57,8 @@ template <> struct Load8<float> {
 // parallelism relies on bit-identical per-clip results, tests/test_fullsize_gpu.py).
 __host__ __device__ inline int gn_chunks(int samples, int rows) {
     (void)samples;
-    int want = rows / 64;
-    if (want > 1024) want = 1024;
+    int want = rows / (rows >= 2048 ? 64 : 16);      // short samples (the 576- and 144-pixel levels): 16-row chunks, or 64 .. 288 workgroups
+    if (want > 1024) want = 1024;                    //   walk 47 .. 94 MB (1.6 TB/s measured)
     return want < 1 ? 1 : want;
 }
 
@@ -450,56 +450,85 @@ __global__ __launch_bounds__(256) void ln_kernel(const T* __restrict__ X, int ld
     }
 }
 
-// LayerNorm for the UNet's widths (C a multiple of 8 * LPR): LPR lanes per row, 64 / LPR rows per wave, NV 16-byte vectors
-// per lane.  The one-wave-per-row kernel above keeps a single 16-byte load per lane in flight and, at C = 320, only 40 of
-// its 64 lanes busy; here every lane has NV loads outstanding (a wave requests 64 / LPR whole rows at once), the lanes
-// of a row read consecutive 16-byte vectors (128 B per request at LPR = 8), the two reductions take log2(LPR) butterfly
-// steps, and gamma / beta are fetched once per wave instead of once per row.
+// LayerNorm for the UNet's widths (C = 8 * LPR * NV): LPR lanes per row, 64 / LPR rows per wave, NV 16-byte vectors per lane.
+// Every request of a lane — its NV payload vectors AND the gamma / beta of its 8 NV channels — is issued before anything waits
+// (rounds 1-3 fetched gamma / beta inside the store loop: the compiler serialised them into seven L2 round trips per wave, and the
+// butterflies ran on ds_bpermute); the payload stays packed in registers and is decoded once per pass (sum, squared deviations,
+// apply), the two reductions are DPP steps inside a 16-lane row (+ one cross-row exchange at LPR = 32).  NV <= 5 keeps gamma /
+// beta at <= 80 registers: 320 = 8 x 5, 640 = 16 x 5, 1280 = 32 x 5, 512 = 16 x 4, 1024 = 32 x 4.
+template <int CTRL>
+__device__ __forceinline__ float ln_dpp_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+template <int LPR>
+__device__ __forceinline__ float ln_group_sum(float v) {       // every lane of an LPR-lane group ends with the group's total
+    v = ln_dpp_add<0xB1>(v);                                   // quad_perm [1,0,3,2]
+    v = ln_dpp_add<0x4E>(v);                                   // quad_perm [2,3,0,1]
+    v = ln_dpp_add<0x141>(v);                                  // row_half_mirror
+    if constexpr (LPR >= 16) v = ln_dpp_add<0x140>(v);         // row_mirror
+    if constexpr (LPR >= 32) v += __shfl_xor(v, 16, 64);
+    return v;
+}
+
 template <int LPR, int NV, typename T>
 __global__ __launch_bounds__(256) void ln_rows_kernel(const T* __restrict__ X, int ldx, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, h16* __restrict__ Y, int ldy,
                                                        int rows, float eps) {
     constexpr int RPW = 64 / LPR;                       // rows per wave
     constexpr int C = LPR * NV * 8;
+    constexpr int NR = Load8<T>::NR;
     const int lane = threadIdx.x & 63;
     const int sub = lane & (LPR - 1);
     int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / LPR;
     const bool live = row < rows;
-    if (!live) row = rows - 1;                          // keeps the butterflies uniform; nothing is stored for it
-    float x[NV][8];
+    if (!live) row = rows - 1;                          // keeps the reductions uniform; nothing is stored for it
+    u32x4 raw[NV][NR];
+    f32x4 g[NV][2], b[NV][2];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) Load8<T>::raw(X + row * ldx + (sub + LPR * i) * 8, ldx, raw[i]);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (sub + LPR * i) * 8;
+        g[i][0] = *reinterpret_cast<const f32x4*>(gamma + c); g[i][1] = *reinterpret_cast<const f32x4*>(gamma + c + 4);
+        b[i][0] = *reinterpret_cast<const f32x4*>(beta + c); b[i][1] = *reinterpret_cast<const f32x4*>(beta + c + 4);
+    }
+    __builtin_amdgcn_sched_barrier(0);                  // requests above, arithmetic below
+    // (and pinned in this unconditional block: left alone, the gamma / beta loads sink into the `live` branch that consumes them)
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        asm volatile("" : "+v"(g[i][0]), "+v"(g[i][1]), "+v"(b[i][0]), "+v"(b[i][1]));
+#pragma unroll
+        for (int k = 0; k < NR; ++k) asm volatile("" : "+v"(raw[i][k]));
+    }
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) Load8<T>::get(X + row * ldx + (sub + LPR * i) * 8, ldx, x[i]);
+    for (int i = 0; i < NV; ++i) {
+        float x[8];
+        Load8<T>::decode(raw[i], x);
 #pragma unroll
-    for (int i = 0; i < NV; ++i)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) s += x[i][e];
-#pragma unroll
-    for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-    const float mean = s / (float)C;
+        for (int e = 0; e < 8; ++e) s += x[e];
+    }
+    const float mean = ln_group_sum<LPR>(s) / (float)C;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < NV; ++i)
+    for (int i = 0; i < NV; ++i) {
+        float x[8];
+        Load8<T>::decode(raw[i], x);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { const float d = x[i][e] - mean; q = fmaf(d, d, q); }
-#pragma unroll
-    for (int o = LPR / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
-    const float rstd = rsqrtf(q / (float)C + eps);
+        for (int e = 0; e < 8; ++e) { const float d = x[e] - mean; q = fmaf(d, d, q); }
+    }
+    const float rstd = rsqrtf(ln_group_sum<LPR>(q) / (float)C + eps);
     if (!live) return;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        const int v = sub + LPR * i;
-        const f32x4 g0 = *reinterpret_cast<const f32x4*>(gamma + v * 8);
-        const f32x4 g1 = *reinterpret_cast<const f32x4*>(gamma + v * 8 + 4);
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(beta + v * 8);
-        const f32x4 b1 = *reinterpret_cast<const f32x4*>(beta + v * 8 + 4);
-        float o[8];
+        float x[8], o[8];
+        Load8<T>::decode(raw[i], x);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            o[e] = fmaf((x[i][e] - mean) * rstd, g0[e], b0[e]);
-            o[4 + e] = fmaf((x[i][4 + e] - mean) * rstd, g1[e], b1[e]);
+            o[e] = fmaf((x[e] - mean) * rstd, g[i][0][e], b[i][0][e]);
+            o[4 + e] = fmaf((x[4 + e] - mean) * rstd, g[i][1][e], b[i][1][e]);
         }
-        store8_operand(Y + row * ldy + v * 8, ldy / PLANES, o);
+        store8_operand(Y + row * ldy + (sub + LPR * i) * 8, ldy / PLANES, o);
     }
 }
 
@@ -621,10 +650,10 @@ extern "C" int mudg_layernorm(const void* X, int ldx, int x_fp32, const float* g
     static int rows_kernel = -1;            // MUDG_LN_ROWS=0: the one-wave-per-row kernel for every width (A/B, tests)
     if (rows_kernel < 0) rows_kernel = mudg_variant("LN_ROWS", 1);
     if (rows_kernel && C == 320) launch_ln_rows<8, 5>(x_fp32, X, ldx, gamma, beta, Y, ldy, rows, eps, s);
-    else if (rows_kernel && C == 512) launch_ln_rows<8, 8>(x_fp32, X, ldx, gamma, beta, Y, ldy, rows, eps, s);
-    else if (rows_kernel && C == 640) launch_ln_rows<8, 10>(x_fp32, X, ldx, gamma, beta, Y, ldy, rows, eps, s);
-    else if (rows_kernel && C == 1024) launch_ln_rows<16, 8>(x_fp32, X, ldx, gamma, beta, Y, ldy, rows, eps, s);
-    else if (rows_kernel && C == 1280) launch_ln_rows<16, 10>(x_fp32, X, ldx, gamma, beta, Y, ldy, rows, eps, s);
+    else if (rows_kernel && C == 512) launch_ln_rows<16, 4>(x_fp32, X, ldx, gamma, beta, Y, ldy, rows, eps, s);
+    else if (rows_kernel && C == 640) launch_ln_rows<16, 5>(x_fp32, X, ldx, gamma, beta, Y, ldy, rows, eps, s);
+    else if (rows_kernel && C == 1024) launch_ln_rows<32, 4>(x_fp32, X, ldx, gamma, beta, Y, ldy, rows, eps, s);
+    else if (rows_kernel && C == 1280) launch_ln_rows<32, 5>(x_fp32, X, ldx, gamma, beta, Y, ldy, rows, eps, s);
     else if (nvec <= 64 * 3) {
         if (x_fp32 == KIND_F16) hipLaunchKernelGGL((ln_kernel<3, StreamH>), grid, dim3(256), 0, s, (const StreamH*)X, ldx, gamma, beta, (h16*)Y, ldy, rows, C, eps);
         else if (x_fp32) hipLaunchKernelGGL((ln_kernel<3, float>), grid, dim3(256), 0, s, (const float*)X, ldx, gamma, beta, (h16*)Y, ldy, rows, C, eps);

@@ -31,6 +31,12 @@ rocprofv3 --kernel-trace --stats -d /tmp/pt -- python bench.py --steps 2 --warmu
 python tools/rocprof_summary.py trace $(find /tmp/pt -name "*.db" | head -1) > $OUT/kernel_trace.md
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pf -- python bench.py --steps 1 --warmup 0 --no-graph --no-cpu-baseline --no-profile --no-decode --no-children > /tmp/pf.log 2>&1
 python tools/rocprof_summary.py pmc $(find /tmp/pf -name "*.db" | head -1) > $OUT/pmc_fetch.md
+# the memory-bound families by launch geometry (= by shape), from the same eager step
+for k in gn_ ln_ tattn; do python tools/rocprof_summary.py grids $(find /tmp/pf -name "*.db" | head -1) $k; echo; done > $OUT/norm_grids_unet.md
+# the norm kernels alone on the UNet's shapes (tools/exp_norm.py), and their per-kernel durations
+rocprofv3 --kernel-trace -d /tmp/pnk -- python tools/exp_norm.py > $OUT/norm_kernels.txt 2>/dev/null
+for k in gn_ ln_; do python tools/rocprof_summary.py grids $(find /tmp/pnk -name "*.db" | head -1) $k; echo; done > $OUT/norm_grids_alone.md
+MUDG_DEBUG_VARIANTS=1 MUDG_GN_REG=0 python tools/exp_norm.py 2>/dev/null | grep fold > $OUT/norm_kernels_lds_table_apply.txt
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pw -- python bench.py --steps 1 --warmup 0 --no-graph --no-cpu-baseline --no-profile --no-decode --no-children > /tmp/pw.log 2>&1
 python tools/rocprof_summary.py pmc $(find /tmp/pw -name "*.db" | head -1) > $OUT/pmc_write.md
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d /tmp/pm -- python bench.py --steps 1 --warmup 0 --no-graph --no-cpu-baseline --no-profile --no-decode --no-children > /tmp/pm.log 2>&1
