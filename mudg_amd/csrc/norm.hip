@@ -62,37 +62,54 @@ __host__ __device__ inline int gn_chunks(int samples, int rows) {
     return want < 1 ? 1 : want;
 }
 
-// Pass 1: per (sample, row-chunk) per-group partial sum / sum of squares.
+// Vectors per sweep of the statistics pass: a divisor of nvec, <= 256; the largest one whose row classes (256 / nvp of them) keep
+// at least 240 lanes busy, else the one that keeps most busy.
+inline int gn_stats_sweep(int nvec) {
+    int best = 1, used = 0;
+    for (int d = nvec < 256 ? nvec : 256; d >= 1; --d) {
+        if (nvec % d) continue;
+        const int u = (256 / d) * d;
+        if (u >= 240) return d;
+        if (u > used) { used = u; best = d; }
+    }
+    return best;
+}
+
+// Pass 1: per (sample, row-chunk) per-group partial sum / sum of squares.  A workgroup takes the chunk's rows nvp channel vectors at a
+// time (gn_stats_sweep: the largest divisor of C / 8 that keeps >= 240 of the 256 lanes busy): thread (rsub, v) owns vector v of rows rsub, rsub + 256 / nvp, ... (240 of 256 lanes busy at 40 / 80 / 120
+// vectors per row; the first kernel gave a wave one row and 64 vectors, 40 of 64 lanes at C = 320), four requests in flight per lane,
+// the row classes of a vector folded through LDS in a fixed order, then channels -> groups.
 template <typename T>
 __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ X, const T* __restrict__ X2,
                                                         int csplit, int ldx, int ldx2, int rows, int C, int groups,
-                                                        int nchunks, float* __restrict__ part_out) {
-    __shared__ float part[4][64][16];
-    __shared__ float chsum[GN_CMAX * 2];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+                                                        int nchunks, int nvp, float* __restrict__ part_out) {
+    extern __shared__ float gn_lds[];
+    float* part = gn_lds;                               // [256][16]: a thread's eight sums and eight sums of squares
+    float* chsum = gn_lds + 256 * 16;                   // [C][2]
+    const int tid = threadIdx.x;
     const int chunk = blockIdx.x, smp = blockIdx.y;
     const int rpc = (rows + nchunks - 1) / nchunks;
     const int r0 = chunk * rpc, r1 = (r0 + rpc < rows) ? r0 + rpc : rows;
     const int nvec = C >> 3;
+    const int RP = 256 / nvp;                           // row classes (nvp: vectors per sweep, a divisor of nvec chosen by the host)
+    const int rsub = tid / nvp, vl = tid - rsub * nvp;
     const int64_t srow = (int64_t)smp * rows;
+    constexpr int NR = Load8<T>::NR;
 
-    for (int vbase = 0; vbase < nvec; vbase += 64) {
-        const int v = vbase + lane;
+    for (int vbase = 0; vbase < nvec; vbase += nvp) {
+        const int v = vbase + vl;
         float s[8], q[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
-        if (v < nvec) {
+        if (rsub < RP && v < nvec) {
             const int c0 = v * 8;
             const T* base = X; int cc = c0, ld = ldx;
             if (c0 >= csplit) { base = X2; cc = c0 - csplit; ld = ldx2; }
-            // four rows' requests in flight per lane (pinned before any is decoded, as in gn_apply_kernel); the rows are still
-            // accumulated in ascending order
-            for (int r = r0 + wave; r < r1; r += 16) {
-                constexpr int NR = Load8<T>::NR;
+            for (int r = r0 + rsub; r < r1; r += 4 * RP) {
                 u32x4 raw[4][NR];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const int rr = (r + 4 * u < r1) ? r + 4 * u : r;
+                    const int rr = (r + u * RP < r1) ? r + u * RP : r;
                     Load8<T>::raw(base + (srow + rr) * ld + cc, ld, raw[u]);
                 }
                 if constexpr (NR == 1) asm volatile("" : "+v"(raw[0][0]), "+v"(raw[1][0]), "+v"(raw[2][0]), "+v"(raw[3][0]));
@@ -103,7 +120,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ X, 
                 static_assert(NR <= 3, "the pin above lists its operands");
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    if (r + 4 * u >= r1) break;
+                    if (r + u * RP >= r1) break;
                     float xv[8];
                     Load8<T>::decode(raw[u], xv);
 #pragma unroll
@@ -112,15 +129,14 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const T* __restrict__ X, 
             }
         }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { part[wave][lane][e] = s[e]; part[wave][lane][8 + e] = q[e]; }
+        for (int e = 0; e < 8; ++e) { part[tid * 16 + e] = s[e]; part[tid * 16 + 8 + e] = q[e]; }
         __syncthreads();
-        for (int i = tid; i < 64 * 16; i += 256) {
+        for (int i = tid; i < nvp * 16; i += 256) {
             const int ln = i >> 4, j = i & 15;
-            const int vv = vbase + ln;
-            if (vv < nvec) {
-                const float t = ((part[0][ln][j] + part[1][ln][j]) + part[2][ln][j]) + part[3][ln][j];
-                const int ch = vv * 8 + (j & 7);
-                chsum[ch * 2 + (j >> 3)] = t;
+            if (vbase + ln < nvec) {
+                float t = 0.f;
+                for (int k = 0; k < RP; ++k) t += part[(k * nvp + ln) * 16 + j];
+                chsum[((vbase + ln) * 8 + (j & 7)) * 2 + (j >> 3)] = t;
             }
         }
         __syncthreads();
@@ -591,15 +607,17 @@ extern "C" int mudg_groupnorm(const void* X, const void* X2, int csplit, int ldx
     float* part = ws;
     float* stat = ws + (int64_t)samples * nchunks * groups * 2;
     const int slot = mudg_prof_begin(MUDG_FAM_GNORM, s);
+    const size_t stats_lds = (256 * 16 + 2 * (size_t)C) * sizeof(float);
+    const int nvp = gn_stats_sweep(C >> 3);
     if (x_fp32 == KIND_F16)
-        hipLaunchKernelGGL(gn_stats_kernel<StreamH>, dim3(nchunks, samples), dim3(256), 0, s, (const StreamH*)X, (const StreamH*)X2,
-                           csplit, ldx, ldx2, rows, C, groups, nchunks, part);
+        hipLaunchKernelGGL(gn_stats_kernel<StreamH>, dim3(nchunks, samples), dim3(256), stats_lds, s, (const StreamH*)X, (const StreamH*)X2,
+                           csplit, ldx, ldx2, rows, C, groups, nchunks, nvp, part);
     else if (x_fp32)
-        hipLaunchKernelGGL(gn_stats_kernel<float>, dim3(nchunks, samples), dim3(256), 0, s, (const float*)X, (const float*)X2,
-                           csplit, ldx, ldx2, rows, C, groups, nchunks, part);
+        hipLaunchKernelGGL(gn_stats_kernel<float>, dim3(nchunks, samples), dim3(256), stats_lds, s, (const float*)X, (const float*)X2,
+                           csplit, ldx, ldx2, rows, C, groups, nchunks, nvp, part);
     else
-        hipLaunchKernelGGL(gn_stats_kernel<h16>, dim3(nchunks, samples), dim3(256), 0, s, (const h16*)X, (const h16*)X2,
-                           csplit, ldx, ldx2, rows, C, groups, nchunks, part);
+        hipLaunchKernelGGL(gn_stats_kernel<h16>, dim3(nchunks, samples), dim3(256), stats_lds, s, (const h16*)X, (const h16*)X2,
+                           csplit, ldx, ldx2, rows, C, groups, nchunks, nvp, part);
     const int ng = samples * groups;
     hipLaunchKernelGGL(gn_finalize_kernel, dim3((ng + 3) / 4), dim3(256), 0, s, part, stat, samples, groups, nchunks,
                        (double)rows * (C / groups), eps);

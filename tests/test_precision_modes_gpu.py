@@ -52,7 +52,7 @@ def test_parity_suites_in_operand_mode(cuda, mode):
     skip = {} if (CUT in suites or mode == "fp16") else {"MUDG_SKIP_FULLSIZE_ORACLE": "1", "MUDG_SKIP_CONFIG0_CUT": "1"}
     env = dict(os.environ, MUDG_PARITY_CHILD="1", **env_add, **skip)
     r = subprocess.run([sys.executable, "-m", "pytest", *suites, "-m", "gpu", "-q", "-s", "-p", "no:cacheprovider"],
-                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=2700)
     tail = "\n".join(l for l in r.stdout.splitlines() if "rel-L2" in l or "passed" in l or "failed" in l)
     print(tail)
     assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
