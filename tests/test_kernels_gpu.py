@@ -323,7 +323,7 @@ def test_groupnorm_two_sources(cuda):
     assert rel_l2(y, ref) < TOL_BF16
 
 
-@pytest.mark.parametrize("rows,c", [(10, 320), (77, 1280), (5, 2048), (3, 64), (9, 512)])
+@pytest.mark.parametrize("rows,c", [(10, 320), (77, 1280), (5, 2048), (3, 64), (9, 512), (33, 640), (7, 1024), (130, 320)])
 def test_layernorm(cuda, rows, c):
     from mudg_amd import ops
     x = (rnd(rows, c, seed=1).float() * 3 - 1).to(BF)
