@@ -227,6 +227,39 @@ __global__ __launch_bounds__(G::NTH, G::WIDE ? 2 : ((SB && !fused_planes(FAST)) 
             vx2[i] = (MODE == 0 && !rv[i]) ? OOB : (unsigned)rel * (unsigned)(X2 ? p.ldx2 : p.ldx) * 2u + cb;
         }
     }
+    // XSHARE (same-size stride-1 3x3 convs, slab-major K, the one-stage kernels): the taps (dy, 0), (dy, 1), (dy, 2) read the same
+    // 128 source pixels shifted by one, so the activation tile is staged ONCE per dy — the centre tap's tile plus one halo pixel on
+    // either side (a 1-KiB piece behind the W tile: row 0 = the pixel before the tile, row 1 = the pixel after it) — and the dx = 0 /
+    // dx = 2 K-steps fetch their weights only and read the fragments one row up / down.  144 -> 51 activation pieces per 64-channel
+    // slab; the stage stays 33 KiB (four workgroups per CU).  Rows whose tap leaves the image vertically are zero-filled by the DMA as
+    // before; a horizontal neighbour that belongs to the next image row is zeroed when the fragment is read (x == 0 / x == W - 1).
+    constexpr bool XSHARE_OK = MODE == 1 && FAST && SB && !FUSED && !G::WIDE && PLANES == 1;
+    const bool xshare = XSHARE_OK && (vflags & VF_XS);
+    unsigned xedge = 0;      // bits 0-3: x == 0 / x == W - 1 of the lane's two fragment rows; bits 8-10 (halo lanes): dy validity of their pixel
+    if constexpr (XSHARE_OK) if (xshare) {
+        if (wave == 0 && rsub < 2) {
+            const int rl = rsub == 0 ? 0 : BM - 1, dxh = rsub == 0 ? 0 : 2;
+            const int m = m0 + rl;
+            if (m < p.M) {
+                const int hw = p.Hout * p.Wout;
+                const int f = m / hw, r = m - f * hw;
+                const int oy = r / p.Wout, ox = r - oy * p.Wout;
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const int iy = oy - 1 + dy, ix = ox - 1 + dxh;
+                    if (iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win) xedge |= 256u << dy;
+                }
+            }
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int m = m0 + wm * 64 + mi * 32 + l31;
+            const int ox = m % p.Wout;
+            if (ox == 0) xedge |= 1u << (2 * mi);
+            if (ox == p.Wout - 1) xedge |= 2u << (2 * mi);
+        }
+    }
+    int dx_m = 0;                                                 // XSHARE: dx of the K-step being multiplied
 
     auto issue_fast = [&](int kt, int buf) {
         const bool s2 = c_s >= p.csplit;
@@ -248,13 +281,29 @@ __global__ __launch_bounds__(G::NTH, G::WIDE ? 2 : ((SB && !fused_planes(FAST)) 
 #pragma unroll
         for (int pl = 0; pl < XT; ++pl) {            // FUSED: piece pl of both operands into its own tile of the stage
             const int so = soff + pl * (ld / PLANES) * 2, sow = soffw + pl * (p.ldw / PLANES) * 2;
+            bool xstage = true;
+            int xtap = tap_s, sox = so;
+            if constexpr (XSHARE_OK) if (xshare) {
+                const int dy = tap_s / 3, dxs = tap_s - 3 * dy;
+                xstage = dxs == 0;                           // the dy group's first K-step stages the centre tile (+ halo) for all three
+                xtap = tap_s + 1;
+                sox = so + ld * 2;                           // centre tap: one pixel right of (dy, 0)
+                if (xstage && wave == 0) {                   // the halo piece: lanes rsub 0 / 1 fetch the pixel before / after the tile
+                    // lane rsub 0: the pixel before the tile (row 0 at tap (dy, 0)); rsub 1: the pixel after it (row 127 at tap (dy, 2))
+                    const unsigned v = (rsub < 2 && ((xedge >> (8 + dy)) & 1u)) ? (unsigned)(rsub ? BM + 1 : 0) * (unsigned)ld * 2u + (unsigned)slot * 16u : OOB;
+                    lptr_t lh = (lptr_t)(Ws + XT * TILE_W);
+                    if (s2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rX2, lh, 16, (int)v, so, 0, 0);
+                    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, lh, 16, (int)v, so, 0, 0);
+                }
+            }
+            if (xstage)
 #pragma unroll
             for (int i = 0; i < XI; ++i) {
                 unsigned v = s2 ? vx2[i] : vx[i];
-                if (MODE != 0) v = ((vmask[i] >> tap_s) & 1u) ? v : OOB;
+                if (MODE != 0) v = ((vmask[i] >> xtap) & 1u) ? v : OOB;
                 lptr_t lx = (lptr_t)(Xs + (buf * XT + pl) * TILE_X + (XROWS * wave + 8 * i) * LDSLD);
-                if (s2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rX2, lx, 16, (int)v, so, 0, 0);
-                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, lx, 16, (int)v, so, 0, 0);
+                if (s2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rX2, lx, 16, (int)v, sox, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, lx, 16, (int)v, sox, 0, 0);
             }
 #pragma unroll
             for (int i = 0; i < WI; ++i) {
@@ -373,6 +422,37 @@ __global__ __launch_bounds__(G::NTH, G::WIDE ? 2 : ((SB && !fused_planes(FAST)) 
                             acc[ni][mi] = MFMA_32x32x16(wf[wp][ni], xf[xp][mi], acc[ni][mi]);
                 }
             }
+            return;
+        }
+        if constexpr (XSHARE_OK) {
+            // XSHARE: fragment rows one up / down from the staged centre tile (d = dx - 1); the tile's first / last row reaches into
+            // the halo piece (rows 0 / 1 behind the W tile), a row whose neighbour belongs to another image row reads that piece's
+            // row 2, which the DMA zero-filled.  Without XSHARE d = 0 and no edges: the plain fragment rows.
+            const int d = xshare ? dx_m - 1 : 0;
+            int xo[MI];                                  // element offset from Xs | swizzle key << 20
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int rr = wm * 64 + mi * 32 + l31 + d;
+                const int hs = TILE_X + XT * TILE_W;      // the halo piece, in elements from Xs
+                const bool edge = (d < 0 && ((xedge >> (2 * mi)) & 1u)) || (d > 0 && ((xedge >> (2 * mi)) & 2u));
+                xo[mi] = edge ? hs + 2 * LDSLD : (rr < 0 ? hs : (rr >= BM ? hs + LDSLD : (rr * LDSLD) | (((rr >> 1) & 7) << 20)));
+            }
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                const int off = ((ks * 2 + hi) ^ sw) << 3;
+                h16x8 wf[NI], xf[MI];
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) wf[ni] = *reinterpret_cast<const h16x8*>(ws + G::nioff(ni) * 32 * LDSLD + off);
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+                    xf[mi] = *reinterpret_cast<const h16x8*>(Xs + cur * XT * TILE_X + (xo[mi] & 0xfffff) + (((ks * 2 + hi) ^ (xo[mi] >> 20)) << 3));
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi)
+                        acc[ni][mi] = MFMA_32x32x16(wf[ni], xf[mi], acc[ni][mi]);
+            }
+            dx_m = dx_m == 2 ? 0 : dx_m + 1;
             return;
         }
 #pragma unroll
@@ -949,7 +1029,12 @@ bool use_single_buffer(const MudgGemmDesc& d) {
     if (mode == 0) return false;
     if (mode == 2) return true;
     const int64_t tiles = (int64_t)((d.M + G128::BM - 1) / G128::BM) * ((d.N + G128::BN - 1) / G128::BN) * d.batch;
-    return tiles >= (d.mode == 1 ? 2048 : 768);
+    // (3x3 convs whose dx taps share a staged tile — XSHARE, one-stage kernel only — switch at half the tile count: 18432 x 1280 x
+    //  11520 551 -> 530 us, x 23040 1072 -> 1040; 4608 rows stay on the two-stage kernel, 170 against 224 us.  Both kernels add the
+    //  same products in the same order: the choice changes no bits.)
+    const bool xs = PLANES == 1 && d.mode == 1 && d.korder && !d.subpixel && !d.upsample && d.stride == 1 && d.pad == 1 && d.Hin == d.Hout &&
+                    d.Win == d.Wout;
+    return tiles >= (d.mode == 1 ? (xs ? 1024 : 2048) : 768);
 }
 
 // Variant switch GEMM_PERSIST=0: the non-persistent 128 x 128 kernels (A/B measurements); 2 / 3 / 4: that many persistent
@@ -1114,6 +1199,13 @@ extern "C" int mudg_gemm(const MudgGemmDesc* dp, void* stream) {
     const int rbytes = d.res_fp32 == KIND_F32 ? 4 : 2;
     if (d.R && aligned16(d.R) && ((int64_t)d.ldr * rbytes) % (d.res_fp32 ? 16 : 16 * PLANES) == 0 && ((int64_t)d.sR * rbytes) % 16 == 0) vflags |= VF_R;
 
+    {   // XSHARE (see gemm_kernel): same-size stride-1 3x3 convs with the slab-major K order.  Variant switch CONV_XSHARE=0: off.
+        static int xs = -1;
+        if (xs < 0) xs = mudg_variant("CONV_XSHARE", 1);
+        if (xs && d.mode == 1 && d.korder && !d.subpixel && !d.upsample && d.stride == 1 && d.pad == 1 && d.Hin == d.Hout && d.Win == d.Wout &&
+            d.K == 9 * d.Cin && (d.Cin & 63) == 0)
+            vflags |= VF_XS;
+    }
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     const int fam = d.mode == 0 ? MUDG_FAM_GEMM : (d.mode == 1 ? MUDG_FAM_CONV : MUDG_FAM_TCONV);
     const int slot = mudg_prof_begin(fam, s);
