@@ -296,6 +296,9 @@ __global__ __launch_bounds__(G::NTH, G::WIDE ? 2 : ((SB && !fused_planes(FAST)) 
                     else __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, lh, 16, (int)v, so, 0, 0);
                 }
             }
+#ifdef GEMM_EXP_NOX      // ablation (wrong results, profiles/r4/ablation_fetch_first_ktile_only.txt): activation tiles fetched for K-tile 0 only
+            xstage = xstage && kt == 0;
+#endif
             if (xstage)
 #pragma unroll
             for (int i = 0; i < XI; ++i) {
@@ -305,6 +308,9 @@ __global__ __launch_bounds__(G::NTH, G::WIDE ? 2 : ((SB && !fused_planes(FAST)) 
                 if (s2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rX2, lx, 16, (int)v, sox, 0, 0);
                 else __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, lx, 16, (int)v, sox, 0, 0);
             }
+#ifdef GEMM_EXP_NOW      // ablation (wrong results): weight tiles fetched for K-tile 0 only
+            if (kt == 0)
+#endif
 #pragma unroll
             for (int i = 0; i < WI; ++i) {
                 // W rows beyond N are never multiplied (their waves are idle, see wave_live): skip the zero-fill pieces
