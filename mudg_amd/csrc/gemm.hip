@@ -69,7 +69,8 @@ template <typename G> constexpr int stage_elems(bool fast) { return (fused_plane
 template <typename G> constexpr int epi_rows(bool fast, bool sb) { return (G::WIDE || sb || fused_planes(fast)) ? 64 : G::BM; }
 constexpr int WSTG = 132;                        // wide tiles: fp32 per staging row of a 128-column pass (128 + 4 pad)
 template <typename G> constexpr int smem_main(bool fast, bool sb) {
-    const int loop = ((sb || fused_planes(fast)) ? 1 : 2) * stage_elems<G>(fast) * 2;
+    const bool one = sb || fused_planes(fast);
+    const int loop = (one ? 1 : 2) * stage_elems<G>(fast) * 2 + ((one && !G::WIDE) ? 1024 * (fused_planes(fast) ? PLANES : 1) : 0);   // + XSHARE's halo pieces
     const int stg = G::WIDE ? G::BM * WSTG * 4 + G::BN * 4 : epi_rows<G>(fast, sb) * G::STGLD * 4 + G::BN * 4;
     return loop > stg ? loop : stg;
 }
@@ -233,7 +234,7 @@ __global__ __launch_bounds__(G::NTH, G::WIDE ? 2 : ((SB && !fused_planes(FAST)) 
     // dx = 2 K-steps fetch their weights only and read the fragments one row up / down.  144 -> 51 activation pieces per 64-channel
     // slab; the stage stays 33 KiB (four workgroups per CU).  Rows whose tap leaves the image vertically are zero-filled by the DMA as
     // before; a horizontal neighbour that belongs to the next image row is zeroed when the fragment is read (x == 0 / x == W - 1).
-    constexpr bool XSHARE_OK = MODE == 1 && FAST && SB && !FUSED && !G::WIDE && PLANES == 1;
+    constexpr bool XSHARE_OK = MODE == 1 && FAST && ONEBUF && !G::WIDE && PLANES <= 2;      // the one-stage kernels: SB (16-bit builds), fused pieces (bf16x3)
     const bool xshare = XSHARE_OK && (vflags & VF_XS);
     unsigned xedge = 0;      // bits 0-3: x == 0 / x == W - 1 of the lane's two fragment rows; bits 8-10 (halo lanes): dy validity of their pixel
     if constexpr (XSHARE_OK) if (xshare) {
@@ -291,7 +292,7 @@ __global__ __launch_bounds__(G::NTH, G::WIDE ? 2 : ((SB && !fused_planes(FAST)) 
                 if (xstage && wave == 0) {                   // the halo piece: lanes rsub 0 / 1 fetch the pixel before / after the tile
                     // lane rsub 0: the pixel before the tile (row 0 at tap (dy, 0)); rsub 1: the pixel after it (row 127 at tap (dy, 2))
                     const unsigned v = (rsub < 2 && ((xedge >> (8 + dy)) & 1u)) ? (unsigned)(rsub ? BM + 1 : 0) * (unsigned)ld * 2u + (unsigned)slot * 16u : OOB;
-                    lptr_t lh = (lptr_t)(Ws + XT * TILE_W);
+                    lptr_t lh = (lptr_t)(Ws + XT * TILE_W + pl * 512);
                     if (s2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rX2, lh, 16, (int)v, so, 0, 0);
                     else __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, lh, 16, (int)v, so, 0, 0);
                 }
@@ -404,6 +405,60 @@ __global__ __launch_bounds__(G::NTH, G::WIDE ? 2 : ((SB && !fused_planes(FAST)) 
         if (!wave_live) return;
         const h16* xs = Xs + cur * XT * TILE_X + (wm * 64 + l31) * LDSLD;
         const h16* ws = Ws + cur * XT * TILE_W + (wn * (32 * G::WSTRIDE) + l31) * LDSLD;
+        if constexpr (XSHARE_OK) {
+            // XSHARE: fragment rows one up / down from the staged centre tile (d = dx - 1); the tile's first / last row reaches into
+            // the halo piece (rows 0 / 1 behind the W tiles, one piece per plane), a row whose neighbour belongs to another image row
+            // reads that piece's row 2, which the DMA zero-filled.  Without XSHARE d = 0 and no edges: the plain fragment rows.
+            const int d = xshare ? dx_m - 1 : 0;
+            int xo[MI];                                  // element offset inside a plane's tile (or from the plane's halo piece, bit 19) | swizzle key << 20
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+                const int rr = wm * 64 + mi * 32 + l31 + d;
+                const bool edge = (d < 0 && ((xedge >> (2 * mi)) & 1u)) || (d > 0 && ((xedge >> (2 * mi)) & 2u));
+                xo[mi] = edge ? (1 << 19) + 2 * LDSLD : (rr < 0 ? (1 << 19) : (rr >= BM ? (1 << 19) + LDSLD : (rr * LDSLD) | (((rr >> 1) & 7) << 20)));
+            }
+            auto xfrag = [&](int pl, int mi, int ks) {
+                const int o = xo[mi] & 0x7ffff;
+                const h16* base = (xo[mi] & (1 << 19)) ? Ws + XT * TILE_W + pl * 512 : Xs + (cur * XT + pl) * TILE_X;
+                return *reinterpret_cast<const h16x8*>(base + o + (((ks * 2 + hi) ^ (xo[mi] >> 20)) << 3));
+            };
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                const int off = ((ks * 2 + hi) ^ sw) << 3;
+                if constexpr (FUSED) {
+                    h16x8 wf[2][NI], xf[2][MI];
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl) {
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni) wf[pl][ni] = *reinterpret_cast<const h16x8*>(ws + pl * TILE_W + G::nioff(ni) * 32 * LDSLD + off);
+#pragma unroll
+                        for (int mi = 0; mi < MI; ++mi) xf[pl][mi] = xfrag(pl, mi, ks);
+                    }
+#pragma unroll
+                    for (int term = 0; term < 3; ++term) {
+                        const int wp = term == 1 ? 1 : 0, xp = term == 0 ? 1 : 0;
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                            for (int mi = 0; mi < MI; ++mi)
+                                acc[ni][mi] = MFMA_32x32x16(wf[wp][ni], xf[xp][mi], acc[ni][mi]);
+                    }
+                } else {
+                    h16x8 wf[NI], xf[MI];
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) wf[ni] = *reinterpret_cast<const h16x8*>(ws + G::nioff(ni) * 32 * LDSLD + off);
+#pragma unroll
+                    for (int mi = 0; mi < MI; ++mi) xf[mi] = xfrag(0, mi, ks);
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                        for (int mi = 0; mi < MI; ++mi)
+                            acc[ni][mi] = MFMA_32x32x16(wf[ni], xf[mi], acc[ni][mi]);
+                }
+            }
+            dx_m = dx_m == 2 ? 0 : dx_m + 1;
+            return;
+        }
         if constexpr (FUSED) {
             // x = x0 + x1, w = w0 + w1 (bf16 pieces): x1 w0 + x0 w1 + x0 w0 per fragment pair — the bf16 x bf16 products are
             // exact in the fp32 accumulator; what is dropped (x1 w1) is 2^-18 relative.  Small terms first within a k-step.
@@ -428,37 +483,6 @@ __global__ __launch_bounds__(G::NTH, G::WIDE ? 2 : ((SB && !fused_planes(FAST)) 
                             acc[ni][mi] = MFMA_32x32x16(wf[wp][ni], xf[xp][mi], acc[ni][mi]);
                 }
             }
-            return;
-        }
-        if constexpr (XSHARE_OK) {
-            // XSHARE: fragment rows one up / down from the staged centre tile (d = dx - 1); the tile's first / last row reaches into
-            // the halo piece (rows 0 / 1 behind the W tile), a row whose neighbour belongs to another image row reads that piece's
-            // row 2, which the DMA zero-filled.  Without XSHARE d = 0 and no edges: the plain fragment rows.
-            const int d = xshare ? dx_m - 1 : 0;
-            int xo[MI];                                  // element offset from Xs | swizzle key << 20
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
-                const int rr = wm * 64 + mi * 32 + l31 + d;
-                const int hs = TILE_X + XT * TILE_W;      // the halo piece, in elements from Xs
-                const bool edge = (d < 0 && ((xedge >> (2 * mi)) & 1u)) || (d > 0 && ((xedge >> (2 * mi)) & 2u));
-                xo[mi] = edge ? hs + 2 * LDSLD : (rr < 0 ? hs : (rr >= BM ? hs + LDSLD : (rr * LDSLD) | (((rr >> 1) & 7) << 20)));
-            }
-#pragma unroll
-            for (int ks = 0; ks < BK / 16; ++ks) {
-                const int off = ((ks * 2 + hi) ^ sw) << 3;
-                h16x8 wf[NI], xf[MI];
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni) wf[ni] = *reinterpret_cast<const h16x8*>(ws + G::nioff(ni) * 32 * LDSLD + off);
-#pragma unroll
-                for (int mi = 0; mi < MI; ++mi)
-                    xf[mi] = *reinterpret_cast<const h16x8*>(Xs + cur * XT * TILE_X + (xo[mi] & 0xfffff) + (((ks * 2 + hi) ^ (xo[mi] >> 20)) << 3));
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-                    for (int mi = 0; mi < MI; ++mi)
-                        acc[ni][mi] = MFMA_32x32x16(wf[ni], xf[mi], acc[ni][mi]);
-            }
-            dx_m = dx_m == 2 ? 0 : dx_m + 1;
             return;
         }
 #pragma unroll
