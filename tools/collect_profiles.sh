@@ -20,6 +20,9 @@ MUDG_ATTN_FP8=1 python bench.py --no-cpu-baseline --no-children 2>/dev/null | ta
 # same box, same library (the debug-variants build): the one-tile contraction kernels only vs the shipped selection rule
 MUDG_DEBUG_VARIANTS=1 MUDG_GEMM_PERSIST=0 python bench.py --no-cpu-baseline --no-children --steps 10 --warmup 3 2>/dev/null | tail -1 > $OUT/bench_onetile_kernels.json
 MUDG_DEBUG_VARIANTS=1 MUDG_GEMM_PERSIST=1 python bench.py --no-cpu-baseline --no-children --steps 10 --warmup 3 2>/dev/null | tail -1 > $OUT/bench_persistent_rule.json
+# same box, same library: the 3x3 convs without / with the shared activation stage of their dx taps (XSHARE)
+MUDG_DEBUG_VARIANTS=1 MUDG_CONV_XSHARE=0 python bench.py --no-cpu-baseline --no-children --steps 10 --warmup 3 2>/dev/null | tail -1 > $OUT/bench_conv_unshared.json
+MUDG_DEBUG_VARIANTS=1 MUDG_CONV_XSHARE=1 python bench.py --no-cpu-baseline --no-children --steps 10 --warmup 3 2>/dev/null | tail -1 > $OUT/bench_conv_xshare.json
 # the CPU baseline as a measurement: one full MDM512 oracle forward on this host
 if [ "$2" = "cpufull" ]; then
   python bench.py --steps 3 --warmup 1 --cpu-baseline full --no-decode 2>/dev/null | tail -1 | python -c "
