@@ -230,7 +230,7 @@ __global__ __launch_bounds__(G::NTH, G::WIDE ? 2 : ((SB && !fused_planes(FAST)) 
     }
     // XSHARE (same-size stride-1 3x3 convs, slab-major K, the one-stage kernels): the taps (dy, 0), (dy, 1), (dy, 2) read the same
     // 128 source pixels shifted by one, so the activation tile is staged ONCE per dy — the centre tap's tile plus one halo pixel on
-    // either side (a 1-KiB piece behind the W tile: row 0 = the pixel before the tile, row 1 = the pixel after it) — and the dx = 0 /
+    // either side (a 1-KiB piece behind the W tile: row 7 = the pixel before the tile, row 0 = the pixel after it, rows 1 - 6 zero) — and the dx = 0 /
     // dx = 2 K-steps fetch their weights only and read the fragments one row up / down.  144 -> 51 activation pieces per 64-channel
     // slab; the stage stays 33 KiB (four workgroups per CU).  Rows whose tap leaves the image vertically are zero-filled by the DMA as
     // before; a horizontal neighbour that belongs to the next image row is zeroed when the fragment is read (x == 0 / x == W - 1).
@@ -238,8 +238,8 @@ __global__ __launch_bounds__(G::NTH, G::WIDE ? 2 : ((SB && !fused_planes(FAST)) 
     const bool xshare = XSHARE_OK && (vflags & VF_XS);
     unsigned xedge = 0;      // bits 0-3: x == 0 / x == W - 1 of the lane's two fragment rows; bits 8-10 (halo lanes): dy validity of their pixel
     if constexpr (XSHARE_OK) if (xshare) {
-        if (wave == 0 && rsub < 2) {
-            const int rl = rsub == 0 ? 0 : BM - 1, dxh = rsub == 0 ? 0 : 2;
+        if (wave == 0 && (rsub == 0 || rsub == 7)) {       // piece row 7: the pixel before the tile; piece row 0: the pixel after it
+            const int rl = rsub == 7 ? 0 : BM - 1, dxh = rsub == 7 ? 0 : 2;
             const int m = m0 + rl;
             if (m < p.M) {
                 const int hw = p.Hout * p.Wout;
@@ -290,8 +290,10 @@ __global__ __launch_bounds__(G::NTH, G::WIDE ? 2 : ((SB && !fused_planes(FAST)) 
                 xtap = tap_s + 1;
                 sox = so + ld * 2;                           // centre tap: one pixel right of (dy, 0)
                 if (xstage && wave == 0) {                   // the halo piece: lanes rsub 0 / 1 fetch the pixel before / after the tile
-                    // lane rsub 0: the pixel before the tile (row 0 at tap (dy, 0)); rsub 1: the pixel after it (row 127 at tap (dy, 2))
-                    const unsigned v = (rsub < 2 && ((xedge >> (8 + dy)) & 1u)) ? (unsigned)(rsub ? BM + 1 : 0) * (unsigned)ld * 2u + (unsigned)slot * 16u : OOB;
+                    // lanes rsub 7: the pixel before the tile (row 0 at tap (dy, 0)), stored like a row -1 (odd row, swizzle key 7); rsub 0: the
+                    // pixel after it (row BM - 1 at tap (dy, 2)), like a row BM (even, key 0); rows 1 - 6 of the piece are zero-filled
+                    const unsigned v = ((rsub == 0 || rsub == 7) && ((xedge >> (8 + dy)) & 1u))
+                                       ? (unsigned)(rsub == 0 ? BM + 1 : 0) * (unsigned)ld * 2u + (unsigned)(slot ^ (rsub == 7 ? 7 : 0)) * 16u : OOB;
                     lptr_t lh = (lptr_t)(Ws + XT * TILE_W + pl * 512);
                     if (s2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rX2, lh, 16, (int)v, so, 0, 0);
                     else __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, lh, 16, (int)v, so, 0, 0);
@@ -407,15 +409,18 @@ __global__ __launch_bounds__(G::NTH, G::WIDE ? 2 : ((SB && !fused_planes(FAST)) 
         const h16* ws = Ws + cur * XT * TILE_W + (wn * (32 * G::WSTRIDE) + l31) * LDSLD;
         if constexpr (XSHARE_OK) {
             // XSHARE: fragment rows one up / down from the staged centre tile (d = dx - 1); the tile's first / last row reaches into
-            // the halo piece (rows 0 / 1 behind the W tiles, one piece per plane), a row whose neighbour belongs to another image row
-            // reads that piece's row 2, which the DMA zero-filled.  Without XSHARE d = 0 and no edges: the plain fragment rows.
+            // the halo piece (rows 7 / 0 behind the W tiles, one piece per plane), a row whose neighbour belongs to another image row
+            // reads one of that piece's zero rows.  Without XSHARE d = 0 and no edges: the plain fragment rows.
             const int d = xshare ? dx_m - 1 : 0;
             int xo[MI];                                  // element offset inside a plane's tile (or from the plane's halo piece, bit 19) | swizzle key << 20
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {
                 const int rr = wm * 64 + mi * 32 + l31 + d;
                 const bool edge = (d < 0 && ((xedge >> (2 * mi)) & 1u)) || (d > 0 && ((xedge >> (2 * mi)) & 2u));
-                xo[mi] = edge ? (1 << 19) + 2 * LDSLD : (rr < 0 ? (1 << 19) : (rr >= BM ? (1 << 19) + LDSLD : (rr * LDSLD) | (((rr >> 1) & 7) << 20)));
+                // every substitute row keeps the bank pattern of the row it stands for (row parity and swizzle key): conflict-free reads
+                const int key = ((rr >> 1) & 7) << 20;
+                xo[mi] = edge ? ((1 << 19) + (2 + (rr & 1)) * LDSLD) | key
+                              : (rr < 0 ? ((1 << 19) + 7 * LDSLD) | key : (rr >= BM ? (1 << 19) | key : (rr * LDSLD) | key));
             }
             auto xfrag = [&](int pl, int mi, int ks) {
                 const int o = xo[mi] & 0x7ffff;
