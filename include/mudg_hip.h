@@ -93,7 +93,11 @@ typedef struct MudgGemmDesc {
                              downsample, which pads (0,1,0,1): only bottom/right, ae_modules.py:104-106) */
     int korder;           /* mode 1: 0 = W's K axis is [tap][Cin]; 1 = [Cin/64][tap][64] (needs Cin % 64 == 0): the nine
                              taps of a 64-channel slab are consecutive K tiles, so the shifted re-reads of the input
-                             hit L2 instead of coming back after a whole sweep over Cin */
+                             hit L2 instead of coming back after a whole sweep over Cin.
+                             mode 2: 1 = the same slab-major order [Cin/64][tap][64]; needs T = 16, HW % 8 == 0, Cin % 64 == 0, one
+                             source, the 16-bit or bf16x3 builds.  A 128-row tile is then 8 pixels x 16 frames of one clip (the
+                             three temporal taps of a row are rows of the same tile), and `stats` blocks are those TILES, in
+                             clip order: only a clip-level GroupNorm may fold them */
     /* mode 2 */
     int T, HW;
     float* stats;         /* NULL, or fp32 [ceil(M/128)][Nout][2]: the epilogue also writes, per 128-row block and output

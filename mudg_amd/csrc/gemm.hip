@@ -135,11 +135,27 @@ __global__ __launch_bounds__(G::NTH, G::WIDE ? 2 : ((SB && !fused_planes(FAST)) 
         tm = first + (r - tn * gsz);
     }
     const int m0 = tm * BM, n0 = tn * BN;
+    // TMAP (temporal convs of 16-frame clips, slab-major K; host flag VF_TM): tile tm is NOT 128 consecutive rows but 8 pixels x 16
+    // frames of one clip — logical row r of the tile is frame r / 8, pixel r % 8 — so that the three temporal taps of an output row
+    // are rows of the SAME tile, 8 up / down.  The one-stage kernels then stage the activation tile once per 64-channel slab for all
+    // three taps (TSHARE: 48 -> 16 activation pieces per slab; frames -1 and 16 are the zero rows of a spare piece); every kernel
+    // maps rows this way when the flag is set (loader, residual, result, GroupNorm partial blocks), so that the partial sums a
+    // consumer folds do not depend on which kernel ran.
+    constexpr bool TMAP_OK = MODE == 2 && FAST && !G::WIDE && PLANES <= 2 && BM == 128;
+    const bool tmap = TMAP_OK && (vflags & VF_TM);
+    auto phys = [&](int64_t m) -> int64_t {            // logical row -> row of X / Y / R
+        if constexpr (!TMAP_OK) return m;
+        if (!tmap) return m;
+        const int64_t t_ = m >> 7; const int r = (int)(m & 127);
+        const int per = p.HW >> 3;                     // tiles per clip
+        const int64_t b = t_ / per; const int pb = (int)(t_ - b * per);
+        return (b * p.T + (r >> 3)) * p.HW + pb * 8 + (r & 7);
+    };
     const int64_t bz = blockIdx.z;
     // Sub-pixel form of "nearest-2x upsample, then 3x3 conv" (MudgGemmDesc.subpixel): batch entry z = 2 py + px computes the
     // output pixels (2 oy + py, 2 ox + px) from the 2x2 low-resolution neighbourhood that their nine taps collapse onto.
     const bool sub = MODE == 1 && p.subpixel;
-    const int ntaps = sub ? 4 : 9;
+    const int ntaps = MODE == 2 ? 3 : (sub ? 4 : 9);
     const int dy0 = sub ? (int)(blockIdx.z >> 1) : 0, dx0 = sub ? (int)(blockIdx.z & 1) : 0;
     const h16* X = reinterpret_cast<const h16*>(p.X) + bz * p.sX;
     const h16* X2 = p.X2 ? reinterpret_cast<const h16*>(p.X2) + bz * p.sX : nullptr;
@@ -169,7 +185,7 @@ __global__ __launch_bounds__(G::NTH, G::WIDE ? 2 : ((SB && !fused_planes(FAST)) 
             rb[i] = oy * p.stride - p.pad;
             rc[i] = ox * p.stride - p.pad;
         } else if (MODE == 2) {
-            rb[i] = (m / p.HW) % p.T;
+            rb[i] = tmap ? (rl >> 3) : (m / p.HW) % p.T;
         }
     }
     const bool tap_uniform = MODE != 0 && (p.Cin & 63) == 0;     // a 64-wide K tile never straddles two taps
@@ -188,6 +204,7 @@ __global__ __launch_bounds__(G::NTH, G::WIDE ? 2 : ((SB && !fused_planes(FAST)) 
             const int oy = r / p.Wout, ox = r - oy * p.Wout;
             pix0 = ((int64_t)f * p.Hin + oy * p.stride) * p.Win + ox * p.stride;
         }
+        if constexpr (TMAP_OK) if (tmap) pix0 = phys(m0);
         const int64_t shift = MODE == 1 ? -(int64_t)(p.pad * p.Win + p.pad) : (MODE == 2 ? -(int64_t)p.HW : 0);
         rX = make_rsrc(X + (pix0 + shift) * p.ldx);
         rX2 = X2 ? make_rsrc(X2 + (pix0 + shift) * p.ldx2) : rX;
@@ -201,6 +218,7 @@ __global__ __launch_bounds__(G::NTH, G::WIDE ? 2 : ((SB && !fused_planes(FAST)) 
         for (int i = 0; i < XI; ++i) {
             const int rl = XROWS * wave + 8 * i + rsub;
             int rel = rl;
+            if constexpr (TMAP_OK) if (tmap) rel = (int)(phys(m0 + rl) - pix0);
             unsigned mask = rv[i] ? 1u : 0u;
             if (MODE == 1) {
                 rel = (int)((int64_t)(ra[i] + (rb[i] + p.pad) * p.Win + rc[i] + p.pad) - pix0);
@@ -234,6 +252,8 @@ __global__ __launch_bounds__(G::NTH, G::WIDE ? 2 : ((SB && !fused_planes(FAST)) 
     // dx = 2 K-steps fetch their weights only and read the fragments one row up / down.  144 -> 51 activation pieces per 64-channel
     // slab; the stage stays 33 KiB (four workgroups per CU).  Rows whose tap leaves the image vertically are zero-filled by the DMA as
     // before; a horizontal neighbour that belongs to the next image row is zeroed when the fragment is read (x == 0 / x == W - 1).
+    constexpr bool TSHARE_OK = TMAP_OK && ONEBUF;                  // the one-stage kernels share the staged tile between the three temporal taps
+    const bool tshare = TSHARE_OK && tmap;
     constexpr bool XSHARE_OK = MODE == 1 && FAST && ONEBUF && !G::WIDE && PLANES <= 2;      // the one-stage kernels: SB (16-bit builds), fused pieces (bf16x3)
     const bool xshare = XSHARE_OK && (vflags & VF_XS);
     unsigned xedge = 0;      // bits 0-3: x == 0 / x == W - 1 of the lane's two fragment rows; bits 8-10 (halo lanes): dy validity of their pixel
@@ -284,6 +304,13 @@ __global__ __launch_bounds__(G::NTH, G::WIDE ? 2 : ((SB && !fused_planes(FAST)) 
             const int so = soff + pl * (ld / PLANES) * 2, sow = soffw + pl * (p.ldw / PLANES) * 2;
             bool xstage = true;
             int xtap = tap_s, sox = so;
+            if constexpr (TSHARE_OK) if (tshare) {
+                xstage = tap_s == 0;                         // the slab's first K-step stages the centre frame rows for all three taps
+                xtap = 1;
+                sox = so + p.HW * ld * 2;                    // tap 1 = the rows themselves (the descriptor is based one frame back)
+                if (xstage && wave == 0)                     // a piece of zero rows behind the W tile(s): frames -1 and 16
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (lptr_t)(Ws + XT * TILE_W + pl * 512), 16, (int)OOB, 0, 0, 0);
+            }
             if constexpr (XSHARE_OK) if (xshare) {
                 const int dy = tap_s / 3, dxs = tap_s - 3 * dy;
                 xstage = dxs == 0;                           // the dy group's first K-step stages the centre tile (+ halo) for all three
@@ -326,7 +353,7 @@ __global__ __launch_bounds__(G::NTH, G::WIDE ? 2 : ((SB && !fused_planes(FAST)) 
             c_s += BK;
         } else {                                   // select form: the branchy update sent tap_s / c_s to scratch memory
             const int t1 = tap_s + 1, c1 = c_s + BK;
-            const bool slab = MODE == 1 && p.korder;
+            const bool slab = (MODE == 1 || MODE == 2) && p.korder;
             const bool wrap = slab ? (t1 == ntaps) : (c1 == p.Cin);
             tap_s = slab ? (wrap ? 0 : t1) : (wrap ? t1 : tap_s);
             c_s = slab ? (wrap ? c1 : c_s) : (wrap ? 0 : c1);
@@ -348,7 +375,7 @@ __global__ __launch_bounds__(G::NTH, G::WIDE ? 2 : ((SB && !fused_planes(FAST)) 
         const int k0 = kt * BK;
         int tap_u = 0, c_u = 0;
         if (MODE != 0 && tap_uniform) {
-            if (MODE == 1 && p.korder) { const int slab = kt / 9; tap_u = kt - slab * 9; c_u = slab * 64; }
+            if ((MODE == 1 || MODE == 2) && p.korder) { const int slab = kt / ntaps; tap_u = kt - slab * ntaps; c_u = slab * 64; }
             else { tap_u = k0 / p.Cin; c_u = k0 - tap_u * p.Cin; }
         }
 #pragma unroll
@@ -407,16 +434,18 @@ __global__ __launch_bounds__(G::NTH, G::WIDE ? 2 : ((SB && !fused_planes(FAST)) 
         if (!wave_live) return;
         const h16* xs = Xs + cur * XT * TILE_X + (wm * 64 + l31) * LDSLD;
         const h16* ws = Ws + cur * XT * TILE_W + (wn * (32 * G::WSTRIDE) + l31) * LDSLD;
-        if constexpr (XSHARE_OK) {
+        if constexpr (XSHARE_OK || TSHARE_OK) {
+            // TSHARE: the fragment rows of temporal tap dt are the staged rows 8 (dt - 1) further; frames -1 / 16 are zero rows.
             // XSHARE: fragment rows one up / down from the staged centre tile (d = dx - 1); the tile's first / last row reaches into
             // the halo piece (rows 7 / 0 behind the W tiles, one piece per plane), a row whose neighbour belongs to another image row
             // reads one of that piece's zero rows.  Without XSHARE d = 0 and no edges: the plain fragment rows.
-            const int d = xshare ? dx_m - 1 : 0;
+            const int d = MODE == 2 ? (tshare ? 8 * (dx_m - 1) : 0) : (xshare ? dx_m - 1 : 0);
             int xo[MI];                                  // element offset inside a plane's tile (or from the plane's halo piece, bit 19) | swizzle key << 20
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {
                 const int rr = wm * 64 + mi * 32 + l31 + d;
-                const bool edge = (d < 0 && ((xedge >> (2 * mi)) & 1u)) || (d > 0 && ((xedge >> (2 * mi)) & 2u));
+                const bool edge = MODE == 2 ? (rr < 0 || rr >= BM)
+                                            : ((d < 0 && ((xedge >> (2 * mi)) & 1u)) || (d > 0 && ((xedge >> (2 * mi)) & 2u)));
                 // every substitute row keeps the bank pattern of the row it stands for (row parity and swizzle key): conflict-free reads
                 const int key = ((rr >> 1) & 7) << 20;
                 xo[mi] = edge ? ((1 << 19) + (2 + (rr & 1)) * LDSLD) | key
@@ -857,6 +886,7 @@ __global__ __launch_bounds__(G::NTH, G::WIDE ? 2 : ((SB && !fused_planes(FAST)) 
     for (int row = r0; row < PROWS; row += rstep) {
         const int m = m0 + pass * PROWS + row;
         if (m >= p.M || nvalid == 0) break;
+        const int64_t mp = phys(m);                 // TMAP: where logical row m lives in R / Y
         float v[8];
         {
             const f32x4 a = *reinterpret_cast<const f32x4*>(&stg[row * STGLD + cc * 8]);
@@ -871,7 +901,7 @@ __global__ __launch_bounds__(G::NTH, G::WIDE ? 2 : ((SB && !fused_planes(FAST)) 
             for (int j = 0; j < 8; ++j) if (j < nvalid) v[j] += withb ? p.bias[n + j] + gb[j] : gb[j];
         }
         if (R) {
-            const h16* rp = R + (int64_t)m * p.ldr + n;
+            const h16* rp = R + mp * p.ldr + n;
             if (nvalid == 8 && (vflags & VF_R)) {
                 float rr[8];
                 load8_operand(rp, p.ldr / PLANES, rr);
@@ -883,7 +913,7 @@ __global__ __launch_bounds__(G::NTH, G::WIDE ? 2 : ((SB && !fused_planes(FAST)) 
             }
         }
         if (Rf) {
-            const float* rp = Rf + (int64_t)m * p.ldr + n;
+            const float* rp = Rf + mp * p.ldr + n;
             if (nvalid == 8 && (vflags & VF_R)) {
                 const f32x4 a = *reinterpret_cast<const f32x4*>(rp), b = *reinterpret_cast<const f32x4*>(rp + 4);
 #pragma unroll
@@ -894,7 +924,7 @@ __global__ __launch_bounds__(G::NTH, G::WIDE ? 2 : ((SB && !fused_planes(FAST)) 
             }
         }
         if (Rh) {
-            const _Float16* rp = Rh + (int64_t)m * p.ldr + n;
+            const _Float16* rp = Rh + mp * p.ldr + n;
             if (nvalid == 8 && (vflags & VF_R)) {
                 float rr[8];
                 load8_f16(rp, rr);
@@ -912,7 +942,7 @@ __global__ __launch_bounds__(G::NTH, G::WIDE ? 2 : ((SB && !fused_planes(FAST)) 
                 gs[j] += t; gq[j] = fmaf(t, t, gq[j]);
             }
         }
-        const int64_t yoff = bz * p.sY + (int64_t)m * p.ldy + n;
+        const int64_t yoff = bz * p.sY + mp * p.ldy + n;
         if (p.out_fp32 == KIND_F16) {
             _Float16* yp = reinterpret_cast<_Float16*>(p.Y) + yoff;
             if (nvalid == 8 && (vflags & VF_Y)) {
@@ -953,7 +983,7 @@ __global__ __launch_bounds__(G::NTH, G::WIDE ? 2 : ((SB && !fused_planes(FAST)) 
                 u32x2 w8;
                 w8[0] = mx_pack4_e4m3(r8[0], r8[1], r8[2], r8[3], inv);
                 w8[1] = mx_pack4_e4m3(r8[4], r8[5], r8[6], r8[7], inv);
-                *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned char*>(p.Y8) + (int64_t)m * p.ldy8 + n) = w8;
+                *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned char*>(p.Y8) + mp * p.ldy8 + n) = w8;
                 if ((cc & 3) == 0) reinterpret_cast<unsigned char*>(p.S8)[(int64_t)m * p.lds8 + (n >> 5)] = (unsigned char)(E + 127);
             }
 #endif
@@ -1099,6 +1129,7 @@ bool use_persistent() { return persist_mode() != 0; }
 // Variant switch GEMM_PERSIST: 0 = never, 1 = this rule, 2 / 3 / 4 = every eligible problem at that many workgroups per CU.
 bool persistent_ok(const MudgGemmDesc& d, int vflags) {
     if (!use_persistent() || PLANES > 2) return false;
+    if (d.mode == 2 && d.korder) return false;            // slab-major temporal convs (TMAP): the one-tile kernels' row mapping and K walk
     if (d.act || !(vflags & VF_Y) || (d.R && !(vflags & VF_R))) return false;
     if ((d.geglu ? d.N / 2 : d.N) % 8 != 0) return false;
     if (d.geglu && (d.mode != 0 || d.R || d.gbias || d.stats)) return false;
@@ -1162,6 +1193,7 @@ bool mudg_gemm_fast_ok(const MudgGemmDesc& d) {
         soff += (int64_t)(2 * d.Win + 2) * ld * 2;
     } else if (d.mode == 2) {
         soff += (int64_t)2 * d.HW * ld * 2;
+        if (d.korder) rel = (int64_t)(d.T - 1) * d.HW + 8;      // TMAP: a tile's rows span all frames of a clip
     }
     const int64_t lim = (int64_t)1 << 31;
     return rel * ld * 2 + 128 + soff + 16 < lim && (int64_t)(255 + (PLANES > 1)) * d.ldw * 2 + (int64_t)d.K * 2 + 144 < lim;
@@ -1234,6 +1266,11 @@ extern "C" int mudg_gemm(const MudgGemmDesc* dp, void* stream) {
     const int rbytes = d.res_fp32 == KIND_F32 ? 4 : 2;
     if (d.R && aligned16(d.R) && ((int64_t)d.ldr * rbytes) % (d.res_fp32 ? 16 : 16 * PLANES) == 0 && ((int64_t)d.sR * rbytes) % 16 == 0) vflags |= VF_R;
 
+    if (d.mode == 2 && d.korder) {      // TMAP / TSHARE (see gemm_kernel): slab-major temporal convs are defined for 16-frame clips on the descriptor loader
+        MUDG_REQUIRE(PLANES <= 2 && d.T == 16 && (d.HW & 7) == 0 && (d.Cin & 63) == 0 && d.K == 3 * d.Cin && !d.X2 && d.M == (d.M / (d.T * d.HW)) * d.T * d.HW,
+                     "mudg_gemm: temporal conv with korder = 1 needs T = 16, HW %% 8 == 0, Cin %% 64 == 0, K = 3 Cin, one source, whole clips");
+        if (mudg_gemm_fast_ok(d)) vflags |= VF_TM;      // else: the generic loader walks the slab-major K axis over plain 128-row tiles
+    }
     {   // XSHARE (see gemm_kernel): same-size stride-1 3x3 convs with the slab-major K order.  Variant switch CONV_XSHARE=0: off.
         static int xs = -1;
         if (xs < 0) xs = mudg_variant("CONV_XSHARE", 1);

@@ -6,6 +6,7 @@
 constexpr int BK = 64;
 constexpr int LDSLD = 64;                       // h16 elements per LDS row: unpadded, XOR-swizzled (see gemm.hip)
 constexpr int VF_Y = 1, VF_R = 2;               // 16-byte access allowed on Y / R
+constexpr int VF_TM = 8;                        // temporal conv: a tile is 8 pixels x 16 frames (gemm.hip, TMAP / TSHARE)
 constexpr int VF_XS = 4;                        // 3x3 conv: the three dx taps of a dy share one staged activation tile (gemm.hip, XSHARE)
 
 typedef const __attribute__((address_space(1))) void* gptr_t;

@@ -143,10 +143,14 @@ def conv3x3_subpixel(mod):
     return cached(mod, "w3x3sub", (w,), build)
 
 
-def tconv(mod):
-    """(Cout, Cin, 3, 1, 1) -> [Cout][tap][Cin] bf16."""
+def tconv(mod, slab=False):
+    """(Cout, Cin, 3, 1, 1) -> [Cout][tap][Cin] bf16, or (slab: ops.tconv3's korder 1) [Cout][Cin/64][tap][64]."""
     w = mod.weight
     _need_cuda(w, type(mod).__name__)
+    if slab:
+        cout, cin = w.shape[0], w.shape[1]
+        return cached(mod, "wt_slab", (w,), lambda: operand(w.detach()[:, :, :, 0, 0].permute(0, 2, 1).reshape(cout, 3, cin // 64, 64)
+                                                                 .permute(0, 2, 1, 3).reshape(cout, -1)))
     return cached(mod, "wt", (w,), lambda: operand(w.detach()[:, :, :, 0, 0].permute(0, 2, 1).reshape(w.shape[0], -1)))
 
 

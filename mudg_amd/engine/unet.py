@@ -29,6 +29,7 @@ from . import packing as pk
 
 import os as _os
 _LEAN_ATTENTION = _os.environ.get("MUDG_ATTN_LEAN", "1") != "0"       # A/B switch, read once
+_TCONV_SLAB = _os.environ.get("MUDG_TCONV_SLAB", "1") != "0"         # A/B switch: slab-major temporal convs (tiles of 8 pixels x 16 frames)
 _FP8_ATTENTION = _os.environ.get("MUDG_ATTN_FP8", "0") == "1"         # opt-in: MX-fp8 scores in the long self-attention
 
 
@@ -118,8 +119,11 @@ def temporal_conv_block(mod, x, ctx, hw):
         norm, conv = seq[0], seq[-1]
         y = _gn(norm, y, None, ctx.B, ctx.T * hw, True)
         last = i == len(stages) - 1
-        y = ops.tconv3(y, pk.tconv(conv), clips=ctx.B, t=ctx.T, hw=hw, cin=conv.weight.shape[1],
-                       bias=pk.f32(conv, "bias"), residual=x if last else None, out_stream=last, stats=True)
+        # conv1-3 feed the block's own clip-level GroupNorms: tiles of 8 pixels x 16 frames, one staged slab for the three taps
+        # (korder 1).  conv4's partials go to whatever follows (a frame-level norm reads 128 consecutive rows): the plain order.
+        slab = not last and _TCONV_SLAB and ops.tconv3_slab_ok(ctx.T, hw, conv.weight.shape[1])
+        y = ops.tconv3(y, pk.tconv(conv, slab), clips=ctx.B, t=ctx.T, hw=hw, cin=conv.weight.shape[1],
+                       bias=pk.f32(conv, "bias"), residual=x if last else None, out_stream=last, stats=True, korder=int(slab))
     return y
 
 

@@ -90,7 +90,7 @@ def repeat_rows(t, times):
     for i in range(times):
         dst[i * rows:(i + 1) * rows].copy_(src)
     ws = getattr(t, GN_ATTR, None)
-    if ws is not None and getattr(t, GN_ATTR + "_version", -1) == _version(t) and rows % 128 == 0:
+    if ws is not None and getattr(t, GN_ATTR + "_version", -1) == _version(t) and rows % 128 == 0 and not getattr(t, GN_ATTR + "_clips", 0):
         setattr(out, GN_ATTR, ws.repeat(times, 1, 1))
         setattr(out, GN_ATTR + "_version", _version(out))
     return out
@@ -222,8 +222,16 @@ def conv3x3_up2(x, wsub, *, frames, hin, win, cin, bias=None, out_fp32=False, ou
     return out
 
 
-def tconv3(x, w, *, clips, t, hw, cin, out=None, bias=None, residual=None, out_fp32=False, stats=False, out_stream=False):
-    """(3,1,1) temporal convolution, pad (1,0,0), on rows ordered ((b t) hw); w packed [Cout][3*cin]."""
+def tconv3_slab_ok(t, hw, cin):
+    """Whether mudg_gemm accepts korder = 1 for this temporal conv (MudgGemmDesc.korder, mode 2)."""
+    return hip.planes() <= 2 and t == 16 and hw % 8 == 0 and cin % 64 == 0
+
+
+def tconv3(x, w, *, clips, t, hw, cin, out=None, bias=None, residual=None, out_fp32=False, stats=False, out_stream=False, korder=0):
+    """(3,1,1) temporal convolution, pad (1,0,0), on rows ordered ((b t) hw); w packed [Cout][3*cin], K axis [tap][cin] (korder 0)
+    or [cin/64][tap][64] (korder 1: 16-frame clips; the kernels then tile a clip as 8 pixels x 16 frames and stage a 64-channel slab
+    once for the three taps).  With korder = 1 the GroupNorm partials of `stats` are per such TILE, not per 128 consecutive rows:
+    they are tagged and only a clip-level GroupNorm (samples = clips) takes them."""
     _rows(x); _rows(w)
     M, N = clips * t * hw, w.shape[0]
     if out is None:
@@ -240,8 +248,10 @@ def tconv3(x, w, *, clips, t, hw, cin, out=None, bias=None, residual=None, out_f
     d.ldr = residual.stride(0) if residual is not None else 0
     d.csplit, d.batch, d.alpha, d.mode = cin, 1, 1.0, 2
     d.Cin, d.T, d.HW = cin, t, hw
+    d.korder = korder
     if stats:
         _attach_stats(d, out, M, N)
+        setattr(out, GN_ATTR + "_clips", clips if korder else 0)
     hip.check(hip.lib().mudg_gemm(C.byref(d), _stream()), "mudg_gemm[tconv3]")
     return out
 
@@ -321,6 +331,9 @@ def groupnorm(x, gamma, beta, *, samples, rows, eps, silu, groups=32, x2=None, o
         out = empty_rows(samples * rows, c, H16(), x.device)
     def partials(t):
         ws = getattr(t, GN_ATTR, None)
+        tiled = getattr(t, GN_ATTR + "_clips", 0)          # partials per (8 pixels x 16 frames) tile of a clip (tconv3, korder 1)
+        if tiled and tiled != samples:
+            return None
         return ws if ws is not None and getattr(t, GN_ATTR + "_version", -1) == _version(t) else None
 
     p1 = partials(x) if fused else None

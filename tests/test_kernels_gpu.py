@@ -497,6 +497,37 @@ def test_large_gemm_tconv3(cuda):
     assert rel_l2(got, ref) < TOL_BF16
 
 
+@pytest.mark.parametrize("clips,hw,c,cout", [(2, 1024, 128, 192), (1, 72, 64, 64), (3, 2304, 320, 320)])
+def test_tconv3_slab_major_tiles_of_8_pixels_by_16_frames(cuda, clips, hw, c, cout):
+    """ops.tconv3(korder=1): a tile is 8 pixels x 16 frames of a clip, the three taps share one staged slab (one-stage kernels) — the
+    same convolution (vs torch, vs the tap-major kernel: equal sums in another K order), residual and bias included; its GroupNorm
+    partials serve a clip-level norm, and a frame-level norm must NOT take them (it falls back to its own statistics pass)."""
+    from mudg_amd import hip, ops
+    if not ops.tconv3_slab_ok(16, hw, c):
+        pytest.skip("korder 1 belongs to the 16-bit and bf16x3 builds")
+    t = 16
+    x = rnd(clips, c, t, hw, 1, seed=1)
+    wt = rnd(cout, c, 3, 1, 1, seed=2, scale=0.05)
+    b = torch.randn(cout, generator=torch.Generator().manual_seed(3))
+    rows = x.permute(0, 2, 3, 4, 1).reshape(-1, c).contiguous()
+    res = rnd(clips * t * hw, cout, seed=4)
+    ref = F.conv3d(x.float(), wt.float(), b, padding=(1, 0, 0)).permute(0, 2, 3, 4, 1).reshape(-1, cout) + res.float()
+    w_tap = wt[:, :, :, 0, 0].permute(0, 2, 1).reshape(cout, 3 * c).contiguous()
+    w_slab = wt[:, :, :, 0, 0].permute(0, 2, 1).reshape(cout, 3, c // 64, 64).permute(0, 2, 1, 3).reshape(cout, 3 * c).contiguous()
+    kw = dict(clips=clips, t=t, hw=hw, cin=c, bias=b.to(cuda), residual=res.to(cuda), stats=True)
+    y0 = ops.tconv3(rows.to(cuda), w_tap.to(cuda), **kw)
+    y1 = ops.tconv3(rows.to(cuda), w_slab.to(cuda), korder=1, **kw)
+    assert rel_l2(y1, ref) < TOL_BF16 and rel_l2(y1, y0.float().cpu()) < 2e-3
+    gam, bet = torch.ones(cout, device=cuda), torch.zeros(cout, device=cuda)
+    if (t * hw) % 128 == 0:
+        fused = ops.groupnorm(y1, gam, bet, samples=clips, rows=t * hw, eps=1e-5, silu=True)          # the tiles' partials
+        plain = ops.groupnorm(y1, gam, bet, samples=clips, rows=t * hw, eps=1e-5, silu=True, fused=False)
+        assert rel_l2(fused, plain.float().cpu()) < 5e-4
+    frame = ops.groupnorm(y1, gam, bet, samples=clips * t, rows=hw, eps=1e-5, silu=False)               # must not use them
+    fref = F.group_norm(y1.float().cpu().reshape(clips * t, hw, cout).transpose(1, 2), 32, None, None, 1e-5).transpose(1, 2).reshape(-1, cout)
+    assert rel_l2(frame, fref) < TOL_BF16
+
+
 def test_ddim_step_three_way_guidance(cuda):
     from mudg_amd import ops
     g = torch.Generator().manual_seed(2)

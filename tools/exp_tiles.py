@@ -36,7 +36,7 @@ if not only or "tconv" in only:
     for (clips, t, hw, c) in T:
         hw = HWS.get(hw, hw)
         x, w = rn(clips * t * hw, c), rn(c, 3 * c)
-        sec = timeit(lambda: ops.tconv3(x, w, clips=clips, t=t, hw=hw, cin=c, stats=STATS), iters=10)
+        sec = timeit(lambda: ops.tconv3(x, w, clips=clips, t=t, hw=hw, cin=c, stats=STATS, korder=int(os.environ.get("TKORDER", "0"))), iters=10)
         M = clips * t * hw
         print(f"{tag} tconv {M} {c} {3*c}: {sec*1e6:8.1f} us {2.0*M*c*3*c/sec/1e12:7.1f} TF", flush=True)
 C = [(32, 72, 128, 320, 320), (32, 72, 128, 640, 320), (32, 72, 128, 960, 320), (32, 36, 64, 640, 640), (32, 36, 64, 1280, 640),
