@@ -23,6 +23,9 @@ MUDG_DEBUG_VARIANTS=1 MUDG_GEMM_PERSIST=1 python bench.py --no-cpu-baseline --no
 # same box, same library: the 3x3 convs without / with the shared activation stage of their dx taps (XSHARE)
 MUDG_DEBUG_VARIANTS=1 MUDG_CONV_XSHARE=0 python bench.py --no-cpu-baseline --no-children --steps 10 --warmup 3 2>/dev/null | tail -1 > $OUT/bench_conv_unshared.json
 MUDG_DEBUG_VARIANTS=1 MUDG_CONV_XSHARE=1 python bench.py --no-cpu-baseline --no-children --steps 10 --warmup 3 2>/dev/null | tail -1 > $OUT/bench_conv_xshare.json
+# same box: the temporal convs on plain 128-row tiles / on tiles of 8 pixels x 16 frames with the shared slab stage (TMAP / TSHARE)
+MUDG_TCONV_SLAB=0 python bench.py --no-cpu-baseline --no-children --steps 10 --warmup 3 2>/dev/null | tail -1 > $OUT/bench_tconv_plain_tiles.json
+MUDG_TCONV_SLAB=1 python bench.py --no-cpu-baseline --no-children --steps 10 --warmup 3 2>/dev/null | tail -1 > $OUT/bench_tconv_tshare.json
 # the CPU baseline as a measurement: one full MDM512 oracle forward on this host
 if [ "$2" = "cpufull" ]; then
   python bench.py --steps 3 --warmup 1 --cpu-baseline full --no-decode 2>/dev/null | tail -1 | python -c "
