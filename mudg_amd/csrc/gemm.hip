@@ -1269,6 +1269,8 @@ extern "C" int mudg_gemm(const MudgGemmDesc* dp, void* stream) {
     if (d.mode == 2 && d.korder) {      // TMAP / TSHARE (see gemm_kernel): slab-major temporal convs are defined for 16-frame clips on the descriptor loader
         MUDG_REQUIRE(PLANES <= 2 && d.T == 16 && (d.HW & 7) == 0 && (d.Cin & 63) == 0 && d.K == 3 * d.Cin && !d.X2 && d.M == (d.M / (d.T * d.HW)) * d.T * d.HW,
                      "mudg_gemm: temporal conv with korder = 1 needs T = 16, HW %% 8 == 0, Cin %% 64 == 0, K = 3 Cin, one source, whole clips");
+        // (the group-bias index of the epilogue is the LOGICAL row / rows_per_group: with the tile mapping that is the clip, nothing finer)
+        MUDG_REQUIRE(!d.gbias || d.rows_per_group % (d.T * d.HW) == 0, "mudg_gemm: temporal conv with korder = 1 takes a group bias per clip(s) only");
         if (mudg_gemm_fast_ok(d)) vflags |= VF_TM;      // else: the generic loader walks the slab-major K axis over plain 128-row tiles
     }
     {   // XSHARE (see gemm_kernel): same-size stride-1 3x3 convs with the slab-major K order.  Variant switch CONV_XSHARE=0: off.

@@ -105,6 +105,7 @@ def _drop_stats(t):
     sums a previous producer hung on it would be stale."""
     if t is not None and getattr(t, GN_ATTR, None) is not None:
         setattr(t, GN_ATTR, None)
+        setattr(t, GN_ATTR + "_clips", 0)
 
 
 def _version(t):
@@ -120,6 +121,7 @@ def _attach_stats(d, out, M, nout):
     d.stats = ws.data_ptr()
     setattr(out, GN_ATTR, ws)
     setattr(out, GN_ATTR + "_version", _version(out))     # a later torch in-place op on `out` invalidates the partials
+    setattr(out, GN_ATTR + "_clips", 0)                   # (the tiling tag of an earlier slab-major tconv3 into the same `out=` is stale)
 
 
 def gemm(x, w, *, out=None, bias=None, gbias=None, rows_per_group=0, residual=None, x2=None, geglu=False,

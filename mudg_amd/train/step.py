@@ -63,7 +63,9 @@ class AdamW(torch.optim.Optimizer):
 
     def _table(self, gi, ps):
         from .. import hip
-        key = tuple((p.data_ptr(), p.grad.data_ptr(), p.numel()) for p in ps)
+        # the table bakes in the addresses of the moments too: load_state_dict (or any reassignment of state[p][...]) replaces them
+        key = tuple((p.data_ptr(), p.grad.data_ptr(), self.state[p]["exp_avg"].data_ptr(), self.state[p]["exp_avg_sq"].data_ptr(),
+                     p.numel()) for p in ps)
         hit = self._tables.get(gi)
         if hit is not None and hit[0] == key:
             return hit[1], hit[2]
@@ -193,10 +195,14 @@ class GradientAllReducer:
         self._pending = [len(b) for b in self.buckets]
         self._next = 0                                    # buckets are launched strictly in index order
         self._hooks = []
-        if overlap:
-            where = {id(p): i for i, b in enumerate(self.buckets) for p in b}
-            for p in self.params:
-                self._hooks.append(p.register_post_accumulate_grad_hook(lambda q, i=where[id(p)]: self._ready(i)))
+        # Which parameters actually received a gradient since the last finished step.  In a one-rank job a parameter that never did
+        # gets .grad = None back when the reducer is called (below): torch.optim.AdamW — and this package's — then skips it (no
+        # state, no step count, no weight decay), exactly as without a reducer.  With several ranks every parameter keeps its
+        # bucket view (another rank may have touched it; the zeros of this one are its contribution), as under DDP's bucket views.
+        self._touched = set()
+        where = {id(p): i for i, b in enumerate(self.buckets) for p in b}
+        for p in self.params:
+            self._hooks.append(p.register_post_accumulate_grad_hook(lambda q, i=where[id(p)]: self._ready(i, id(q))))
 
     def attach(self):
         """Point every parameter's .grad at its slice of the flat buckets (keeping a gradient that is already there)."""
@@ -236,8 +242,9 @@ class GradientAllReducer:
         else:                                             # gloo (CPU tests): sum, then scale
             self._works[i] = (dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True), True)
 
-    def _ready(self, i):
-        if not self.sync or not self._active():
+    def _ready(self, i, pid=None):
+        self._touched.add(pid)
+        if not self.overlap or not self.sync or not self._active():
             return
         self._pending[i] -= 1
         while self._next < len(self.buckets) and self._pending[self._next] <= 0:
@@ -247,8 +254,15 @@ class GradientAllReducer:
     def __call__(self):
         """After backward(): finish the gradient averaging (in place, in the buckets).  Returns the number of collectives."""
         import torch.distributed as dist
-        if not self._active() or not self.sync:
+        if not self.sync:
             return 0
+        if not self._active():                            # one rank: nothing to average; untouched parameters get grad None back
+            for p in self.params:
+                if id(p) not in self._touched:
+                    p.grad = None
+            self._touched.clear()
+            return 0
+        self._touched.clear()
         world = dist.get_world_size(self.group)
         for i in range(self._next, len(self.buckets)):    # not launched under backward (or overlap off): now, in order
             self._launch(i)

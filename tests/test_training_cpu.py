@@ -119,3 +119,26 @@ def test_training_entry_points_exist_and_reject_what_is_not_built():
         model.configure_optimizers().step() if False else model.p_losses(
             torch.zeros(1, 4, 4, 8, 8), {"c_crossattn": [torch.zeros(1, 141, 64)], "c_concat": [torch.zeros(1, 8, 4, 8, 8)]},
             torch.zeros(1, dtype=torch.long), class_label=torch.zeros(1, 1, dtype=torch.long))
+
+
+def test_one_rank_reducer_leaves_untouched_parameters_without_a_gradient():
+    """the reducer binds every .grad to a zero-filled bucket view; in a one-rank job a parameter that never received a
+    gradient must look to the optimiser as it does without a reducer (grad None: no state, no step, no weight decay)."""
+    from mudg_amd.train.step import GradientAllReducer
+    used, unused = torch.nn.Parameter(torch.ones(6)), torch.nn.Parameter(torch.ones(4))
+    red = GradientAllReducer([used, unused], bucket_mb=1)
+    opt = torch.optim.AdamW([used, unused], lr=0.1, weight_decay=0.5)
+    for _ in range(2):
+        red.zero_grad()
+        assert used.grad is not None and unused.grad is not None            # views into the bucket while backward runs
+        red.sync = False                                                    # a local micro-batch: nothing is dropped yet
+        (used * 2).sum().backward()
+        assert red() == 0 and unused.grad is not None
+        red.sync = True
+        (used * 3).sum().backward()
+        assert red() == 0
+        assert unused.grad is None and torch.equal(used.grad, torch.full((6,), 5.0))
+        assert used.grad.data_ptr() == red._views[id(used)].data_ptr()
+        opt.step()
+    assert torch.equal(unused.detach(), torch.ones(4)) and unused not in opt.state
+    assert not torch.equal(used.detach(), torch.ones(6))

@@ -520,3 +520,33 @@ def test_multi_tensor_adamw_equals_torch_over_many_tensors(cuda):
         mine.step(); ref.step()
     for i, (p, q) in enumerate(zip(ps, qs)):
         check(f"multi-tensor AdamW tensor {i} {tuple(p.shape)}", p, q, 1e-6)
+
+
+def test_adamw_load_state_dict_replaces_the_moments_the_kernel_reads(cuda):
+    """The multi-tensor launch reads a cached table of raw addresses, the moments' included: optimizer.load_state_dict (which
+    replaces the moment tensors) must rebuild it, or the kernel would keep updating the freed buffers and ignore the restored ones."""
+    from mudg_amd.train import step
+    shapes = [(33,), (128, 9), (5,)]
+    ps = [torch.nn.Parameter(rnd(*s, seed=i).to(cuda)) for i, s in enumerate(shapes)]
+    qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    mine, ref = step.AdamW(ps, lr=2e-3, weight_decay=0.01), torch.optim.AdamW(qs, lr=2e-3, weight_decay=0.01)
+
+    def one(it):
+        for i, (p, q) in enumerate(zip(ps, qs)):
+            gr = rnd(*p.shape, seed=50 * it + i).to(cuda)
+            if p.grad is None:
+                p.grad, q.grad = gr.clone(), gr.clone()
+            else:                                           # in place: the parameter / gradient addresses (the old cache key) stay the same
+                p.grad.copy_(gr); q.grad.copy_(gr)
+        mine.step(); ref.step()
+    one(0); one(1)
+    saved_m, saved_r = copy.deepcopy(mine.state_dict()), copy.deepcopy(ref.state_dict())
+    saved_p = [p.detach().clone() for p in ps]
+    one(2); one(3)
+    with torch.no_grad():
+        for p, q, s in zip(ps, qs, saved_p):
+            p.copy_(s); q.copy_(s)
+    mine.load_state_dict(saved_m); ref.load_state_dict(saved_r)
+    one(2); one(3)
+    for i, (p, q) in enumerate(zip(ps, qs)):
+        check(f"AdamW after load_state_dict, tensor {i}", p, q, 1e-6)
