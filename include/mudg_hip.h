@@ -99,8 +99,9 @@ typedef struct MudgGemmDesc {
                              three temporal taps of a row are rows of the same tile), and `stats` blocks are those TILES, in
                              clip order: only a clip-level GroupNorm may fold them */
     /* mode 2 */
-    int T, HW;
-    float* stats;         /* NULL, or fp32 [ceil(M/128)][Nout][2]: the epilogue also writes, per 128-row block and output
+    int T, HW;            /* mode 0: HW may carry a HINT — the rows of one frame of the matrix (0 = none).  Results never depend on it; it lets
+                             the library choose a tile height that divides a frame (mudg_gemm_stats_rows) */
+    float* stats;         /* NULL, or fp32 [ceil(M/rows)][Nout][2], rows = mudg_gemm_stats_rows(d) (128 | 288): the epilogue also writes, per row block and output
                              channel, the sum and the sum of squares of the values it stored (as stored: after rounding to
                              bf16 when Y is bf16) — the first pass of the GroupNorm that consumes Y
                              (mudg_groupnorm_fused).  Needs batch == 1 and no GEGLU. */
@@ -119,6 +120,12 @@ typedef struct MudgGemmDesc {
     int ldy8, lds8;
 } MudgGemmDesc;
 int mudg_gemm(const MudgGemmDesc* d, void* stream);
+/* Height of the row blocks in which mudg_gemm will write `stats` for this problem: 128, or 288 where the 288 x 320-tile kernel of
+ * the 16-bit builds runs it (same-size 3x3 convs, temporal convs with korder 0 and plain GEMMs with N % 320 == 0 whose frames are
+ * whole 288-row tiles: Hout * Wout, HW — for mode 0 the caller's hint in HW — a multiple of 288).  `stats` then holds
+ * fp32 [ceil(M / rows)][Nout][2], and the consumer (mudg_groupnorm_fused) is told the same height.  The answer depends on the
+ * descriptor's geometry, strides and pointer alignment, never on M: a clip's results do not depend on the batch it travels in. */
+int mudg_gemm_stats_rows(const MudgGemmDesc* d);
 /* 1 when `d` (mode 1, subpixel = 1) can run: batch 4, stride 1, pad 1, korder 1, Cin % 64 == 0, no X2 / R / gbias / stats /
  * upsample, and offsets within reach of the buffer-descriptor loader; else the caller uses upsample = 1 with 3x3 weights. */
 int mudg_conv_subpixel_ok(const MudgGemmDesc* d);
@@ -197,6 +204,13 @@ int mudg_groupnorm_fused(const void* X, const void* X2, int csplit, int ldx, int
                          const float* gamma, const float* beta, void* Y, int ldy,
                          int samples, int rows, int C, int groups, float eps, int silu,
                          const float* P1, const float* P2, float* ws, void* stream);
+
+/* The same with the height of the partial blocks stated per source (mudg_gemm_stats_rows of the producer: 128 | 288; `rows` must be
+ * a multiple of both; mudg_groupnorm_fused = 128, 128). */
+int mudg_groupnorm_fused_rows(const void* X, const void* X2, int csplit, int ldx, int ldx2, int x_fp32,
+                              const float* gamma, const float* beta, void* Y, int ldy,
+                              int samples, int rows, int C, int groups, float eps, int silu,
+                              const float* P1, int p1_rows, const float* P2, int p2_rows, float* ws, void* stream);
 
 /* LayerNorm over the last dim (attention.py:363-365, eps 1e-5). */
 int mudg_layernorm(const void* X, int ldx, int x_fp32, const float* gamma, const float* beta,

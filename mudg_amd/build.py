@@ -20,7 +20,7 @@ OUT_FP16 = os.path.join(HERE, "libmudg_hip_fp16.so")
 OUT_X3 = os.path.join(HERE, "libmudg_hip_x3.so")
 OUT_X6 = os.path.join(HERE, "libmudg_hip_x6.so")
 OUT_DBG = os.path.join(HERE, "libmudg_hip_dbg.so")      # bf16 + kernel-variant switches (tests / tools only; hip.py loads it under MUDG_DEBUG_VARIANTS=1)
-SOURCES = ["capi.hip", "gemm.hip", "pgemm.hip", "attention.hip", "norm.hip", "misc.hip", "post.hip", "train.hip", "attention_bwd.hip", "wgrad.hip"]
+SOURCES = ["capi.hip", "gemm.hip", "pgemm.hip", "wgemm.hip", "attention.hip", "norm.hip", "misc.hip", "post.hip", "train.hip", "attention_bwd.hip", "wgrad.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-ffp-contract=off", *os.environ.get("MUDG_EXTRA_HIPCC_FLAGS", "").split()]      # extra flags: kernel experiments only
 

@@ -1199,6 +1199,26 @@ bool mudg_gemm_fast_ok(const MudgGemmDesc& d) {
     return rel * ld * 2 + 128 + soff + 16 < lim && (int64_t)(255 + (PLANES > 1)) * d.ldw * 2 + (int64_t)d.K * 2 + 144 < lim;
 }
 
+// Whether Y / R can be accessed in whole 16-byte pieces (VF_Y / VF_R).
+static int access_flags(const MudgGemmDesc& d) {
+    int vflags = 0;
+    const int ybytes = d.out_fp32 == KIND_F32 ? 4 : 2;
+    if (aligned16(d.Y) && ((int64_t)d.ldy * ybytes) % (d.out_fp32 ? 16 : 16 * PLANES) == 0 && ((int64_t)d.sY * ybytes) % 16 == 0) vflags |= VF_Y;
+    const int rbytes = d.res_fp32 == KIND_F32 ? 4 : 2;
+    if (d.R && aligned16(d.R) && ((int64_t)d.ldr * rbytes) % (d.res_fp32 ? 16 : 16 * PLANES) == 0 && ((int64_t)d.sR * rbytes) % 16 == 0) vflags |= VF_R;
+    return vflags;
+}
+
+// Height of the row blocks `stats` will be written in for this problem (mudg_hip.h): 288 where the 288 x 320 kernel runs it, else 128.
+extern "C" int mudg_gemm_stats_rows(const MudgGemmDesc* dp) {
+    if (!dp) return 128;
+    MudgGemmDesc d = *dp;
+    if (d.batch < 1) d.batch = 1;
+    if (!d.X2) d.csplit = d.mode == 0 ? d.K : d.Cin;
+    if (d.out_fp32 < 0 || d.out_fp32 > 2 || d.res_fp32 < 0 || d.res_fp32 > 2 || d.mode < 0 || d.mode > 2) return 128;
+    return mudg_wgemm_ok(d, access_flags(d)) ? 288 : 128;
+}
+
 extern "C" int mudg_conv_subpixel_ok(const MudgGemmDesc* dp) {
     if (!dp) return 0;
     MudgGemmDesc d = *dp;
@@ -1259,12 +1279,8 @@ extern "C" int mudg_gemm(const MudgGemmDesc* dp, void* stream) {
                      d.ldy8 >= d.N && d.lds8 >= d.N / 32 && (reinterpret_cast<uintptr_t>(d.Y8) & 7u) == 0,
                      "mudg_gemm: Y8 needs S8, an operand-kind Y, N %% 32 == 0, no GEGLU / sub-pixel / batch, ldy8 %% 8 == 0");
     }
-    int vflags = 0;
     MUDG_REQUIRE(d.out_fp32 >= 0 && d.out_fp32 <= 2 && d.res_fp32 >= 0 && d.res_fp32 <= 2, "mudg_gemm: out_fp32 / res_fp32 are 0 (operand), 1 (fp32) or 2 (fp16)");
-    const int ybytes = d.out_fp32 == KIND_F32 ? 4 : 2;
-    if (aligned16(d.Y) && ((int64_t)d.ldy * ybytes) % (d.out_fp32 ? 16 : 16 * PLANES) == 0 && ((int64_t)d.sY * ybytes) % 16 == 0) vflags |= VF_Y;
-    const int rbytes = d.res_fp32 == KIND_F32 ? 4 : 2;
-    if (d.R && aligned16(d.R) && ((int64_t)d.ldr * rbytes) % (d.res_fp32 ? 16 : 16 * PLANES) == 0 && ((int64_t)d.sR * rbytes) % 16 == 0) vflags |= VF_R;
+    int vflags = access_flags(d);
 
     if (d.mode == 2 && d.korder) {      // TMAP / TSHARE (see gemm_kernel): slab-major temporal convs are defined for 16-frame clips on the descriptor loader
         MUDG_REQUIRE(PLANES <= 2 && d.T == 16 && (d.HW & 7) == 0 && (d.Cin & 63) == 0 && d.K == 3 * d.Cin && !d.X2 && d.M == (d.M / (d.T * d.HW)) * d.T * d.HW,
@@ -1289,7 +1305,9 @@ extern "C" int mudg_gemm(const MudgGemmDesc* dp, void* stream) {
         constexpr bool F = decltype(fast)::value, S = decltype(sb)::value;
         return d.mode == 0 ? launch<G, 0, F, S>(d, vflags, s) : (d.mode == 1 ? launch<G, 1, F, S>(d, vflags, s) : launch<G, 2, F, S>(d, vflags, s));
     };
-    if (mudg_gemm_fast_ok(d)) {
+    if (mudg_wgemm_ok(d, vflags)) {
+        rc = mudg_wgemm_launch(d, vflags, s);
+    } else if (mudg_gemm_fast_ok(d)) {
 #if MUDG_PLANES == 1
         const int wide = use_wide(d);
         if (wide) rc = wide == 5 ? by_mode(G320{}, std::true_type{}, std::false_type{}) : by_mode(G256{}, std::true_type{}, std::false_type{});

@@ -57,3 +57,6 @@ int mudg_current_device();
 const float* mudg_phi_table();                  // device Phi table, or nullptr (split-operand builds / variant switch)
 // pgemm.hip: the persistent 128 x 128 kernel; wgs = workgroups per CU (4 | 3: one K-tile stage, 2: two)
 int mudg_pgemm_launch(const MudgGemmDesc& d, int vflags, int wgs, hipStream_t s);
+// wgemm.hip: the 288 x 320 eight-wave tile (16-bit builds); _ok = eligible AND selected by its M-independent rule
+bool mudg_wgemm_ok(const MudgGemmDesc& d, int vflags);
+int mudg_wgemm_launch(const MudgGemmDesc& d, int vflags, hipStream_t s);

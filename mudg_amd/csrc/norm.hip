@@ -179,13 +179,29 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
 // wave butterfly and a fixed 4-term sum, so the result does not depend on scheduling.
 __global__ __launch_bounds__(256) void gn_finalize_ch_kernel(const float* __restrict__ P1, const float* __restrict__ P2,
                                                               int csplit, int C, float* __restrict__ stat, int samples,
-                                                              int groups, int blocks_per_sample, double count, float eps) {
+                                                              int groups, int blocks_per_sample, int blocks_per_sample2, double count, float eps) {
     __shared__ double red[4][2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = blockIdx.x;
     const int smp = i / groups, g = i - smp * groups;
     const int cpg = C / groups, c0 = g * cpg;
     double a = 0.0, b = 0.0;
+    if (blocks_per_sample2 != blocks_per_sample) {
+        // the two sources' producers wrote blocks of different heights (128 | 288): each source's blocks on their own, source 1 first
+        for (int src = 0; src < 2; ++src) {
+            const int bps = src ? blocks_per_sample2 : blocks_per_sample;
+            const int lo = src ? (c0 > csplit ? c0 : csplit) : c0, hi = src ? c0 + cpg : (c0 + cpg < csplit ? c0 + cpg : csplit);
+            for (int rb = tid; rb < bps && lo < hi; rb += 256) {
+                const int64_t blk = (int64_t)smp * bps + rb;
+                float sa = 0.f, sb = 0.f;
+                for (int c = lo; c < hi; ++c) {
+                    const f32x2 q = *reinterpret_cast<const f32x2*>(src ? P2 + (blk * (C - csplit) + (c - csplit)) * 2 : P1 + (blk * csplit + c) * 2);
+                    sa += q[0]; sb += q[1];
+                }
+                a += (double)sa; b += (double)sb;
+            }
+        }
+    } else
     for (int rb = tid; rb < blocks_per_sample; rb += 256) {
         const int64_t blk = (int64_t)smp * blocks_per_sample + rb;
         float sa = 0.f, sb = 0.f;                 // <= 80 channels of one block: fp32 is exact enough before the fp64 fold
@@ -627,13 +643,26 @@ extern "C" int mudg_groupnorm(const void* X, const void* X2, int csplit, int ldx
     return rc;
 }
 
+extern "C" int mudg_groupnorm_fused_rows(const void* X, const void* X2, int csplit, int ldx, int ldx2, int x_fp32,
+                                         const float* gamma, const float* beta, void* Y, int ldy, int samples, int rows, int C,
+                                         int groups, float eps, int silu, const float* P1, int p1_rows, const float* P2, int p2_rows,
+                                         float* ws, void* stream);
 extern "C" int mudg_groupnorm_fused(const void* X, const void* X2, int csplit, int ldx, int ldx2, int x_fp32,
                                     const float* gamma, const float* beta, void* Y, int ldy, int samples, int rows, int C,
                                     int groups, float eps, int silu, const float* P1, const float* P2, float* ws, void* stream) {
+    return mudg_groupnorm_fused_rows(X, X2, csplit, ldx, ldx2, x_fp32, gamma, beta, Y, ldy, samples, rows, C, groups, eps, silu, P1, 128, P2, 128,
+                                     ws, stream);
+}
+extern "C" int mudg_groupnorm_fused_rows(const void* X, const void* X2, int csplit, int ldx, int ldx2, int x_fp32,
+                                         const float* gamma, const float* beta, void* Y, int ldy, int samples, int rows, int C,
+                                         int groups, float eps, int silu, const float* P1, int p1_rows, const float* P2, int p2_rows,
+                                         float* ws, void* stream) {
     MUDG_REQUIRE(X && Y && gamma && beta && ws && P1, "mudg_groupnorm_fused: null pointer");
+    MUDG_REQUIRE((p1_rows == 128 || p1_rows == 288) && (!X2 || p2_rows == 128 || p2_rows == 288), "mudg_groupnorm_fused: partial blocks are 128 or 288 rows high");
+    if (!X2) p2_rows = p1_rows;
+    MUDG_REQUIRE(rows % p1_rows == 0 && rows % p2_rows == 0, "mudg_groupnorm_fused: rows=%d per sample must be whole partial blocks (%d / %d rows)", rows, p1_rows, p2_rows);
     MUDG_REQUIRE(samples > 0 && rows > 0 && C > 0 && groups > 0, "mudg_groupnorm_fused: empty problem");
     MUDG_REQUIRE(C % groups == 0 && (C & 7) == 0 && C <= GN_CMAX && groups <= 256, "mudg_groupnorm_fused: C=%d groups=%d unsupported", C, groups);
-    MUDG_REQUIRE(rows % 128 == 0, "mudg_groupnorm_fused: rows=%d per sample must be a multiple of the 128-row partial blocks", rows);
     MUDG_REQUIRE(x_fp32 >= 0 && x_fp32 <= 2, "mudg_groupnorm_fused: x_fp32 is 0 (operand), 1 (fp32) or 2 (fp16)");
     const int xq = x_fp32 == KIND_F32 ? 4 : (x_fp32 == KIND_F16 ? 8 : 8 * PLANES);
     MUDG_REQUIRE(ldx % xq == 0 && ldy % (8 * PLANES) == 0 && aligned16(X) && aligned16(Y), "mudg_groupnorm_fused: alignment");
@@ -646,7 +675,7 @@ extern "C" int mudg_groupnorm_fused(const void* X, const void* X2, int csplit, i
     const int slot = mudg_prof_begin(MUDG_FAM_GNORM, s);
     const int ng = samples * groups;
     hipLaunchKernelGGL(gn_finalize_ch_kernel, dim3(ng), dim3(256), 0, s, P1, P2, csplit, C, stat, samples, groups,
-                       rows / 128, (double)rows * (C / groups), eps);
+                       rows / p1_rows, rows / p2_rows, (double)rows * (C / groups), eps);
     launch_gn_apply(x_fp32, X, X2, csplit, ldx, ldx2, gamma, beta, Y, ldy, samples, rows, C, groups, silu, stat, s);
     const int rc = mudg_check_launch("mudg_groupnorm_fused");
     mudg_prof_end(slot, s, 0.0, (double)samples * rows * C * (x_fp32 == KIND_F32 ? 6.0 : 4.0));

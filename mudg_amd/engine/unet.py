@@ -61,10 +61,11 @@ def _ln(mod, x):
     return ops.layernorm(x, pk.f32(mod, "weight"), pk.f32(mod, "bias"), eps=mod.eps)
 
 
-def _linear(mod, x, residual=None, x2=None, stream=False, stats=False):
+def _linear(mod, x, residual=None, x2=None, stream=False, stats=False, hw=0):
     """stream=True: the result is a residual-stream tensor and is written in ops.STREAM() (see module docstring).
-    stats=True: the result feeds a GroupNorm next — the epilogue also writes that norm's partial sums."""
-    return ops.gemm(x, pk.linear(mod), bias=pk.f32(mod, "bias"), residual=residual, x2=x2, out_stream=stream, stats=stats)
+    stats=True: the result feeds a GroupNorm next — the epilogue also writes that norm's partial sums.
+    hw: the rows of one frame (a hint for the library's tile choice, MudgGemmDesc.HW in mode 0)."""
+    return ops.gemm(x, pk.linear(mod), bias=pk.f32(mod, "bias"), residual=residual, x2=x2, out_stream=stream, stats=stats, frame_rows=hw)
 
 
 def _conv3x3(mod, x, frames, h, w, *, stride=1, upsample=False, gbias=None, rows_per_group=0, residual=None, x2=None,
@@ -105,10 +106,10 @@ def _vt_projection(mod, src_rows, batches, n_per_batch):
     return out, out.stride(0)
 
 
-def _feed_forward(ff, x_norm, residual, stream=True):
+def _feed_forward(ff, x_norm, residual, stream=True, hw=0):
     wg, bg = pk.geglu(ff.net[0].proj)
-    hidden = ops.gemm(x_norm, wg, bias=bg, geglu=True)
-    return _linear(ff.net[2], hidden, residual=residual, stream=stream)
+    hidden = ops.gemm(x_norm, wg, bias=bg, geglu=True, frame_rows=hw)
+    return _linear(ff.net[2], hidden, residual=residual, stream=stream, hw=hw)
 
 
 def temporal_conv_block(mod, x, ctx, hw):
@@ -121,7 +122,9 @@ def temporal_conv_block(mod, x, ctx, hw):
         last = i == len(stages) - 1
         # conv1-3 feed the block's own clip-level GroupNorms: tiles of 8 pixels x 16 frames, one staged slab for the three taps
         # (korder 1).  conv4's partials go to whatever follows (a frame-level norm reads 128 consecutive rows): the plain order.
-        slab = not last and _TCONV_SLAB and ops.tconv3_slab_ok(ctx.T, hw, conv.weight.shape[1])
+        # (where the library runs the conv on its 288 x 320 tile — whole-tile frames — the plain order is asked for: its tiles are rows)
+        slab = (not last and _TCONV_SLAB and ops.tconv3_slab_ok(ctx.T, hw, conv.weight.shape[1])
+                and not ops.tconv3_wide(ctx.T, hw, conv.weight.shape[1], conv.weight.shape[0]))
         y = ops.tconv3(y, pk.tconv(conv, slab), clips=ctx.B, t=ctx.T, hw=hw, cin=conv.weight.shape[1],
                        bias=pk.f32(conv, "bias"), residual=x if last else None, out_stream=last, stats=True, korder=int(slab))
     return y
@@ -140,7 +143,7 @@ def res_block(mod, x, x2, h, w, ctx):
             raise RuntimeError("identity skip with a concatenated input")
         skip = x
     else:   # 1x1 conv on the raw stream: the MFMA operand copy is bf16, the result goes back to the fp32 stream
-        skip = _linear(mod.skip_connection, ops.cast_bf16(x), x2=None if x2 is None else ops.cast_bf16(x2), stream=True)
+        skip = _linear(mod.skip_connection, ops.cast_bf16(x), x2=None if x2 is None else ops.cast_bf16(x2), stream=True, hw=hw)
     out = _conv3x3(mod.out_layers[3], a, frames, h, w, residual=skip, stream=True)
     if mod.use_temporal_conv:
         out = temporal_conv_block(mod.temopral_conv, out, ctx, hw)
@@ -172,18 +175,18 @@ def spatial_block(blk, hcur, frames, hw, ctx, last):
         qk, q8, s8 = ops.gemm(n1, wqk, fp8=True)
         fp8 = (q8[:, :c], s8[:, :c // 32], q8[:, c:], s8[:, c // 32:])
     else:
-        qk = ops.gemm(n1, wqk)
+        qk = ops.gemm(n1, wqk, frame_rows=hw)
     vt, ldv = _vt_projection(a1.to_v, n1, frames, hw)
     att = ops.empty_rows(frames * hw, c, ops.H16(), hcur.device)
     ops.attention(qk[:, :c], qk[:, c:], vt, att, frames=frames, heads=heads, nq=hw, nk=hw, ldvt=ldv, svt=c * ldv,
                   scale=a1.scale, q_prescaled=lean, fp8=fp8)
-    hcur = _linear(a1.to_out[0], att, residual=hcur, stream=True)
+    hcur = _linear(a1.to_out[0], att, residual=hcur, stream=True, hw=hw)
     if ctx.replicas > 1:        # first use of the context in this forward: from here on the guidance replicas differ
         hcur = ctx.fan_out(hcur)
         frames = ctx.B * ctx.T
     # text (+ image) cross-attention: two softmaxes, outputs summed (image_cross_attention_scale == 1)
     n2 = _ln(blk.norm2, hcur)
-    q2 = ops.gemm(n2, pk.linear(a2.to_q))
+    q2 = ops.gemm(n2, pk.linear(a2.to_q), frame_rows=hw)
     key = id(a2)
     if key not in ctx.kv_cache:
         ctx.kv_cache[key] = _cross_kv(a2, ctx)
@@ -196,40 +199,40 @@ def spatial_block(blk, hcur, frames, hw, ctx, last):
                   svt=c * ld_text, kv_div=ctx.T, scale=a2.scale, k2=k_img, vt2=vt_img, nk2=ctx.n_img,
                   ldvt2=ld_img if k_img is not None else None, svt2=c * ld_img if k_img is not None else None,
                   kv_div2=ctx.img_div)
-    hcur = _linear(a2.to_out[0], att2, residual=hcur, stream=True)
+    hcur = _linear(a2.to_out[0], att2, residual=hcur, stream=True, hw=hw)
     # the last block's output only feeds proj_out (an MFMA operand), so it is written as bf16 directly
-    return _feed_forward(blk.ff, _ln(blk.norm3, hcur), hcur, stream=not last)
+    return _feed_forward(blk.ff, _ln(blk.norm3, hcur), hcur, stream=not last, hw=hw)
 
 
 def spatial_transformer(mod, x, h, w, ctx):
     hw = h * w
-    cur = _linear(mod.proj_in, _gn(mod.norm, x, None, ctx.B * ctx.T, hw, False), stream=True)
+    cur = _linear(mod.proj_in, _gn(mod.norm, x, None, ctx.B * ctx.T, hw, False), stream=True, hw=hw)
     n = len(mod.transformer_blocks)
     for i, blk in enumerate(mod.transformer_blocks):
         shared = ctx.replicas
         cur = spatial_block(blk, cur, ctx.B * ctx.T, hw, ctx, i == n - 1)
         if ctx.replicas != shared:          # the block fanned the batch out: so must the residual input
             x = ops.repeat_rows(x, shared)
-    return _linear(mod.proj_out, cur, residual=x, stream=True, stats=True)
+    return _linear(mod.proj_out, cur, residual=x, stream=True, stats=True, hw=hw)
 
 
 def temporal_block(blk, hcur, hw, ctx, last):
     for attn, norm in ((blk.attn1, blk.norm1), (blk.attn2, blk.norm2)):     # both are self-attention over T
         c = hcur.shape[1]
-        qkv = ops.gemm(_ln(norm, hcur), pk.linear_cat(attn, "qkv", (attn.to_q, attn.to_k, attn.to_v)))
+        qkv = ops.gemm(_ln(norm, hcur), pk.linear_cat(attn, "qkv", (attn.to_q, attn.to_k, attn.to_v)), frame_rows=hw)
         att = ops.empty_rows(hcur.shape[0], c, ops.H16(), hcur.device)
         ops.temporal_attention(qkv, att, clips=ctx.B, t=ctx.T, hw=hw, heads=attn.heads, scale=attn.scale)
-        hcur = _linear(attn.to_out[0], att, residual=hcur, stream=True)
-    return _feed_forward(blk.ff, _ln(blk.norm3, hcur), hcur, stream=not last)
+        hcur = _linear(attn.to_out[0], att, residual=hcur, stream=True, hw=hw)
+    return _feed_forward(blk.ff, _ln(blk.norm3, hcur), hcur, stream=not last, hw=hw)
 
 
 def temporal_transformer(mod, x, h, w, ctx):
     hw = h * w
-    cur = _linear(mod.proj_in, _gn(mod.norm, x, None, ctx.B, ctx.T * hw, False), stream=True)
+    cur = _linear(mod.proj_in, _gn(mod.norm, x, None, ctx.B, ctx.T * hw, False), stream=True, hw=hw)
     n = len(mod.transformer_blocks)
     for i, blk in enumerate(mod.transformer_blocks):
         cur = temporal_block(blk, cur, hw, ctx, i == n - 1)
-    return _linear(mod.proj_out, cur, residual=x, stream=True, stats=True)
+    return _linear(mod.proj_out, cur, residual=x, stream=True, stats=True, hw=hw)
 
 
 def run_stage(seq, x, x2, h, w, ctx):

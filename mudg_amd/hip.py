@@ -121,6 +121,7 @@ SIGNATURES = {
     "mudg_operand_dtype": (_I, []),
     "mudg_last_error": (C.c_char_p, []),
     "mudg_gemm": (_I, [C.POINTER(GemmDesc), _P]),
+    "mudg_gemm_stats_rows": (_I, [C.POINTER(GemmDesc)]),
     "mudg_conv_subpixel_ok": (_I, [C.POINTER(GemmDesc)]),
     "mudg_attention": (_I, [C.POINTER(AttnDesc), _P]),
     "mudg_quantize_mxfp8": (_I, [_P, _I, _L, _I, _P, _I, _P, _I, _P]),
@@ -128,6 +129,7 @@ SIGNATURES = {
     "mudg_groupnorm_ws_floats": (_L, [_I, _I, _I]),
     "mudg_groupnorm": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P, _P]),
     "mudg_groupnorm_fused": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P, _P, _P, _P]),
+    "mudg_groupnorm_fused_rows": (_I, [_P, _P, _I, _I, _I, _I, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _P, _I, _P, _I, _P, _P]),
     "mudg_layernorm": (_I, [_P, _I, _I, _P, _P, _P, _I, _I, _I, _F, _P]),
     "mudg_softmax_rows": (_I, [_P, _I, _P, _I, _I, _I, _P]),
     "mudg_timestep_embedding": (_I, [_P, _P, _P, _I, _I, _P]),

@@ -7,6 +7,7 @@ count (views into wider buffers are fine as long as stride(1) == 1 and rows are 
 from __future__ import annotations
 
 import ctypes as C
+import functools
 import math
 from typing import Optional
 
@@ -90,14 +91,17 @@ def repeat_rows(t, times):
     for i in range(times):
         dst[i * rows:(i + 1) * rows].copy_(src)
     ws = getattr(t, GN_ATTR, None)
-    if ws is not None and getattr(t, GN_ATTR + "_version", -1) == _version(t) and rows % 128 == 0 and not getattr(t, GN_ATTR + "_clips", 0):
+    brows = getattr(t, GN_ATTR + "_rows", 128)
+    if ws is not None and getattr(t, GN_ATTR + "_version", -1) == _version(t) and rows % brows == 0 and not getattr(t, GN_ATTR + "_clips", 0):
         setattr(out, GN_ATTR, ws.repeat(times, 1, 1))
         setattr(out, GN_ATTR + "_version", _version(out))
+        setattr(out, GN_ATTR + "_rows", brows)
     return out
 
 
 # ------------------------------------------------------------------------------------------------ GEMM family
-GN_ATTR = "_mudg_gn_partials"      # python attribute a producer leaves on its output: fp32 [ceil(M/128)][N][2] partial sums
+GN_ATTR = "_mudg_gn_partials"      # python attribute a producer leaves on its output: fp32 [ceil(M/rows)][N][2] partial sums per block of
+                                   # `rows` rows (attribute GN_ATTR + "_rows": 128, or 288 where the 288 x 320-tile kernel ran the problem)
 
 
 def _drop_stats(t):
@@ -116,9 +120,12 @@ def _version(t):
 
 
 def _attach_stats(d, out, M, nout):
-    """Ask the epilogue for GroupNorm partials of `out` (MudgGemmDesc.stats) and hang them on the tensor."""
-    ws = torch.empty(((M + 127) // 128, nout, 2), dtype=torch.float32, device=out.device)
+    """Ask the epilogue for GroupNorm partials of `out` (MudgGemmDesc.stats) and hang them on the tensor.  Call it on the finished
+    descriptor: the height of the partial blocks depends on which kernel the library will run (mudg_gemm_stats_rows)."""
+    brows = hip.lib().mudg_gemm_stats_rows(C.byref(d))
+    ws = torch.empty(((M + brows - 1) // brows, nout, 2), dtype=torch.float32, device=out.device)
     d.stats = ws.data_ptr()
+    setattr(out, GN_ATTR + "_rows", brows)
     setattr(out, GN_ATTR, ws)
     setattr(out, GN_ATTR + "_version", _version(out))     # a later torch in-place op on `out` invalidates the partials
     setattr(out, GN_ATTR + "_clips", 0)                   # (the tiling tag of an earlier slab-major tconv3 into the same `out=` is stale)
@@ -126,8 +133,9 @@ def _attach_stats(d, out, M, nout):
 
 def gemm(x, w, *, out=None, bias=None, gbias=None, rows_per_group=0, residual=None, x2=None, geglu=False,
          out_fp32=False, alpha=1.0, batch=1, sx=0, sw=0, sy=0, sr=0, M=None, N=None, K=None, ldy=None, gelu=False,
-         stats=False, out_stream=False, fp8=False):
-    """out[m, n] = epilogue(alpha * sum_k x[m, k] w[n, k]); see MudgGemmDesc.  The result is an MFMA operand matrix by
+         stats=False, out_stream=False, fp8=False, frame_rows=0):
+    """out[m, n] = epilogue(alpha * sum_k x[m, k] w[n, k]); see MudgGemmDesc.  frame_rows: a hint — the rows of one frame of x
+    (results never depend on it; it lets the library pick a tile height that divides a frame).  The result is an MFMA operand matrix by
     default, fp32 with out_fp32, the residual-stream dtype (STREAM()) with out_stream; `out=` decides by its dtype.
     fp8=True (16-bit builds, operand result, N % 32 == 0): returns (out, e4m3 bytes [M, N] uint8, E8M0 scales [M, N / 32] uint8) —
     the MX-fp8 copy of the result written by the same epilogue (MudgGemmDesc.Y8), bit-equal to quantize_mxfp8(out)."""
@@ -156,12 +164,13 @@ def gemm(x, w, *, out=None, bias=None, gbias=None, rows_per_group=0, residual=No
     d.rows_per_group, d.out_fp32, d.geglu, d.alpha, d.mode = rows_per_group, kind(out), int(geglu), alpha, 0
     d.res_fp32 = kind(residual) if residual is not None else 0
     d.act = int(gelu)
-    if stats:
-        _attach_stats(d, out, M, nout)
+    d.HW = int(frame_rows)
     if fp8:
         y8 = torch.empty((M, nout), dtype=torch.uint8, device=x.device)
         s8 = torch.empty((M, nout // 32), dtype=torch.uint8, device=x.device)
         d.Y8, d.S8, d.ldy8, d.lds8 = y8.data_ptr(), s8.data_ptr(), y8.stride(0), s8.stride(0)
+    if stats:
+        _attach_stats(d, out, M, nout)
     hip.check(hip.lib().mudg_gemm(C.byref(d), _stream()), "mudg_gemm")
     return (out, y8, s8) if fp8 else out
 
@@ -227,6 +236,19 @@ def conv3x3_up2(x, wsub, *, frames, hin, win, cin, bias=None, out_fp32=False, ou
 def tconv3_slab_ok(t, hw, cin):
     """Whether mudg_gemm accepts korder = 1 for this temporal conv (MudgGemmDesc.korder, mode 2)."""
     return hip.planes() <= 2 and t == 16 and hw % 8 == 0 and cin % 64 == 0
+
+
+@functools.lru_cache(maxsize=None)
+def tconv3_wide(t, hw, cin, cout):
+    """Whether the library runs this temporal conv (plain K order, korder 0) on its 288 x 320-tile kernel — the caller then does not
+    ask for the slab-major order, whose 8-pixel x 16-frame tiles belong to the 128 x 128 kernels.  A dry query: nothing is read."""
+    d = hip.GemmDesc()
+    d.X, d.W, d.Y = 256, 256, 256                     # aligned placeholders
+    d.M, d.N, d.K = 16 * t * hw, cout, 3 * cin
+    d.ldx, d.ldw, d.ldy = cin, 3 * cin, cout
+    d.csplit, d.batch, d.alpha, d.mode = cin, 1, 1.0, 2
+    d.Cin, d.T, d.HW = cin, t, hw
+    return hip.lib().mudg_gemm_stats_rows(C.byref(d)) == 288
 
 
 def tconv3(x, w, *, clips, t, hw, cin, out=None, bias=None, residual=None, out_fp32=False, stats=False, out_stream=False, korder=0):
@@ -335,21 +357,22 @@ def groupnorm(x, gamma, beta, *, samples, rows, eps, silu, groups=32, x2=None, o
         ws = getattr(t, GN_ATTR, None)
         tiled = getattr(t, GN_ATTR + "_clips", 0)          # partials per (8 pixels x 16 frames) tile of a clip (tconv3, korder 1)
         if tiled and tiled != samples:
-            return None
-        return ws if ws is not None and getattr(t, GN_ATTR + "_version", -1) == _version(t) else None
+            return None, 128
+        ok_ = ws is not None and getattr(t, GN_ATTR + "_version", -1) == _version(t)
+        return (ws if ok_ else None), getattr(t, GN_ATTR + "_rows", 128)
 
-    p1 = partials(x) if fused else None
-    p2 = partials(x2) if (fused and x2 is not None) else None
-    ok = p1 is not None and rows % 128 == 0 and p1.shape[1] == x.shape[1] and p1.shape[0] * 128 >= samples * rows
+    p1, r1 = partials(x) if fused else (None, 128)
+    p2, r2 = partials(x2) if (fused and x2 is not None) else (None, r1)
+    ok = p1 is not None and rows % r1 == 0 and p1.shape[1] == x.shape[1] and p1.shape[0] * r1 >= samples * rows
     if ok and x2 is not None:
-        ok = p2 is not None and p2.shape[1] == x2.shape[1] and p2.shape[0] == p1.shape[0]
+        ok = p2 is not None and rows % r2 == 0 and p2.shape[1] == x2.shape[1] and p2.shape[0] * r2 >= samples * rows
     if ok:
         ws = torch.empty(2 * samples * groups, dtype=torch.float32, device=x.device)
-        hip.check(hip.lib().mudg_groupnorm_fused(x.data_ptr(), _ptr(x2), x.shape[1], x.stride(0),
-                                                 x2.stride(0) if x2 is not None else 0, kind(x),
-                                                 gamma.data_ptr(), beta.data_ptr(),
-                                                 out.data_ptr(), out.stride(0), samples, rows, c, groups, eps, int(silu),
-                                                 p1.data_ptr(), _ptr(p2), ws.data_ptr(), _stream()), "mudg_groupnorm_fused")
+        hip.check(hip.lib().mudg_groupnorm_fused_rows(x.data_ptr(), _ptr(x2), x.shape[1], x.stride(0),
+                                                      x2.stride(0) if x2 is not None else 0, kind(x),
+                                                      gamma.data_ptr(), beta.data_ptr(),
+                                                      out.data_ptr(), out.stride(0), samples, rows, c, groups, eps, int(silu),
+                                                      p1.data_ptr(), r1, _ptr(p2), r2, ws.data_ptr(), _stream()), "mudg_groupnorm_fused")
         return (out, ws.reshape(samples * groups, 2)) if return_stats else out
     n = hip.lib().mudg_groupnorm_ws_floats(samples, groups, rows)
     ws = torch.empty(n, dtype=torch.float32, device=x.device)
