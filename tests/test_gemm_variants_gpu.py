@@ -4,7 +4,8 @@ the generic 64-bit-address path of all kernels with the buffer-descriptor (FAST)
 short-K kernel forced on / off for every FAST problem, the phase-scheduled large-tile kernel forced on / off, the persistent kernel
 off / forced at 4, 3 and 2 workgroups per CU for every problem it accepts (its residual-seed / GroupNorm-partial variants included), both
 flash-attention kernels (32 / 64 queries per wave) forced, the LDS-table GroupNorm apply kernel and the VALU temporal-attention kernel
-(the defaults are the register-table kernel and the MFMA kernel), the 3x3 convs without the shared activation stage of their dx taps."""
+(the defaults are the register-table kernel and the MFMA kernel), the 3x3 convs without the shared activation stage of their dx taps, the 288 x 320 tile forced for every problem it can run (and, in
+that child, its bit-identity with the 128 x 128 kernels: test_wide288_is_bit_identical_to_the_one_tile_kernels)."""
 import os
 import subprocess
 import sys
@@ -30,6 +31,7 @@ SELECT = "gemm or conv or tconv or resblock or transformer or geglu or fused or 
     {"MUDG_ATTN_Q": "64"},
     {"MUDG_GN_REG": "0", "MUDG_TATTN_MFMA": "0"},
     {"MUDG_CONV_XSHARE": "0"},
+    {"MUDG_GEMM_W288": "2"},
 ], ids=lambda e: ",".join(f"{k[5:]}={v}" for k, v in e.items()))
 def test_kernel_parity_under_variant(cuda, env):
     if os.environ.get("MUDG_DEBUG_VARIANTS") == "1":

@@ -556,7 +556,8 @@ def test_groupnorm_fused_partials_match_the_two_pass_norm(cuda, out_fp32):
     a = ops.conv3x3(x.to(cuda), w1.to(cuda), frames=frames, hin=h, win=w, cin=cin, residual=res.to(cuda) if out_fp32 else None,
                     out_fp32=out_fp32, stats=True)
     b = ops.gemm(x.to(cuda), w2.to(cuda), out_fp32=out_fp32, stats=True)
-    assert getattr(a, ops.GN_ATTR).shape == (frames * 2, c1, 2) and getattr(b, ops.GN_ATTR).shape == (frames * 2, c2, 2)
+    ra, rb = getattr(a, ops.GN_ATTR + "_rows"), getattr(b, ops.GN_ATTR + "_rows")      # 128; 288 where the variant child forces the 288 x 320 tile
+    assert getattr(a, ops.GN_ATTR).shape == (-(-frames * h * w // ra), c1, 2) and getattr(b, ops.GN_ATTR).shape == (-(-frames * h * w // rb), c2, 2)
     gam = (1 + 0.1 * torch.randn(c1 + c2, generator=g)).to(cuda)
     bet = (0.1 * torch.randn(c1 + c2, generator=g)).to(cuda)
     for samples, rows in ((frames, h * w), (2, 3 * h * w)):          # per-frame and per-clip statistics from the same partials
@@ -742,13 +743,14 @@ def test_persistent_plain_gemm_with_residual_seed_and_groupnorm_partials(cuda, k
     kw = dict(out_stream=kind == "stream", out_fp32=kind == "f32")
     y = ops.gemm(x.to(cuda), w.to(cuda), bias=b.to(cuda), residual=res.to(cuda), stats=True, **kw)
     assert rel_l2(y, ref) < (TOL_F32 if kind == "f32" else TOL_BF16)
-    stats = getattr(y, ops.GN_ATTR)                        # [ceil(M / 128)][N][2]: sum and sum of squares of the stored values
-    assert tuple(stats.shape) == ((M + 127) // 128, N, 2)
-    yf = torch.nn.functional.pad(y.float().cpu(), (0, 0, 0, (-M) % 128)).reshape(-1, 128, N)
+    stats = getattr(y, ops.GN_ATTR)                        # [ceil(M / rows)][N][2]: sum and sum of squares of the stored values
+    rows = getattr(y, ops.GN_ATTR + "_rows")               # 128 (288 in the variant child that forces the 288 x 320 tile)
+    assert tuple(stats.shape) == ((M + rows - 1) // rows, N, 2)
+    yf = torch.nn.functional.pad(y.float().cpu(), (0, 0, 0, (-M) % rows)).reshape(-1, rows, N)
     assert rel_l2(stats[..., 0], yf.sum(1)) < 1e-5 and rel_l2(stats[..., 1], (yf * yf).sum(1)) < 1e-5
-    sub = 128 * 37
+    sub = 128 * 36                                         # whole blocks of either height
     part = ops.gemm(x[:sub].to(cuda), w.to(cuda), bias=b.to(cuda), residual=res[:sub].to(cuda), stats=True, **kw)
-    assert torch.equal(part, y[:sub]) and torch.equal(getattr(part, ops.GN_ATTR), stats[:37])
+    assert torch.equal(part, y[:sub]) and torch.equal(getattr(part, ops.GN_ATTR), stats[:sub // rows])
 
 
 def test_persistent_rule_takes_ragged_widths_and_scaled_residuals_elsewhere(cuda):
@@ -765,3 +767,130 @@ def test_persistent_rule_takes_ragged_widths_and_scaled_residuals_elsewhere(cuda
     assert rel_l2(y2, 0.5 * (x.float() @ w8.float().t()) + r[:, :1280]) < TOL_F32
     y3 = ops.gemm(x.to(cuda), w8.to(cuda), gelu=True, out_fp32=True)
     assert rel_l2(y3, F.gelu(x.float() @ w8.float().t())) < 1e-4
+
+
+# ---------------------------------------------------------------------------------------------- the 288 x 320 tile (csrc/wgemm.hip)
+def _conv_ref(x, w, frames, h, wd, cin, cout, korder):
+    """fp32 conv2d of the bf16-rounded inputs; w is the packed [Cout][9 cin] matrix in tap-major (0) or slab-major (1) K order."""
+    if korder:
+        wk = w.float().reshape(cout, cin // 64, 9, 64).permute(0, 2, 1, 3).reshape(cout, 3, 3, cin)
+    else:
+        wk = w.float().reshape(cout, 3, 3, cin)
+    xi = x.float().reshape(frames, h, wd, cin).permute(0, 3, 1, 2)
+    return F.conv2d(xi, wk.permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1).reshape(frames * h * wd, cout)
+
+
+def _wide_build():
+    return _hip.planes() == 1           # the kernel belongs to the 16-bit builds; the split-operand builds keep their own
+
+
+@pytest.mark.parametrize("kind,korder", [("operand", 1), ("stream", 0), ("f32", 1)])
+def test_wide288_conv_group_bias_residual_two_sources_and_partials(cuda, kind, korder):
+    """Frames of 576 = 2 x 288 pixels: the library's rule sends the conv to the 288 x 320 tile (16-bit builds).  Bias + per-frame
+    group bias, a residual of every storage kind, the input split over two channel sources, GroupNorm partials per 288-row block."""
+    from mudg_amd import ops
+    f, h, wd, c1, c2, cout = 3, 24, 24, 64, 128, 320
+    cin, M = c1 + c2, 3 * 24 * 24
+    xa, xb = rnd(M, c1, seed=1), rnd(M, c2, seed=2)
+    w = rnd(cout, 9 * cin, seed=3, scale=0.03)
+    b = torch.randn(cout, generator=torch.Generator().manual_seed(4)) * 0.1
+    gb = torch.randn(f, cout, generator=torch.Generator().manual_seed(5))
+    r = torch.randn(M, cout, generator=torch.Generator().manual_seed(6))
+    res = {"operand": r.to(BF), "stream": r.to(ops.STREAM()), "f32": r}[kind]
+    ref = _conv_ref(torch.cat([xa, xb], 1), w, f, h, wd, cin, cout, korder) + b + gb.repeat_interleave(h * wd, 0) + res.float()
+    kw = dict(out_stream=kind == "stream", out_fp32=kind == "f32")
+    y = ops.conv3x3(xa.to(cuda), w.to(cuda), x2=xb.to(cuda), frames=f, hin=h, win=wd, cin=cin, korder=korder, bias=b.to(cuda), gbias=gb.to(cuda),
+                    rows_per_group=h * wd, residual=res.to(cuda), stats=True, **kw)
+    assert rel_l2(y, ref) < (TOL_F32 if kind == "f32" else TOL_BF16)
+    rows = getattr(y, ops.GN_ATTR + "_rows")
+    assert rows == (288 if _wide_build() else 128)
+    stats = getattr(y, ops.GN_ATTR)
+    assert tuple(stats.shape) == (M // rows if M % rows == 0 else M // rows + 1, cout, 2)
+    if M % rows == 0:
+        yf = y.float().cpu().reshape(-1, rows, cout)
+        assert rel_l2(stats[..., 0], yf.sum(1)) < 1e-5 and rel_l2(stats[..., 1], (yf * yf).sum(1)) < 1e-5
+    # a frame's rows and partial blocks do not depend on what else is in the launch
+    one = ops.conv3x3(xa[:h * wd].to(cuda), w.to(cuda), x2=xb[:h * wd].to(cuda), frames=1, hin=h, win=wd, cin=cin, korder=korder, bias=b.to(cuda),
+                      gbias=gb[:1].to(cuda), rows_per_group=h * wd, residual=res[:h * wd].to(cuda), stats=True, **kw)
+    assert torch.equal(one, y[:h * wd]) and torch.equal(getattr(one, ops.GN_ATTR), stats[:h * wd // rows])
+
+
+def test_wide288_plain_gemm_ragged_rows_and_temporal_conv(cuda):
+    from mudg_amd import ops
+    M, N, K = 288 * 5 + 100, 320, 1280                    # K >= 1280 at N = 320 with a frame hint of whole tiles: the rule's plain-GEMM case
+    x, w = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.03)
+    b = torch.randn(N, generator=torch.Generator().manual_seed(3)) * 0.1
+    r = rnd(M, N, seed=4).to(ops.STREAM())
+    ref = x.float() @ w.float().t() + b + r.float()
+    y = ops.gemm(x.to(cuda), w.to(cuda), bias=b.to(cuda), residual=r.to(cuda), out_stream=True, stats=True, frame_rows=288)
+    assert rel_l2(y, ref) < TOL_BF16
+    rows = getattr(y, ops.GN_ATTR + "_rows")
+    assert rows == (288 if _wide_build() else 128) and getattr(y, ops.GN_ATTR).shape[0] == (M + rows - 1) // rows
+    y0 = ops.gemm(x.to(cuda), w.to(cuda), bias=b.to(cuda), residual=r.to(cuda), out_stream=True)           # no hint: the 128 x 128 kernels, the same bits
+    assert torch.equal(y0, y)
+    # temporal conv (plain K order), N = 640: clips of 4 frames x 288 pixels; the first and last frame of a clip see zero padding
+    clips, t, hw, c, co = 2, 4, 288, 128, 640
+    xt, wt = rnd(clips * t * hw, c, seed=5), rnd(co, 3 * c, seed=6, scale=0.05)
+    bt = torch.randn(co, generator=torch.Generator().manual_seed(7)) * 0.1
+    xi = xt.float().reshape(clips, t, hw, c).permute(0, 3, 1, 2)                                            # (clip, c, t, hw)
+    wk = wt.float().reshape(co, 3, c).permute(0, 2, 1)                                                     # (co, c, tap)
+    ref = F.conv2d(xi, wk[..., None], padding=(1, 0)).permute(0, 2, 3, 1).reshape(clips * t * hw, co) + bt
+    assert ops.tconv3_wide(t, hw, c, co) == _wide_build()
+    yt = ops.tconv3(xt.to(cuda), wt.to(cuda), clips=clips, t=t, hw=hw, cin=c, bias=bt.to(cuda), stats=True)
+    assert rel_l2(yt, ref) < TOL_BF16
+    rows = getattr(yt, ops.GN_ATTR + "_rows")
+    yf = yt.float().cpu().reshape(-1, rows, co)
+    assert rel_l2(getattr(yt, ops.GN_ATTR)[..., 0], yf.sum(1)) < 1e-5
+
+
+def test_wide288_partials_feed_the_groupnorm_also_next_to_128_row_partials(cuda):
+    """GroupNorm over two channel sources whose producers wrote partial blocks of different heights (a 288 x 320-tile conv and a
+    128 x 128-tile GEMM): the fused norm folds each source's blocks on their own; against the norm that takes its own statistics."""
+    from mudg_amd import ops
+    f, h, wd, cin = 2, 24, 48, 64                          # 1152 = 4 x 288 = 9 x 128 rows per frame
+    M = f * h * wd
+    x, w1 = rnd(M, cin, seed=1), rnd(320, 9 * cin, seed=2, scale=0.05)
+    a = ops.conv3x3(x.to(cuda), w1.to(cuda), frames=f, hin=h, win=wd, cin=cin, korder=1, stats=True, out_stream=True)
+    bsrc = ops.gemm(x.to(cuda), rnd(160, cin, seed=3, scale=0.1).to(cuda), stats=True, out_stream=True)     # N = 160: the 128 x 128 kernels
+    if _wide_build():
+        assert getattr(a, ops.GN_ATTR + "_rows") == 288 and getattr(bsrc, ops.GN_ATTR + "_rows") == 128
+    g = torch.randn(480, generator=torch.Generator().manual_seed(4)).to(cuda)
+    bt = torch.randn(480, generator=torch.Generator().manual_seed(5)).to(cuda)
+    for x1, x2 in ((a, None), (a, bsrc), (bsrc, a)):
+        c = x1.shape[1] + (x2.shape[1] if x2 is not None else 0)
+        fused = ops.groupnorm(x1, g[:c], bt[:c], samples=f, rows=h * wd, eps=1e-5, silu=True, groups=32, x2=x2)
+        plain = ops.groupnorm(x1, g[:c], bt[:c], samples=f, rows=h * wd, eps=1e-5, silu=True, groups=32, x2=x2, fused=False)
+        assert rel_l2(fused, plain) < 2e-3                 # (both round to operands; the statistics agree to fp32 rounding)
+        xs = torch.cat([x1.float()] + ([x2.float()] if x2 is not None else []), 1).cpu().reshape(f, h * wd, 32, c // 32)
+        mean, var = xs.mean((1, 3), keepdim=True), xs.var((1, 3), unbiased=False, keepdim=True)
+        ref = F.silu(((xs - mean) / torch.sqrt(var + 1e-5)).reshape(M, c) * g[:c].cpu() + bt[:c].cpu())
+        assert rel_l2(fused, ref) < TOL_BF16
+
+
+def test_wide288_is_bit_identical_to_the_one_tile_kernels(cuda):
+    """Debug-variants build only (the switch is read at every call there): the same problem on the 128 x 128 kernels and on the
+    288 x 320 tile gives the same bits — the K-tile order is the same and v_mfma_f32_16x16x32 adds its 32 products as two
+    v_mfma_f32_32x32x16 add their 16 each."""
+    import os
+    if os.environ.get("MUDG_DEBUG_VARIANTS") != "1":
+        pytest.skip("needs the debug-variants build (tests/test_gemm_variants_gpu.py runs it)")
+    from mudg_amd import ops
+    f, h, wd, cin, cout = 2, 24, 36, 128, 640
+    x, w = rnd(f * h * wd, cin, seed=1).to(cuda), rnd(cout, 9 * cin, seed=2, scale=0.03).to(cuda)
+    r = rnd(f * h * wd, cout, seed=3).to(ops.STREAM()).to(cuda)
+    xm, wm = rnd(288 * 7 + 31, 640, seed=4).to(cuda), rnd(960, 640, seed=5, scale=0.03).to(cuda)
+    outs = []
+    saved = os.environ.get("MUDG_GEMM_W288")
+    try:
+        for v in ("0", "2"):
+            os.environ["MUDG_GEMM_W288"] = v
+            outs.append((ops.conv3x3(x, w, frames=f, hin=h, win=wd, cin=cin, korder=1, residual=r, out_stream=True),
+                         ops.conv3x3(x, w, frames=f, hin=h, win=wd, cin=cin, korder=0, out_fp32=True),
+                         ops.gemm(xm, wm, out_fp32=True), ops.tconv3(x, w[:, :3 * cin].contiguous(), clips=1, t=2, hw=h * wd, cin=cin)))
+    finally:
+        if saved is None:
+            os.environ.pop("MUDG_GEMM_W288", None)
+        else:
+            os.environ["MUDG_GEMM_W288"] = saved
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
