@@ -42,14 +42,18 @@
 #if MUDG_PLANES == 1
 namespace {
 
-constexpr int WBM = 288, WBN = 320;
-constexpr int WNA = WBM / 16, WNB = WBN / 16;            // 16-row subtiles of the X / W operand tile
-constexpr int W_KS = (WNA + WNB) * 1024;                 // one k half of a buffer
-constexpr int W_BUF = 2 * W_KS;
-constexpr int W_LOOP = 2 * W_BUF;                        // 155648
-constexpr int W_STG = 132;                               // fp32 per staging row of a 128-column pass (+ 4: conflict-free row-per-lane writes)
-constexpr int W_SMEM = W_LOOP;
-static_assert(WBM * W_STG * 4 + WBN * 4 <= W_LOOP, "the staging rows and the column constants reuse the ring");
+constexpr int WBM = 288;
+constexpr int WNA = WBM / 16;                            // 16-row subtiles of the X operand tile
+constexpr int W_TAIL = 2 * 320 * 2 * 4;                  // epilogue hand-off of the GroupNorm partials between the two M halves | Phi table
+static_assert(W_TAIL >= PHI_BYTES, "the GEGLU kernel keeps the Phi table behind the ring");
+template <int NREP> struct WGeo {
+    static constexpr int BN = 64 * NREP;                 // 4 wave columns x NREP fragments of 16
+    static constexpr int NB = BN / 16;                   // 16-row subtiles of the W operand tile
+    static constexpr int KS = (WNA + NB) * 1024;         // one k half of a buffer
+    static constexpr int BUF = 2 * KS;
+    static constexpr int LOOP = 2 * BUF;                 // NREP 5: 155648, NREP 4: 139264
+    static constexpr int SMEM = LOOP + W_TAIL;
+};
 
 #define W_BARRIER()                            \
     do {                                       \
@@ -66,15 +70,38 @@ __device__ __forceinline__ f32x4 mfma16(h16x8 a, h16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 #endif
 }
+template <int CTRL>
+__device__ __forceinline__ float dpp_add16(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+// Sum over the 16 lanes of a DPP row (the 16 pixels of a fragment column), butterfly in a fixed order: every lane gets the total.
+__device__ __forceinline__ float row16_sum(float v) {
+    v = dpp_add16<0xB1>(v);          // quad_perm [1,0,3,2]
+    v = dpp_add16<0x4E>(v);          // quad_perm [2,3,0,1]
+    v = dpp_add16<0x141>(v);         // row_half_mirror
+    v = dpp_add16<0x140>(v);         // row_mirror
+    return v;
+}
 
 struct KPos { int kt, tap, c; };                         // a K-tile: its index along W's K axis, its tap and first input channel
 
-template <int MODE>
-__global__ __launch_bounds__(512, 2) void wgemm_kernel(const MudgGemmDesc p, const int vflags) {
+// NREP = 5: 288 x 320 (every channel count of the UNet is a multiple of 320); NREP = 4 + GEGLU: 288 x 256, a wave's four fragments are
+// one [32 value | 32 gate] block of the packed GEGLU weights.
+template <int MODE, int NREP, bool GEGLU>
+__global__ __launch_bounds__(512, 2) void wgemm_kernel(const MudgGemmDesc p, const int vflags, const float* __restrict__ phi) {
+    using G = WGeo<NREP>;
+    constexpr int WBN = G::BN, W_KS = G::KS, W_BUF = G::BUF;
+    constexpr int NPAIR = NREP / 2;                      // fragment pairs whose 2 x 4 accumulator registers are 8 consecutive channels
+    static_assert(!GEGLU || (MODE == 0 && NREP == 4), "GEGLU: plain GEMM on the 256-wide tile");
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;             // waves wc and wc + 4 share a SIMD: the two M halves
+    float* tail = reinterpret_cast<float*>(smem + G::LOOP);
+    if (GEGLU && phi) {                                  // visible after the K loop's barriers
+        for (int t4 = tid * 4; t4 < PHI_N; t4 += 512 * 4) *reinterpret_cast<f32x4*>(&tail[t4]) = *reinterpret_cast<const f32x4*>(&phi[t4]);
+        if (tid == 0) tail[PHI_N] = phi[PHI_N];
+    }
 
     // XCD-aware tile numbering (gemm.hip): every XCD a contiguous tile range, walked in 8-row groups column by column
     const int ntn = p.N / WBN, ntm = (p.M + WBM - 1) / WBM;
@@ -111,12 +138,17 @@ __global__ __launch_bounds__(512, 2) void wgemm_kernel(const MudgGemmDesc p, con
     const int ldx2e = X2 ? p.ldx2 : p.ldx;
     const unsigned va1 = (unsigned)(srow * p.ldx) * 2u + (unsigned)schunk * 16u;
     const unsigned va2 = (unsigned)(srow * ldx2e) * 2u + (unsigned)schunk * 16u;
-    const unsigned vw = (unsigned)(srow * p.ldw) * 2u + (unsigned)schunk * 16u;
-    // this wave's pieces per k half: the X half wr (9 subtiles) over its four waves as 3 2 2 2; W (20 subtiles) over the eight
-    // waves as 2 3 3 2 | 2 3 3 2: five pieces per k half for wc 0-2, four for wc 3
+    // W rows are fetched PERMUTED, so that the epilogue can leave the accumulators in 16-byte pieces: subtile j of a wave column
+    // (j = 2 p + odd) holds in its row r = 4 q + e the channel 32 p + 8 q + 4 odd + e of the wave's 16 NREP columns — lane (pixel, q) of
+    // the MFMA result then owns, over the fragment pair p, the 8 CONSECUTIVE channels 32 p + 8 q .. + 7.  The fifth fragment of the
+    // 320-wide tile has no partner and keeps its rows (4 consecutive channels per lane).  Free: a row permutation of the source.
+    const unsigned vw_pair = (unsigned)((8 * (srow >> 2) + (srow & 3)) * p.ldw) * 2u + (unsigned)schunk * 16u;
+    const unsigned vw_single = (unsigned)(srow * p.ldw) * 2u + (unsigned)schunk * 16u;
+    // this wave's pieces per k half: the X half wr (9 subtiles) over its four waves as 3 2 2 2; W (4 NREP subtiles) over the eight
+    // waves as 2 3 3 2 | 2 3 3 2 (NREP 5) or two each (NREP 4)
     const int a_first = wc == 0 ? 0 : 1 + 2 * wc, a_cnt = wc == 0 ? 3 : 2;
-    const int b_cnt = (wc == 0 || wc == 3) ? 2 : 3;
-    const int b_first = wr * 10 + (wc == 0 ? 0 : (wc == 1 ? 2 : (wc == 2 ? 5 : 8)));
+    const int b_cnt = NREP == 5 ? ((wc == 0 || wc == 3) ? 2 : 3) : 2;
+    const int b_first = NREP == 5 ? wr * 10 + (wc == 0 ? 0 : (wc == 1 ? 2 : (wc == 2 ? 5 : 8))) : wave * 2;
     // validity of the lane's source row per tap (bit t): rows beyond M, taps that leave the image / the clip -> zero-filled by the DMA
     unsigned amask[3];
 #pragma unroll
@@ -175,8 +207,11 @@ __global__ __launch_bounds__(512, 2) void wgemm_kernel(const MudgGemmDesc p, con
 #pragma unroll
             for (int q = 0; q < 3; ++q)
                 if (q < b_cnt) {
-                    const int st = b_first + q;
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(base + (WNA + st) * 1024), 16, (int)vw, soffw + st * 16 * p.ldw * 2, 0, 0);
+                    const int st = b_first + q, wcol = st / NREP, j = st - wcol * NREP;
+                    const bool single = j >= 2 * NPAIR;
+                    const int row0 = wcol * 16 * NREP + (single ? 32 * NPAIR : 32 * (j >> 1) + 4 * (j & 1));       // first channel of the piece
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(base + (WNA + st) * 1024), 16, (int)(single ? vw_single : vw_pair),
+                                                             soffw + row0 * p.ldw * 2, 0, 0);
                 }
         }
     };
@@ -185,21 +220,21 @@ __global__ __launch_bounds__(512, 2) void wgemm_kernel(const MudgGemmDesc p, con
     const int fbyte0 = (lane & 15) * 64 + (lane >> 4) * 16;
     const int fbyte = fbyte0 ^ (((fbyte0 >> 9) & 1) << 5);
     const char* a_base = smem + (wr * 9) * 1024 + fbyte;
-    const char* b_base = smem + (WNA + wc * 5) * 1024 + fbyte;
+    const char* b_base = smem + (WNA + wc * NREP) * 1024 + fbyte;
 
-    f32x4 acc[9][5];
+    f32x4 acc[9][NREP];
 #pragma unroll
     for (int i = 0; i < 9; ++i)
 #pragma unroll
-        for (int j = 0; j < 5; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    h16x8 af[3], bf[5];
+        for (int j = 0; j < NREP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    h16x8 af[3], bf[NREP];
     auto read_a = [&](int buf, int ks, int third) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) af[i] = *reinterpret_cast<const h16x8*>(a_base + buf * W_BUF + ks * W_KS + (third * 3 + i) * 1024);
     };
     auto read_b = [&](int buf, int ks) {
 #pragma unroll
-        for (int j = 0; j < 5; ++j) bf[j] = *reinterpret_cast<const h16x8*>(b_base + buf * W_BUF + ks * W_KS + j * 1024);
+        for (int j = 0; j < NREP; ++j) bf[j] = *reinterpret_cast<const h16x8*>(b_base + buf * W_BUF + ks * W_KS + j * 1024);
     };
     auto mma = [&](auto third_tag) {
         constexpr int third = decltype(third_tag)::value;
@@ -208,14 +243,15 @@ __global__ __launch_bounds__(512, 2) void wgemm_kernel(const MudgGemmDesc p, con
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
-            for (int j = 0; j < 5; ++j)                 // operands swapped: a lane ends up with 4 consecutive channels of one pixel
+            for (int j = 0; j < NREP; ++j)              // operands swapped: a lane ends up with 4 consecutive (permuted) channels of one pixel
                 acc[third * 3 + i][j] = mfma16(bf[j], af[i], acc[third * 3 + i][j]);
     };
-    // "everything but the pieces issued after the k half that is about to be read": that half's successor (n pieces) plus the W
-    // pieces of the one after (issued in this phase)
+    // "everything but the pieces issued after the k half that is about to be read": that half's successor (a_cnt + b_cnt pieces) plus
+    // the W pieces of the one after (b_cnt, issued in this phase): 7 | 8 | 6 (NREP 5: wc 0 | 1, 2 | 3), 7 | 6 (NREP 4: wc 0 | others)
     auto wait_half = [&](bool more) {
         if (!more) W_VMCNT(0);
-        else if (a_cnt + b_cnt == 5) { if (b_cnt == 3) W_VMCNT(8); else W_VMCNT(7); }
+        else if (a_cnt + 2 * b_cnt == 8) W_VMCNT(8);
+        else if (a_cnt + 2 * b_cnt == 7) W_VMCNT(7);
         else W_VMCNT(6);
     };
     using T0 = std::integral_constant<int, 0>; using T1 = std::integral_constant<int, 1>; using T2 = std::integral_constant<int, 2>;
@@ -278,126 +314,206 @@ __global__ __launch_bounds__(512, 2) void wgemm_kernel(const MudgGemmDesc p, con
     }
     if (wr == 0) W_BARRIER();                            // evens out the stagger: every fragment read has retired, every DMA has landed
 
-    // ------------------------------------------------------------------ epilogue
-    float* stg = reinterpret_cast<float*>(smem);
-    float* sbias = stg + WBM * W_STG;
-    if (tid < WBN) {
-        float b = p.bias ? p.bias[n0 + tid] : 0.f;
-        if (p.gbias) b += p.gbias[(int64_t)(m0 / p.rows_per_group) * p.N + n0 + tid];      // host-checked: one group per tile
-        sbias[tid] = b;
-    }
-    __syncthreads();
+    // ------------------------------------------------------------------ epilogue: straight from the accumulators
+    // Lane (pixel px = lane % 16, q = lane / 16) holds, for each of its 9 rows m = m0 + 144 wr + 16 i + px and each fragment pair p,
+    // the 8 consecutive output channels 16 NREP wc + 32 p + 8 q .. + 7: one 16-byte piece per row (operand / fp16 result; two for
+    // fp32), four lanes = 64 contiguous bytes of the row.  A piece is value = alpha acc + (bias + group bias), GEGLU'd, + residual, rounded,
+    // summed into the GroupNorm partials, stored.  The residual pieces of all nine rows are requested before the first is used.
+    const int px = lane & 15, q4 = lane >> 4;
     const float alpha = p.alpha;
-    const int cc = tid & 15, rr = tid >> 4;              // store loop: 16 eight-channel chunks x 32 row classes (rows rr + 32 k, k = 0..8)
     const int RK = p.R ? p.res_fp32 : 3, OK = p.out_fp32;
     const char* Rb = reinterpret_cast<const char*>(p.R);
     const int rsz = RK == KIND_F32 ? 4 : 2;
-    auto run_pass = [&](auto qtag) __attribute__((always_inline)) {
-        constexpr int q = decltype(qtag)::value;
-        // ---- accumulators -> staging (fp32, + bias): the fragments whose 16 columns lie in [128 q, 128 q + 128)
+    const int64_t mrow = (int64_t)m0 + wr * 144 + px;    // row of i = 0
+    float* sred = tail;                                  // [M half][tile column][2]: GroupNorm partials meet here
+    const float* phis = tail;                            // GEGLU: the Phi table
+    const int64_t gb0 = p.gbias ? (int64_t)(m0 / p.rows_per_group) * p.N : 0;          // host-checked: one group per tile
+
+    auto piece8 = [&](auto ptag) __attribute__((always_inline)) {
+        constexpr int P = decltype(ptag)::value;         // fragment pair: accumulator fragments 2 P (channels + 0..3) and 2 P + 1 (+ 4..7)
+        const int cw = n0 + wc * 16 * NREP + (GEGLU ? 0 : 32 * P) + 8 * q4;           // first W row (bias index) of the value
+        const int n = GEGLU ? (n0 >> 1) + wc * 32 + 8 * q4 : cw;                        // first output channel
+        float bv[8], bg[8];
 #pragma unroll
-        for (int j = 0; j < 5; ++j) {
-            const int c0 = 80 * wc + 16 * j;
-            if ((c0 >> 7) == q) {
-                const f32x4 sb = *reinterpret_cast<const f32x4*>(&sbias[c0 + 4 * (lane >> 4)]);
-                float* dst = stg + (wr * 144 + (lane & 15)) * W_STG + (c0 & 127) + 4 * (lane >> 4);
+        for (int e = 0; e < 8; ++e) {
+            bv[e] = p.bias ? p.bias[cw + e] : 0.f;
+            if (p.gbias) bv[e] += p.gbias[gb0 + cw + e];
+            bg[e] = (GEGLU && p.bias) ? p.bias[cw + 32 + e] : 0.f;
+        }
+        u32x4 ra[9];
+        if (RK == KIND_F16 || RK == KIND_OPERAND) {
 #pragma unroll
-                for (int i = 0; i < 9; ++i) {
-                    f32x4 v;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = alpha * acc[i][j][e] + sb[e];
-                    *reinterpret_cast<f32x4*>(dst + i * 16 * W_STG) = v;
+            for (int i = 0; i < 9; ++i) {
+                const int64_t m = mrow + 16 * i;
+                ra[i] = zero16();
+                if (m < p.M) {
+                    const char* rp = Rb + (m * p.ldr + n) * rsz;
+                    ra[i] = ld16(rp);
                 }
             }
         }
-        __syncthreads();
-        // ---- staging -> HBM
-        constexpr int ncols = q < 2 ? 128 : 64;
-        const bool live = cc * 8 < ncols;
-        const int n = n0 + q * 128 + cc * 8;
         float gs[8], gq[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { gs[j] = 0.f; gq[j] = 0.f; }
+        for (int e = 0; e < 8; ++e) { gs[e] = 0.f; gq[e] = 0.f; }
 #pragma unroll
-        for (int kb = 0; kb < 9; kb += 3) {
-            float v[3][8];
-            u32x4 ra[3], rb[3];
-            bool ok[3];
+        for (int i = 0; i < 9; ++i) {
+            const int64_t m = mrow + 16 * i;
+            const bool live = m < p.M;
+            float v[8];
+            if constexpr (GEGLU) {
 #pragma unroll
-            for (int u = 0; u < 3; ++u) {                // every residual request of the batch before the first use
-                const int64_t m = (int64_t)m0 + rr + 32 * (kb + u);
-                ok[u] = live && m < p.M;
-                ra[u] = zero16(); rb[u] = zero16();
-                if (RK != 3 && ok[u]) {
-                    const char* rp = Rb + (m * p.ldr + n) * rsz;
-                    ra[u] = ld16(rp);
-                    if (RK == KIND_F32) rb[u] = ld16(rp + 16);
+                for (int e = 0; e < 8; ++e) {
+                    const float val = alpha * acc[i][e >> 2][e & 3] + bv[e];
+                    const float gate = alpha * acc[i][2 + (e >> 2)][e & 3] + bg[e];
+                    v[e] = val * (phi ? gelu_lut(gate, phis) : gelu_fast(gate));
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = alpha * acc[i][2 * P + (e >> 2)][e & 3] + bv[e];
+            }
+            if (RK == KIND_F32) {
+                if (live) {
+                    const float* rp = reinterpret_cast<const float*>(Rb) + m * p.ldr + n;
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(rp), b = *reinterpret_cast<const f32x4*>(rp + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] += a[e]; v[4 + e] += b[e]; }
+                }
+            } else if (RK == KIND_F16) {
+                union { u32x4 w; f16x8 h; } t; t.w = ra[i];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += (float)t.h[e];
+            } else if (RK == KIND_OPERAND) {
+                const h16x8 t = as_h16x8(ra[i]);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += (float)t[e];
+            }
+            if (!GEGLU && p.stats) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float t = live ? (OK == KIND_F32 ? v[e] : (OK == KIND_F16 ? (float)f16_sat(v[e]) : (float)(h16)v[e])) : 0.f;
+                    gs[e] += t; gq[e] = fmaf(t, t, gq[e]);
                 }
             }
-#pragma unroll
-            for (int u = 0; u < 3; ++u) {
-                const int row = rr + 32 * (kb + u);
-                const f32x4 a = *reinterpret_cast<const f32x4*>(&stg[row * W_STG + cc * 8]);
-                const f32x4 b = *reinterpret_cast<const f32x4*>(&stg[row * W_STG + cc * 8 + 4]);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { v[u][j] = a[j]; v[u][4 + j] = b[j]; }
-            }
-#pragma unroll
-            for (int u = 0; u < 3; ++u) {
-                if (!ok[u]) continue;
-                const int64_t m = (int64_t)m0 + rr + 32 * (kb + u);
-                if (RK == KIND_F32) {
-                    union { u32x4 w; f32x4 f; } ta, tb; ta.w = ra[u]; tb.w = rb[u];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) { v[u][j] += ta.f[j]; v[u][4 + j] += tb.f[j]; }
-                } else if (RK == KIND_F16) {
-                    union { u32x4 w; f16x8 h; } t; t.w = ra[u];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[u][j] += (float)t.h[j];
-                } else if (RK == KIND_OPERAND) {
-                    const h16x8 t = as_h16x8(ra[u]);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[u][j] += (float)t[j];
-                }
-                if (p.stats) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float t = OK == KIND_F32 ? v[u][j] : (OK == KIND_F16 ? (float)f16_sat(v[u][j]) : (float)(h16)v[u][j]);
-                        gs[j] += t; gq[j] = fmaf(t, t, gq[j]);
-                    }
-                }
+            if (live) {
                 const int64_t yoff = m * p.ldy + n;
-                if (OK == KIND_F16) store8_f16(reinterpret_cast<_Float16*>(p.Y) + yoff, v[u]);
+                if (OK == KIND_F16) store8_f16(reinterpret_cast<_Float16*>(p.Y) + yoff, v);
                 else if (OK == KIND_F32) {
                     float* yp = reinterpret_cast<float*>(p.Y) + yoff;
                     f32x4 a, b;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { a[j] = v[u][j]; b[j] = v[u][4 + j]; }
+                    for (int e = 0; e < 4; ++e) { a[e] = v[e]; b[e] = v[4 + e]; }
                     *reinterpret_cast<f32x4*>(yp) = a;
                     *reinterpret_cast<f32x4*>(yp + 4) = b;
-                } else store8_operand(reinterpret_cast<h16*>(p.Y) + yoff, p.ldy, v[u]);
+                } else store8_operand(reinterpret_cast<h16*>(p.Y) + yoff, p.ldy, v);
             }
         }
-        __syncthreads();                                 // the staging rows are free again
-        if (p.stats) {
-            // per 288-row block (= this tile) and channel: the 32 row classes of a chunk folded in a fixed order
-            float* red = stg;
+        if (!GEGLU && p.stats) {
+            // the 16 pixels of the fragment column (a DPP row) folded in a fixed order; lane px = 0 of each q hands its M half's sums over
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { red[tid * 17 + j] = gs[j]; red[tid * 17 + 8 + j] = gq[j]; }
-            __syncthreads();
-            if (tid < 256) {
-                const int c2 = tid >> 4, j = tid & 15;
-                float t = 0.f;
-                for (int k = 0; k < 32; ++k) t += red[(k * 16 + c2) * 17 + j];
-                const int n2 = n0 + q * 128 + c2 * 8 + (j & 7);
-                if (c2 * 8 < ncols) p.stats[((int64_t)tm * p.N + n2) * 2 + (j >> 3)] = t;
+            for (int e = 0; e < 8; ++e) { gs[e] = row16_sum(gs[e]); gq[e] = row16_sum(gq[e]); }
+            if (px == 0) {
+                float* d = sred + ((wr * WBN) + wc * 16 * NREP + 32 * P + 8 * q4) * 2;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { d[2 * e] = gs[e]; d[2 * e + 1] = gq[e]; }
             }
-            __syncthreads();
         }
     };
-    run_pass(T0{});
-    run_pass(T1{});
-    run_pass(T2{});
+    // the unpaired fifth fragment of the 320-wide tile: 4 consecutive channels per lane (8-byte operand / fp16 pieces)
+    auto piece4 = [&]() __attribute__((always_inline)) {
+        constexpr int J = 2 * NPAIR;
+        const int n = n0 + wc * 16 * NREP + 32 * NPAIR + 4 * q4;
+        float bv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            bv[e] = p.bias ? p.bias[n + e] : 0.f;
+            if (p.gbias) bv[e] += p.gbias[gb0 + n + e];
+        }
+        u32x2 ra[9];
+        if (RK == KIND_F16 || RK == KIND_OPERAND) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                const int64_t m = mrow + 16 * i;
+                ra[i] = u32x2{0u, 0u};
+                if (m < p.M) ra[i] = *reinterpret_cast<const u32x2*>(Rb + (m * p.ldr + n) * 2);
+            }
+        }
+        float gs[4], gq[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { gs[e] = 0.f; gq[e] = 0.f; }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const int64_t m = mrow + 16 * i;
+            const bool live = m < p.M;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = alpha * acc[i][J < NREP ? J : 0][e] + bv[e];
+            if (RK == KIND_F32) {
+                if (live) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(Rb) + m * p.ldr + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += a[e];
+                }
+            } else if (RK == KIND_F16) {
+                union { u32x2 w; _Float16 h[4]; } t; t.w = ra[i];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += (float)t.h[e];
+            } else if (RK == KIND_OPERAND) {
+                Pack8 t; t.u = ra[i];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += (float)t.h[e];
+            }
+            if (p.stats) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float t = live ? (OK == KIND_F32 ? v[e] : (OK == KIND_F16 ? (float)f16_sat(v[e]) : (float)(h16)v[e])) : 0.f;
+                    gs[e] += t; gq[e] = fmaf(t, t, gq[e]);
+                }
+            }
+            if (live) {
+                const int64_t yoff = m * p.ldy + n;
+                if (OK == KIND_F16) {
+                    union { u32x2 w; _Float16 h[4]; } t;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t.h[e] = f16_sat(v[e]);
+                    *reinterpret_cast<u32x2*>(reinterpret_cast<_Float16*>(p.Y) + yoff) = t.w;
+                } else if (OK == KIND_F32) {
+                    f32x4 a;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) a[e] = v[e];
+                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.Y) + yoff) = a;
+                } else {
+                    Pack8 t;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t.h[e] = (h16)v[e];
+                    *reinterpret_cast<u32x2*>(reinterpret_cast<h16*>(p.Y) + yoff) = t.u;
+                }
+            }
+        }
+        if (p.stats) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { gs[e] = row16_sum(gs[e]); gq[e] = row16_sum(gq[e]); }
+            if (px == 0) {
+                float* d = sred + ((wr * WBN) + wc * 16 * NREP + 32 * NPAIR + 4 * q4) * 2;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { d[2 * e] = gs[e]; d[2 * e + 1] = gq[e]; }
+            }
+        }
+    };
+    if constexpr (GEGLU) {
+        piece8(T0{});
+    } else {
+        piece8(T0{});
+        if constexpr (NPAIR > 1) piece8(T1{});
+        if constexpr (NREP & 1) piece4();
+        if (p.stats) {
+            // per 288-row block (= this tile) and channel: M half 0 + M half 1
+            __syncthreads();
+            if (tid < WBN) {
+                const float s0 = sred[tid * 2] + sred[(WBN + tid) * 2], s1 = sred[tid * 2 + 1] + sred[(WBN + tid) * 2 + 1];
+                *reinterpret_cast<f32x2*>(&p.stats[((int64_t)tm * p.N + n0 + tid) * 2]) = f32x2{s0, s1};
+            }
+        }
+    }
 }
 
 // Variant switch GEMM_W288 (debug-variants build; read at every call so that one process can compare kernels): 0 = never, 1 = the rule
@@ -408,21 +524,22 @@ int variant() { return mudg_variant("GEMM_W288", 1); }
 
 // What the kernel can run at all.
 static bool wgemm_eligible(const MudgGemmDesc& d, int vflags) {
-    if (d.batch != 1 || d.geglu || d.act || d.Y8 || d.subpixel || (d.mode == 1 && d.upsample)) return false;
-    if (d.N % WBN != 0 || !(vflags & VF_Y) || (d.R && !(vflags & VF_R))) return false;
+    if (d.batch != 1 || d.act || d.Y8 || d.subpixel || (d.mode == 1 && d.upsample)) return false;
+    if (d.geglu ? (d.mode != 0 || d.N % 256 != 0 || d.R || d.gbias || d.stats) : d.N % 320 != 0) return false;
+    if (!(vflags & VF_Y) || (d.R && !(vflags & VF_R))) return false;
     const int cin = d.mode == 0 ? d.K : d.Cin;
     if ((d.K & 63) || (cin & 63) || (d.csplit & 63)) return false;
     if (d.mode == 1 && (d.stride != 1 || d.pad != 1 || d.Hin != d.Hout || d.Win != d.Wout || d.K != 9 * d.Cin)) return false;
     if (d.mode == 2 && (d.korder || d.K != 3 * d.Cin)) return false;       // (korder 1 means tiles of 8 pixels x 16 frames to the callers: gemm.hip)
     if (d.gbias && (d.rows_per_group % WBM != 0)) return false;            // one group per tile: the group bias rides in the column constants
-    if (d.out_fp32 == KIND_OPERAND && (d.ldy & 7)) return false;
+    if ((d.ldy & 7) || (d.R && (d.ldr & 7))) return false;                 // 8-byte pieces of the unpaired fragment
     // 32-bit reach of the descriptor offsets
     const int64_t ld = d.X2 && d.ldx2 > d.ldx ? d.ldx2 : d.ldx;
     int64_t rows = WBM + 16;
     if (d.mode == 1) rows += 2 * (int64_t)d.Win + 2;
     if (d.mode == 2) rows += 2 * (int64_t)d.HW;
     const int64_t lim = (int64_t)1 << 31;
-    return rows * ld * 2 + (int64_t)cin * 2 + 256 < lim && (int64_t)(WBN + 16) * d.ldw * 2 + (int64_t)d.K * 2 + 256 < lim;
+    return rows * ld * 2 + (int64_t)cin * 2 + 256 < lim && (int64_t)(320 + 16) * d.ldw * 2 + (int64_t)d.K * 2 + 256 < lim;
 }
 
 // Where it is used.  The rule never looks at M (see the header): `S`, the rows of one frame (mode 0: the caller's hint in d.HW), must be
@@ -433,30 +550,36 @@ bool mudg_wgemm_ok(const MudgGemmDesc& d, int vflags) {
     if (mode == 2) return true;
     const int S = d.mode == 1 ? d.Hout * d.Wout : d.HW;
     if (S <= 0 || S % WBM != 0) return false;
-    // Measured per shape against the 128 x 128 kernels (tools/exp_w288.py, profiles/r5/w288_*.txt): 3x3 convs + 17 ... + 36 %;
-    // temporal convs + 1 / + 6 / + 18 % at N = 320 / 640 / 1280; plain GEMMs only where K is long enough for the main loop to outweigh
-    // the (un-overlapped) epilogue of a tile that is alone on its CU.
-    if (d.mode == 1) return true;
-    if (d.mode == 2) return d.N >= 640;
-    return d.K >= 2560 || (d.K >= 1280 && d.N == 320);
+    // Measured per shape against the 128 x 128 kernels (tools/exp_w288.py, profiles/r5/w288_shapes.txt): 3x3 convs + 15 ... + 39 %, temporal
+    // convs + 11 ... + 27 %, plain GEMMs with K >= 1280 + 3 ... + 29 % (with or without a residual), GEGLU + 8 % at K = 1280; at shorter K a
+    // tile is five or ten K-steps between a first-fetch latency and an epilogue that nothing overlaps on a CU holding one workgroup:
+    // - 4 ... - 26 %, those stay on the 128 x 128 kernels (four workgroups per CU).
+    if (d.mode != 0) return true;
+    return d.K >= 1280;
+}
+
+template <int MODE, int NREP, bool GEGLU>
+static int wgemm_launch_one(const MudgGemmDesc& d, int vflags, hipStream_t s, int slot) {
+    static bool attr_done[MAX_DEVICES][4] = {};
+    const int dev = mudg_current_device();
+    if (dev < 0) MUDG_FAIL(MUDG_ELAUNCH, "gemm: no current device");
+    using G = WGeo<NREP>;
+    if (!attr_done[dev][slot]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgemm_kernel<MODE, NREP, GEGLU>), hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM);
+        if (e != hipSuccess) MUDG_FAIL(MUDG_ELAUNCH, "gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_done[dev][slot] = true;
+    }
+    const int tiles = ((d.M + WBM - 1) / WBM) * (d.N / G::BN);
+    const float* phi = GEGLU ? mudg_phi_table() : nullptr;
+    hipLaunchKernelGGL((wgemm_kernel<MODE, NREP, GEGLU>), dim3(tiles), dim3(512), G::SMEM, s, d, vflags, phi);
+    return mudg_check_launch("mudg_gemm");
 }
 
 int mudg_wgemm_launch(const MudgGemmDesc& d, int vflags, hipStream_t s) {
-    static bool attr_done[MAX_DEVICES][3] = {};
-    const int dev = mudg_current_device();
-    if (dev < 0) MUDG_FAIL(MUDG_ELAUNCH, "gemm: no current device");
-    const void* fn = d.mode == 0 ? reinterpret_cast<const void*>(&wgemm_kernel<0>)
-                   : (d.mode == 1 ? reinterpret_cast<const void*>(&wgemm_kernel<1>) : reinterpret_cast<const void*>(&wgemm_kernel<2>));
-    if (!attr_done[dev][d.mode]) {
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, W_SMEM);
-        if (e != hipSuccess) MUDG_FAIL(MUDG_ELAUNCH, "gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_done[dev][d.mode] = true;
-    }
-    const int tiles = ((d.M + WBM - 1) / WBM) * (d.N / WBN);
-    if (d.mode == 0) hipLaunchKernelGGL((wgemm_kernel<0>), dim3(tiles), dim3(512), W_SMEM, s, d, vflags);
-    else if (d.mode == 1) hipLaunchKernelGGL((wgemm_kernel<1>), dim3(tiles), dim3(512), W_SMEM, s, d, vflags);
-    else hipLaunchKernelGGL((wgemm_kernel<2>), dim3(tiles), dim3(512), W_SMEM, s, d, vflags);
-    return mudg_check_launch("mudg_gemm");
+    if (d.geglu) return wgemm_launch_one<0, 4, true>(d, vflags, s, 3);
+    if (d.mode == 0) return wgemm_launch_one<0, 5, false>(d, vflags, s, 0);
+    if (d.mode == 1) return wgemm_launch_one<1, 5, false>(d, vflags, s, 1);
+    return wgemm_launch_one<2, 5, false>(d, vflags, s, 2);
 }
 #else
 bool mudg_wgemm_ok(const MudgGemmDesc&, int) { return false; }

@@ -69,6 +69,9 @@ if what in ("parity", "all"):
         xa, xb = rn(f * h * wd, 64), rn(f * h * wd, 64)
         report(f"conv korder {korder} two sources fp32 out", both(lambda: ops.conv3x3(xa, w, x2=xb, frames=f, hin=h, win=wd, cin=cin, korder=korder, bias=b,
                                                                                      out_fp32=True)))
+    for M, N, K in ((288 * 4 + 40, 512, 320), (288 * 2, 2560, 128)):
+        x, w, b = rn(M, K), rn(N, K), torch.randn(N, device="cuda")
+        report(f"geglu {M}x{N}x{K}", both(lambda: ops.gemm(x, w, bias=b, geglu=True, frame_rows=288)))
     clips, t, hw, c, co = 2, 4, 288, 128, 320
     x, w, b = rn(clips * t * hw, c), rn(co, 3 * c), torch.randn(co, device="cuda")
     r = rn(clips * t * hw, co).to(ops.STREAM())
@@ -99,6 +102,13 @@ if what in ("time", "all"):
                 ts.append(timeit(lambda: ops.gemm(x, w, bias=b, residual=r, out_stream=bool(resid), frame_rows=hw), iters=10))
             print(f"gemm {M} {N} {K} residual={resid}: 128x128 {ts[0]*1e6:8.1f} us {2.0*M*N*K/ts[0]/1e12:7.1f} TF | 288x320 {ts[1]*1e6:8.1f} us {2.0*M*N*K/ts[1]/1e12:7.1f} TF"
                   f"  x{ts[0]/ts[1]:.3f}", flush=True)
+    for (M, N, K, hw) in [(294912, 2560, 320, 9216), (73728, 5120, 640, 2304), (18432, 10240, 1280, 576), (147456, 2560, 320, 9216)]:
+        x, w, b = rn(M, K), rn(N, K), torch.randn(N, device="cuda")
+        ts = []
+        for v in ("0", "2"):
+            os.environ["MUDG_GEMM_W288"] = v
+            ts.append(timeit(lambda: ops.gemm(x, w, bias=b, geglu=True, frame_rows=hw), iters=10))
+        print(f"geglu {M} {N} {K}: 128x128 {ts[0]*1e6:8.1f} us {2.0*M*N*K/ts[0]/1e12:7.1f} TF | 288x256 {ts[1]*1e6:8.1f} us {2.0*M*N*K/ts[1]/1e12:7.1f} TF  x{ts[0]/ts[1]:.3f}", flush=True)
     T = [(2, 16, 9216, 320), (2, 16, 2304, 640), (2, 16, 576, 1280)]
     for (clips, t, hw, c) in T:
         x, w = rn(clips * t * hw, c), rn(c, 3 * c)
