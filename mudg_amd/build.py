@@ -19,6 +19,7 @@ OUT = os.path.join(HERE, "libmudg_hip.so")
 OUT_FP16 = os.path.join(HERE, "libmudg_hip_fp16.so")
 OUT_X3 = os.path.join(HERE, "libmudg_hip_x3.so")
 OUT_X6 = os.path.join(HERE, "libmudg_hip_x6.so")
+OUT_X3_DBG = os.path.join(HERE, "libmudg_hip_x3_dbg.so")  # bf16x3 + kernel-variant switches (same use)
 OUT_DBG = os.path.join(HERE, "libmudg_hip_dbg.so")      # bf16 + kernel-variant switches (tests / tools only; hip.py loads it under MUDG_DEBUG_VARIANTS=1)
 SOURCES = ["capi.hip", "gemm.hip", "pgemm.hip", "wgemm.hip", "attention.hip", "norm.hip", "misc.hip", "post.hip", "train.hip", "attention_bwd.hip", "wgrad.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
@@ -80,7 +81,7 @@ def build(force: bool = False, verbose: bool = True, only=None) -> str:
     kernel runs; the variant tests and the A/B tools load it).  The five libraries are built side by side;
     `only` (or `--only dbg,bf16` on the command line) restricts the set while iterating on a kernel."""
     jobs = {"fp16": (OUT_FP16, ["-DMUDG_OPERAND_FP16"]), "x3": (OUT_X3, ["-DMUDG_PLANES=2"]), "x6": (OUT_X6, ["-DMUDG_PLANES=3"]),
-            "dbg": (OUT_DBG, ["-DMUDG_DEBUG_VARIANTS"]), "bf16": (OUT, [])}
+            "dbg": (OUT_DBG, ["-DMUDG_DEBUG_VARIANTS"]), "x3dbg": (OUT_X3_DBG, ["-DMUDG_PLANES=2", "-DMUDG_DEBUG_VARIANTS"]), "bf16": (OUT, [])}
     tags = [t for t in jobs if only is None or t in only]
     with ThreadPoolExecutor(max_workers=len(tags)) as ex:
         list(ex.map(lambda t: _build_one(jobs[t][0], jobs[t][1], t, force, verbose), tags))

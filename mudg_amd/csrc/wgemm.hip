@@ -36,10 +36,26 @@
 // Summation order over K is the K-tile order of the other kernels, but v_mfma_f32_16x16x32 adds 32 products per instruction where
 // v_mfma_f32_32x32x16 adds 16: results differ from the 128 x 128 kernels' in the last bits.  The selection rule (wgemm_ok) therefore
 // never looks at M — a clip's result must not depend on the batch it travels in — only at the problem's per-frame geometry.
+//
+// bf16x3 build (MUDG_PLANES = 2), same tile, same epilogue: a k half holds both bf16 pieces of both operands (x0, x1, w0, w1: 76 KiB),
+// so the ring is two k halves and a phase re-stages what was read two phases before it.  Per k half h, nine phases:
+//   p   fragment reads              MFMAs (15)   DMA issued (this wave's share)             wait at the end of the MFMA section
+//   0   w0 (5), x1 rows 0-2 (3)     w0 x1        x0 rows 3-5 of k half h + 1
+//   1   x0 rows 0-2                 w0 x0        x0 rows 6-8 of k half h + 1                x0 rows 3-5 of k half h
+//   2   x1 rows 3-5                 w0 x1        w0, x1 rows 0-2 of k half h + 2
+//   3   x0 rows 3-5                 w0 x0        -                                          x0 rows 6-8 of k half h
+//   4   x1 rows 6-8                 w0 x1        x1 rows 3-5 of k half h + 2
+//   5   x0 rows 6-8                 w0 x0        -
+//   6   w1 (5), x0 rows 0-2         w1 x0        x1 rows 6-8 of k half h + 2
+//   7   x0 rows 3-5                 w1 x0        -                                          w0, x1 rows 0-2 of k half h + 1
+//   8   x0 rows 6-8                 w1 x0        w1, x0 rows 0-2 of k half h + 2            x0 rows 0-2 (and all before) of k half h + 1
+// x1 w0 + x0 w0 + x0 w1 per k half (x1 w1, 2^-18 relative, is dropped as in the 128 x 128 fused-piece kernel); 135 MFMAs per 37
+// fragment reads; a piece is re-staged two phases after its last read and has nine or more phases to land; accumulators + fragments
+// = 212 registers, as in the 16-bit builds.
 #include "gemm_shared.h"
 #include <type_traits>
 
-#if MUDG_PLANES == 1
+#if MUDG_PLANES <= 2
 namespace {
 
 constexpr int WBM = 288;
@@ -49,9 +65,10 @@ static_assert(W_TAIL >= PHI_BYTES, "the GEGLU kernel keeps the Phi table behind 
 template <int NREP> struct WGeo {
     static constexpr int BN = 64 * NREP;                 // 4 wave columns x NREP fragments of 16
     static constexpr int NB = BN / 16;                   // 16-row subtiles of the W operand tile
-    static constexpr int KS = (WNA + NB) * 1024;         // one k half of a buffer
-    static constexpr int BUF = 2 * KS;
-    static constexpr int LOOP = 2 * BUF;                 // NREP 5: 155648, NREP 4: 139264
+    static constexpr int PL = (WNA + NB) * 1024;         // one operand piece (plane) of a k half: the X subtiles, then the W subtiles
+    static constexpr int KS = PLANES * PL;               // one k half
+    static constexpr int BUF = 2 * KS;                   // (16-bit builds) one K-tile buffer
+    static constexpr int LOOP = (4 / PLANES) * KS;       // 16-bit: two K-tile buffers; bf16x3: two k halves.  NREP 5: 155648, NREP 4: 139264
     static constexpr int SMEM = LOOP + W_TAIL;
 };
 
@@ -70,6 +87,12 @@ __device__ __forceinline__ f32x4 mfma16(h16x8 a, h16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
 #endif
 }
+// The same instruction with the accumulator tied to its result register: in the bf16x3 loop (224 live accumulator and fragment
+// registers under branches) the register allocator otherwise splits accumulator live ranges — copies at every phase, then spills.
+__device__ __forceinline__ void mfma16_inplace(h16x8 a, h16x8 b, f32x4& c) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ unsigned opaque(unsigned v) { asm volatile("" : "+v"(v)); return v; }
 template <int CTRL>
 __device__ __forceinline__ float dpp_add16(float v) {
     return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
@@ -144,16 +167,18 @@ __global__ __launch_bounds__(512, 2) void wgemm_kernel(const MudgGemmDesc p, con
     // 320-wide tile has no partner and keeps its rows (4 consecutive channels per lane).  Free: a row permutation of the source.
     const unsigned vw_pair = (unsigned)((8 * (srow >> 2) + (srow & 3)) * p.ldw) * 2u + (unsigned)schunk * 16u;
     const unsigned vw_single = (unsigned)(srow * p.ldw) * 2u + (unsigned)schunk * 16u;
-    // this wave's pieces per k half: the X half wr (9 subtiles) over its four waves as 3 2 2 2; W (4 NREP subtiles) over the eight
-    // waves as 2 3 3 2 | 2 3 3 2 (NREP 5) or two each (NREP 4)
-    const int a_first = wc == 0 ? 0 : 1 + 2 * wc, a_cnt = wc == 0 ? 3 : 2;
+    // this wave's pieces per k half.  W (4 NREP subtiles per piece) over the eight waves as 2 3 3 2 | 2 3 3 2 (NREP 5) or two each
+    // (NREP 4).  X: 16-bit builds — the X half wr (9 subtiles) over its four waves as 3 2 2 2; bf16x3 — a row third (3 subtiles) per
+    // staging point over the waves wc = 0, 1, 2 (slot q of amask = third q)
+    const int a_first = PLANES == 1 ? (wc == 0 ? 0 : 1 + 2 * wc) : wc, a_cnt = PLANES == 1 ? (wc == 0 ? 3 : 2) : (wc < 3 ? 3 : 0);
+    constexpr int a_step = PLANES == 1 ? 1 : 3;
     const int b_cnt = NREP == 5 ? ((wc == 0 || wc == 3) ? 2 : 3) : 2;
     const int b_first = NREP == 5 ? wr * 10 + (wc == 0 ? 0 : (wc == 1 ? 2 : (wc == 2 ? 5 : 8))) : wave * 2;
     // validity of the lane's source row per tap (bit t): rows beyond M, taps that leave the image / the clip -> zero-filled by the DMA
     unsigned amask[3];
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
-        const int m = m0 + (wr * 9 + a_first + q) * 16 + srow;
+        const int m = m0 + (wr * 9 + a_first + q * a_step) * 16 + srow;
         unsigned mask = 0;
         if (q < a_cnt && m < p.M) {
             if (MODE == 0) mask = 1;
@@ -183,134 +208,285 @@ __global__ __launch_bounds__(512, 2) void wgemm_kernel(const MudgGemmDesc p, con
         k.tap = slab ? (wrap ? 0 : t1) : (wrap ? t1 : k.tap);
         k.c = slab ? (wrap ? c1 : k.c) : (wrap ? 0 : c1);
     };
-    // part: 0 = all of this wave's pieces of k half ks of K-tile k, 1 = its X pieces, 2 = its W pieces
-    auto stage = [&](const KPos& k, int ks, int buf, int part) {
-        char* base = smem + buf * W_BUF + ks * W_KS;
-        if (part != 2) {
-            const bool s2 = k.c >= p.csplit;
-            const int cc = s2 ? k.c - p.csplit : k.c;
-            const int ld = s2 ? ldx2e : p.ldx;
-            int soff = (cc + ks * 32) * 2;
-            if (MODE == 1) { const int dy = k.tap / 3, dx = k.tap - 3 * dy; soff += (dy * p.Win + dx) * ld * 2; }
-            if (MODE == 2) soff += k.tap * p.HW * ld * 2;
+    f32x4 acc[9][NREP];
 #pragma unroll
-            for (int q = 0; q < 3; ++q)
-                if (q < a_cnt) {
-                    const int st = wr * 9 + a_first + q;
-                    const unsigned v = ((amask[q] >> k.tap) & 1u) ? (s2 ? va2 : va1) : OOB;
-                    if (s2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rX2, (lptr_t)(base + st * 1024), 16, (int)v, soff + st * 16 * ld * 2, 0, 0);
-                    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (lptr_t)(base + st * 1024), 16, (int)v, soff + st * 16 * ld * 2, 0, 0);
-                }
-        }
-        if (part != 1) {
-            const int soffw = (k.kt * BK + ks * 32) * 2;
+    for (int i = 0; i < 9; ++i)
 #pragma unroll
-            for (int q = 0; q < 3; ++q)
-                if (q < b_cnt) {
-                    const int st = b_first + q, wcol = st / NREP, j = st - wcol * NREP;
-                    const bool single = j >= 2 * NPAIR;
-                    const int row0 = wcol * 16 * NREP + (single ? 32 * NPAIR : 32 * (j >> 1) + 4 * (j & 1));       // first channel of the piece
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(base + (WNA + st) * 1024), 16, (int)(single ? vw_single : vw_pair),
-                                                             soffw + row0 * p.ldw * 2, 0, 0);
-                }
-        }
-    };
-
+        for (int j = 0; j < NREP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     // fragment reads: a 16 x 32 fragment is one subtile; lane l holds row l % 16, 16-byte k chunk l / 16
     const int fbyte0 = (lane & 15) * 64 + (lane >> 4) * 16;
     const int fbyte = fbyte0 ^ (((fbyte0 >> 9) & 1) << 5);
     const char* a_base = smem + (wr * 9) * 1024 + fbyte;
     const char* b_base = smem + (WNA + wc * NREP) * 1024 + fbyte;
 
-    f32x4 acc[9][NREP];
-#pragma unroll
-    for (int i = 0; i < 9; ++i)
-#pragma unroll
-        for (int j = 0; j < NREP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    h16x8 af[3], bf[NREP];
-    auto read_a = [&](int buf, int ks, int third) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) af[i] = *reinterpret_cast<const h16x8*>(a_base + buf * W_BUF + ks * W_KS + (third * 3 + i) * 1024);
-    };
-    auto read_b = [&](int buf, int ks) {
-#pragma unroll
-        for (int j = 0; j < NREP; ++j) bf[j] = *reinterpret_cast<const h16x8*>(b_base + buf * W_BUF + ks * W_KS + j * 1024);
-    };
-    auto mma = [&](auto third_tag) {
-        constexpr int third = decltype(third_tag)::value;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);              // (register-only MFMAs may otherwise be hoisted above the wait)
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < NREP; ++j)              // operands swapped: a lane ends up with 4 consecutive (permuted) channels of one pixel
-                acc[third * 3 + i][j] = mfma16(bf[j], af[i], acc[third * 3 + i][j]);
-    };
-    // "everything but the pieces issued after the k half that is about to be read": that half's successor (a_cnt + b_cnt pieces) plus
-    // the W pieces of the one after (b_cnt, issued in this phase): 7 | 8 | 6 (NREP 5: wc 0 | 1, 2 | 3), 7 | 6 (NREP 4: wc 0 | others)
-    auto wait_half = [&](bool more) {
-        if (!more) W_VMCNT(0);
-        else if (a_cnt + 2 * b_cnt == 8) W_VMCNT(8);
-        else if (a_cnt + 2 * b_cnt == 7) W_VMCNT(7);
-        else W_VMCNT(6);
-    };
     using T0 = std::integral_constant<int, 0>; using T1 = std::integral_constant<int, 1>; using T2 = std::integral_constant<int, 2>;
-
     const int nk = p.K / BK;
-    KPos kA{0, 0, 0};
-    stage(kA, 0, 0, 0);
-    stage(kA, 1, 0, 0);
-    advance(kA);                                         // kA = K-tile t + 1, kB = K-tile t + 2 at the top of iteration t
-    if (nk > 1) stage(kA, 0, 1, 0);
-    KPos kB = kA;
-    advance(kB);
-    if (nk <= 1) W_VMCNT(0); else if (a_cnt + b_cnt == 5) W_VMCNT(10); else W_VMCNT(8);      // ks 0 of tile 0 has landed
-    W_BARRIER();
-    if (wr == 1) W_BARRIER();                            // the stagger: M-half 1 runs one barrier behind M-half 0
+    if constexpr (PLANES == 1) {
+        // part: 0 = all of this wave's pieces of k half ks of K-tile k, 1 = its X pieces, 2 = its W pieces
+        auto stage = [&](const KPos& k, int ks, int buf, int part) {
+            char* base = smem + buf * W_BUF + ks * W_KS;
+            if (part != 2) {
+                const bool s2 = k.c >= p.csplit;
+                const int cc = s2 ? k.c - p.csplit : k.c;
+                const int ld = s2 ? ldx2e : p.ldx;
+                int soff = (cc + ks * 32) * 2;
+                if (MODE == 1) { const int dy = k.tap / 3, dx = k.tap - 3 * dy; soff += (dy * p.Win + dx) * ld * 2; }
+                if (MODE == 2) soff += k.tap * p.HW * ld * 2;
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    if (q < a_cnt) {
+                        const int st = wr * 9 + a_first + q;
+                        const unsigned v = ((amask[q] >> k.tap) & 1u) ? (s2 ? va2 : va1) : OOB;
+                        if (s2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rX2, (lptr_t)(base + st * 1024), 16, (int)v, soff + st * 16 * ld * 2, 0, 0);
+                        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (lptr_t)(base + st * 1024), 16, (int)v, soff + st * 16 * ld * 2, 0, 0);
+                    }
+            }
+            if (part != 1) {
+                const int soffw = (k.kt * BK + ks * 32) * 2;
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    if (q < b_cnt) {
+                        const int st = b_first + q, wcol = st / NREP, j = st - wcol * NREP;
+                        const bool single = j >= 2 * NPAIR;
+                        const int row0 = wcol * 16 * NREP + (single ? 32 * NPAIR : 32 * (j >> 1) + 4 * (j & 1));       // first channel of the piece
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(base + (WNA + st) * 1024), 16, (int)(single ? vw_single : vw_pair),
+                                                                 soffw + row0 * p.ldw * 2, 0, 0);
+                    }
+            }
+        };
 
-    for (int t = 0; t < nk; ++t) {
-        const int buf = t & 1;
-        const bool n1 = t + 1 < nk, n2 = t + 2 < nk;
-        // phase 0
-        read_b(buf, 0);
-        read_a(buf, 0, 0);
-        W_BARRIER();
-        mma(T0{});
-        W_BARRIER();
-        // phase 1
-        read_a(buf, 0, 1);
-        if (n1) stage(kA, 1, buf ^ 1, 2);
-        W_BARRIER();
-        mma(T1{});
-        wait_half(n1);                                   // ks 1 of tile t
-        W_BARRIER();
-        // phase 2
-        read_a(buf, 0, 2);
-        if (n1) stage(kA, 1, buf ^ 1, 1);
-        W_BARRIER();
-        mma(T2{});
-        W_BARRIER();
-        // phase 3
-        read_b(buf, 1);
-        read_a(buf, 1, 0);
-        W_BARRIER();
-        mma(T0{});
-        W_BARRIER();
-        // phase 4
-        read_a(buf, 1, 1);
-        if (n2) stage(kB, 0, buf, 2);
-        W_BARRIER();
-        mma(T1{});
-        wait_half(n2);                                   // ks 0 of tile t + 1
-        W_BARRIER();
-        // phase 5
-        read_a(buf, 1, 2);
-        if (n2) stage(kB, 0, buf, 1);
-        W_BARRIER();
-        mma(T2{});
-        W_BARRIER();
-        kA = kB;
+        h16x8 af[3], bf[NREP];
+        auto read_a = [&](int buf, int ks, int third) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) af[i] = *reinterpret_cast<const h16x8*>(a_base + buf * W_BUF + ks * W_KS + (third * 3 + i) * 1024);
+        };
+        auto read_b = [&](int buf, int ks) {
+#pragma unroll
+            for (int j = 0; j < NREP; ++j) bf[j] = *reinterpret_cast<const h16x8*>(b_base + buf * W_BUF + ks * W_KS + j * 1024);
+        };
+        auto mma = [&](auto third_tag) {
+            constexpr int third = decltype(third_tag)::value;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);              // (register-only MFMAs may otherwise be hoisted above the wait)
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < NREP; ++j)              // operands swapped: a lane ends up with 4 consecutive (permuted) channels of one pixel
+                    acc[third * 3 + i][j] = mfma16(bf[j], af[i], acc[third * 3 + i][j]);
+        };
+        // "everything but the pieces issued after the k half that is about to be read": that half's successor (a_cnt + b_cnt pieces) plus
+        // the W pieces of the one after (b_cnt, issued in this phase): 7 | 8 | 6 (NREP 5: wc 0 | 1, 2 | 3), 7 | 6 (NREP 4: wc 0 | others)
+        auto wait_half = [&](bool more) {
+            if (!more) W_VMCNT(0);
+            else if (a_cnt + 2 * b_cnt == 8) W_VMCNT(8);
+            else if (a_cnt + 2 * b_cnt == 7) W_VMCNT(7);
+            else W_VMCNT(6);
+        };
+
+        KPos kA{0, 0, 0};
+        stage(kA, 0, 0, 0);
+        stage(kA, 1, 0, 0);
+        advance(kA);                                         // kA = K-tile t + 1, kB = K-tile t + 2 at the top of iteration t
+        if (nk > 1) stage(kA, 0, 1, 0);
+        KPos kB = kA;
         advance(kB);
+        if (nk <= 1) W_VMCNT(0); else if (a_cnt + b_cnt == 5) W_VMCNT(10); else W_VMCNT(8);      // ks 0 of tile 0 has landed
+        W_BARRIER();
+        if (wr == 1) W_BARRIER();                            // the stagger: M-half 1 runs one barrier behind M-half 0
+
+        for (int t = 0; t < nk; ++t) {
+            const int buf = t & 1;
+            const bool n1 = t + 1 < nk, n2 = t + 2 < nk;
+            // phase 0
+            read_b(buf, 0);
+            read_a(buf, 0, 0);
+            W_BARRIER();
+            mma(T0{});
+            W_BARRIER();
+            // phase 1
+            read_a(buf, 0, 1);
+            if (n1) stage(kA, 1, buf ^ 1, 2);
+            W_BARRIER();
+            mma(T1{});
+            wait_half(n1);                                   // ks 1 of tile t
+            W_BARRIER();
+            // phase 2
+            read_a(buf, 0, 2);
+            if (n1) stage(kA, 1, buf ^ 1, 1);
+            W_BARRIER();
+            mma(T2{});
+            W_BARRIER();
+            // phase 3
+            read_b(buf, 1);
+            read_a(buf, 1, 0);
+            W_BARRIER();
+            mma(T0{});
+            W_BARRIER();
+            // phase 4
+            read_a(buf, 1, 1);
+            if (n2) stage(kB, 0, buf, 2);
+            W_BARRIER();
+            mma(T1{});
+            wait_half(n2);                                   // ks 0 of tile t + 1
+            W_BARRIER();
+            // phase 5
+            read_a(buf, 1, 2);
+            if (n2) stage(kB, 0, buf, 1);
+            W_BARRIER();
+            mma(T2{});
+            W_BARRIER();
+            kA = kB;
+            advance(kB);
+        }
+    } else {
+        // ---------------------------------------------------------------- bf16x3: both pieces of both operands per k half, ring of two k halves
+        constexpr int W_PL = G::PL;
+        const int wclass = wc == 3 ? 2 : ((NREP == 5 && wc != 0) ? 1 : 0);      // (W pieces, X pieces) per staging point: (2,1) (3,1) (2,0)
+        // X subtile of row third `third` of this wave's M half, piece pl, of k half ks of K-tile k -> ring slot `slot` (waves wc < 3)
+        auto stage_x = [&](const KPos& k, int ks, int slot, int pl, auto third_tag) {
+            constexpr int third = decltype(third_tag)::value;
+            if (wc >= 3) return;
+            char* base = smem + slot * W_KS + pl * W_PL;
+            const bool s2 = k.c >= p.csplit;
+            const int cc = s2 ? k.c - p.csplit : k.c;
+            const int ld = s2 ? ldx2e : p.ldx;
+            int soff = (cc + ks * 32) * 2 + pl * ld;             // piece pl of a row: ld / 2 elements further
+            if (MODE == 1) { const int dy = k.tap / 3, dx = k.tap - 3 * dy; soff += (dy * p.Win + dx) * ld * 2; }
+            if (MODE == 2) soff += k.tap * p.HW * ld * 2;
+            const int st = wr * 9 + 3 * third + wc;
+            // (opaque: otherwise every staging point's selected offset is hoisted out of the K loop as one more live register — 20 of them
+            //  spill, and a reload between two DMA issues drains the ring)
+            const unsigned v = ((opaque(amask[third]) >> k.tap) & 1u) ? (s2 ? opaque(va2) : opaque(va1)) : OOB;
+            if (s2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rX2, (lptr_t)(base + st * 1024), 16, (int)v, soff + st * 16 * ld * 2, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (lptr_t)(base + st * 1024), 16, (int)v, soff + st * 16 * ld * 2, 0, 0);
+        };
+        auto stage_w = [&](const KPos& k, int ks, int slot, int pl) {
+            char* base = smem + slot * W_KS + pl * W_PL;
+            const int soffw = (k.kt * BK + ks * 32) * 2 + pl * p.ldw;
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                if (q < b_cnt) {
+                    const int st = b_first + q, wcol = st / NREP, j = st - wcol * NREP;
+                    const bool single = j >= 2 * NPAIR;
+                    const int row0 = wcol * 16 * NREP + (single ? 32 * NPAIR : 32 * (j >> 1) + 4 * (j & 1));
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(base + (WNA + st) * 1024), 16, (int)(single ? opaque(vw_single) : opaque(vw_pair)),
+                                                             soffw + row0 * p.ldw * 2, 0, 0);
+                }
+        };
+        // Counted waits.  With b W pieces and x X pieces per staging point, the pieces a wave has issued AFTER the ones the phase two
+        // ahead will read (the table in the header; the issue order of the loop below): kind 0 = 2 b + 6 x, kind 1 = 2 b + 8 x,
+        // kind 2 = 3 b + 6 x.  Near the end of K some staging points are skipped: then everything is awaited.
+        auto wait3 = [&](int kind, bool counted) {
+            if (!counted) { W_VMCNT(0); return; }
+            if (wclass == 0) { if (kind == 0) W_VMCNT(10); else W_VMCNT(12); }
+            else if (wclass == 1) { if (kind == 0) W_VMCNT(12); else if (kind == 1) W_VMCNT(14); else W_VMCNT(15); }
+            else { if (kind == 2) W_VMCNT(6); else W_VMCNT(4); }
+        };
+        h16x8 bw[NREP], af[3];
+        const int a_off = (int)(a_base - smem), b_off = (int)(b_base - smem);
+        auto read_w = [&](const char* sb, int pl) {
+#pragma unroll
+            for (int j = 0; j < NREP; ++j) bw[j] = *reinterpret_cast<const h16x8*>(sb + b_off + pl * W_PL + j * 1024);
+        };
+        auto read_x = [&](const char* sb, int pl, int third) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) af[i] = *reinterpret_cast<const h16x8*>(sb + a_off + pl * W_PL + (third * 3 + i) * 1024);
+        };
+        auto mma3 = [&](auto third_tag) {
+            constexpr int third = decltype(third_tag)::value;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < NREP; ++j) mfma16_inplace(bw[j], af[i], acc[third * 3 + i][j]);
+        };
+
+        const int NH = 2 * nk;                               // k halves
+        KPos kC{0, 0, 0};
+        // both k halves of K-tile 0, in the order the loop would have issued them (the counted waits rely on it)
+        stage_w(kC, 0, 0, 0); stage_x(kC, 0, 0, 1, T0{});
+        stage_x(kC, 0, 0, 1, T1{});
+        stage_x(kC, 0, 0, 1, T2{});
+        stage_w(kC, 0, 0, 1); stage_x(kC, 0, 0, 0, T0{});
+        stage_x(kC, 0, 0, 0, T1{});
+        stage_x(kC, 0, 0, 0, T2{});
+        stage_w(kC, 1, 1, 0); stage_x(kC, 1, 1, 1, T0{});
+        stage_x(kC, 1, 1, 1, T1{});
+        stage_x(kC, 1, 1, 1, T2{});
+        stage_w(kC, 1, 1, 1); stage_x(kC, 1, 1, 0, T0{});
+        KPos kN = kC;
+        advance(kN);                                         // kC = the K-tile of k half h, kN = the next one
+        wait3(0, true);                                      // w0, x1 rows 0-2, x0 rows 0-2 of k half 0 have landed
+        W_BARRIER();
+        if (wr == 1) W_BARRIER();                            // the stagger: M-half 1 runs one barrier behind M-half 0
+
+        for (int h = 0; h < NH; ++h) {
+            const int ks = h & 1;                            // = the ring slot of k half h
+            const bool n1 = h + 1 < NH, n2 = h + 2 < NH;
+            const char* sb = smem + ks * W_KS;
+            const KPos k1 = ks ? kN : kC;                    // K-tile of k half h + 1 (its k half: ks ^ 1); k half h + 2: (kN, ks)
+            // phase 0: w0 x1 rows 0-2
+            read_w(sb, 0);
+            read_x(sb, 1, 0);
+            if (n1) stage_x(k1, ks ^ 1, ks ^ 1, 0, T1{});
+            W_BARRIER();
+            mma3(T0{});
+            W_BARRIER();
+            // phase 1: w0 x0 rows 0-2
+            read_x(sb, 0, 0);
+            if (n1) stage_x(k1, ks ^ 1, ks ^ 1, 0, T2{});
+            W_BARRIER();
+            mma3(T0{});
+            wait3(0, n1);                                    // x0 rows 3-5 of this k half
+            W_BARRIER();
+            // phase 2: w0 x1 rows 3-5
+            read_x(sb, 1, 1);
+            if (n2) { stage_w(kN, ks, ks, 0); stage_x(kN, ks, ks, 1, T0{}); }
+            W_BARRIER();
+            mma3(T1{});
+            W_BARRIER();
+            // phase 3: w0 x0 rows 3-5
+            read_x(sb, 0, 1);
+            W_BARRIER();
+            mma3(T1{});
+            wait3(2, n2);                                    // x0 rows 6-8 of this k half
+            W_BARRIER();
+            // phase 4: w0 x1 rows 6-8
+            read_x(sb, 1, 2);
+            if (n2) stage_x(kN, ks, ks, 1, T1{});
+            W_BARRIER();
+            mma3(T2{});
+            W_BARRIER();
+            // phase 5: w0 x0 rows 6-8
+            read_x(sb, 0, 2);
+            W_BARRIER();
+            mma3(T2{});
+            W_BARRIER();
+            // phase 6: w1 x0 rows 0-2
+            read_w(sb, 1);
+            read_x(sb, 0, 0);
+            if (n2) stage_x(kN, ks, ks, 1, T2{});
+            W_BARRIER();
+            mma3(T0{});
+            W_BARRIER();
+            // phase 7: w1 x0 rows 3-5
+            read_x(sb, 0, 1);
+            W_BARRIER();
+            mma3(T1{});
+            wait3(1, n2);                                    // w0, x1 rows 0-2 of k half h + 1
+            W_BARRIER();
+            // phase 8: w1 x0 rows 6-8
+            read_x(sb, 0, 2);
+            if (n2) { stage_w(kN, ks, ks, 1); stage_x(kN, ks, ks, 0, T0{}); }
+            W_BARRIER();
+            mma3(T2{});
+            wait3(0, n2);                                    // x0 rows 0-2 (and everything issued before them) of k half h + 1
+            W_BARRIER();
+            if (ks) { kC = kN; advance(kN); }
+        }
+        // the MFMAs above are inline assembly: the compiler does not know that the epilogue's first reads depend on matrix results
+        asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     }
     if (wr == 0) W_BARRIER();                            // evens out the stagger: every fragment read has retired, every DMA has landed
 
@@ -341,7 +517,7 @@ __global__ __launch_bounds__(512, 2) void wgemm_kernel(const MudgGemmDesc p, con
             bg[e] = (GEGLU && p.bias) ? p.bias[cw + 32 + e] : 0.f;
         }
         u32x4 ra[9];
-        if (RK == KIND_F16 || RK == KIND_OPERAND) {
+        if (RK == KIND_F16 || (RK == KIND_OPERAND && PLANES == 1)) {
 #pragma unroll
             for (int i = 0; i < 9; ++i) {
                 const int64_t m = mrow + 16 * i;
@@ -383,14 +559,21 @@ __global__ __launch_bounds__(512, 2) void wgemm_kernel(const MudgGemmDesc p, con
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += (float)t.h[e];
             } else if (RK == KIND_OPERAND) {
-                const h16x8 t = as_h16x8(ra[i]);
+                if constexpr (PLANES == 1) {
+                    const h16x8 t = as_h16x8(ra[i]);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += (float)t[e];
+                    for (int e = 0; e < 8; ++e) v[e] += (float)t[e];
+                } else if (live) {
+                    float rr[8];
+                    load8_operand(reinterpret_cast<const h16*>(Rb) + m * p.ldr + n, p.ldr / PLANES, rr);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += rr[e];
+                }
             }
             if (!GEGLU && p.stats) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float t = live ? (OK == KIND_F32 ? v[e] : (OK == KIND_F16 ? (float)f16_sat(v[e]) : (float)(h16)v[e])) : 0.f;
+                    const float t = live ? (OK == KIND_F32 ? v[e] : (OK == KIND_F16 ? (float)f16_sat(v[e]) : operand_round(v[e]))) : 0.f;
                     gs[e] += t; gq[e] = fmaf(t, t, gq[e]);
                 }
             }
@@ -404,7 +587,7 @@ __global__ __launch_bounds__(512, 2) void wgemm_kernel(const MudgGemmDesc p, con
                     for (int e = 0; e < 4; ++e) { a[e] = v[e]; b[e] = v[4 + e]; }
                     *reinterpret_cast<f32x4*>(yp) = a;
                     *reinterpret_cast<f32x4*>(yp + 4) = b;
-                } else store8_operand(reinterpret_cast<h16*>(p.Y) + yoff, p.ldy, v);
+                } else store8_operand(reinterpret_cast<h16*>(p.Y) + yoff, p.ldy / PLANES, v);
             }
         }
         if (!GEGLU && p.stats) {
@@ -429,7 +612,7 @@ __global__ __launch_bounds__(512, 2) void wgemm_kernel(const MudgGemmDesc p, con
             if (p.gbias) bv[e] += p.gbias[gb0 + n + e];
         }
         u32x2 ra[9];
-        if (RK == KIND_F16 || RK == KIND_OPERAND) {
+        if (RK == KIND_F16 || (RK == KIND_OPERAND && PLANES == 1)) {
 #pragma unroll
             for (int i = 0; i < 9; ++i) {
                 const int64_t m = mrow + 16 * i;
@@ -458,14 +641,23 @@ __global__ __launch_bounds__(512, 2) void wgemm_kernel(const MudgGemmDesc p, con
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] += (float)t.h[e];
             } else if (RK == KIND_OPERAND) {
-                Pack8 t; t.u = ra[i];
+                if constexpr (PLANES == 1) {
+                    Pack8 t; t.u = ra[i];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += (float)t.h[e];
+                    for (int e = 0; e < 4; ++e) v[e] += (float)t.h[e];
+                } else if (live) {
+#pragma unroll
+                    for (int pl = 0; pl < PLANES; ++pl) {
+                        Pack8 t; t.u = *reinterpret_cast<const u32x2*>(reinterpret_cast<const h16*>(Rb) + m * p.ldr + pl * (p.ldr / PLANES) + n);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += (float)t.h[e];
+                    }
+                }
             }
             if (p.stats) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float t = live ? (OK == KIND_F32 ? v[e] : (OK == KIND_F16 ? (float)f16_sat(v[e]) : (float)(h16)v[e])) : 0.f;
+                    const float t = live ? (OK == KIND_F32 ? v[e] : (OK == KIND_F16 ? (float)f16_sat(v[e]) : operand_round(v[e]))) : 0.f;
                     gs[e] += t; gq[e] = fmaf(t, t, gq[e]);
                 }
             }
@@ -482,10 +674,13 @@ __global__ __launch_bounds__(512, 2) void wgemm_kernel(const MudgGemmDesc p, con
                     for (int e = 0; e < 4; ++e) a[e] = v[e];
                     *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.Y) + yoff) = a;
                 } else {
-                    Pack8 t;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) t.h[e] = (h16)v[e];
-                    *reinterpret_cast<u32x2*>(reinterpret_cast<h16*>(p.Y) + yoff) = t.u;
+                    for (int pl = 0; pl < PLANES; ++pl) {               // the pieces of store8_operand, four channels wide
+                        Pack8 t;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { t.h[e] = (h16)v[e]; v[e] -= (float)t.h[e]; }
+                        *reinterpret_cast<u32x2*>(reinterpret_cast<h16*>(p.Y) + yoff + pl * (p.ldy / PLANES)) = t.u;
+                    }
                 }
             }
         }
@@ -535,11 +730,11 @@ static bool wgemm_eligible(const MudgGemmDesc& d, int vflags) {
     if ((d.ldy & 7) || (d.R && (d.ldr & 7))) return false;                 // 8-byte pieces of the unpaired fragment
     // 32-bit reach of the descriptor offsets
     const int64_t ld = d.X2 && d.ldx2 > d.ldx ? d.ldx2 : d.ldx;
-    int64_t rows = WBM + 16;
+    int64_t rows = WBM + 16 + (PLANES > 1);                                // (the second piece of a row: ld / 2 elements further)
     if (d.mode == 1) rows += 2 * (int64_t)d.Win + 2;
     if (d.mode == 2) rows += 2 * (int64_t)d.HW;
     const int64_t lim = (int64_t)1 << 31;
-    return rows * ld * 2 + (int64_t)cin * 2 + 256 < lim && (int64_t)(320 + 16) * d.ldw * 2 + (int64_t)d.K * 2 + 256 < lim;
+    return rows * ld * 2 + (int64_t)cin * 2 + 256 < lim && (int64_t)(320 + 16 + (PLANES > 1)) * d.ldw * 2 + (int64_t)d.K * 2 + 256 < lim;
 }
 
 // Where it is used.  The rule never looks at M (see the header): `S`, the rows of one frame (mode 0: the caller's hint in d.HW), must be
@@ -555,6 +750,10 @@ bool mudg_wgemm_ok(const MudgGemmDesc& d, int vflags) {
     // tile is five or ten K-steps between a first-fetch latency and an epilogue that nothing overlaps on a CU holding one workgroup:
     // - 4 ... - 26 %, those stay on the 128 x 128 kernels (four workgroups per CU).
     if (d.mode != 0) return true;
+    // bf16x3 (same tool with MUDG_OPERAND=bf16x3, profiles/r5/w288_x3_shapes.txt; the 128 x 128 side is the fused-piece kernel, one-tile or
+    // persistent as gemm.hip selects): 3x3 convs + 6 ... + 26 %, temporal convs + 3 ... + 9 %, plain GEMMs + 5 ... + 19 % from K = 2560
+    // and at the N = 320 / K = 1280 feed-forward output; - 1 ... - 14 % on the other K <= 1280 problems and on every GEGLU (- 0 ... - 7 %).
+    if (PLANES == 2) return !d.geglu && (d.K >= 2560 || (d.K >= 1280 && d.N <= 320));
     return d.K >= 1280;
 }
 

@@ -195,9 +195,9 @@ def lib() -> C.CDLL:
         path = LIB_PATHS[_operand]
         if os.environ.get("MUDG_DEBUG_VARIANTS") == "1":
             # tests / A/B tools: the bf16 build that honours the MUDG_<switch> kernel-variant variables (csrc/common.h)
-            if _operand != "bf16":
-                raise MudgError("MUDG_DEBUG_VARIANTS=1 exists for the bf16 build only")
-            path = os.path.join(_HERE, "libmudg_hip_dbg.so")
+            if _operand not in ("bf16", "bf16x3"):
+                raise MudgError("MUDG_DEBUG_VARIANTS=1 exists for the bf16 and bf16x3 builds only")
+            path = os.path.join(_HERE, "libmudg_hip_dbg.so" if _operand == "bf16" else "libmudg_hip_x3_dbg.so")
         if not os.path.exists(path):
             raise MudgError(
                 f"{path} is missing: build it with `python -m mudg_amd.build` (hipcc, gfx950). "

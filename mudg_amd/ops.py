@@ -245,7 +245,8 @@ def tconv3_wide(t, hw, cin, cout):
     d = hip.GemmDesc()
     d.X, d.W, d.Y = 256, 256, 256                     # aligned placeholders
     d.M, d.N, d.K = 16 * t * hw, cout, 3 * cin
-    d.ldx, d.ldw, d.ldy = cin, 3 * cin, cout
+    pl = hip.planes()
+    d.ldx, d.ldw, d.ldy = pl * cin, pl * 3 * cin, pl * cout
     d.csplit, d.batch, d.alpha, d.mode = cin, 1, 1.0, 2
     d.Cin, d.T, d.HW = cin, t, hw
     return hip.lib().mudg_gemm_stats_rows(C.byref(d)) == 288

@@ -41,3 +41,17 @@ def test_kernel_parity_under_variant(cuda, env):
                        cwd=ROOT, env=dict(os.environ, MUDG_DEBUG_VARIANTS="1", **env), capture_output=True, text=True, timeout=900)
     print("\n".join(l for l in r.stdout.splitlines() if "passed" in l or "failed" in l))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("env", [{"MUDG_GEMM_W288": "2"}, {"MUDG_GEMM_W288": "0"}], ids=lambda e: ",".join(f"{k[5:]}={v}" for k, v in e.items()))
+def test_kernel_parity_under_variant_in_the_bf16x3_build(cuda, env):
+    """The bf16x3 build's own debug-variants library (libmudg_hip_x3_dbg.so): its 288 x 320 kernel forced for every problem it can run
+    (short K, GEGLU on the 288 x 256 tile, ragged M — the rule sends none of those to it), and switched off (every conv / temporal conv on
+    the fused-piece 128 x 128 kernels), under the mode-agnostic kernel suite and the UNet parity tests."""
+    if os.environ.get("MUDG_DEBUG_VARIANTS") == "1" or os.environ.get("MUDG_PARITY_CHILD") == "1":
+        pytest.skip("already running under a variant switch / inside a mode child")
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_operand_modes_gpu.py", "tests/test_unet_gpu.py", "-m", "gpu", "-q", "-p", "no:cacheprovider"],
+                       cwd=ROOT, env=dict(os.environ, MUDG_DEBUG_VARIANTS="1", MUDG_OPERAND="bf16x3", MUDG_PARITY_CHILD="1", MUDG_SKIP_FULLSIZE_ORACLE="1",
+                                          MUDG_SKIP_CONFIG0_CUT="1", **env), capture_output=True, text=True, timeout=900)
+    print("\n".join(l for l in r.stdout.splitlines() if "passed" in l or "failed" in l))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

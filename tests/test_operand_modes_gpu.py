@@ -306,6 +306,75 @@ def test_groupnorm_fused_statistics_from_the_producing_conv(cuda):
         assert rel(value(fused), value(plain)) < max(TOL_OP, 1e-6)
 
 
+# the 288 x 320 tile (csrc/wgemm.hip): the 16-bit builds and bf16x3 (a variant child may switch it off: tests/test_gemm_variants_gpu.py)
+WIDE_BUILD = _hip.planes() <= 2 and not (os.environ.get("MUDG_DEBUG_VARIANTS") == "1" and os.environ.get("MUDG_GEMM_W288") == "0")
+
+
+@pytest.mark.parametrize("res_kind,korder", [("operand", 1), ("f32", 0), ("none", 1)])
+def test_wide288_conv_in_every_operand_mode(cuda, res_kind, korder):
+    """Frames of 576 = 2 x 288 pixels: the library's rule sends the 3x3 conv to the 288 x 320 tile (bf16x3: both pieces of both operands
+    per k half, three MFMAs per fragment pair).  Two channel sources, bias + per-frame group bias, a residual, GroupNorm partials per
+    288-row block of what was stored, and a frame's rows do not depend on the batch."""
+    from mudg_amd import ops
+    from test_kernels_gpu import pack_conv, pack_conv_slab
+    f, h, wd, c1, c2, cout = 3, 24, 24, 64, 128, 320
+    cin, M = c1 + c2, 3 * 24 * 24
+    xa, xav = operand(_rows(f32(f, c1, h, wd, seed=1)), cuda)
+    xb, xbv = operand(_rows(f32(f, c2, h, wd, seed=2)), cuda)
+    wt = f32(cout, cin, 3, 3, seed=3, scale=0.03)
+    wp, wpv = operand(pack_conv_slab(wt) if korder else pack_conv(wt), cuda)
+    wq = (wpv.reshape(cout, cin // 64, 9, 64).permute(0, 2, 1, 3).reshape(cout, 3, 3, cin) if korder else wpv.reshape(cout, 3, 3, cin)).permute(0, 3, 1, 2)
+    b, gb = f32(cout, seed=4, scale=0.1), f32(f, cout, seed=5)
+    r32 = f32(M, cout, seed=6)
+    res, resv = (None, 0.0) if res_kind == "none" else (operand(r32, cuda) if res_kind == "operand" else (r32.to(cuda), r32.double()))
+    xin = _unrows(torch.cat([xav, xbv], 1), f, h, wd)
+    ref = _rows(F.conv2d(xin, wq, b.double(), padding=1)) + gb.double().repeat_interleave(h * wd, 0) + resv
+    kw = dict(frames=f, hin=h, win=wd, cin=cin, korder=korder, bias=b.to(cuda), rows_per_group=h * wd, stats=True, out_fp32=res_kind == "f32")
+    y = ops.conv3x3(xa, wp, x2=xb, gbias=gb.to(cuda), residual=res, **kw)
+    assert rel(value(y), ref) < (TOL_F32 if res_kind == "f32" else TOL_OP)
+    rows = getattr(y, ops.GN_ATTR + "_rows")
+    assert rows == (288 if WIDE_BUILD else 128)
+    stats = getattr(y, ops.GN_ATTR)
+    if M % rows == 0:
+        yv = value(y).reshape(-1, rows, cout)
+        assert rel(stats[..., 0], yv.sum(1)) < 1e-5 and rel(stats[..., 1], (yv * yv).sum(1)) < 1e-5
+    n1 = h * wd
+    one = ops.conv3x3(xa[:n1], wp, x2=xb[:n1], gbias=gb[:1].to(cuda), residual=None if res is None else res[:n1], **dict(kw, frames=1))
+    assert torch.equal(value(one), value(y)[:n1]) and (n1 % rows or torch.equal(getattr(one, ops.GN_ATTR), stats[:n1 // rows]))
+
+
+def test_wide288_gemm_and_temporal_conv_in_every_operand_mode(cuda):
+    """A plain GEMM with a frame hint of whole 288-row tiles, ragged in M (K = 2560: on the 288 x 320 tile under every build's rule), and a
+    temporal conv in the plain K order on clips of 4 frames x 288 pixels (first / last frame of a clip see zero padding)."""
+    from mudg_amd import ops
+    M, N, K = 288 * 5 + 100, 320, 2560
+    x, xv = operand(f32(M, K, seed=1), cuda)
+    w, wv = operand(f32(N, K, seed=2, scale=0.02), cuda)
+    b, r32 = f32(N, seed=3, scale=0.1), f32(M, N, seed=4)
+    y = ops.gemm(x, w, bias=b.to(cuda), residual=r32.to(cuda), stats=True, frame_rows=288)
+    assert rel(value(y), xv @ wv.t() + b.double() + r32.double()) < TOL_OP
+    rows = getattr(y, ops.GN_ATTR + "_rows")
+    assert rows == (288 if WIDE_BUILD else 128) and getattr(y, ops.GN_ATTR).shape[0] == (M + rows - 1) // rows
+    y32 = ops.gemm(x, w, bias=b.to(cuda), out_fp32=True, frame_rows=288)
+    assert rel(y32, xv @ wv.t() + b.double()) < TOL_F32
+    assert torch.equal(ops.gemm(x[:288 * 2], w, bias=b.to(cuda), out_fp32=True, frame_rows=288), y32[:288 * 2])
+    clips, t, hw, c, co = 2, 4, 288, 128, 640
+    xt, xtv = operand(f32(clips * t * hw, c, seed=5), cuda)
+    wt, wtv = operand(f32(co, 3 * c, seed=6, scale=0.05), cuda)
+    bt = f32(co, seed=7, scale=0.1)
+    xi = xtv.reshape(clips, t, hw, c).permute(0, 3, 1, 2)                                       # (clip, c, t, hw)
+    wk = wtv.reshape(co, 3, c).permute(0, 2, 1)                                                # (co, c, tap)
+    ref = F.conv2d(xi, wk[..., None], padding=(1, 0)).permute(0, 2, 3, 1).reshape(clips * t * hw, co) + bt.double()
+    assert ops.tconv3_wide(t, hw, c, co) == WIDE_BUILD
+    yt = ops.tconv3(xt, wt, clips=clips, t=t, hw=hw, cin=c, bias=bt.to(cuda), stats=True)
+    assert rel(value(yt), ref) < TOL_OP
+    rows = getattr(yt, ops.GN_ATTR + "_rows")
+    yv = value(yt).reshape(-1, rows, co)
+    assert rel(getattr(yt, ops.GN_ATTR)[..., 0], yv.sum(1)) < 1e-5
+    one = ops.tconv3(xt[:t * hw], wt, clips=1, t=t, hw=hw, cin=c, bias=bt.to(cuda), stats=True)
+    assert torch.equal(value(one), value(yt)[:t * hw])
+
+
 def test_softmax_rows_and_layout_kernels(cuda):
     from mudg_amd import ops
     s = f32(50, 333, seed=1) * 3

@@ -1,14 +1,34 @@
 #!/usr/bin/env python3
 """The 288 x 320-tile kernel (csrc/wgemm.hip) against the 128 x 128 kernels on the same inputs: parity of results and GroupNorm
 partials on small problems of every mode / epilogue, then per-shape timings of the MDM1024 shapes with either kernel.
-    MUDG_DEBUG_VARIANTS=1 python tools/exp_w288.py [parity|time|all]"""
+    MUDG_DEBUG_VARIANTS=1 [MUDG_OPERAND=bf16x3] python tools/exp_w288.py [parity|time|all]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("MUDG_DEBUG_VARIANTS", "1")
 import torch
 import torch.nn.functional as F
-from mudg_amd import ops
-from tools.kernel_bench import timeit, rn
+from mudg_amd import hip, ops
+from tools.kernel_bench import timeit
+
+
+def rn(*shape):
+    """A random operand matrix of the loaded build (MUDG_OPERAND=bf16x3: both pieces, through mudg_cast_rows)."""
+    x = torch.randn(*shape, device="cuda") * 0.5
+    return ops.cast_bf16(x) if hip.planes() > 1 else x.to(ops.H16())
+
+
+def val(t):
+    """The values an operand matrix stands for, in fp64 (bf16x3: the sum of its pieces)."""
+    if hip.planes() > 1:
+        c = t.shape[1]
+        return sum(t._base[:, p * c:(p + 1) * c].double() for p in range(hip.planes()))
+    return t.double()
+
+
+def rs(*shape):
+    """A random residual-stream matrix."""
+    return (torch.randn(*shape, device="cuda") * 0.5).to(ops.STREAM())
+
 
 what = sys.argv[1] if len(sys.argv) > 1 else "all"
 
@@ -31,6 +51,8 @@ def rel(a, b):
 
 def report(name, res, samples_rows=None):
     (y0, p0, r0), (y1, p1, r1) = res
+    if y0.dtype == ops.H16():
+        y0, y1 = val(y0), val(y1)
     line = f"{name}: result rel-L2 {rel(y1, y0):.2e}"
     if p0 is not None:
         assert r1 == 288 and r0 == 128, (r0, r1)
@@ -47,7 +69,7 @@ if what in ("parity", "all"):
     for M, N, K in ((288 * 5, 640, 320), (288 * 3 + 100, 320, 1280), (288 * 9, 960, 64)):
         x, w = rn(M, K), rn(N, K)
         b = torch.randn(N, device="cuda")
-        r = rn(M, N).to(ops.STREAM())
+        r = rs(M, N)
         report(f"gemm {M}x{N}x{K} bias+residual, stream out", both(lambda: ops.gemm(x, w, bias=b, residual=r, out_stream=True, frame_rows=288)))
         report(f"gemm {M}x{N}x{K} fp32 out", both(lambda: ops.gemm(x, w, bias=b, out_fp32=True, frame_rows=288)))
     M, N, K = 288 * 8, 320, 640
@@ -61,7 +83,7 @@ if what in ("parity", "all"):
         f, h, wd, cin, cout = 3, 24, 36, 128, 320
         x, w, b = rn(f * h * wd, cin), rn(cout, 9 * cin), torch.randn(cout, device="cuda")
         emb = torch.randn(f, cout, device="cuda")
-        r = rn(f * h * wd, cout).to(ops.STREAM())
+        r = rs(f * h * wd, cout)
         report(f"conv korder {korder} bias+gbias+stats", both(lambda: ops.conv3x3(x, w, frames=f, hin=h, win=wd, cin=cin, korder=korder, bias=b, gbias=emb,
                                                                                  rows_per_group=h * wd, stats=True)), h * wd)
         report(f"conv korder {korder} residual, stream out, stats", both(lambda: ops.conv3x3(x, w, frames=f, hin=h, win=wd, cin=cin, korder=korder, bias=b,
@@ -74,7 +96,7 @@ if what in ("parity", "all"):
         report(f"geglu {M}x{N}x{K}", both(lambda: ops.gemm(x, w, bias=b, geglu=True, frame_rows=288)))
     clips, t, hw, c, co = 2, 4, 288, 128, 320
     x, w, b = rn(clips * t * hw, c), rn(co, 3 * c), torch.randn(co, device="cuda")
-    r = rn(clips * t * hw, co).to(ops.STREAM())
+    r = rs(clips * t * hw, co)
     report("tconv bias+stats", both(lambda: ops.tconv3(x, w, clips=clips, t=t, hw=hw, cin=c, bias=b, stats=True)), t * hw)
     report("tconv residual, stream out", both(lambda: ops.tconv3(x, w, clips=clips, t=t, hw=hw, cin=c, bias=b, residual=r, out_stream=True)))
     # against fp64 references (the kernels' own operand rounding in both)
@@ -83,8 +105,8 @@ if what in ("parity", "all"):
     os.environ["MUDG_GEMM_W288"] = "2"
     y = ops.conv3x3(x, w, frames=f, hin=h, win=wd, cin=cin, korder=0, out_fp32=True)
     os.environ["MUDG_GEMM_W288"] = "1"
-    xi = x.double().reshape(f, h, wd, cin).permute(0, 3, 1, 2)
-    wi = w.double().reshape(cout, 3, 3, cin).permute(0, 3, 1, 2)
+    xi = val(x).reshape(f, h, wd, cin).permute(0, 3, 1, 2)
+    wi = val(w).reshape(cout, 3, 3, cin).permute(0, 3, 1, 2)
     ref = F.conv2d(xi, wi, padding=1).permute(0, 2, 3, 1).reshape(f * h * wd, cout)
     print(f"conv vs fp64 conv2d: {rel(y, ref):.2e}", flush=True)
 
@@ -95,7 +117,7 @@ if what in ("time", "all"):
         for (M, N, K, hw) in G:
             x, w = rn(M, K), rn(N, K)
             b = torch.randn(N, device="cuda")
-            r = rn(M, N).to(ops.STREAM()) if resid else None
+            r = rs(M, N) if resid else None
             ts = []
             for v in ("0", "2"):
                 os.environ["MUDG_GEMM_W288"] = v
