@@ -38,20 +38,19 @@
 // never looks at M — a clip's result must not depend on the batch it travels in — only at the problem's per-frame geometry.
 //
 // bf16x3 build (MUDG_PLANES = 2), same tile, same epilogue: a k half holds both bf16 pieces of both operands (x0, x1, w0, w1: 76 KiB),
-// so the ring is two k halves and a phase re-stages what was read two phases before it.  Per k half h, nine phases:
-//   p   fragment reads              MFMAs (15)   DMA issued (this wave's share)             wait at the end of the MFMA section
-//   0   w0 (5), x1 rows 0-2 (3)     w0 x1        x0 rows 3-5 of k half h + 1
-//   1   x0 rows 0-2                 w0 x0        x0 rows 6-8 of k half h + 1                x0 rows 3-5 of k half h
-//   2   x1 rows 3-5                 w0 x1        w0, x1 rows 0-2 of k half h + 2
-//   3   x0 rows 3-5                 w0 x0        -                                          x0 rows 6-8 of k half h
-//   4   x1 rows 6-8                 w0 x1        x1 rows 3-5 of k half h + 2
-//   5   x0 rows 6-8                 w0 x0        -
-//   6   w1 (5), x0 rows 0-2         w1 x0        x1 rows 6-8 of k half h + 2
-//   7   x0 rows 3-5                 w1 x0        -                                          w0, x1 rows 0-2 of k half h + 1
-//   8   x0 rows 6-8                 w1 x0        w1, x0 rows 0-2 of k half h + 2            x0 rows 0-2 (and all before) of k half h + 1
-// x1 w0 + x0 w0 + x0 w1 per k half (x1 w1, 2^-18 relative, is dropped as in the 128 x 128 fused-piece kernel); 135 MFMAs per 37
-// fragment reads; a piece is re-staged two phases after its last read and has nine or more phases to land; accumulators + fragments
-// = 212 registers, as in the 16-bit builds.
+// so the ring is two k halves and a piece is re-staged two phases after its last read.  Per k half h, three phases of 45 MFMAs:
+//   p   fragment reads                          MFMAs                     DMA issued (this wave's share)          wait at the end of the MFMA section
+//   0   w0, w1 (10), x1 / x0 rows 0-2 (6)       w0 x1, w0 x0, w1 x0       x1 / x0 rows 3-5 of k half h + 1        x rows 6-8 of k half h
+//   1   x1 / x0 rows 3-5                        (rows 3-5)                x1 / x0 rows 6-8 of k half h + 1        w0, w1, x rows 0-2 of k half h + 1
+//   2   x1 / x0 rows 6-8                        (rows 6-8)                w0, w1, x1 / x0 rows 0-2 of h + 2       x rows 3-5 of k half h + 1
+// x1 w0 + x0 w0 + x0 w1 per k half (x1 w1, 2^-18 relative, is dropped as in the 128 x 128 fused-piece kernel); 135 MFMAs per 28 fragment
+// reads and 6 barriers.  Accumulators + fragments = 244 of the 256 registers: the MFMAs are inline assembly with the accumulator tied to
+// its result (the register allocator otherwise splits accumulator live ranges: copies at every phase, then spills), the per-lane DMA
+// state is two packed registers, and nothing of the K loop spills (a scratch reload between two DMA issues would drain the ring).
+// Measured on the way (same box, MI355X, tools/exp_w288.py under MUDG_OPERAND=bf16x3; profiles/r5/w288_x3_phases.txt): nine phases of 15
+// MFMAs (the 16-bit loop's shape, w0 x1 | w0 x0 | w1 x0 per row third) 398-444 TFLOP/s on the 3x3 convs, six phases (30 30 30 15 15 15)
+// 422-468, these three 468-521 (= 1400-1560 TFLOP/s of MFMA work; the 128 x 128 fused-piece kernels: 345-415): what a barrier slot
+// costs beside its MFMAs (~140 cycles) is amortised over three times as many of them.
 #include "gemm_shared.h"
 #include <type_traits>
 
@@ -90,7 +89,11 @@ __device__ __forceinline__ f32x4 mfma16(h16x8 a, h16x8 b, f32x4 c) {
 // The same instruction with the accumulator tied to its result register: in the bf16x3 loop (224 live accumulator and fragment
 // registers under branches) the register allocator otherwise splits accumulator live ranges — copies at every phase, then spills.
 __device__ __forceinline__ void mfma16_inplace(h16x8 a, h16x8 b, f32x4& c) {
+#ifdef MUDG_OPERAND_FP16
+    asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+#else
     asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
+#endif
 }
 __device__ __forceinline__ unsigned opaque(unsigned v) { asm volatile("" : "+v"(v)); return v; }
 template <int CTRL>
@@ -114,6 +117,14 @@ template <int MODE, int NREP, bool GEGLU>
 __global__ __launch_bounds__(512, 2) void wgemm_kernel(const MudgGemmDesc p, const int vflags, const float* __restrict__ phi) {
     using G = WGeo<NREP>;
     constexpr int WBN = G::BN, W_KS = G::KS, W_BUF = G::BUF;
+    // The 16-bit builds run six phases of 15 MFMAs per K-tile (table above), bf16x3 three phases of 45 per k half.  The three-phase loop also
+    // runs the 16-bit operands (-DMUDG_W1_THREE: a unit = a K-tile, 30 MFMAs per phase, bit-identical results) and was measured: - 3 ... - 8 %
+    // on every shape (profiles/r5/w288_16bit_phases.txt) — there a phase's loads (8 DMA pieces + 16 fragment reads) outlast its MFMAs.
+#ifdef MUDG_W1_THREE
+    constexpr bool SIX = false;
+#else
+    constexpr bool SIX = PLANES == 1;
+#endif
     constexpr int NPAIR = NREP / 2;                      // fragment pairs whose 2 x 4 accumulator registers are 8 consecutive channels
     static_assert(!GEGLU || (MODE == 0 && NREP == 4), "GEGLU: plain GEMM on the 256-wide tile");
     extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -168,10 +179,10 @@ __global__ __launch_bounds__(512, 2) void wgemm_kernel(const MudgGemmDesc p, con
     const unsigned vw_pair = (unsigned)((8 * (srow >> 2) + (srow & 3)) * p.ldw) * 2u + (unsigned)schunk * 16u;
     const unsigned vw_single = (unsigned)(srow * p.ldw) * 2u + (unsigned)schunk * 16u;
     // this wave's pieces per k half.  W (4 NREP subtiles per piece) over the eight waves as 2 3 3 2 | 2 3 3 2 (NREP 5) or two each
-    // (NREP 4).  X: 16-bit builds — the X half wr (9 subtiles) over its four waves as 3 2 2 2; bf16x3 — a row third (3 subtiles) per
-    // staging point over the waves wc = 0, 1, 2 (slot q of amask = third q)
-    const int a_first = PLANES == 1 ? (wc == 0 ? 0 : 1 + 2 * wc) : wc, a_cnt = PLANES == 1 ? (wc == 0 ? 3 : 2) : (wc < 3 ? 3 : 0);
-    constexpr int a_step = PLANES == 1 ? 1 : 3;
+    // (NREP 4).  X: a row third (3 subtiles) per staging point over the waves wc = 0, 1, 2 (slot q of amask = third q); the six-phase
+    // loop (SIX, kept for A/B measurements) — the X half wr (9 subtiles) over its four waves as 3 2 2 2
+    const int a_first = SIX ? (wc == 0 ? 0 : 1 + 2 * wc) : wc, a_cnt = SIX ? (wc == 0 ? 3 : 2) : (wc < 3 ? 3 : 0);
+    constexpr int a_step = SIX ? 1 : 3;
     const int b_cnt = NREP == 5 ? ((wc == 0 || wc == 3) ? 2 : 3) : 2;
     const int b_first = NREP == 5 ? wr * 10 + (wc == 0 ? 0 : (wc == 1 ? 2 : (wc == 2 ? 5 : 8))) : wave * 2;
     // validity of the lane's source row per tap (bit t): rows beyond M, taps that leave the image / the clip -> zero-filled by the DMA
@@ -221,7 +232,7 @@ __global__ __launch_bounds__(512, 2) void wgemm_kernel(const MudgGemmDesc p, con
 
     using T0 = std::integral_constant<int, 0>; using T1 = std::integral_constant<int, 1>; using T2 = std::integral_constant<int, 2>;
     const int nk = p.K / BK;
-    if constexpr (PLANES == 1) {
+    if constexpr (SIX) {
         // part: 0 = all of this wave's pieces of k half ks of K-tile k, 1 = its X pieces, 2 = its W pieces
         auto stage = [&](const KPos& k, int ks, int buf, int part) {
             char* base = smem + buf * W_BUF + ks * W_KS;
@@ -339,151 +350,124 @@ __global__ __launch_bounds__(512, 2) void wgemm_kernel(const MudgGemmDesc p, con
             advance(kB);
         }
     } else {
-        // ---------------------------------------------------------------- bf16x3: both pieces of both operands per k half, ring of two k halves
-        constexpr int W_PL = G::PL;
-        const int wclass = wc == 3 ? 2 : ((NREP == 5 && wc != 0) ? 1 : 0);      // (W pieces, X pieces) per staging point: (2,1) (3,1) (2,0)
-        // X subtile of row third `third` of this wave's M half, piece pl, of k half ks of K-tile k -> ring slot `slot` (waves wc < 3)
-        auto stage_x = [&](const KPos& k, int ks, int slot, int pl, auto third_tag) {
+        // ---------------------------------------------------------------- the three-phase loop (header): a UNIT is what one ring slot holds — a
+        // K-tile (16-bit builds: its two k halves are the slot's two pieces) or a k half (bf16x3: the two bf16 pieces of both operands)
+        constexpr int W_PL = G::PL, W_SLOT = 2 * G::PL;
+        const int wclass = wc == 3 ? 2 : ((NREP == 5 && wc != 0) ? 1 : 0);      // (W pieces, X pieces) per staging point and piece: (2,1) (3,1) (2,0)
+        // Per-lane DMA state of the K loop in TWO registers (the loop keeps 244 accumulator and fragment registers): lanepk = source
+        // row | permuted W row << 8 | 16-byte chunk offset << 16, maskpk = the three row thirds' tap masks, 9 bits each; the byte offsets
+        // are rebuilt per piece (two extractions + one multiply-add).  opaque(): without it every staging point's offset is hoisted out
+        // of the loop as one more live register, they spill, and a reload between two DMA issues drains the ring.
+        const unsigned lanepk = (unsigned)srow | ((unsigned)(8 * (srow >> 2) + (srow & 3)) << 8) | ((unsigned)(schunk * 16) << 16);
+        const unsigned maskpk = amask[0] | (amask[1] << 9) | (amask[2] << 18);
+        auto lane_off = [&](int rowshift, int ld2) -> unsigned {           // rowshift 0: the X / unpaired-W row, 8: the permuted W row
+            const unsigned lp = opaque(lanepk);
+            return ((lp >> rowshift) & 0xffu) * (unsigned)ld2 + (lp >> 16);
+        };
+        // X subtile of row third `third` of this wave's M half, piece pc of the unit (K-tile k, k half kh: bf16x3 only — in the 16-bit builds
+        // the piece IS the k half) -> ring slot `slot` (waves wc < 3)
+        auto stage_x = [&](const KPos& k, int kh, int slot, int pc, auto third_tag) {
             constexpr int third = decltype(third_tag)::value;
             if (wc >= 3) return;
-            char* base = smem + slot * W_KS + pl * W_PL;
+            const int ks = PLANES == 2 ? kh : pc, plane = PLANES == 2 ? pc : 0;
+            char* base = smem + slot * W_SLOT + pc * W_PL;
             const bool s2 = k.c >= p.csplit;
             const int cc = s2 ? k.c - p.csplit : k.c;
             const int ld = s2 ? ldx2e : p.ldx;
-            int soff = (cc + ks * 32) * 2 + pl * ld;             // piece pl of a row: ld / 2 elements further
+            int soff = (cc + ks * 32) * 2 + plane * ld;          // bf16 piece 1 of a row: ld / 2 elements further
             if (MODE == 1) { const int dy = k.tap / 3, dx = k.tap - 3 * dy; soff += (dy * p.Win + dx) * ld * 2; }
             if (MODE == 2) soff += k.tap * p.HW * ld * 2;
             const int st = wr * 9 + 3 * third + wc;
-            // (opaque: otherwise every staging point's selected offset is hoisted out of the K loop as one more live register — 20 of them
-            //  spill, and a reload between two DMA issues drains the ring)
-            const unsigned v = ((opaque(amask[third]) >> k.tap) & 1u) ? (s2 ? opaque(va2) : opaque(va1)) : OOB;
+            const unsigned v = ((opaque(maskpk) >> (9 * third + k.tap)) & 1u) ? lane_off(0, ld * 2) : OOB;
             if (s2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rX2, (lptr_t)(base + st * 1024), 16, (int)v, soff + st * 16 * ld * 2, 0, 0);
             else __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (lptr_t)(base + st * 1024), 16, (int)v, soff + st * 16 * ld * 2, 0, 0);
         };
-        auto stage_w = [&](const KPos& k, int ks, int slot, int pl) {
-            char* base = smem + slot * W_KS + pl * W_PL;
-            const int soffw = (k.kt * BK + ks * 32) * 2 + pl * p.ldw;
+        auto stage_w = [&](const KPos& k, int kh, int slot, int pc) {
+            const int ks = PLANES == 2 ? kh : pc, plane = PLANES == 2 ? pc : 0;
+            char* base = smem + slot * W_SLOT + pc * W_PL;
+            const int soffw = (k.kt * BK + ks * 32) * 2 + plane * p.ldw;
 #pragma unroll
             for (int q = 0; q < 3; ++q)
                 if (q < b_cnt) {
                     const int st = b_first + q, wcol = st / NREP, j = st - wcol * NREP;
                     const bool single = j >= 2 * NPAIR;
                     const int row0 = wcol * 16 * NREP + (single ? 32 * NPAIR : 32 * (j >> 1) + 4 * (j & 1));
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(base + (WNA + st) * 1024), 16, (int)(single ? opaque(vw_single) : opaque(vw_pair)),
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(base + (WNA + st) * 1024), 16, (int)lane_off(single ? 0 : 8, p.ldw * 2),
                                                              soffw + row0 * p.ldw * 2, 0, 0);
                 }
         };
-        // Counted waits.  With b W pieces and x X pieces per staging point, the pieces a wave has issued AFTER the ones the phase two
-        // ahead will read (the table in the header; the issue order of the loop below): kind 0 = 2 b + 6 x, kind 1 = 2 b + 8 x,
-        // kind 2 = 3 b + 6 x.  Near the end of K some staging points are skipped: then everything is awaited.
+        // both pieces of a staging point (piece 1 first: in bf16x3 it is read first)
+        auto stage_x2 = [&](const KPos& k, int kh, int slot, auto third_tag) { stage_x(k, kh, slot, 1, third_tag); stage_x(k, kh, slot, 0, third_tag); };
+        auto stage_w2 = [&](const KPos& k, int kh, int slot) { stage_w(k, kh, slot, 0); stage_w(k, kh, slot, 1); };
+        // Counted waits.  With b W pieces and x X pieces per (piece, staging point), what a wave has issued AFTER the pieces the phase two
+        // ahead will read (header table, issue order of the loop below): kind 0 = 2 b + 4 x, kind 1 = 4 x.  Near the end of K staging
+        // points are skipped: then everything is awaited.
         auto wait3 = [&](int kind, bool counted) {
             if (!counted) { W_VMCNT(0); return; }
-            if (wclass == 0) { if (kind == 0) W_VMCNT(10); else W_VMCNT(12); }
-            else if (wclass == 1) { if (kind == 0) W_VMCNT(12); else if (kind == 1) W_VMCNT(14); else W_VMCNT(15); }
-            else { if (kind == 2) W_VMCNT(6); else W_VMCNT(4); }
+            if (wclass == 0) { if (kind == 0) W_VMCNT(8); else W_VMCNT(4); }
+            else if (wclass == 1) { if (kind == 0) W_VMCNT(10); else W_VMCNT(4); }
+            else { if (kind == 0) W_VMCNT(4); else W_VMCNT(0); }
         };
-        h16x8 bw[NREP], af[3];
+        h16x8 bw0[NREP], bw1[NREP], a0[3], a1[3];
         const int a_off = (int)(a_base - smem), b_off = (int)(b_base - smem);
-        auto read_w = [&](const char* sb, int pl) {
+        auto read_w = [&](h16x8 (&dst)[NREP], const char* sb, int pc) {
 #pragma unroll
-            for (int j = 0; j < NREP; ++j) bw[j] = *reinterpret_cast<const h16x8*>(sb + b_off + pl * W_PL + j * 1024);
+            for (int j = 0; j < NREP; ++j) dst[j] = *reinterpret_cast<const h16x8*>(sb + b_off + pc * W_PL + j * 1024);
         };
-        auto read_x = [&](const char* sb, int pl, int third) {
+        auto read_x = [&](h16x8 (&dst)[3], const char* sb, int pc, int third) {
 #pragma unroll
-            for (int i = 0; i < 3; ++i) af[i] = *reinterpret_cast<const h16x8*>(sb + a_off + pl * W_PL + (third * 3 + i) * 1024);
+            for (int i = 0; i < 3; ++i) dst[i] = *reinterpret_cast<const h16x8*>(sb + a_off + pc * W_PL + (third * 3 + i) * 1024);
         };
-        auto mma3 = [&](auto third_tag) {
+        auto mma3 = [&](auto third_tag, const h16x8 (&b)[NREP], const h16x8 (&a)[3]) {
             constexpr int third = decltype(third_tag)::value;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 3; ++i)
 #pragma unroll
-                for (int j = 0; j < NREP; ++j) mfma16_inplace(bw[j], af[i], acc[third * 3 + i][j]);
+                for (int j = 0; j < NREP; ++j) mfma16_inplace(b[j], a[i], acc[third * 3 + i][j]);
+        };
+        // a phase: fragments of row third `third` (and, first, the unit's W fragments) | barrier | 30 (16-bit: k half 0, then k half 1 — the
+        // K order of the 128 x 128 kernels) or 45 MFMAs (bf16x3: x1 w0, x0 w0, x0 w1)
+        auto reads = [&](const char* sb, int third, bool with_w) {
+            if (with_w) read_w(bw0, sb, 0);
+            read_x(a1, sb, 1, third);
+            read_x(a0, sb, 0, third);
+            if (with_w) read_w(bw1, sb, 1);
+        };
+        auto multiply = [&](auto third_tag) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (PLANES == 2) { mma3(third_tag, bw0, a1); mma3(third_tag, bw0, a0); mma3(third_tag, bw1, a0); }
+            else { mma3(third_tag, bw0, a0); mma3(third_tag, bw1, a1); }
         };
 
-        const int NH = 2 * nk;                               // k halves
-        KPos kC{0, 0, 0};
-        // both k halves of K-tile 0, in the order the loop would have issued them (the counted waits rely on it)
-        stage_w(kC, 0, 0, 0); stage_x(kC, 0, 0, 1, T0{});
-        stage_x(kC, 0, 0, 1, T1{});
-        stage_x(kC, 0, 0, 1, T2{});
-        stage_w(kC, 0, 0, 1); stage_x(kC, 0, 0, 0, T0{});
-        stage_x(kC, 0, 0, 0, T1{});
-        stage_x(kC, 0, 0, 0, T2{});
-        stage_w(kC, 1, 1, 0); stage_x(kC, 1, 1, 1, T0{});
-        stage_x(kC, 1, 1, 1, T1{});
-        stage_x(kC, 1, 1, 1, T2{});
-        stage_w(kC, 1, 1, 1); stage_x(kC, 1, 1, 0, T0{});
-        KPos kN = kC;
-        advance(kN);                                         // kC = the K-tile of k half h, kN = the next one
-        wait3(0, true);                                      // w0, x1 rows 0-2, x0 rows 0-2 of k half 0 have landed
+        const int NU = PLANES * nk;                          // units
+        KPos kC{0, 0, 0}, kN{0, 0, 0};                       // bf16x3: the K-tile of unit u and the next one; 16-bit: the K-tiles of units u + 1 and u + 2
+        if constexpr (PLANES == 2) { advance(kN); } else { advance(kC); kN = kC; advance(kN); }
+        {   // units 0 and 1, in the order the loop would have issued them (the counted waits rely on it)
+            const KPos k0{0, 0, 0};
+            stage_w2(k0, 0, 0); stage_x2(k0, 0, 0, T0{});
+            stage_x2(k0, 0, 0, T1{});
+            stage_x2(k0, 0, 0, T2{});
+            if (NU > 1) { const KPos& k1 = PLANES == 2 ? k0 : kC; stage_w2(k1, 1, 1); stage_x2(k1, 1, 1, T0{}); }
+        }
+        wait3(0, NU > 1);                                    // W and the X rows 0-5 of unit 0 have landed
         W_BARRIER();
         if (wr == 1) W_BARRIER();                            // the stagger: M-half 1 runs one barrier behind M-half 0
-
-        for (int h = 0; h < NH; ++h) {
-            const int ks = h & 1;                            // = the ring slot of k half h
-            const bool n1 = h + 1 < NH, n2 = h + 2 < NH;
-            const char* sb = smem + ks * W_KS;
-            const KPos k1 = ks ? kN : kC;                    // K-tile of k half h + 1 (its k half: ks ^ 1); k half h + 2: (kN, ks)
-            // phase 0: w0 x1 rows 0-2
-            read_w(sb, 0);
-            read_x(sb, 1, 0);
-            if (n1) stage_x(k1, ks ^ 1, ks ^ 1, 0, T1{});
-            W_BARRIER();
-            mma3(T0{});
-            W_BARRIER();
-            // phase 1: w0 x0 rows 0-2
-            read_x(sb, 0, 0);
-            if (n1) stage_x(k1, ks ^ 1, ks ^ 1, 0, T2{});
-            W_BARRIER();
-            mma3(T0{});
-            wait3(0, n1);                                    // x0 rows 3-5 of this k half
-            W_BARRIER();
-            // phase 2: w0 x1 rows 3-5
-            read_x(sb, 1, 1);
-            if (n2) { stage_w(kN, ks, ks, 0); stage_x(kN, ks, ks, 1, T0{}); }
-            W_BARRIER();
-            mma3(T1{});
-            W_BARRIER();
-            // phase 3: w0 x0 rows 3-5
-            read_x(sb, 0, 1);
-            W_BARRIER();
-            mma3(T1{});
-            wait3(2, n2);                                    // x0 rows 6-8 of this k half
-            W_BARRIER();
-            // phase 4: w0 x1 rows 6-8
-            read_x(sb, 1, 2);
-            if (n2) stage_x(kN, ks, ks, 1, T1{});
-            W_BARRIER();
-            mma3(T2{});
-            W_BARRIER();
-            // phase 5: w0 x0 rows 6-8
-            read_x(sb, 0, 2);
-            W_BARRIER();
-            mma3(T2{});
-            W_BARRIER();
-            // phase 6: w1 x0 rows 0-2
-            read_w(sb, 1);
-            read_x(sb, 0, 0);
-            if (n2) stage_x(kN, ks, ks, 1, T2{});
-            W_BARRIER();
-            mma3(T0{});
-            W_BARRIER();
-            // phase 7: w1 x0 rows 3-5
-            read_x(sb, 0, 1);
-            W_BARRIER();
-            mma3(T1{});
-            wait3(1, n2);                                    // w0, x1 rows 0-2 of k half h + 1
-            W_BARRIER();
-            // phase 8: w1 x0 rows 6-8
-            read_x(sb, 0, 2);
-            if (n2) { stage_w(kN, ks, ks, 1); stage_x(kN, ks, ks, 0, T0{}); }
-            W_BARRIER();
-            mma3(T2{});
-            wait3(0, n2);                                    // x0 rows 0-2 (and everything issued before them) of k half h + 1
-            W_BARRIER();
-            if (ks) { kC = kN; advance(kN); }
+        for (int u = 0; u < NU; ++u) {
+            const int slot = u & 1;
+            const bool n1 = u + 1 < NU, n2 = u + 2 < NU;
+            const char* sb = smem + slot * W_SLOT;
+            const KPos k1 = PLANES == 2 ? (slot ? kN : kC) : kC;     // unit u + 1 (bf16x3: its k half is slot ^ 1); unit u + 2 is (kN, slot)
+            reads(sb, 0, true);
+            if (n1) stage_x2(k1, slot ^ 1, slot ^ 1, T1{});
+            W_BARRIER(); multiply(T0{}); wait3(0, n1); W_BARRIER();
+            reads(sb, 1, false);
+            if (n1) stage_x2(k1, slot ^ 1, slot ^ 1, T2{});
+            W_BARRIER(); multiply(T1{}); wait3(1, n1); W_BARRIER();
+            reads(sb, 2, false);
+            if (n2) { stage_w2(kN, slot, slot); stage_x2(kN, slot, slot, T0{}); }
+            W_BARRIER(); multiply(T2{}); wait3(0, n2); W_BARRIER();
+            if (PLANES == 1 || slot) { kC = kN; advance(kN); }
         }
         // the MFMAs above are inline assembly: the compiler does not know that the epilogue's first reads depend on matrix results
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
@@ -751,9 +735,9 @@ bool mudg_wgemm_ok(const MudgGemmDesc& d, int vflags) {
     // - 4 ... - 26 %, those stay on the 128 x 128 kernels (four workgroups per CU).
     if (d.mode != 0) return true;
     // bf16x3 (same tool with MUDG_OPERAND=bf16x3, profiles/r5/w288_x3_shapes.txt; the 128 x 128 side is the fused-piece kernel, one-tile or
-    // persistent as gemm.hip selects): 3x3 convs + 6 ... + 26 %, temporal convs + 3 ... + 9 %, plain GEMMs + 5 ... + 19 % from K = 2560
-    // and at the N = 320 / K = 1280 feed-forward output; - 1 ... - 14 % on the other K <= 1280 problems and on every GEGLU (- 0 ... - 7 %).
-    if (PLANES == 2) return !d.geglu && (d.K >= 2560 || (d.K >= 1280 && d.N <= 320));
+    // persistent as gemm.hip selects): 3x3 convs + 28 ... + 37 %, temporal convs + 19 ... + 27 %, GEGLU + 6 ... + 14 %, plain GEMMs + 3 ...
+    // + 33 % down to K = 320: three times the MFMAs per staged byte and per epilogue — every problem whose frames are whole tiles.
+    if (PLANES == 2) return true;
     return d.K >= 1280;
 }
 
