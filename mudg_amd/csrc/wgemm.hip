@@ -109,6 +109,241 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
+// Which columns of a tile a wave column owns.  A wave's NREP fragments are NREP / 2 PAIRS (32 channels: a lane's 2 x 4 accumulator
+// registers are 8 consecutive ones, a 16-byte piece of a 16-bit result row) and, on the 320-wide tile, one unpaired fragment (16
+// channels, 8-byte pieces).  The pairs of all four wave columns come first, 32 channels each — so every 16-byte-per-lane store (four
+// lanes = 64 contiguous bytes) starts on a 64-byte boundary of the row and the two pairs of a wave fill one 128-byte line; the four
+// unpaired fragments follow at channel 256.  (A wave column as 80 CONSECUTIVE channels put the pieces of the odd wave columns across
+// sector boundaries: the epilogue ran at half the store / residual-fetch rate.)  Free: which W rows a wave's fragments fetch.
+template <int NREP> __device__ __forceinline__ int wave_pair_col(int wc, int pair) { return 32 * ((NREP / 2) * wc + pair); }
+template <int NREP> __device__ __forceinline__ int wave_single_col(int wc) { return 32 * (NREP / 2) * 4 + 16 * wc; }
+
+// Epilogue of a tile, straight from the accumulators (shared by the one-tile and the persistent kernel).
+// Lane (pixel px = lane % 16, q = lane / 16) holds, for each of its 9 rows m = m0 + 144 wr + 16 i + px and each fragment pair p,
+// the 8 consecutive output channels wave_pair_col(wc, p) + 8 q .. + 7: one 16-byte piece per row (operand / fp16 result; two for
+// fp32), four lanes = 64 contiguous bytes of the row.  A piece is value = alpha acc + (bias + group bias), GEGLU'd, + residual, rounded,
+// summed into the GroupNorm partials, stored.  The residual pieces of all nine rows are requested before the first is used.
+template <int NREP, bool GEGLU>
+__device__ __forceinline__ void w_epilogue(const MudgGemmDesc& p, f32x4 (&acc)[9][NREP], const int m0, const int n0, const int tm, const int wr, const int wc,
+                                           const int lane, const int tid, float* tail, const float* __restrict__ phi) {
+    constexpr int WBN = 64 * NREP, NPAIR = NREP / 2;
+    using T0 = std::integral_constant<int, 0>; using T1 = std::integral_constant<int, 1>;
+    const int px = lane & 15, q4 = lane >> 4;
+    const float alpha = p.alpha;
+    const int RK = p.R ? p.res_fp32 : 3, OK = p.out_fp32;
+    const char* Rb = reinterpret_cast<const char*>(p.R);
+    const int rsz = RK == KIND_F32 ? 4 : 2;
+    const int64_t mrow = (int64_t)m0 + wr * 144 + px;    // row of i = 0
+    float* sred = tail;                                  // [M half][tile column][2]: GroupNorm partials meet here
+    const float* phis = tail;                            // GEGLU: the Phi table
+    const int64_t gb0 = p.gbias ? (int64_t)(m0 / p.rows_per_group) * p.N : 0;          // host-checked: one group per tile
+
+    auto piece8 = [&](auto ptag) __attribute__((always_inline)) {
+        constexpr int P = decltype(ptag)::value;         // fragment pair: accumulator fragments 2 P (channels + 0..3) and 2 P + 1 (+ 4..7)
+        const int cw = n0 + wave_pair_col<NREP>(wc, GEGLU ? 0 : P) + 8 * q4;          // first W row (bias index) of the value
+        const int n = GEGLU ? (n0 >> 1) + wc * 32 + 8 * q4 : cw;                        // first output channel
+        float bv[8], bg[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            bv[e] = p.bias ? p.bias[cw + e] : 0.f;
+            if (p.gbias) bv[e] += p.gbias[gb0 + cw + e];
+            bg[e] = (GEGLU && p.bias) ? p.bias[cw + 32 + e] : 0.f;
+        }
+        u32x4 ra[9];
+        if (RK == KIND_F16 || (RK == KIND_OPERAND && PLANES == 1)) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                const int64_t m = mrow + 16 * i;
+                ra[i] = zero16();
+                if (m < p.M) {
+                    const char* rp = Rb + (m * p.ldr + n) * rsz;
+                    ra[i] = ld16(rp);
+                }
+            }
+        }
+        float gs[8], gq[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { gs[e] = 0.f; gq[e] = 0.f; }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const int64_t m = mrow + 16 * i;
+            const bool live = m < p.M;
+            float v[8];
+            if constexpr (GEGLU) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float val = alpha * acc[i][e >> 2][e & 3] + bv[e];
+                    const float gate = alpha * acc[i][2 + (e >> 2)][e & 3] + bg[e];
+                    v[e] = val * (phi ? gelu_lut(gate, phis) : gelu_fast(gate));
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = alpha * acc[i][2 * P + (e >> 2)][e & 3] + bv[e];
+            }
+            if (RK == KIND_F32) {
+                if (live) {
+                    const float* rp = reinterpret_cast<const float*>(Rb) + m * p.ldr + n;
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(rp), b = *reinterpret_cast<const f32x4*>(rp + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[e] += a[e]; v[4 + e] += b[e]; }
+                }
+            } else if (RK == KIND_F16) {
+                union { u32x4 w; f16x8 h; } t; t.w = ra[i];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += (float)t.h[e];
+            } else if (RK == KIND_OPERAND) {
+                if constexpr (PLANES == 1) {
+                    const h16x8 t = as_h16x8(ra[i]);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += (float)t[e];
+                } else if (live) {
+                    float rr[8];
+                    load8_operand(reinterpret_cast<const h16*>(Rb) + m * p.ldr + n, p.ldr / PLANES, rr);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += rr[e];
+                }
+            }
+            if (!GEGLU && p.stats) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float t = live ? (OK == KIND_F32 ? v[e] : (OK == KIND_F16 ? (float)f16_sat(v[e]) : operand_round(v[e]))) : 0.f;
+                    gs[e] += t; gq[e] = fmaf(t, t, gq[e]);
+                }
+            }
+            if (live) {
+                const int64_t yoff = m * p.ldy + n;
+                if (OK == KIND_F16) store8_f16(reinterpret_cast<_Float16*>(p.Y) + yoff, v);
+                else if (OK == KIND_F32) {
+                    float* yp = reinterpret_cast<float*>(p.Y) + yoff;
+                    f32x4 a, b;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { a[e] = v[e]; b[e] = v[4 + e]; }
+                    *reinterpret_cast<f32x4*>(yp) = a;
+                    *reinterpret_cast<f32x4*>(yp + 4) = b;
+                } else store8_operand(reinterpret_cast<h16*>(p.Y) + yoff, p.ldy / PLANES, v);
+            }
+        }
+        if (!GEGLU && p.stats) {
+            // the 16 pixels of the fragment column (a DPP row) folded in a fixed order; lane px = 0 of each q hands its M half's sums over
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { gs[e] = row16_sum(gs[e]); gq[e] = row16_sum(gq[e]); }
+            if (px == 0) {
+                float* d = sred + ((wr * WBN) + wave_pair_col<NREP>(wc, P) + 8 * q4) * 2;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { d[2 * e] = gs[e]; d[2 * e + 1] = gq[e]; }
+            }
+        }
+    };
+    // the unpaired fifth fragment of the 320-wide tile: 4 consecutive channels per lane (8-byte operand / fp16 pieces)
+    auto piece4 = [&]() __attribute__((always_inline)) {
+        constexpr int J = 2 * NPAIR;
+        const int n = n0 + wave_single_col<NREP>(wc) + 4 * q4;
+        float bv[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            bv[e] = p.bias ? p.bias[n + e] : 0.f;
+            if (p.gbias) bv[e] += p.gbias[gb0 + n + e];
+        }
+        u32x2 ra[9];
+        if (RK == KIND_F16 || (RK == KIND_OPERAND && PLANES == 1)) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                const int64_t m = mrow + 16 * i;
+                ra[i] = u32x2{0u, 0u};
+                if (m < p.M) ra[i] = *reinterpret_cast<const u32x2*>(Rb + (m * p.ldr + n) * 2);
+            }
+        }
+        float gs[4], gq[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { gs[e] = 0.f; gq[e] = 0.f; }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const int64_t m = mrow + 16 * i;
+            const bool live = m < p.M;
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = alpha * acc[i][J < NREP ? J : 0][e] + bv[e];
+            if (RK == KIND_F32) {
+                if (live) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(Rb) + m * p.ldr + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += a[e];
+                }
+            } else if (RK == KIND_F16) {
+                union { u32x2 w; _Float16 h[4]; } t; t.w = ra[i];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += (float)t.h[e];
+            } else if (RK == KIND_OPERAND) {
+                if constexpr (PLANES == 1) {
+                    Pack8 t; t.u = ra[i];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += (float)t.h[e];
+                } else if (live) {
+#pragma unroll
+                    for (int pl = 0; pl < PLANES; ++pl) {
+                        Pack8 t; t.u = *reinterpret_cast<const u32x2*>(reinterpret_cast<const h16*>(Rb) + m * p.ldr + pl * (p.ldr / PLANES) + n);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += (float)t.h[e];
+                    }
+                }
+            }
+            if (p.stats) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float t = live ? (OK == KIND_F32 ? v[e] : (OK == KIND_F16 ? (float)f16_sat(v[e]) : operand_round(v[e]))) : 0.f;
+                    gs[e] += t; gq[e] = fmaf(t, t, gq[e]);
+                }
+            }
+            if (live) {
+                const int64_t yoff = m * p.ldy + n;
+                if (OK == KIND_F16) {
+                    union { u32x2 w; _Float16 h[4]; } t;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t.h[e] = f16_sat(v[e]);
+                    *reinterpret_cast<u32x2*>(reinterpret_cast<_Float16*>(p.Y) + yoff) = t.w;
+                } else if (OK == KIND_F32) {
+                    f32x4 a;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) a[e] = v[e];
+                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.Y) + yoff) = a;
+                } else {
+#pragma unroll
+                    for (int pl = 0; pl < PLANES; ++pl) {               // the pieces of store8_operand, four channels wide
+                        Pack8 t;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { t.h[e] = (h16)v[e]; v[e] -= (float)t.h[e]; }
+                        *reinterpret_cast<u32x2*>(reinterpret_cast<h16*>(p.Y) + yoff + pl * (p.ldy / PLANES)) = t.u;
+                    }
+                }
+            }
+        }
+        if (p.stats) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { gs[e] = row16_sum(gs[e]); gq[e] = row16_sum(gq[e]); }
+            if (px == 0) {
+                float* d = sred + ((wr * WBN) + wave_single_col<NREP>(wc) + 4 * q4) * 2;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { d[2 * e] = gs[e]; d[2 * e + 1] = gq[e]; }
+            }
+        }
+    };
+    if constexpr (GEGLU) {
+        piece8(T0{});
+    } else {
+        piece8(T0{});
+        if constexpr (NPAIR > 1) piece8(T1{});
+        if constexpr (NREP & 1) piece4();
+        if (p.stats) {
+            // per 288-row block (= this tile) and channel: M half 0 + M half 1
+            __syncthreads();
+            if (tid < WBN) {
+                const float s0 = sred[tid * 2] + sred[(WBN + tid) * 2], s1 = sred[tid * 2 + 1] + sred[(WBN + tid) * 2 + 1];
+                *reinterpret_cast<f32x2*>(&p.stats[((int64_t)tm * p.N + n0 + tid) * 2]) = f32x2{s0, s1};
+            }
+        }
+    }
+}
+
 struct KPos { int kt, tap, c; };                         // a K-tile: its index along W's K axis, its tap and first input channel
 
 // NREP = 5: 288 x 320 (every channel count of the UNet is a multiple of 320); NREP = 4 + GEGLU: 288 x 256, a wave's four fragments are
@@ -259,7 +494,7 @@ __global__ __launch_bounds__(512, 2) void wgemm_kernel(const MudgGemmDesc p, con
                     if (q < b_cnt) {
                         const int st = b_first + q, wcol = st / NREP, j = st - wcol * NREP;
                         const bool single = j >= 2 * NPAIR;
-                        const int row0 = wcol * 16 * NREP + (single ? 32 * NPAIR : 32 * (j >> 1) + 4 * (j & 1));       // first channel of the piece
+                        const int row0 = single ? wave_single_col<NREP>(wcol) : wave_pair_col<NREP>(wcol, j >> 1) + 4 * (j & 1);       // first channel of the piece
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(base + (WNA + st) * 1024), 16, (int)(single ? vw_single : vw_pair),
                                                                  soffw + row0 * p.ldw * 2, 0, 0);
                     }
@@ -391,7 +626,7 @@ __global__ __launch_bounds__(512, 2) void wgemm_kernel(const MudgGemmDesc p, con
                 if (q < b_cnt) {
                     const int st = b_first + q, wcol = st / NREP, j = st - wcol * NREP;
                     const bool single = j >= 2 * NPAIR;
-                    const int row0 = wcol * 16 * NREP + (single ? 32 * NPAIR : 32 * (j >> 1) + 4 * (j & 1));
+                    const int row0 = single ? wave_single_col<NREP>(wcol) : wave_pair_col<NREP>(wcol, j >> 1) + 4 * (j & 1);
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(base + (WNA + st) * 1024), 16, (int)lane_off(single ? 0 : 8, p.ldw * 2),
                                                              soffw + row0 * p.ldw * 2, 0, 0);
                 }
@@ -474,226 +709,208 @@ __global__ __launch_bounds__(512, 2) void wgemm_kernel(const MudgGemmDesc p, con
     }
     if (wr == 0) W_BARRIER();                            // evens out the stagger: every fragment read has retired, every DMA has landed
 
-    // ------------------------------------------------------------------ epilogue: straight from the accumulators
-    // Lane (pixel px = lane % 16, q = lane / 16) holds, for each of its 9 rows m = m0 + 144 wr + 16 i + px and each fragment pair p,
-    // the 8 consecutive output channels 16 NREP wc + 32 p + 8 q .. + 7: one 16-byte piece per row (operand / fp16 result; two for
-    // fp32), four lanes = 64 contiguous bytes of the row.  A piece is value = alpha acc + (bias + group bias), GEGLU'd, + residual, rounded,
-    // summed into the GroupNorm partials, stored.  The residual pieces of all nine rows are requested before the first is used.
-    const int px = lane & 15, q4 = lane >> 4;
-    const float alpha = p.alpha;
-    const int RK = p.R ? p.res_fp32 : 3, OK = p.out_fp32;
-    const char* Rb = reinterpret_cast<const char*>(p.R);
-    const int rsz = RK == KIND_F32 ? 4 : 2;
-    const int64_t mrow = (int64_t)m0 + wr * 144 + px;    // row of i = 0
-    float* sred = tail;                                  // [M half][tile column][2]: GroupNorm partials meet here
-    const float* phis = tail;                            // GEGLU: the Phi table
-    const int64_t gb0 = p.gbias ? (int64_t)(m0 / p.rows_per_group) * p.N : 0;          // host-checked: one group per tile
+    w_epilogue<NREP, GEGLU>(p, acc, m0, n0, tm, wr, wc, lane, tid, tail, phi);
+}
 
-    auto piece8 = [&](auto ptag) __attribute__((always_inline)) {
-        constexpr int P = decltype(ptag)::value;         // fragment pair: accumulator fragments 2 P (channels + 0..3) and 2 P + 1 (+ 4..7)
-        const int cw = n0 + wc * 16 * NREP + (GEGLU ? 0 : 32 * P) + 8 * q4;           // first W row (bias index) of the value
-        const int n = GEGLU ? (n0 >> 1) + wc * 32 + 8 * q4 : cw;                        // first output channel
-        float bv[8], bg[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            bv[e] = p.bias ? p.bias[cw + e] : 0.f;
-            if (p.gbias) bv[e] += p.gbias[gb0 + cw + e];
-            bg[e] = (GEGLU && p.bias) ? p.bias[cw + 32 + e] : 0.f;
-        }
-        u32x4 ra[9];
-        if (RK == KIND_F16 || (RK == KIND_OPERAND && PLANES == 1)) {
-#pragma unroll
-            for (int i = 0; i < 9; ++i) {
-                const int64_t m = mrow + 16 * i;
-                ra[i] = zero16();
-                if (m < p.M) {
-                    const char* rp = Rb + (m * p.ldr + n) * rsz;
-                    ra[i] = ld16(rp);
-                }
-            }
-        }
-        float gs[8], gq[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { gs[e] = 0.f; gq[e] = 0.f; }
-#pragma unroll
-        for (int i = 0; i < 9; ++i) {
-            const int64_t m = mrow + 16 * i;
-            const bool live = m < p.M;
-            float v[8];
-            if constexpr (GEGLU) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float val = alpha * acc[i][e >> 2][e & 3] + bv[e];
-                    const float gate = alpha * acc[i][2 + (e >> 2)][e & 3] + bg[e];
-                    v[e] = val * (phi ? gelu_lut(gate, phis) : gelu_fast(gate));
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = alpha * acc[i][2 * P + (e >> 2)][e & 3] + bv[e];
-            }
-            if (RK == KIND_F32) {
-                if (live) {
-                    const float* rp = reinterpret_cast<const float*>(Rb) + m * p.ldr + n;
-                    const f32x4 a = *reinterpret_cast<const f32x4*>(rp), b = *reinterpret_cast<const f32x4*>(rp + 4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { v[e] += a[e]; v[4 + e] += b[e]; }
-                }
-            } else if (RK == KIND_F16) {
-                union { u32x4 w; f16x8 h; } t; t.w = ra[i];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += (float)t.h[e];
-            } else if (RK == KIND_OPERAND) {
-                if constexpr (PLANES == 1) {
-                    const h16x8 t = as_h16x8(ra[i]);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += (float)t[e];
-                } else if (live) {
-                    float rr[8];
-                    load8_operand(reinterpret_cast<const h16*>(Rb) + m * p.ldr + n, p.ldr / PLANES, rr);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += rr[e];
-                }
-            }
-            if (!GEGLU && p.stats) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    const float t = live ? (OK == KIND_F32 ? v[e] : (OK == KIND_F16 ? (float)f16_sat(v[e]) : operand_round(v[e]))) : 0.f;
-                    gs[e] += t; gq[e] = fmaf(t, t, gq[e]);
-                }
-            }
-            if (live) {
-                const int64_t yoff = m * p.ldy + n;
-                if (OK == KIND_F16) store8_f16(reinterpret_cast<_Float16*>(p.Y) + yoff, v);
-                else if (OK == KIND_F32) {
-                    float* yp = reinterpret_cast<float*>(p.Y) + yoff;
-                    f32x4 a, b;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { a[e] = v[e]; b[e] = v[4 + e]; }
-                    *reinterpret_cast<f32x4*>(yp) = a;
-                    *reinterpret_cast<f32x4*>(yp + 4) = b;
-                } else store8_operand(reinterpret_cast<h16*>(p.Y) + yoff, p.ldy / PLANES, v);
-            }
-        }
-        if (!GEGLU && p.stats) {
-            // the 16 pixels of the fragment column (a DPP row) folded in a fixed order; lane px = 0 of each q hands its M half's sums over
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { gs[e] = row16_sum(gs[e]); gq[e] = row16_sum(gq[e]); }
-            if (px == 0) {
-                float* d = sred + ((wr * WBN) + wc * 16 * NREP + 32 * P + 8 * q4) * 2;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) { d[2 * e] = gs[e]; d[2 * e + 1] = gq[e]; }
-            }
-        }
-    };
-    // the unpaired fifth fragment of the 320-wide tile: 4 consecutive channels per lane (8-byte operand / fp16 pieces)
-    auto piece4 = [&]() __attribute__((always_inline)) {
-        constexpr int J = 2 * NPAIR;
-        const int n = n0 + wc * 16 * NREP + 32 * NPAIR + 4 * q4;
-        float bv[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            bv[e] = p.bias ? p.bias[n + e] : 0.f;
-            if (p.gbias) bv[e] += p.gbias[gb0 + n + e];
-        }
-        u32x2 ra[9];
-        if (RK == KIND_F16 || (RK == KIND_OPERAND && PLANES == 1)) {
-#pragma unroll
-            for (int i = 0; i < 9; ++i) {
-                const int64_t m = mrow + 16 * i;
-                ra[i] = u32x2{0u, 0u};
-                if (m < p.M) ra[i] = *reinterpret_cast<const u32x2*>(Rb + (m * p.ldr + n) * 2);
-            }
-        }
-        float gs[4], gq[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { gs[e] = 0.f; gq[e] = 0.f; }
-#pragma unroll
-        for (int i = 0; i < 9; ++i) {
-            const int64_t m = mrow + 16 * i;
-            const bool live = m < p.M;
-            float v[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = alpha * acc[i][J < NREP ? J : 0][e] + bv[e];
-            if (RK == KIND_F32) {
-                if (live) {
-                    const f32x4 a = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(Rb) + m * p.ldr + n);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += a[e];
-                }
-            } else if (RK == KIND_F16) {
-                union { u32x2 w; _Float16 h[4]; } t; t.w = ra[i];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += (float)t.h[e];
-            } else if (RK == KIND_OPERAND) {
-                if constexpr (PLANES == 1) {
-                    Pack8 t; t.u = ra[i];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += (float)t.h[e];
-                } else if (live) {
-#pragma unroll
-                    for (int pl = 0; pl < PLANES; ++pl) {
-                        Pack8 t; t.u = *reinterpret_cast<const u32x2*>(reinterpret_cast<const h16*>(Rb) + m * p.ldr + pl * (p.ldr / PLANES) + n);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += (float)t.h[e];
-                    }
-                }
-            }
-            if (p.stats) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float t = live ? (OK == KIND_F32 ? v[e] : (OK == KIND_F16 ? (float)f16_sat(v[e]) : operand_round(v[e]))) : 0.f;
-                    gs[e] += t; gq[e] = fmaf(t, t, gq[e]);
-                }
-            }
-            if (live) {
-                const int64_t yoff = m * p.ldy + n;
-                if (OK == KIND_F16) {
-                    union { u32x2 w; _Float16 h[4]; } t;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) t.h[e] = f16_sat(v[e]);
-                    *reinterpret_cast<u32x2*>(reinterpret_cast<_Float16*>(p.Y) + yoff) = t.w;
-                } else if (OK == KIND_F32) {
-                    f32x4 a;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) a[e] = v[e];
-                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.Y) + yoff) = a;
-                } else {
-#pragma unroll
-                    for (int pl = 0; pl < PLANES; ++pl) {               // the pieces of store8_operand, four channels wide
-                        Pack8 t;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { t.h[e] = (h16)v[e]; v[e] -= (float)t.h[e]; }
-                        *reinterpret_cast<u32x2*>(reinterpret_cast<h16*>(p.Y) + yoff + pl * (p.ldy / PLANES)) = t.u;
-                    }
-                }
-            }
-        }
-        if (p.stats) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { gs[e] = row16_sum(gs[e]); gq[e] = row16_sum(gq[e]); }
-            if (px == 0) {
-                float* d = sred + ((wr * WBN) + wc * 16 * NREP + 32 * NPAIR + 4 * q4) * 2;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { d[2 * e] = gs[e]; d[2 * e + 1] = gq[e]; }
-            }
-        }
-    };
-    if constexpr (GEGLU) {
-        piece8(T0{});
-    } else {
-        piece8(T0{});
-        if constexpr (NPAIR > 1) piece8(T1{});
-        if constexpr (NREP & 1) piece4();
-        if (p.stats) {
-            // per 288-row block (= this tile) and channel: M half 0 + M half 1
-            __syncthreads();
-            if (tid < WBN) {
-                const float s0 = sred[tid * 2] + sred[(WBN + tid) * 2], s1 = sred[tid * 2 + 1] + sred[(WBN + tid) * 2 + 1];
-                *reinterpret_cast<f32x2*>(&p.stats[((int64_t)tm * p.N + n0 + tid) * 2]) = f32x2{s0, s1};
-            }
-        }
+#if MUDG_PLANES == 1
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// The persistent form for plain GEMMs / GEGLU (MODE 0, whole 288-row tiles, K >= 128): one workgroup per CU walks every gridDim / 8-th
+// tile of its XCD's range, and the K-tiles of its tiles form ONE stream through the LDS ring — while the last K-tiles of a tile are
+// multiplied the first 1.5 K-tiles of the next tile are already being staged, the epilogue (accumulators -> HBM, no LDS) runs with the
+// ring full, and its stores drain under the next tile's first phases.  What a one-tile workgroup pays per tile and this form does not:
+// the launch of a workgroup, the first-fetch latency, the drain of the stores before the CU is handed on — at K = 320 more than the
+// K loop itself — and the lockstep of 256 CUs that all fetch, then all multiply, then all store.  Per tile the arithmetic is the
+// one-tile kernel's, instruction for instruction: the same bits.
+// Counted waits across an epilogue: the two waits of a tile's first K-tile retire pieces issued BEFORE the epilogue, so the epilogue's
+// stores (27 | 45 per lane: 16-bit | fp32 results; 9 | 18 GEGLU) are younger than what they wait for and are added to the count.
+#define W_VMCNT_CASE(n) case n: W_VMCNT(n); break;
+__device__ __forceinline__ void w_vmcnt_runtime(int n) {          // n: wave-uniform
+    switch (n) {
+        W_VMCNT_CASE(15) W_VMCNT_CASE(16) W_VMCNT_CASE(24) W_VMCNT_CASE(25)
+        W_VMCNT_CASE(33) W_VMCNT_CASE(34) W_VMCNT_CASE(35) W_VMCNT_CASE(51) W_VMCNT_CASE(52) W_VMCNT_CASE(53)
+        default: W_VMCNT(0); break;
     }
 }
+
+template <int NREP, bool GEGLU>
+__global__ __launch_bounds__(512, 2) void wgemm_pkernel(const MudgGemmDesc p, const int vflags, const float* __restrict__ phi, const int ntiles) {
+    using G = WGeo<NREP>;
+    constexpr int WBN = G::BN, W_KS = G::KS, W_BUF = G::BUF, NPAIR = NREP / 2;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    float* tail = reinterpret_cast<float*>(smem + G::LOOP);
+    if (GEGLU && phi) {
+        for (int t4 = tid * 4; t4 < PHI_N; t4 += 512 * 4) *reinterpret_cast<f32x4*>(&tail[t4]) = *reinterpret_cast<const f32x4*>(&phi[t4]);
+        if (tid == 0) tail[PHI_N] = phi[PHI_N];
+    }
+    // this workgroup's tiles: the XCD's contiguous range of the one-tile kernel's numbering, every (gridDim / 8)-th tile of it
+    const int ntn = p.N / WBN, ntm = p.M / WBM;
+    const int xcd = blockIdx.x & 7, stride = gridDim.x >> 3;
+    const int q8 = ntiles >> 3, r8 = ntiles & 7;
+    const int first = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8, count = q8 + (xcd < r8 ? 1 : 0);
+    int li = blockIdx.x >> 3;                              // (host: ntiles >= gridDim, so every workgroup has a tile)
+    const h16* X = reinterpret_cast<const h16*>(p.X);
+    const h16* X2 = p.X2 ? reinterpret_cast<const h16*>(p.X2) : nullptr;
+    const h16* W = reinterpret_cast<const h16*>(p.W);
+    const int ldx2e = X2 ? p.ldx2 : p.ldx;
+    // ONE descriptor per operand for the whole problem: a tile's first row rides in the scalar offset of its pieces (host: the 32-bit reach)
+    const __amdgpu_buffer_rsrc_t rX = make_rsrc(X), rX2 = X2 ? make_rsrc(X2) : rX, rW = make_rsrc(W);
+    struct Tile { int m0, n0, tm; };
+    auto locate = [&](int local) {
+        const int tile = first + local;
+        const int per = 8 * ntn, g = tile / per, f8 = g * 8;
+        const int gsz = (ntm - f8) < 8 ? (ntm - f8) : 8;
+        const int r = tile - g * per;
+        const int tn = r / gsz, tm = f8 + (r - tn * gsz);
+        return Tile{tm * WBM, tn * WBN, tm};
+    };
+    Tile cur = locate(li), nxt = cur;
+    if (li + stride < count) nxt = locate(li + stride);
+
+    const int pos = lane * 16;
+    const int sbyte = pos ^ (((pos >> 9) & 1) << 5);
+    const int srow = sbyte >> 6, schunk = (sbyte >> 4) & 3;
+    const unsigned va1 = (unsigned)(srow * p.ldx) * 2u + (unsigned)schunk * 16u;
+    const unsigned va2 = (unsigned)(srow * ldx2e) * 2u + (unsigned)schunk * 16u;
+    const unsigned vw_pair = (unsigned)((8 * (srow >> 2) + (srow & 3)) * p.ldw) * 2u + (unsigned)schunk * 16u;
+    const unsigned vw_single = (unsigned)(srow * p.ldw) * 2u + (unsigned)schunk * 16u;
+    const int a_first = wc == 0 ? 0 : 1 + 2 * wc, a_cnt = wc == 0 ? 3 : 2;
+    const int b_cnt = NREP == 5 ? ((wc == 0 || wc == 3) ? 2 : 3) : 2;
+    const int b_first = NREP == 5 ? wr * 10 + (wc == 0 ? 0 : (wc == 1 ? 2 : (wc == 2 ? 5 : 8))) : wave * 2;
+    // pieces of k half ks of K-tile kt of the current (sel 0) or the next (sel 1) tile -> ring buffer buf; part as in the one-tile kernel
+    auto stage = [&](int sel, int kt, int ks, int buf, int part) {
+        char* base = smem + buf * W_BUF + ks * W_KS;
+        if (part != 2) {
+            const int c = kt * BK;
+            const bool s2 = c >= p.csplit;
+            const int cc = s2 ? c - p.csplit : c;
+            const int ld = s2 ? ldx2e : p.ldx;
+            const int soff = (cc + ks * 32) * 2 + (sel ? nxt.m0 : cur.m0) * ld * 2;
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                if (q < a_cnt) {
+                    const int st = wr * 9 + a_first + q;
+                    if (s2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rX2, (lptr_t)(base + st * 1024), 16, (int)va2, soff + st * 16 * ld * 2, 0, 0);
+                    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (lptr_t)(base + st * 1024), 16, (int)va1, soff + st * 16 * ld * 2, 0, 0);
+                }
+        }
+        if (part != 1) {
+            const int soffw = (kt * BK + ks * 32) * 2 + (sel ? nxt.n0 : cur.n0) * p.ldw * 2;
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                if (q < b_cnt) {
+                    const int st = b_first + q, wcol = st / NREP, j = st - wcol * NREP;
+                    const bool single = j >= 2 * NPAIR;
+                    const int row0 = single ? wave_single_col<NREP>(wcol) : wave_pair_col<NREP>(wcol, j >> 1) + 4 * (j & 1);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(base + (WNA + st) * 1024), 16, (int)(single ? vw_single : vw_pair),
+                                                             soffw + row0 * p.ldw * 2, 0, 0);
+                }
+        }
+    };
+    const int fbyte0 = (lane & 15) * 64 + (lane >> 4) * 16;
+    const int fbyte = fbyte0 ^ (((fbyte0 >> 9) & 1) << 5);
+    const char* a_base = smem + (wr * 9) * 1024 + fbyte;
+    const char* b_base = smem + (WNA + wc * NREP) * 1024 + fbyte;
+    f32x4 acc[9][NREP];
+    h16x8 af[3], bf[NREP];
+    auto read_a = [&](int buf, int ks, int third) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) af[i] = *reinterpret_cast<const h16x8*>(a_base + buf * W_BUF + ks * W_KS + (third * 3 + i) * 1024);
+    };
+    auto read_b = [&](int buf, int ks) {
+#pragma unroll
+        for (int j = 0; j < NREP; ++j) bf[j] = *reinterpret_cast<const h16x8*>(b_base + buf * W_BUF + ks * W_KS + j * 1024);
+    };
+    auto mma = [&](auto third_tag) {
+        constexpr int third = decltype(third_tag)::value;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < NREP; ++j) acc[third * 3 + i][j] = mfma16(bf[j], af[i], acc[third * 3 + i][j]);
+    };
+    const int base_cnt = a_cnt + 2 * b_cnt;                // the one-tile kernel's wait_half count: 7 | 8 | 6
+    const int nst = GEGLU ? (p.out_fp32 == KIND_F32 ? 18 : 9) : (p.out_fp32 == KIND_F32 ? 45 : 27);       // epilogue stores per lane
+    auto wait_half = [&](bool more, bool fresh) {
+        if (!more) W_VMCNT(0);
+        else if (fresh) w_vmcnt_runtime(base_cnt + nst);
+        else if (base_cnt == 8) W_VMCNT(8);
+        else if (base_cnt == 7) W_VMCNT(7);
+        else W_VMCNT(6);
+    };
+    using T0 = std::integral_constant<int, 0>; using T1 = std::integral_constant<int, 1>; using T2 = std::integral_constant<int, 2>;
+    const int nk = p.K / BK;                               // >= 2 (host)
+
+    stage(0, 0, 0, 0, 0);
+    stage(0, 0, 1, 0, 0);
+    stage(0, 1, 0, 1, 0);
+    if (a_cnt + b_cnt == 5) W_VMCNT(10); else W_VMCNT(8);  // ks 0 of the first K-tile has landed
+    W_BARRIER();
+    if (wr == 1) W_BARRIER();                              // the stagger: M-half 1 runs one barrier behind M-half 0
+    int buf = 0;
+    bool fresh = false;                                    // the K-tile that follows an epilogue
+    for (;;) {
+        const bool has_next = li + stride < count;
+#pragma unroll
+        for (int i = 0; i < 9; ++i)
+#pragma unroll
+            for (int j = 0; j < NREP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int t = 0; t < nk; ++t, buf ^= 1) {
+            const bool in1 = t + 1 < nk, in2 = t + 2 < nk;
+            const bool n1 = in1 || has_next, n2 = in2 || has_next;
+            const int sel1 = in1 ? 0 : 1, kt1 = in1 ? t + 1 : 0;
+            const int sel2 = in2 ? 0 : 1, kt2 = in2 ? t + 2 : t + 2 - nk;
+            const bool fr = fresh && t == 0;
+            read_b(buf, 0);
+            read_a(buf, 0, 0);
+            W_BARRIER();
+            mma(T0{});
+            W_BARRIER();
+            read_a(buf, 0, 1);
+            if (n1) stage(sel1, kt1, 1, buf ^ 1, 2);
+            W_BARRIER();
+            mma(T1{});
+            wait_half(n1, fr);
+            W_BARRIER();
+            read_a(buf, 0, 2);
+            if (n1) stage(sel1, kt1, 1, buf ^ 1, 1);
+            W_BARRIER();
+            mma(T2{});
+            W_BARRIER();
+            read_b(buf, 1);
+            read_a(buf, 1, 0);
+            W_BARRIER();
+            mma(T0{});
+            W_BARRIER();
+            read_a(buf, 1, 1);
+            if (n2) stage(sel2, kt2, 0, buf, 2);
+            W_BARRIER();
+            mma(T1{});
+            wait_half(n2, fr);
+            W_BARRIER();
+            read_a(buf, 1, 2);
+            if (n2) stage(sel2, kt2, 0, buf, 1);
+            W_BARRIER();
+            mma(T2{});
+            W_BARRIER();
+        }
+        if (wr == 0) W_BARRIER();                          // evens out the stagger
+        __builtin_amdgcn_sched_barrier(0);
+        w_epilogue<NREP, GEGLU>(p, acc, cur.m0, cur.n0, cur.tm, wr, wc, lane, tid, tail, phi);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!has_next) break;
+        cur = nxt;
+        li += stride;
+        if (li + stride < count) nxt = locate(li + stride);
+        fresh = true;
+        if (wr == 1) W_BARRIER();                          // the stagger again
+    }
+}
+#endif
 
 // Variant switch GEMM_W288 (debug-variants build; read at every call so that one process can compare kernels): 0 = never, 1 = the rule
 // below, 2 = every eligible problem.
@@ -729,16 +946,18 @@ bool mudg_wgemm_ok(const MudgGemmDesc& d, int vflags) {
     if (mode == 2) return true;
     const int S = d.mode == 1 ? d.Hout * d.Wout : d.HW;
     if (S <= 0 || S % WBM != 0) return false;
-    // Measured per shape against the 128 x 128 kernels (tools/exp_w288.py, profiles/r5/w288_shapes.txt): 3x3 convs + 15 ... + 39 %, temporal
-    // convs + 11 ... + 27 %, plain GEMMs with K >= 1280 + 3 ... + 29 % (with or without a residual), GEGLU + 8 % at K = 1280; at shorter K a
-    // tile is five or ten K-steps between a first-fetch latency and an epilogue that nothing overlaps on a CU holding one workgroup:
-    // - 4 ... - 26 %, those stay on the 128 x 128 kernels (four workgroups per CU).
+    // Measured per shape against the 128 x 128 kernels (tools/exp_w288.py, profiles/r5/w288_shapes.txt; MI355X, frames of whole tiles):
+    // 3x3 convs + 21 ... + 38 %, temporal convs + 16 ... + 25 %; plain GEMMs + 10 ... + 29 % from K = 1280 (with or without a residual)
+    // and + 1 ... + 19 % at K = 320 / 640 WITHOUT a residual; with a residual at K <= 640 the 128 x 128 kernels stay ahead (- 2 ... - 12 %:
+    // a tile is five or ten K-steps, then 27 residual fetches in three dependent rounds with nothing else resident on the CU); GEGLU
+    // + 4 ... + 10 % from K = 640 in the persistent form, - 1 % at K = 320 (stays on the persistent 128 x 128 kernel).
     if (d.mode != 0) return true;
     // bf16x3 (same tool with MUDG_OPERAND=bf16x3, profiles/r5/w288_x3_shapes.txt; the 128 x 128 side is the fused-piece kernel, one-tile or
-    // persistent as gemm.hip selects): 3x3 convs + 28 ... + 37 %, temporal convs + 19 ... + 27 %, GEGLU + 6 ... + 14 %, plain GEMMs + 3 ...
-    // + 33 % down to K = 320: three times the MFMAs per staged byte and per epilogue — every problem whose frames are whole tiles.
+    // persistent as gemm.hip selects): 3x3 convs + 27 ... + 44 %, temporal convs + 22 ... + 27 %, GEGLU + 11 ... + 13 %, plain GEMMs + 7 ...
+    // + 37 % down to K = 320: three times the MFMAs per staged byte and per epilogue — every problem whose frames are whole tiles.
     if (PLANES == 2) return true;
-    return d.K >= 1280;
+    if (d.geglu) return d.K >= 640;
+    return d.K >= 1280 || !d.R;
 }
 
 template <int MODE, int NREP, bool GEGLU>
@@ -758,7 +977,53 @@ static int wgemm_launch_one(const MudgGemmDesc& d, int vflags, hipStream_t s, in
     return mudg_check_launch("mudg_gemm");
 }
 
+#if MUDG_PLANES == 1
+// The persistent form (wgemm_pkernel): whole tiles, at least two K-tiles, more tiles than CUs.  Same bits as the one-tile form, so M may
+// decide.  Measured (same box, tools/exp_w288.py with MUDG_GEMM_W288P = 0 / 2, profiles/r5/w288_persistent.txt): GEGLU + 2 ... + 9 % (its
+// epilogue is the longest and fetches nothing); plain GEMMs - 7 ... + 6 % with no pattern worth a rule — a residual's fetches queue
+// behind the next tile's staged pieces, and what persistence saves per tile (launch, first-fetch latency) is small beside what bounds
+// the short-K problems (the epilogue's own traffic).  Variant switch GEMM_W288P: 0 = never, 1 = GEGLU only (the rule), 2 = every
+// problem the kernel can run.
+template <int NREP, bool GEGLU>
+static int wgemm_launch_persistent(const MudgGemmDesc& d, int vflags, hipStream_t s, int slot, int grid) {
+    static bool attr_done[MAX_DEVICES][2] = {};
+    const int dev = mudg_current_device();
+    using G = WGeo<NREP>;
+    if (!attr_done[dev][slot]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgemm_pkernel<NREP, GEGLU>), hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM);
+        if (e != hipSuccess) MUDG_FAIL(MUDG_ELAUNCH, "gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_done[dev][slot] = true;
+    }
+    const int tiles = (d.M / WBM) * (d.N / G::BN);
+    const float* phi = GEGLU ? mudg_phi_table() : nullptr;
+    hipLaunchKernelGGL((wgemm_pkernel<NREP, GEGLU>), dim3(grid), dim3(512), G::SMEM, s, d, vflags, phi, tiles);
+    return mudg_check_launch("mudg_gemm");
+}
+static int persistent_grid(const MudgGemmDesc& d) {
+    static int cus[MAX_DEVICES] = {};
+    const int pv = mudg_variant("GEMM_W288P", 1);
+    if (!pv || (pv == 1 && !d.geglu) || d.mode != 0 || d.M % WBM != 0 || d.K < 2 * BK) return 0;
+    {   // the whole problem behind one descriptor per operand: rows ride in 32-bit scalar offsets
+        const int64_t ld = d.X2 && d.ldx2 > d.ldx ? d.ldx2 : d.ldx, lim = (int64_t)1 << 31;
+        if (((int64_t)d.M + 16) * ld * 2 + (int64_t)d.K * 2 + 256 >= lim || ((int64_t)d.N + 16) * d.ldw * 2 + (int64_t)d.K * 2 + 256 >= lim) return 0;
+    }
+    const int dev = mudg_current_device();
+    if (dev < 0) return 0;
+    if (!cus[dev]) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 8;
+        cus[dev] = n & ~7;                                   // whole XCDs' worth of workgroups
+    }
+    const int tiles = (d.M / WBM) * (d.N / (d.geglu ? 256 : 320));
+    return tiles > cus[dev] ? cus[dev] : 0;
+}
+#endif
+
 int mudg_wgemm_launch(const MudgGemmDesc& d, int vflags, hipStream_t s) {
+#if MUDG_PLANES == 1
+    if (const int grid = persistent_grid(d))
+        return d.geglu ? wgemm_launch_persistent<4, true>(d, vflags, s, 1, grid) : wgemm_launch_persistent<5, false>(d, vflags, s, 0, grid);
+#endif
     if (d.geglu) return wgemm_launch_one<0, 4, true>(d, vflags, s, 3);
     if (d.mode == 0) return wgemm_launch_one<0, 5, false>(d, vflags, s, 0);
     if (d.mode == 1) return wgemm_launch_one<1, 5, false>(d, vflags, s, 1);

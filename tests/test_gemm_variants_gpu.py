@@ -32,6 +32,7 @@ SELECT = "gemm or conv or tconv or resblock or transformer or geglu or fused or 
     {"MUDG_GN_REG": "0", "MUDG_TATTN_MFMA": "0"},
     {"MUDG_CONV_XSHARE": "0"},
     {"MUDG_GEMM_W288": "2"},
+    {"MUDG_GEMM_W288": "2", "MUDG_GEMM_W288P": "2"},
 ], ids=lambda e: ",".join(f"{k[5:]}={v}" for k, v in e.items()))
 def test_kernel_parity_under_variant(cuda, env):
     if os.environ.get("MUDG_DEBUG_VARIANTS") == "1":

@@ -868,6 +868,26 @@ def test_wide288_partials_feed_the_groupnorm_also_next_to_128_row_partials(cuda)
         assert rel_l2(fused, ref) < TOL_BF16
 
 
+def test_wide288_persistent_geglu_walks_a_stream_of_tiles(cuda):
+    """GEGLU at K = 640 with frames of whole 288-row tiles: the library's rule sends it to the 288 x 256 tile, in the persistent form when
+    there are more tiles than CUs (here 40 x 20 = 800: a workgroup walks three or four tiles, the K-tiles of which form one stream through
+    its LDS ring).  Against the fp32 reference; a sub-batch (fewer tiles than CUs: the one-tile form) gives the same bits."""
+    from mudg_amd import ops
+    M, C = 288 * 40, 640
+    x, w = rnd(M, C, seed=1), rnd(8 * C, C, seed=2, scale=0.04)
+    b = torch.randn(8 * C, generator=torch.Generator().manual_seed(3)) * 0.1
+    val, gate = (x.float() @ w.float().t() + b).chunk(2, dim=-1)
+    wp, bp = pack_geglu(w, b)
+    xd, wd, bd = x.to(cuda), wp.to(cuda), bp.to(cuda)
+    y = ops.gemm(xd, wd, bias=bd, geglu=True, frame_rows=288 * 2)
+    assert tuple(y.shape) == (M, 4 * C) and rel_l2(y, val * F.gelu(gate)) < TOL_BF16
+    part = ops.gemm(xd[:288 * 6], wd, bias=bd, geglu=True, frame_rows=288 * 2)            # 6 x 20 = 120 tiles: one per workgroup
+    assert torch.equal(part, y[:288 * 6])
+    assert torch.equal(ops.gemm(xd, wd, bias=bd, geglu=True, frame_rows=288 * 2), y)
+    y32 = ops.gemm(xd, wd, bias=bd, geglu=True, out_fp32=True, frame_rows=288 * 2)
+    assert rel_l2(y32, val * F.gelu(gate)) < 1e-4
+
+
 def test_wide288_is_bit_identical_to_the_one_tile_kernels(cuda):
     """Debug-variants build only (the switch is read at every call there): the same problem on the 128 x 128 kernels and on the
     288 x 320 tile gives the same bits — the K-tile order is the same and v_mfma_f32_16x16x32 adds its 32 products as two
@@ -881,6 +901,7 @@ def test_wide288_is_bit_identical_to_the_one_tile_kernels(cuda):
     x, w = rnd(f * h * wd, cin, seed=1).to(cuda), rnd(cout, 9 * cin, seed=2, scale=0.03).to(cuda)
     r = rnd(f * h * wd, cout, seed=3).to(ops.STREAM()).to(cuda)
     xm, wm = rnd(288 * 7 + 31, 640, seed=4).to(cuda), rnd(960, 640, seed=5, scale=0.03).to(cuda)
+    xl, rl = rnd(288 * 300, 640, seed=6).to(cuda), rnd(288 * 300, 960, seed=7).to(ops.STREAM()).to(cuda)      # 900 tiles: with GEMM_W288P=2 the persistent form
     outs = []
     saved = os.environ.get("MUDG_GEMM_W288")
     try:
@@ -888,7 +909,8 @@ def test_wide288_is_bit_identical_to_the_one_tile_kernels(cuda):
             os.environ["MUDG_GEMM_W288"] = v
             outs.append((ops.conv3x3(x, w, frames=f, hin=h, win=wd, cin=cin, korder=1, residual=r, out_stream=True),
                          ops.conv3x3(x, w, frames=f, hin=h, win=wd, cin=cin, korder=0, out_fp32=True),
-                         ops.gemm(xm, wm, out_fp32=True), ops.tconv3(x, w[:, :3 * cin].contiguous(), clips=1, t=2, hw=h * wd, cin=cin)))
+                         ops.gemm(xm, wm, out_fp32=True), ops.tconv3(x, w[:, :3 * cin].contiguous(), clips=1, t=2, hw=h * wd, cin=cin),
+                         ops.gemm(xl, wm, residual=rl, out_stream=True, stats=True, frame_rows=288)))
     finally:
         if saved is None:
             os.environ.pop("MUDG_GEMM_W288", None)

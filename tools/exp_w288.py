@@ -110,6 +110,37 @@ if what in ("parity", "all"):
     ref = F.conv2d(xi, wi, padding=1).permute(0, 2, 3, 1).reshape(f * h * wd, cout)
     print(f"conv vs fp64 conv2d: {rel(y, ref):.2e}", flush=True)
 
+if what in ("pparity", "all") and hip.planes() == 1:
+    # the persistent form (more tiles than CUs) against the one-tile form of the same kernel and against the 128 x 128 kernels: the same bits
+    torch.manual_seed(1)
+    def three(fn):
+        outs = []
+        for w288, pers in (("0", "1"), ("2", "0"), ("2", "2")):
+            os.environ["MUDG_GEMM_W288"], os.environ["MUDG_GEMM_W288P"] = w288, pers
+            y = fn()
+            torch.cuda.synchronize()
+            outs.append((y, getattr(y, ops.GN_ATTR, None)))
+        os.environ["MUDG_GEMM_W288"] = "1"
+        os.environ.pop("MUDG_GEMM_W288P", None)
+        return outs
+    for name, fn in (
+        ("gemm 201600x320x320 bias+residual stream", lambda: ops.gemm(xs[0], ws[0], bias=bs[0], residual=rs_[0], out_stream=True, frame_rows=288)),
+        ("gemm 201600x320x320 fp32 out, stats", lambda: ops.gemm(xs[0], ws[0], bias=bs[0], out_fp32=True, stats=True, frame_rows=288)),
+        ("gemm 86400x960x640 operand out", lambda: ops.gemm(xs[1], ws[1], frame_rows=288)),
+        ("gemm 86400x640x128 (two K-tiles) fp32 residual", lambda: ops.gemm(xs[2], ws[2], bias=bs[2], residual=r32, frame_rows=288)),
+        ("geglu 86400x2560x320", lambda: ops.gemm(xs[3], ws[3], bias=bs[3], geglu=True, frame_rows=288)),
+        ("geglu 86400x2560x320 fp32 out", lambda: ops.gemm(xs[3], ws[3], bias=bs[3], geglu=True, out_fp32=True, frame_rows=288)),
+    ):
+        if name.startswith("gemm 201600x320x320 bias"):
+            xs = [rn(288 * 700, 320), rn(288 * 300, 640), rn(288 * 300, 128), rn(288 * 300, 320)]
+            ws = [rn(320, 320), rn(960, 640), rn(640, 128), rn(2560, 320)]
+            bs = [torch.randn(320, device="cuda"), None, torch.randn(640, device="cuda"), torch.randn(2560, device="cuda")]
+            rs_ = [rs(288 * 700, 320)]
+            r32 = torch.randn(288 * 300, 640, device="cuda")
+        (y0, p0), (y1, p1), (y2, p2) = three(fn)
+        same = torch.equal(y1, y2) and (p1 is None or torch.equal(p1, p2))
+        print(f"{name}: persistent == one-tile 288 x 320: {same}; == 128 x 128 kernels: {torch.equal(y0, y2)}", flush=True)
+
 if what in ("time", "all"):
     G = [(294912, 320, 320, 9216), (294912, 320, 1280, 9216), (294912, 960, 320, 9216), (294912, 640, 320, 9216), (73728, 640, 640, 2304), (73728, 640, 2560, 2304),
          (73728, 1920, 640, 2304), (73728, 1280, 640, 2304), (18432, 1280, 5120, 576), (18432, 3840, 1280, 576), (18432, 1280, 1280, 576), (18432, 2560, 1280, 576)]
