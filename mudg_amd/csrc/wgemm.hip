@@ -118,11 +118,97 @@ __device__ __forceinline__ float row16_sum(float v) {
 template <int NREP> __device__ __forceinline__ int wave_pair_col(int wc, int pair) { return 32 * ((NREP / 2) * wc + pair); }
 template <int NREP> __device__ __forceinline__ int wave_single_col(int wc) { return 32 * (NREP / 2) * 4 + 16 * wc; }
 
+// A residual as the accumulators' INITIAL VALUE (alpha = 1, host-checked): its 27 pieces per lane are requested when the tile starts — no
+// accumulator is live yet, so all of them are in flight at once, next to the first K-tiles' DMA — instead of three dependent rounds of nine
+// in an epilogue that nothing overlaps on a CU holding one workgroup (the 294912 x 320 x 320 out-projection 178 -> 158 us, 73728 x 640 x 640
+// 102 -> 83, 18432 x 2560 x 1280 135 -> 121).  The
+// sum is ((r + x w) + bias) instead of ((x w + bias) + r): not the bits of the 128 x 128 one-tile kernels, so whether a problem with a
+// residual runs here never depends on M (mudg_wgemm_ok).
+template <int NREP>
+__device__ __forceinline__ void w_seed(const MudgGemmDesc& p, f32x4 (&acc)[9][NREP], const int m0, const int n0, const int wr, const int wc, const int lane) {
+    constexpr int NPAIR = NREP / 2;
+    const int px = lane & 15, q4 = lane >> 4;
+    const int RK = p.res_fp32;
+    const int64_t mrow = (int64_t)m0 + wr * 144 + px;
+    const int np = n0 + 8 * q4, ns = n0 + wave_single_col<NREP>(wc) + 4 * q4;
+    if (RK == KIND_F32) {
+        const float* R = reinterpret_cast<const float*>(p.R);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const int64_t m = mrow + 16 * i;
+            const bool live = m < p.M;
+#pragma unroll
+            for (int P = 0; P < NPAIR; ++P) {
+                const float* rp = R + m * p.ldr + np + wave_pair_col<NREP>(wc, P);
+                acc[i][2 * P] = live ? *reinterpret_cast<const f32x4*>(rp) : f32x4{0.f, 0.f, 0.f, 0.f};
+                acc[i][2 * P + 1] = live ? *reinterpret_cast<const f32x4*>(rp + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            if constexpr (NREP & 1) acc[i][2 * NPAIR] = live ? *reinterpret_cast<const f32x4*>(R + m * p.ldr + ns) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    } else if (RK == KIND_F16 || PLANES == 1) {           // 16-bit storage: the fp16 stream or a one-piece operand matrix
+        const char* R = reinterpret_cast<const char*>(p.R);
+        u32x4 ra[9][NPAIR];
+        u32x2 rs[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const int64_t m = mrow + 16 * i;
+            const bool live = m < p.M;
+#pragma unroll
+            for (int P = 0; P < NPAIR; ++P) ra[i][P] = live ? ld16(R + (m * p.ldr + np + wave_pair_col<NREP>(wc, P)) * 2) : zero16();
+            rs[i] = (live && (NREP & 1)) ? *reinterpret_cast<const u32x2*>(R + (m * p.ldr + ns) * 2) : u32x2{0u, 0u};
+        }
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+#pragma unroll
+            for (int P = 0; P < NPAIR; ++P) {
+                if (RK == KIND_F16) {
+                    union { u32x4 w; f16x8 h; } t; t.w = ra[i][P];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[i][2 * P + (e >> 2)][e & 3] = (float)t.h[e];
+                } else {
+                    const h16x8 t = as_h16x8(ra[i][P]);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[i][2 * P + (e >> 2)][e & 3] = (float)t[e];
+                }
+            }
+            if constexpr (NREP & 1) {
+                if (RK == KIND_F16) {
+                    union { u32x2 w; _Float16 h[4]; } t; t.w = rs[i];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[i][2 * NPAIR][e] = (float)t.h[e];
+                } else {
+                    Pack8 t; t.u = rs[i];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[i][2 * NPAIR][e] = (float)t.h[e];
+                }
+            }
+        }
+    } else {                                              // an operand matrix of the bf16x3 build: the sum of its pieces
+        const h16* R = reinterpret_cast<const h16*>(p.R);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const int64_t m = mrow + 16 * i;
+            const bool live = m < p.M;
+#pragma unroll
+            for (int P = 0; P < NPAIR; ++P) {
+                float rr[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if (live) load8_operand(R + m * p.ldr + np + wave_pair_col<NREP>(wc, P), p.ldr / PLANES, rr);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[i][2 * P + (e >> 2)][e & 3] = rr[e];
+            }
+            if constexpr (NREP & 1) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][2 * NPAIR][e] = live ? load1_operand(R + m * p.ldr + ns + e, p.ldr / PLANES) : 0.f;
+            }
+        }
+    }
+}
+
 // Epilogue of a tile, straight from the accumulators (shared by the one-tile and the persistent kernel).
 // Lane (pixel px = lane % 16, q = lane / 16) holds, for each of its 9 rows m = m0 + 144 wr + 16 i + px and each fragment pair p,
 // the 8 consecutive output channels wave_pair_col(wc, p) + 8 q .. + 7: one 16-byte piece per row (operand / fp16 result; two for
-// fp32), four lanes = 64 contiguous bytes of the row.  A piece is value = alpha acc + (bias + group bias), GEGLU'd, + residual, rounded,
-// summed into the GroupNorm partials, stored.  The residual pieces of all nine rows are requested before the first is used.
+// fp32), four lanes = 64 contiguous bytes of the row.  A piece is value = alpha acc + (bias + group bias), GEGLU'd, rounded, summed into the
+// GroupNorm partials, stored.  A residual is already in the accumulators (w_seed): the epilogue fetches nothing.
 template <int NREP, bool GEGLU>
 __device__ __forceinline__ void w_epilogue(const MudgGemmDesc& p, f32x4 (&acc)[9][NREP], const int m0, const int n0, const int tm, const int wr, const int wc,
                                            const int lane, const int tid, float* tail, const float* __restrict__ phi) {
@@ -130,9 +216,7 @@ __device__ __forceinline__ void w_epilogue(const MudgGemmDesc& p, f32x4 (&acc)[9
     using T0 = std::integral_constant<int, 0>; using T1 = std::integral_constant<int, 1>;
     const int px = lane & 15, q4 = lane >> 4;
     const float alpha = p.alpha;
-    const int RK = p.R ? p.res_fp32 : 3, OK = p.out_fp32;
-    const char* Rb = reinterpret_cast<const char*>(p.R);
-    const int rsz = RK == KIND_F32 ? 4 : 2;
+    const int OK = p.out_fp32;
     const int64_t mrow = (int64_t)m0 + wr * 144 + px;    // row of i = 0
     float* sred = tail;                                  // [M half][tile column][2]: GroupNorm partials meet here
     const float* phis = tail;                            // GEGLU: the Phi table
@@ -148,18 +232,6 @@ __device__ __forceinline__ void w_epilogue(const MudgGemmDesc& p, f32x4 (&acc)[9
             bv[e] = p.bias ? p.bias[cw + e] : 0.f;
             if (p.gbias) bv[e] += p.gbias[gb0 + cw + e];
             bg[e] = (GEGLU && p.bias) ? p.bias[cw + 32 + e] : 0.f;
-        }
-        u32x4 ra[9];
-        if (RK == KIND_F16 || (RK == KIND_OPERAND && PLANES == 1)) {
-#pragma unroll
-            for (int i = 0; i < 9; ++i) {
-                const int64_t m = mrow + 16 * i;
-                ra[i] = zero16();
-                if (m < p.M) {
-                    const char* rp = Rb + (m * p.ldr + n) * rsz;
-                    ra[i] = ld16(rp);
-                }
-            }
         }
         float gs[8], gq[8];
 #pragma unroll
@@ -179,29 +251,6 @@ __device__ __forceinline__ void w_epilogue(const MudgGemmDesc& p, f32x4 (&acc)[9
             } else {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = alpha * acc[i][2 * P + (e >> 2)][e & 3] + bv[e];
-            }
-            if (RK == KIND_F32) {
-                if (live) {
-                    const float* rp = reinterpret_cast<const float*>(Rb) + m * p.ldr + n;
-                    const f32x4 a = *reinterpret_cast<const f32x4*>(rp), b = *reinterpret_cast<const f32x4*>(rp + 4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { v[e] += a[e]; v[4 + e] += b[e]; }
-                }
-            } else if (RK == KIND_F16) {
-                union { u32x4 w; f16x8 h; } t; t.w = ra[i];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += (float)t.h[e];
-            } else if (RK == KIND_OPERAND) {
-                if constexpr (PLANES == 1) {
-                    const h16x8 t = as_h16x8(ra[i]);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += (float)t[e];
-                } else if (live) {
-                    float rr[8];
-                    load8_operand(reinterpret_cast<const h16*>(Rb) + m * p.ldr + n, p.ldr / PLANES, rr);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += rr[e];
-                }
             }
             if (!GEGLU && p.stats) {
 #pragma unroll
@@ -244,15 +293,6 @@ __device__ __forceinline__ void w_epilogue(const MudgGemmDesc& p, f32x4 (&acc)[9
             bv[e] = p.bias ? p.bias[n + e] : 0.f;
             if (p.gbias) bv[e] += p.gbias[gb0 + n + e];
         }
-        u32x2 ra[9];
-        if (RK == KIND_F16 || (RK == KIND_OPERAND && PLANES == 1)) {
-#pragma unroll
-            for (int i = 0; i < 9; ++i) {
-                const int64_t m = mrow + 16 * i;
-                ra[i] = u32x2{0u, 0u};
-                if (m < p.M) ra[i] = *reinterpret_cast<const u32x2*>(Rb + (m * p.ldr + n) * 2);
-            }
-        }
         float gs[4], gq[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) { gs[e] = 0.f; gq[e] = 0.f; }
@@ -263,30 +303,6 @@ __device__ __forceinline__ void w_epilogue(const MudgGemmDesc& p, f32x4 (&acc)[9
             float v[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = alpha * acc[i][J < NREP ? J : 0][e] + bv[e];
-            if (RK == KIND_F32) {
-                if (live) {
-                    const f32x4 a = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(Rb) + m * p.ldr + n);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += a[e];
-                }
-            } else if (RK == KIND_F16) {
-                union { u32x2 w; _Float16 h[4]; } t; t.w = ra[i];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += (float)t.h[e];
-            } else if (RK == KIND_OPERAND) {
-                if constexpr (PLANES == 1) {
-                    Pack8 t; t.u = ra[i];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += (float)t.h[e];
-                } else if (live) {
-#pragma unroll
-                    for (int pl = 0; pl < PLANES; ++pl) {
-                        Pack8 t; t.u = *reinterpret_cast<const u32x2*>(reinterpret_cast<const h16*>(Rb) + m * p.ldr + pl * (p.ldr / PLANES) + n);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += (float)t.h[e];
-                    }
-                }
-            }
             if (p.stats) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -455,10 +471,13 @@ __global__ __launch_bounds__(512, 2) void wgemm_kernel(const MudgGemmDesc p, con
         k.c = slab ? (wrap ? c1 : k.c) : (wrap ? 0 : c1);
     };
     f32x4 acc[9][NREP];
+    if (!GEGLU && p.R) w_seed<NREP>(p, acc, m0, n0, wr, wc, lane);
+    else {
 #pragma unroll
-    for (int i = 0; i < 9; ++i)
+        for (int i = 0; i < 9; ++i)
 #pragma unroll
-        for (int j = 0; j < NREP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < NREP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     // fragment reads: a 16 x 32 fragment is one subtile; lane l holds row l % 16, 16-byte k chunk l / 16
     const int fbyte0 = (lane & 15) * 64 + (lane >> 4) * 16;
     const int fbyte = fbyte0 ^ (((fbyte0 >> 9) & 1) << 5);
@@ -928,6 +947,7 @@ static bool wgemm_eligible(const MudgGemmDesc& d, int vflags) {
     if (d.mode == 1 && (d.stride != 1 || d.pad != 1 || d.Hin != d.Hout || d.Win != d.Wout || d.K != 9 * d.Cin)) return false;
     if (d.mode == 2 && (d.korder || d.K != 3 * d.Cin)) return false;       // (korder 1 means tiles of 8 pixels x 16 frames to the callers: gemm.hip)
     if (d.gbias && (d.rows_per_group % WBM != 0)) return false;            // one group per tile: the group bias rides in the column constants
+    if (d.R && d.alpha != 1.f) return false;                               // the residual seeds the accumulators (w_seed)
     if ((d.ldy & 7) || (d.R && (d.ldr & 7))) return false;                 // 8-byte pieces of the unpaired fragment
     // 32-bit reach of the descriptor offsets
     const int64_t ld = d.X2 && d.ldx2 > d.ldx ? d.ldx2 : d.ldx;
@@ -947,17 +967,14 @@ bool mudg_wgemm_ok(const MudgGemmDesc& d, int vflags) {
     const int S = d.mode == 1 ? d.Hout * d.Wout : d.HW;
     if (S <= 0 || S % WBM != 0) return false;
     // Measured per shape against the 128 x 128 kernels (tools/exp_w288.py, profiles/r5/w288_shapes.txt; MI355X, frames of whole tiles):
-    // 3x3 convs + 21 ... + 38 %, temporal convs + 16 ... + 25 %; plain GEMMs + 10 ... + 29 % from K = 1280 (with or without a residual)
-    // and + 1 ... + 19 % at K = 320 / 640 WITHOUT a residual; with a residual at K <= 640 the 128 x 128 kernels stay ahead (- 2 ... - 12 %:
-    // a tile is five or ten K-steps, then 27 residual fetches in three dependent rounds with nothing else resident on the CU); GEGLU
+    // 3x3 convs + 20 ... + 40 %, temporal convs + 19 ... + 28 %; plain GEMMs + 16 ... + 37 % from K = 1280, + 1 ... + 26 % at K = 320 / 640
+    // (N <= K: every projection of the UNet; - 1 ... - 3 % for N = 2 ... 3 K with a residual, which the UNet does not have); GEGLU
     // + 4 ... + 10 % from K = 640 in the persistent form, - 1 % at K = 320 (stays on the persistent 128 x 128 kernel).
-    if (d.mode != 0) return true;
     // bf16x3 (same tool with MUDG_OPERAND=bf16x3, profiles/r5/w288_x3_shapes.txt; the 128 x 128 side is the fused-piece kernel, one-tile or
-    // persistent as gemm.hip selects): 3x3 convs + 27 ... + 44 %, temporal convs + 22 ... + 27 %, GEGLU + 11 ... + 13 %, plain GEMMs + 7 ...
-    // + 37 % down to K = 320: three times the MFMAs per staged byte and per epilogue — every problem whose frames are whole tiles.
-    if (PLANES == 2) return true;
-    if (d.geglu) return d.K >= 640;
-    return d.K >= 1280 || !d.R;
+    // persistent as gemm.hip selects): 3x3 convs + 27 ... + 44 %, temporal convs + 22 ... + 27 %, GEGLU + 11 ... + 13 %, plain GEMMs + 11 ...
+    // + 42 % down to K = 320: three times the MFMAs per staged byte and per epilogue — every problem whose frames are whole tiles.
+    if (d.mode != 0 || PLANES == 2) return true;
+    return !d.geglu || d.K >= 640;
 }
 
 template <int MODE, int NREP, bool GEGLU>
@@ -1002,7 +1019,7 @@ static int wgemm_launch_persistent(const MudgGemmDesc& d, int vflags, hipStream_
 static int persistent_grid(const MudgGemmDesc& d) {
     static int cus[MAX_DEVICES] = {};
     const int pv = mudg_variant("GEMM_W288P", 1);
-    if (!pv || (pv == 1 && !d.geglu) || d.mode != 0 || d.M % WBM != 0 || d.K < 2 * BK) return 0;
+    if (!pv || (pv == 1 && !d.geglu) || d.mode != 0 || d.R || d.M % WBM != 0 || d.K < 2 * BK) return 0;
     {   // the whole problem behind one descriptor per operand: rows ride in 32-bit scalar offsets
         const int64_t ld = d.X2 && d.ldx2 > d.ldx ? d.ldx2 : d.ldx, lim = (int64_t)1 << 31;
         if (((int64_t)d.M + 16) * ld * 2 + (int64_t)d.K * 2 + 256 >= lim || ((int64_t)d.N + 16) * d.ldw * 2 + (int64_t)d.K * 2 + 256 >= lim) return 0;

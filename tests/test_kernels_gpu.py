@@ -891,8 +891,8 @@ def test_wide288_persistent_geglu_walks_a_stream_of_tiles(cuda):
 def test_wide288_is_bit_identical_to_the_one_tile_kernels(cuda):
     """Debug-variants build only (the switch is read at every call there): the same problem on the 128 x 128 kernels and on the
     288 x 320 tile gives the same bits — the K-tile order is the same and v_mfma_f32_16x16x32 adds its 32 products as two
-    v_mfma_f32_32x32x16 add their 16 each.  (The residual is added last by both; the persistent 128 x 128 kernel adds it first, so the
-    children that force that kernel skip this test.)"""
+    v_mfma_f32_32x32x16 add their 16 each.  (Without a residual: the tile takes one as its accumulators' initial value, the one-tile
+    128 x 128 kernels add it last.)"""
     import os
     if os.environ.get("MUDG_DEBUG_VARIANTS") != "1" or os.environ.get("MUDG_GEMM_PERSIST", "1") not in ("0", "1"):
         pytest.skip("needs the debug-variants build with the default kernel rule (tests/test_gemm_variants_gpu.py runs it)")
@@ -901,16 +901,21 @@ def test_wide288_is_bit_identical_to_the_one_tile_kernels(cuda):
     x, w = rnd(f * h * wd, cin, seed=1).to(cuda), rnd(cout, 9 * cin, seed=2, scale=0.03).to(cuda)
     r = rnd(f * h * wd, cout, seed=3).to(ops.STREAM()).to(cuda)
     xm, wm = rnd(288 * 7 + 31, 640, seed=4).to(cuda), rnd(960, 640, seed=5, scale=0.03).to(cuda)
-    xl, rl = rnd(288 * 300, 640, seed=6).to(cuda), rnd(288 * 300, 960, seed=7).to(ops.STREAM()).to(cuda)      # 900 tiles: with GEMM_W288P=2 the persistent form
+    xl = rnd(288 * 300, 640, seed=6).to(cuda)              # 900 tiles: with GEMM_W288P=2 the persistent form
     outs = []
     saved = os.environ.get("MUDG_GEMM_W288")
     try:
         for v in ("0", "2"):
             os.environ["MUDG_GEMM_W288"] = v
-            outs.append((ops.conv3x3(x, w, frames=f, hin=h, win=wd, cin=cin, korder=1, residual=r, out_stream=True),
+            outs.append((ops.conv3x3(x, w, frames=f, hin=h, win=wd, cin=cin, korder=1, out_stream=True, stats=True),
                          ops.conv3x3(x, w, frames=f, hin=h, win=wd, cin=cin, korder=0, out_fp32=True),
                          ops.gemm(xm, wm, out_fp32=True), ops.tconv3(x, w[:, :3 * cin].contiguous(), clips=1, t=2, hw=h * wd, cin=cin),
-                         ops.gemm(xl, wm, residual=rl, out_stream=True, stats=True, frame_rows=288)))
+                         ops.gemm(xl, wm, out_stream=True, stats=True, frame_rows=288)))
+            res_out = ops.conv3x3(x, w, frames=f, hin=h, win=wd, cin=cin, korder=1, residual=r, out_stream=True)
+            if v == "0":
+                res_ref = res_out
+            else:       # a residual seeds the 288 x 320 tile's accumulators, the one-tile 128 x 128 kernels add it last: fp32 rounding apart
+                assert rel_l2(res_out, res_ref.float().cpu()) < 2e-3 and float((res_out.float() - res_ref.float()).abs().max()) < 0.05
     finally:
         if saved is None:
             os.environ.pop("MUDG_GEMM_W288", None)
