@@ -59,8 +59,8 @@ namespace {
 
 constexpr int WBM = 288;
 constexpr int WNA = WBM / 16;                            // 16-row subtiles of the X operand tile
-constexpr int W_TAIL = 2 * 320 * 2 * 4;                  // epilogue hand-off of the GroupNorm partials between the two M halves | Phi table
-static_assert(W_TAIL >= PHI_BYTES, "the GEGLU kernel keeps the Phi table behind the ring");
+constexpr int W_TAIL = 2 * 320 * 2 * 4;                  // epilogue hand-off of the GroupNorm partials between the two M halves (320-wide tile)
+constexpr int W_TAIL_GEGLU = (PHI_N + 4) * 8;            // the GEGLU tile (256 wide): the Phi table as (value, step to the next entry) pairs
 template <int NREP> struct WGeo {
     static constexpr int BN = 64 * NREP;                 // 4 wave columns x NREP fragments of 16
     static constexpr int NB = BN / 16;                   // 16-row subtiles of the W operand tile
@@ -68,7 +68,7 @@ template <int NREP> struct WGeo {
     static constexpr int KS = PLANES * PL;               // one k half
     static constexpr int BUF = 2 * KS;                   // (16-bit builds) one K-tile buffer
     static constexpr int LOOP = (4 / PLANES) * KS;       // 16-bit: two K-tile buffers; bf16x3: two k halves.  NREP 5: 155648, NREP 4: 139264
-    static constexpr int SMEM = LOOP + W_TAIL;
+    static constexpr int SMEM = LOOP + (NREP == 4 ? W_TAIL_GEGLU : W_TAIL);
 };
 
 #define W_BARRIER()                            \
@@ -115,6 +115,15 @@ __device__ __forceinline__ float row16_sum(float v) {
 // lanes = 64 contiguous bytes) starts on a 64-byte boundary of the row and the two pairs of a wave fill one 128-byte line; the four
 // unpaired fragments follow at channel 256.  (A wave column as 80 CONSECUTIVE channels put the pieces of the odd wave columns across
 // sector boundaries: the epilogue ran at half the store / residual-fetch rate.)  Free: which W rows a wave's fragments fetch.
+// GEGLU's gate through the Phi table of gemm_shared.h held as PAIRS (Phi_i, Phi_{i+1} - Phi_i): one 8-byte LDS read per value instead of two
+// 4-byte ones, v_fract instead of a conversion back and a subtraction — 8 instead of 11 vector instructions, the same bits as gelu_lut
+// (the step is the same fp32 difference, taken once when the workgroup copies the table).
+__device__ __forceinline__ float gelu_lut2(float x, const f32x2* __restrict__ T) {
+    float u = fmaf(x, 64.0f, 512.0f);
+    u = __builtin_amdgcn_fmed3f(u, 0.0f, 1023.99f);
+    const f32x2 t = T[(int)u];
+    return x * fmaf(__builtin_amdgcn_fractf(u), t[1], t[0]);
+}
 template <int NREP> __device__ __forceinline__ int wave_pair_col(int wc, int pair) { return 32 * ((NREP / 2) * wc + pair); }
 template <int NREP> __device__ __forceinline__ int wave_single_col(int wc) { return 32 * (NREP / 2) * 4 + 16 * wc; }
 
@@ -219,7 +228,7 @@ __device__ __forceinline__ void w_epilogue(const MudgGemmDesc& p, f32x4 (&acc)[9
     const int OK = p.out_fp32;
     const int64_t mrow = (int64_t)m0 + wr * 144 + px;    // row of i = 0
     float* sred = tail;                                  // [M half][tile column][2]: GroupNorm partials meet here
-    const float* phis = tail;                            // GEGLU: the Phi table
+    const f32x2* phis = reinterpret_cast<const f32x2*>(tail);      // GEGLU: the Phi table as pairs
     const int64_t gb0 = p.gbias ? (int64_t)(m0 / p.rows_per_group) * p.N : 0;          // host-checked: one group per tile
 
     auto piece8 = [&](auto ptag) __attribute__((always_inline)) {
@@ -246,7 +255,7 @@ __device__ __forceinline__ void w_epilogue(const MudgGemmDesc& p, f32x4 (&acc)[9
                 for (int e = 0; e < 8; ++e) {
                     const float val = alpha * acc[i][e >> 2][e & 3] + bv[e];
                     const float gate = alpha * acc[i][2 + (e >> 2)][e & 3] + bg[e];
-                    v[e] = val * (phi ? gelu_lut(gate, phis) : gelu_fast(gate));
+                    v[e] = val * (phi ? gelu_lut2(gate, phis) : gelu_fast(gate));
                 }
             } else {
 #pragma unroll
@@ -384,8 +393,10 @@ __global__ __launch_bounds__(512, 2) void wgemm_kernel(const MudgGemmDesc p, con
     const int wr = wave >> 2, wc = wave & 3;             // waves wc and wc + 4 share a SIMD: the two M halves
     float* tail = reinterpret_cast<float*>(smem + G::LOOP);
     if (GEGLU && phi) {                                  // visible after the K loop's barriers
-        for (int t4 = tid * 4; t4 < PHI_N; t4 += 512 * 4) *reinterpret_cast<f32x4*>(&tail[t4]) = *reinterpret_cast<const f32x4*>(&phi[t4]);
-        if (tid == 0) tail[PHI_N] = phi[PHI_N];
+        for (int t = tid; t <= PHI_N; t += 512) {         // entry PHI_N exists (x = 8); its step is never used (u < 1024)
+            const float a = phi[t], b = phi[t < PHI_N ? t + 1 : t];
+            *reinterpret_cast<f32x2*>(&tail[2 * t]) = f32x2{a, b - a};
+        }
     }
 
     // XCD-aware tile numbering (gemm.hip): every XCD a contiguous tile range, walked in 8-row groups column by column
@@ -761,8 +772,10 @@ __global__ __launch_bounds__(512, 2) void wgemm_pkernel(const MudgGemmDesc p, co
     const int wr = wave >> 2, wc = wave & 3;
     float* tail = reinterpret_cast<float*>(smem + G::LOOP);
     if (GEGLU && phi) {
-        for (int t4 = tid * 4; t4 < PHI_N; t4 += 512 * 4) *reinterpret_cast<f32x4*>(&tail[t4]) = *reinterpret_cast<const f32x4*>(&phi[t4]);
-        if (tid == 0) tail[PHI_N] = phi[PHI_N];
+        for (int t = tid; t <= PHI_N; t += 512) {         // entry PHI_N exists (x = 8); its step is never used (u < 1024)
+            const float a = phi[t], b = phi[t < PHI_N ? t + 1 : t];
+            *reinterpret_cast<f32x2*>(&tail[2 * t]) = f32x2{a, b - a};
+        }
     }
     // this workgroup's tiles: the XCD's contiguous range of the one-tile kernel's numbering, every (gridDim / 8)-th tile of it
     const int ntn = p.N / WBN, ntm = p.M / WBM;
@@ -937,6 +950,9 @@ int variant() { return mudg_variant("GEMM_W288", 1); }
 
 }  // namespace
 
+#if MUDG_PLANES == 1
+static int persistent_grid(const MudgGemmDesc& d);
+#endif
 // What the kernel can run at all.
 static bool wgemm_eligible(const MudgGemmDesc& d, int vflags) {
     if (d.batch != 1 || d.act || d.Y8 || d.subpixel || (d.mode == 1 && d.upsample)) return false;
@@ -968,13 +984,17 @@ bool mudg_wgemm_ok(const MudgGemmDesc& d, int vflags) {
     if (S <= 0 || S % WBM != 0) return false;
     // Measured per shape against the 128 x 128 kernels (tools/exp_w288.py, profiles/r5/w288_shapes.txt; MI355X, frames of whole tiles):
     // 3x3 convs + 20 ... + 40 %, temporal convs + 19 ... + 28 %; plain GEMMs + 16 ... + 37 % from K = 1280, + 1 ... + 26 % at K = 320 / 640
-    // (N <= K: every projection of the UNet; - 1 ... - 3 % for N = 2 ... 3 K with a residual, which the UNet does not have); GEGLU
-    // + 4 ... + 10 % from K = 640 in the persistent form, - 1 % at K = 320 (stays on the persistent 128 x 128 kernel).
+    // (N <= K: every projection of the UNet; - 1 ... - 3 % for N = 2 ... 3 K with a residual, which the UNet does not have); GEGLU below.
     // bf16x3 (same tool with MUDG_OPERAND=bf16x3, profiles/r5/w288_x3_shapes.txt; the 128 x 128 side is the fused-piece kernel, one-tile or
     // persistent as gemm.hip selects): 3x3 convs + 27 ... + 44 %, temporal convs + 22 ... + 27 %, GEGLU + 11 ... + 13 %, plain GEMMs + 11 ...
     // + 42 % down to K = 320: three times the MFMAs per staged byte and per epilogue — every problem whose frames are whole tiles.
     if (d.mode != 0 || PLANES == 2) return true;
-    return !d.geglu || d.K >= 640;
+#if MUDG_PLANES == 1
+    // GEGLU (bit-identical to the persistent 128 x 128 kernel it replaces, so M may decide): + 7 ... + 16 % in the persistent form (more
+    // tiles than CUs) at every K; the one-tile form + 11 % at K = 1280, - 1 % at K = 640, - 5 ... - 12 % at K = 320.
+    if (d.geglu && d.K < 640) return persistent_grid(d) > 0;
+#endif
+    return true;
 }
 
 template <int MODE, int NREP, bool GEGLU>
