@@ -17,15 +17,15 @@ python bench.py --no-cpu-baseline --operand bf16x3 --steps 4 --warmup 1 2>/dev/n
 python bench.py --no-cpu-baseline --operand bf16x6 --steps 3 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_bf16x6.json
 # BASELINE config 5: MX-fp8 scores in the long self-attention
 MUDG_ATTN_FP8=1 python bench.py --no-cpu-baseline --no-children 2>/dev/null | tail -1 > $OUT/bench_fp8attn.json
-# same box, same library (the debug-variants build): the one-tile contraction kernels only vs the shipped selection rule
-MUDG_DEBUG_VARIANTS=1 MUDG_GEMM_PERSIST=0 python bench.py --no-cpu-baseline --no-children --steps 10 --warmup 3 2>/dev/null | tail -1 > $OUT/bench_onetile_kernels.json
-MUDG_DEBUG_VARIANTS=1 MUDG_GEMM_PERSIST=1 python bench.py --no-cpu-baseline --no-children --steps 10 --warmup 3 2>/dev/null | tail -1 > $OUT/bench_persistent_rule.json
-# same box, same library: the 3x3 convs without / with the shared activation stage of their dx taps (XSHARE)
-MUDG_DEBUG_VARIANTS=1 MUDG_CONV_XSHARE=0 python bench.py --no-cpu-baseline --no-children --steps 10 --warmup 3 2>/dev/null | tail -1 > $OUT/bench_conv_unshared.json
-MUDG_DEBUG_VARIANTS=1 MUDG_CONV_XSHARE=1 python bench.py --no-cpu-baseline --no-children --steps 10 --warmup 3 2>/dev/null | tail -1 > $OUT/bench_conv_xshare.json
-# same box: the temporal convs on plain 128-row tiles / on tiles of 8 pixels x 16 frames with the shared slab stage (TMAP / TSHARE)
-MUDG_TCONV_SLAB=0 python bench.py --no-cpu-baseline --no-children --steps 10 --warmup 3 2>/dev/null | tail -1 > $OUT/bench_tconv_plain_tiles.json
-MUDG_TCONV_SLAB=1 python bench.py --no-cpu-baseline --no-children --steps 10 --warmup 3 2>/dev/null | tail -1 > $OUT/bench_tconv_tshare.json
+# same box, same (debug-variants) library: the 128 x 128 kernels only vs the shipped rule with the 288 x 320 tile (round 5), bf16 and bf16x3
+MUDG_DEBUG_VARIANTS=1 MUDG_GEMM_W288=0 python bench.py --no-cpu-baseline --no-children --steps 10 --warmup 3 2>/dev/null | tail -1 > $OUT/bench_w288_off.json
+MUDG_DEBUG_VARIANTS=1 MUDG_GEMM_W288=1 python bench.py --no-cpu-baseline --no-children --steps 10 --warmup 3 2>/dev/null | tail -1 > $OUT/bench_w288_rule.json
+MUDG_DEBUG_VARIANTS=1 MUDG_GEMM_W288=0 python bench.py --no-cpu-baseline --no-children --operand bf16x3 --steps 4 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_bf16x3_w288_off.json
+MUDG_DEBUG_VARIANTS=1 MUDG_GEMM_W288=1 python bench.py --no-cpu-baseline --no-children --operand bf16x3 --steps 4 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_bf16x3_w288_rule.json
+# every contraction shape of the step on the tile and on the 128 x 128 kernels (the measurement behind the rule in wgemm.hip), both builds
+MUDG_DEBUG_VARIANTS=1 python tools/exp_w288.py time > $OUT/w288_shapes.txt 2>/dev/null
+MUDG_DEBUG_VARIANTS=1 MUDG_OPERAND=bf16x3 python tools/exp_w288.py time > $OUT/w288_x3_shapes.txt 2>/dev/null
+python tools/shape_profile.py > $OUT/shapes_w288.md 2>/dev/null
 # the CPU baseline as a measurement: one full MDM512 oracle forward on this host
 if [ "$2" = "cpufull" ]; then
   python bench.py --steps 3 --warmup 1 --cpu-baseline full --no-decode 2>/dev/null | tail -1 | python -c "
@@ -37,12 +37,6 @@ rocprofv3 --kernel-trace --stats -d /tmp/pt -- python bench.py --steps 2 --warmu
 python tools/rocprof_summary.py trace $(find /tmp/pt -name "*.db" | head -1) > $OUT/kernel_trace.md
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pf -- python bench.py --steps 1 --warmup 0 --no-graph --no-cpu-baseline --no-profile --no-decode --no-children > /tmp/pf.log 2>&1
 python tools/rocprof_summary.py pmc $(find /tmp/pf -name "*.db" | head -1) > $OUT/pmc_fetch.md
-# the memory-bound families by launch geometry (= by shape), from the same eager step
-for k in gn_ ln_ tattn; do python tools/rocprof_summary.py grids $(find /tmp/pf -name "*.db" | head -1) $k; echo; done > $OUT/norm_grids_unet.md
-# the norm kernels alone on the UNet's shapes (tools/exp_norm.py), and their per-kernel durations
-rocprofv3 --kernel-trace -d /tmp/pnk -- python tools/exp_norm.py > $OUT/norm_kernels.txt 2>/dev/null
-for k in gn_ ln_; do python tools/rocprof_summary.py grids $(find /tmp/pnk -name "*.db" | head -1) $k; echo; done > $OUT/norm_grids_alone.md
-MUDG_DEBUG_VARIANTS=1 MUDG_GN_REG=0 python tools/exp_norm.py 2>/dev/null | grep fold > $OUT/norm_kernels_lds_table_apply.txt
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pw -- python bench.py --steps 1 --warmup 0 --no-graph --no-cpu-baseline --no-profile --no-decode --no-children > /tmp/pw.log 2>&1
 python tools/rocprof_summary.py pmc $(find /tmp/pw -name "*.db" | head -1) > $OUT/pmc_write.md
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d /tmp/pm -- python bench.py --steps 1 --warmup 0 --no-graph --no-cpu-baseline --no-profile --no-decode --no-children > /tmp/pm.log 2>&1

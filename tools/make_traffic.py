@@ -14,9 +14,10 @@ def table(path, counter):
     out = {}
     for line in open(path):
         # kernel names: gemm_kernel<Geo<4, 2>, MODE, FAST, SB> (round 3 on; the tile geometry comes first) or gemm_kernel<MODE, ...>
-        m = re.match(r"\| `(p?gemm\w*_kernel)<(?:\(anonymous namespace\)::)?(?:Geo<\d+, \d+>, )?(\d)[^`]*` \| " + counter + r" \| (\d+) \| ([0-9.e+]+) \|", line)
+        # (round 5: wgemm_kernel<MODE, NREP, GEGLU> — the 288 x 320 tile — and its persistent plain-GEMM form wgemm_pkernel<NREP, GEGLU>)
+        m = re.match(r"\| `([pw]?gemm\w*_p?kernel)<(?:\(anonymous namespace\)::)?(?:Geo<\d+, \d+>, )?(\d)[^`]*` \| " + counter + r" \| (\d+) \| ([0-9.e+]+) \|", line)
         if m:
-            fam = FAM[m.group(2)]
+            fam = "gemm" if m.group(1) == "wgemm_pkernel" else FAM[m.group(2)]
             e = out.setdefault(fam, {"kernels": [], "launches": 0, "kib": 0.0})
             e["kernels"].append(f"{m.group(1)}<{m.group(2)},..>")
             e["launches"] += int(m.group(3))
