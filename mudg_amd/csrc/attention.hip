@@ -238,6 +238,193 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const MudgAttnDesc p, cons
     }
 }
 
+// Short key sets — the text (77) + image (16) tokens of the cross-attention — with MANY query tiles: the whole K / V^T of a (frame, head)
+// is three 64-key tiles, so a workgroup stages them ONCE and then walks `xq` query tiles of that (frame, head) with no barrier at all
+// (round 5).  attn_kernel stages the same three tiles for every 128 queries — 24 KB of K / V^T per 32 KB of Q + O — and its workgroup
+// lives for four dependent global round trips: 227 us for the level-0 launch (377 MB: 1.7 TB/s).  Per query row the arithmetic is
+// attn_kernel's, operation for operation: the same bits.
+#if MUDG_PLANES == 1
+constexpr int XK_TILES = 3;                      // key tiles held: two of the first set (Nk <= 128), one of the second (Nk2 <= 64)
+template <bool TWO>
+__global__ __launch_bounds__(256, 2) void xattn_kernel(const MudgAttnDesc p, const int nqt, const int xq, const int nqc, const int total) {
+    extern __shared__ __attribute__((aligned(16))) h16 xlds[];
+    h16* Ks = xlds;
+    h16* Vs = xlds + XK_TILES * ATILE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    int w;
+    {
+        const int q8 = total >> 3, r8 = total & 7;
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        w = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    }
+    const int pair = w / nqc, qc = w - pair * nqc;
+    const int f = pair / p.heads, h = pair - f * p.heads;
+    const h16* Qp = reinterpret_cast<const h16*>(p.Q) + (int64_t)f * p.Nq * p.ldq + h * 64;
+    h16* Op = reinterpret_cast<h16*>(p.O) + (int64_t)f * p.Nq * p.ldo + h * 64;
+    const int nt0 = (p.Nk + KB - 1) / KB;
+
+    // ---- stage every key tile of both sets (rows lrow, lrow + 32 of a tile; 16-byte chunk kc), as attn_kernel's load_tiles / stage
+    {
+        const int lrow = tid >> 3, kc = tid & 7;
+#pragma unroll
+        for (int set = 0; set < (TWO ? 2 : 1); ++set) {
+            const h16* Kp = set == 0 ? reinterpret_cast<const h16*>(p.K) + (int64_t)(f / p.kv_div) * p.Nk * p.ldk + h * 64
+                                     : reinterpret_cast<const h16*>(p.K2) + (int64_t)(f / p.kv_div2) * p.Nk2 * p.ldk2 + h * 64;
+            const h16* Vp = set == 0 ? reinterpret_cast<const h16*>(p.Vt) + (int64_t)(f / p.kv_div) * p.svt + (int64_t)(h * 64) * p.ldvt
+                                     : reinterpret_cast<const h16*>(p.Vt2) + (int64_t)(f / p.kv_div2) * p.svt2 + (int64_t)(h * 64) * p.ldvt2;
+            const int Nk = set == 0 ? p.Nk : p.Nk2, ldk = set == 0 ? p.ldk : p.ldk2, ldvt = set == 0 ? p.ldvt : p.ldvt2;
+            const int nkt = (Nk + KB - 1) / KB;
+            for (int kt = 0; kt < nkt; ++kt) {
+                const int ti = set == 0 ? kt : nt0 + kt, j0 = kt * KB;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int row = lrow + 32 * i, j = j0 + row;
+                    const u32x4 kr = (j < Nk) ? ld16(Kp + (int64_t)j * ldk + kc * 8) : zero16();
+                    const int jc = j0 + kc * 8;
+                    u32x4 v = zero16();
+                    if (jc < Nk) {
+                        v = ld16(Vp + (int64_t)row * ldvt + jc);
+                        if (jc + 8 > Nk) {
+                            h16x8 hv = as_h16x8(v);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) if (jc + e >= Nk) hv[e] = (h16)0.f;
+                            v = as_u32x4(hv);
+                        }
+                    }
+                    st16(&Ks[ti * ATILE + row * ALD + kc * 8], kr);
+                    st16(&Vs[ti * ATILE + row * ALD + kc * 8], v);
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    const float c = p.q_prescaled ? 1.0f : p.scale * 1.4426950408889634f;
+    for (int qi = 0; qi < xq; ++qi) {
+        const int qt = qc * xq + qi;
+        if (qt >= nqt) break;
+        const int q = qt * QB + wave * 32 + l31;
+        const bool qok = q < p.Nq;
+        h16x8 qf[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            qf[ks] = as_h16x8(qok ? ld16(Qp + (int64_t)q * p.ldq + ks * 16 + hi * 8) : zero16());
+        f32x16 o[2], res[TWO ? 2 : 1];
+        float inv = 0.f;
+#pragma unroll
+        for (int set = 0; set < (TWO ? 2 : 1); ++set) {
+            const int Nk = set == 0 ? p.Nk : p.Nk2;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { o[0][r] = 0.f; o[1][r] = 0.f; }
+            float m_run = -INFINITY, l_run = 0.f;
+            const int nkt = (Nk + KB - 1) / KB;
+            for (int kt = 0; kt < nkt; ++kt) {
+                const int ti = set == 0 ? kt : nt0 + kt;
+                f32x16 sc[2];
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sc[sub][r] = 0.f;
+                    const h16* kp = Ks + ti * ATILE + (sub * 32 + l31) * ALD + hi * 8;
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        const h16x8 kf = *reinterpret_cast<const h16x8*>(kp + ks * 16);
+                        sc[sub] = MFMA_32x32x16(kf, qf[ks], sc[sub]);
+                    }
+                }
+                if (kt * KB + KB > Nk) {
+#pragma unroll
+                    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int j = kt * KB + sub * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                            if (j >= Nk) sc[sub][r] = -INFINITY;
+                        }
+                }
+                float mx = sc[0][0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sc[0][r]);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[1][r]);
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                const bool grew = !__all(mx <= m_run);
+                const float m_new = grew ? fmaxf(m_run, mx) : m_run;
+                const float alpha = grew ? __builtin_amdgcn_exp2f((m_run - m_new) * c) : 1.0f;
+                const float mc = m_new * c;
+                m_run = m_new;
+                float ps = 0.f;
+                h16x8 pk[2][2];
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float e = __builtin_amdgcn_exp2f(fmaf(sc[sub][r], c, -mc));
+                        ps += e;
+                        pk[sub][r >> 3][r & 7] = (h16)e;
+                    }
+                l_run = l_run * alpha + ps;
+                if (grew) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { o[0][r] *= alpha; o[1][r] *= alpha; }
+                }
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const h16* vp = Vs + ti * ATILE + (dt * 32 + l31) * ALD + 4 * hi;
+#pragma unroll
+                    for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                        for (int jj = 0; jj < 2; ++jj) {
+                            const int kk = sub * 32 + jj * 16;
+                            const h16x4 lo = *reinterpret_cast<const h16x4*>(vp + kk);
+                            const h16x4 up = *reinterpret_cast<const h16x4*>(vp + kk + 8);
+                            h16x8 vf;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { vf[e] = lo[e]; vf[4 + e] = up[e]; }
+                            o[dt] = MFMA_32x32x16(vf, pk[sub][jj], o[dt]);
+                        }
+                }
+            }
+            const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+            inv = 1.f / l_tot;
+            if (!TWO && p.Lse && qok && hi == 0)
+                p.Lse[((int64_t)f * p.Nq + q) * p.heads + h] = m_run * c + __log2f(l_tot);
+            if (TWO) {
+                if (set == 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { res[0][r] = o[0][r] * inv; res[1][r] = o[1][r] * inv; }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { o[0][r] = fmaf(o[0][r], inv, res[0][r]); o[1][r] = fmaf(o[1][r], inv, res[1][r]); }
+                    inv = 1.f;
+                }
+            }
+        }
+        if (qok) {
+            h16* orow = Op + (int64_t)q * p.ldo;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    h16* dst = orow + dt * 32 + 8 * g + 4 * hi;
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = o[dt][4 * g + j] * inv;
+                    if (p.accumulate) {
+                        Pack8 old; old.u = *reinterpret_cast<const u32x2*>(dst);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] += (float)old.h[j];
+                    }
+                    Pack8 nw;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) nw.h[j] = (h16)v[j];
+                    *reinterpret_cast<u32x2*>(dst) = nw.u;
+                }
+        }
+    }
+}
+#endif
+
 // Variant with 64 query rows per wave (two 32-row blocks): every K / V^T fragment read from LDS feeds two MFMAs instead
 // of one — half the LDS traffic per FLOP — and the two blocks' softmax chains are independent.  Workgroup = 256 queries.
 __global__ __launch_bounds__(256, 2) void attn64q_kernel(const MudgAttnDesc p, const int nqt, const int total) {
@@ -1714,10 +1901,31 @@ extern "C" int mudg_attention(const MudgAttnDesc* dp, void* stream) {
         else if (dma_ok && d.q_prescaled && lean) hipLaunchKernelGGL((attn64d_kernel<true, false>), dim3((unsigned)total2), dim3(256), 0, s, d, nqt2, (int)total2);
         else if (dma_ok) hipLaunchKernelGGL((attn64d_kernel<false, false>), dim3((unsigned)total2), dim3(256), 0, s, d, nqt2, (int)total2);
         else hipLaunchKernelGGL(attn64q_kernel, dim3((unsigned)total2), dim3(256), 0, s, d, nqt2, (int)total2);
-    } else if (d.K2) {
-        hipLaunchKernelGGL(attn_kernel<true>, dim3((unsigned)total), dim3(256), 0, s, d, nqt, (int)total);
     } else {
-        hipLaunchKernelGGL(attn_kernel<false>, dim3((unsigned)total), dim3(256), 0, s, d, nqt, (int)total);
+        // Short key sets with many query tiles (the cross-attention of the fine levels): the key tiles resident, xq query tiles per
+        // workgroup (xattn_kernel: the same bits).  xq from the tile count only: >= 4 workgroups per CU stay.  MUDG_ATTN_X=0: off (A/B).
+        static int xv = -1;
+        if (xv < 0) xv = mudg_variant("ATTN_X", 1);
+        int xq = (int)(total / 1024);
+        xq = xq > 8 ? 8 : xq;
+        if (xv && xq >= 2 && d.Nk <= 2 * KB && (!d.K2 || d.Nk2 <= KB)) {
+            constexpr int smem = 2 * XK_TILES * ATILE * (int)sizeof(h16);
+            static bool attr_done[64] = {};
+            int dev = 0;
+            if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) MUDG_FAIL(MUDG_ELAUNCH, "mudg_attention: hipGetDevice");
+            if (!attr_done[dev]) {
+                hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+                if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&xattn_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+                if (e != hipSuccess) MUDG_FAIL(MUDG_ELAUNCH, "mudg_attention: hipFuncSetAttribute: %s", hipGetErrorString(e));
+                attr_done[dev] = true;
+            }
+            const int nqc = (nqt + xq - 1) / xq;
+            const int64_t totx = (int64_t)nqc * d.F * d.heads;
+            if (d.K2) hipLaunchKernelGGL(xattn_kernel<true>, dim3((unsigned)totx), dim3(256), smem, s, d, nqt, xq, nqc, (int)totx);
+            else hipLaunchKernelGGL(xattn_kernel<false>, dim3((unsigned)totx), dim3(256), smem, s, d, nqt, xq, nqc, (int)totx);
+        }
+        else if (d.K2) hipLaunchKernelGGL(attn_kernel<true>, dim3((unsigned)total), dim3(256), 0, s, d, nqt, (int)total);
+        else hipLaunchKernelGGL(attn_kernel<false>, dim3((unsigned)total), dim3(256), 0, s, d, nqt, (int)total);
     }
 #endif
     const int rc = mudg_check_launch("mudg_attention");

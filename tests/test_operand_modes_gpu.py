@@ -446,6 +446,34 @@ def test_attention_two_key_sets_in_one_launch(cuda):
     assert rel(value(one), value(two)) < 2 * TOL_OP
 
 
+def test_cross_attention_with_resident_key_tiles_walks_many_query_tiles(cuda):
+    """The cross-attention of the fine levels: 77 text + 16 image keys, thousands of 128-query tiles.  In the 16-bit builds a workgroup
+    stages the three key tiles of a (frame, head) once and walks several query tiles (xattn_kernel); a sub-batch small enough for the
+    one-tile-per-workgroup kernel gives the same bits, and both match the fp64 reference.  One set and two sets; a ragged last tile."""
+    from mudg_amd import ops
+    frames, heads, nq, T = 8, 5, 128 * 52 + 40, 4                      # 53 x 40 = 2120 query tiles: two per workgroup
+    c = heads * 64
+    q, qv = operand(f32(frames * nq, c, seed=1), cuda)
+    kt, ktv = operand(f32(frames // T * 77, c, seed=2), cuda)
+    _, vtv = operand(f32(frames // T * 77, c, seed=3), cuda)
+    ki, kiv = operand(f32(frames * 16, c, seed=4), cuda)
+    _, viv = operand(f32(frames * 16, c, seed=5), cuda)
+    vt_t, vt_i = _vt(vtv, frames // T, 77, c, cuda), _vt(viv, frames, 16, c, cuda)
+    both = ops.empty_rows(frames * nq, c, None, cuda)
+    ops.attention(q, kt, vt_t, both, frames=frames, heads=heads, nq=nq, nk=77, kv_div=T, scale=0.125, k2=ki, vt2=vt_i, nk2=16)
+    sel = torch.arange(0, frames * nq, 97)
+    ref = _attention_ref(qv, ktv, vtv, frames, heads, nq, 77, 0.125, T) + _attention_ref(qv, kiv, viv, frames, heads, nq, 16, 0.125, 1)
+    assert rel(value(both)[sel], ref[sel]) < 2 * TOL_OP
+    one = ops.empty_rows(frames * nq, c, None, cuda)
+    ops.attention(q, kt, vt_t, one, frames=frames, heads=heads, nq=nq, nk=77, kv_div=T, scale=0.125)
+    assert rel(value(one)[sel], _attention_ref(qv, ktv, vtv, frames, heads, nq, 77, 0.125, T)[sel]) < TOL_OP
+    # frame 0 alone: 53 x 5 query tiles, the one-tile kernel — the same bits (it shares its text keys with nobody else now: kv_div 1)
+    sub2, sub1 = ops.empty_rows(nq, c, None, cuda), ops.empty_rows(nq, c, None, cuda)
+    ops.attention(q[:nq], kt[:77], vt_t[:c], sub2, frames=1, heads=heads, nq=nq, nk=77, scale=0.125, k2=ki[:16], vt2=vt_i[:c], nk2=16)
+    ops.attention(q[:nq], kt[:77], vt_t[:c], sub1, frames=1, heads=heads, nq=nq, nk=77, scale=0.125)
+    assert torch.equal(value(sub2), value(both)[:nq]) and torch.equal(value(sub1), value(one)[:nq])
+
+
 @pytest.mark.skipif(_hip.planes() > 1, reason="the lean softmax belongs to the 16-bit builds' long self-attention kernel")
 @pytest.mark.parametrize("spread", [1.0, 4.0, 12.0])
 def test_attention_lean_softmax_with_prescaled_q(cuda, spread):
