@@ -166,6 +166,30 @@ def transposed_taps(x, m, ci, p, taps, mode, geo):
 
 
 # ------------------------------------------------------------------------------------------------ linear
+# The rows of one frame of the activation a block is working on: a hint for the library's tile choice (MudgGemmDesc.HW in mode 0: whole
+# 288-row tiles per frame -> the 288 x 320 tile, csrc/wgemm.hip).  Set by the UNet walk (train/unet.py) around a block, read when a Linear
+# runs — also when activation checkpointing replays the block, which sets it again.
+_FRAME_ROWS = [0]
+
+
+class frame_rows:
+    def __init__(self, rows):
+        self.rows = int(rows)
+
+    def __enter__(self):
+        self.saved = _FRAME_ROWS[0]
+        _FRAME_ROWS[0] = self.rows
+
+    def __exit__(self, *exc):
+        _FRAME_ROWS[0] = self.saved
+        return False
+
+
+def _hint(rows):
+    h = _FRAME_ROWS[0]
+    return h if h > 0 and rows % h == 0 else 0
+
+
 class Linear(torch.autograd.Function):
     """y = x W^T (+ b) (+ residual); x [M][K], W [N][K] (nn.Linear / 1x1 conv weight), fp32 in and out."""
 
@@ -176,7 +200,8 @@ class Linear(torch.autograd.Function):
         # what the weight gradient will read: the operand rows themselves (mudg_wgrad) or the fp32 rows (transposed copies)
         ctx.save_for_backward(xo if rows_wgrad_ok(*w2.shape) else x, w2)
         ctx.wshape, ctx.has_b, ctx.has_r = w.shape, b is not None, residual is not None
-        return ops.gemm(xo, op(w2), bias=None if b is None else b.float().contiguous(), residual=residual, out_fp32=True)
+        ctx.hint = _hint(x.shape[0])
+        return ops.gemm(xo, op(w2), bias=None if b is None else b.float().contiguous(), residual=residual, out_fp32=True, frame_rows=ctx.hint)
 
     @staticmethod
     def backward(ctx, dy):
@@ -195,7 +220,7 @@ class Linear(torch.autograd.Function):
             db = K.group_colsum(dy)[0] if want_b else None
         if _need(ctx, 0):
             wt = K.transpose_gather(w2)                                  # [K][N padded]
-            dx = ops.gemm(dyo, wt, out_fp32=True)
+            dx = ops.gemm(dyo, wt, out_fp32=True, frame_rows=ctx.hint)
         if direct:
             dw = K.wgrad(dyo, x, positions=x.shape[0], m=n, c=k).reshape(ctx.wshape)
         elif _need(ctx, 1):

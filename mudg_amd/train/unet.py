@@ -77,6 +77,11 @@ def temporal_conv_block(mod, x, ctx, hw):
 
 
 def res_block(mod, x, h, w, ctx):
+    with F_.frame_rows(h * w):
+        return _res_block(mod, x, h, w, ctx)
+
+
+def _res_block(mod, x, h, w, ctx):
     frames, hw = ctx.B * ctx.T, h * w
     identity = isinstance(mod.skip_connection, nn.Identity)
     a, x = _gn_skip(mod.in_layers[0], x, frames, hw, True)             # x: what the skip branch (identity or 1x1 projection) reads
@@ -105,6 +110,11 @@ def _feed_forward(ff, x_norm, residual):
 
 
 def spatial_block(blk, cur, frames, hw, ctx):
+    with F_.frame_rows(hw):
+        return _spatial_block(blk, cur, frames, hw, ctx)
+
+
+def _spatial_block(blk, cur, frames, hw, ctx):
     a1, a2 = blk.attn1, blk.attn2
     n1, cur = _ln_skip(blk.norm1, cur)
     if hip.planes() == 1:
@@ -131,13 +141,20 @@ def spatial_block(blk, cur, frames, hw, ctx):
 def spatial_transformer(mod, x, h, w, ctx):
     hw, frames = h * w, ctx.B * ctx.T
     n, x = _gn_skip(mod.norm, x, frames, hw, False)
-    cur = _lin(mod.proj_in, n)
+    with F_.frame_rows(hw):
+        cur = _lin(mod.proj_in, n)
     for blk in mod.transformer_blocks:
         cur = _ckpt(blk.checkpoint, spatial_block, blk, cur, frames, hw, ctx)
-    return _lin(mod.proj_out, cur, residual=x)
+    with F_.frame_rows(hw):
+        return _lin(mod.proj_out, cur, residual=x)
 
 
 def temporal_block(blk, cur, hw, ctx):
+    with F_.frame_rows(hw):
+        return _temporal_block(blk, cur, hw, ctx)
+
+
+def _temporal_block(blk, cur, hw, ctx):
     for attn, norm in ((blk.attn1, blk.norm1), (blk.attn2, blk.norm2)):
         n, cur = _ln_skip(norm, cur)
         qkv = _lin_packed((attn.to_q, attn.to_k, attn.to_v), n)                                    # [q | k | v] columns
@@ -150,10 +167,12 @@ def temporal_block(blk, cur, hw, ctx):
 def temporal_transformer(mod, x, h, w, ctx):
     hw = h * w
     n, x = _gn_skip(mod.norm, x, ctx.B, ctx.T * hw, False)
-    cur = _lin(mod.proj_in, n)
+    with F_.frame_rows(hw):
+        cur = _lin(mod.proj_in, n)
     for blk in mod.transformer_blocks:
         cur = _ckpt(blk.checkpoint, temporal_block, blk, cur, hw, ctx)
-    return _lin(mod.proj_out, cur, residual=x)
+    with F_.frame_rows(hw):
+        return _lin(mod.proj_out, cur, residual=x)
 
 
 def run_stage(seq, x, h, w, ctx):
