@@ -99,8 +99,10 @@ typedef struct MudgGemmDesc {
                              three temporal taps of a row are rows of the same tile), and `stats` blocks are those TILES, in
                              clip order: only a clip-level GroupNorm may fold them */
     /* mode 2 */
-    int T, HW;            /* mode 0: HW may carry a HINT — the rows of one frame of the matrix (0 = none).  Results never depend on it; it lets
-                             the library choose a tile height that divides a frame (mudg_gemm_stats_rows) */
+    int T, HW;            /* mode 0: HW may carry a HINT — the rows of one frame of the matrix (0 = none): it lets the library choose a tile
+                             height that divides a frame (mudg_gemm_stats_rows).  Never M decides, so a row's result does not depend on
+                             the batch it travels in; with a residual R the 288-row tile adds R first instead of last (last-bit
+                             differences against the un-hinted call), without one the bits are the same */
     float* stats;         /* NULL, or fp32 [ceil(M/rows)][Nout][2], rows = mudg_gemm_stats_rows(d) (128 | 288): the epilogue also writes, per row block and output
                              channel, the sum and the sum of squares of the values it stored (as stored: after rounding to
                              bf16 when Y is bf16) — the first pass of the GroupNorm that consumes Y
