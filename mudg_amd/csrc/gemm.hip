@@ -1037,11 +1037,13 @@ const h16* zero_page() {
 // Phi(x) = 0.5 erfc(-x / sqrt 2) at x = -8 + i / 64, i = 0..1024, built once on the host in double precision.
 // Variant switch GELU_LUT=0 keeps the erf polynomial (A/B measurements).
 }  // namespace
-const float* mudg_phi_table() {
+const float* mudg_phi_table(bool split_ok) {
     static float* tabs[MAX_DEVICES] = {};
     static int mode = -1;
     if (mode < 0) mode = mudg_variant("GELU_LUT", 1);
-    if (!mode || PLANES > 1) return nullptr;          // the split-operand builds evaluate erf exactly
+    // the split-operand builds evaluate erf (bf16x3: to 1.5e-7); bf16x3's 288 x 256 GEGLU tile asks for the table and interpolates it
+    // to the same accuracy with a cubic (split_ok, wgemm.hip)
+    if (!mode || (PLANES > 1 && !(split_ok && PLANES == 2))) return nullptr;
     const int dev = current_device();
     if (dev < 0) return nullptr;
     float*& tab = tabs[dev];

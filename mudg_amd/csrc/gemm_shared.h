@@ -54,7 +54,7 @@ __device__ __forceinline__ float gelu_lut(float x, const float* __restrict__ T) 
 // Host side (gemm.hip): lazily created per-device state and the kernel-selection rule shared by both launchers.
 constexpr int MAX_DEVICES = 64;
 int mudg_current_device();
-const float* mudg_phi_table();                  // device Phi table, or nullptr (split-operand builds / variant switch)
+const float* mudg_phi_table(bool split_ok = false);      // device Phi table, or nullptr (split-operand builds unless split_ok in bf16x3 / variant switch)
 // pgemm.hip: the persistent 128 x 128 kernel; wgs = workgroups per CU (4 | 3: one K-tile stage, 2: two)
 int mudg_pgemm_launch(const MudgGemmDesc& d, int vflags, int wgs, hipStream_t s);
 // wgemm.hip: the 288 x 320 eight-wave tile (16-bit builds); _ok = eligible AND selected by its M-independent rule

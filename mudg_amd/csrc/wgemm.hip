@@ -124,6 +124,23 @@ __device__ __forceinline__ float gelu_lut2(float x, const f32x2* __restrict__ T)
     const f32x2 t = T[(int)u];
     return x * fmaf(__builtin_amdgcn_fractf(u), t[1], t[0]);
 }
+// bf16x3: the same table with the SLOPE as second entry ((Phi_i, pdf(x_i) / 64): the kernel fills it in when it copies the table) and a
+// cubic Hermite piece between two nodes — error h^4 / 384 max|d4 Phi| = 9e-11 beside the table's own fp32 rounding (6e-8), the class of
+// gelu_fast's 1.5e-7, for 14 vector instructions and one LDS read of two adjacent nodes instead of a polynomial around v_exp and v_rcp.
+__device__ __forceinline__ float gelu_hermite(float x, const f32x2* __restrict__ T) {
+    float u = fmaf(x, 64.0f, 512.0f);
+    u = __builtin_amdgcn_fmed3f(u, 0.0f, 1023.99f);
+    const int i = (int)u;
+    const float t = __builtin_amdgcn_fractf(u);
+    const f32x2 n0 = T[i], n1 = T[i + 1];
+    const float dl = n1[0] - n0[0];
+    const float c3 = fmaf(-2.0f, dl, n0[1] + n1[1]);
+    const float c2 = dl - n0[1] - c3;
+    float r = fmaf(t, c3, c2);
+    r = fmaf(t, r, n0[1]);
+    r = fmaf(t, r, n0[0]);
+    return x * r;
+}
 template <int NREP> __device__ __forceinline__ int wave_pair_col(int wc, int pair) { return 32 * ((NREP / 2) * wc + pair); }
 template <int NREP> __device__ __forceinline__ int wave_single_col(int wc) { return 32 * (NREP / 2) * 4 + 16 * wc; }
 
@@ -255,7 +272,7 @@ __device__ __forceinline__ void w_epilogue(const MudgGemmDesc& p, f32x4 (&acc)[9
                 for (int e = 0; e < 8; ++e) {
                     const float val = alpha * acc[i][e >> 2][e & 3] + bv[e];
                     const float gate = alpha * acc[i][2 + (e >> 2)][e & 3] + bg[e];
-                    v[e] = val * (phi ? gelu_lut2(gate, phis) : gelu_fast(gate));
+                    v[e] = val * (phi ? (PLANES == 2 ? gelu_hermite(gate, phis) : gelu_lut2(gate, phis)) : gelu_fast(gate));
                 }
             } else {
 #pragma unroll
@@ -395,7 +412,10 @@ __global__ __launch_bounds__(512, 2) void wgemm_kernel(const MudgGemmDesc p, con
     if (GEGLU && phi) {                                  // visible after the K loop's barriers
         for (int t = tid; t <= PHI_N; t += 512) {         // entry PHI_N exists (x = 8); its step is never used (u < 1024)
             const float a = phi[t], b = phi[t < PHI_N ? t + 1 : t];
-            *reinterpret_cast<f32x2*>(&tail[2 * t]) = f32x2{a, b - a};
+            if constexpr (PLANES == 2) {                 // (value, slope x node distance): gelu_hermite
+                const float xt = -8.0f + (float)t * (1.0f / 64.0f);
+                *reinterpret_cast<f32x2*>(&tail[2 * t]) = f32x2{a, expf(-0.5f * xt * xt) * (0.3989422804014327f / 64.0f)};
+            } else *reinterpret_cast<f32x2*>(&tail[2 * t]) = f32x2{a, b - a};
         }
     }
 
@@ -774,7 +794,10 @@ __global__ __launch_bounds__(512, 2) void wgemm_pkernel(const MudgGemmDesc p, co
     if (GEGLU && phi) {
         for (int t = tid; t <= PHI_N; t += 512) {         // entry PHI_N exists (x = 8); its step is never used (u < 1024)
             const float a = phi[t], b = phi[t < PHI_N ? t + 1 : t];
-            *reinterpret_cast<f32x2*>(&tail[2 * t]) = f32x2{a, b - a};
+            if constexpr (PLANES == 2) {                 // (value, slope x node distance): gelu_hermite
+                const float xt = -8.0f + (float)t * (1.0f / 64.0f);
+                *reinterpret_cast<f32x2*>(&tail[2 * t]) = f32x2{a, expf(-0.5f * xt * xt) * (0.3989422804014327f / 64.0f)};
+            } else *reinterpret_cast<f32x2*>(&tail[2 * t]) = f32x2{a, b - a};
         }
     }
     // this workgroup's tiles: the XCD's contiguous range of the one-tile kernel's numbering, every (gridDim / 8)-th tile of it
@@ -1009,7 +1032,7 @@ static int wgemm_launch_one(const MudgGemmDesc& d, int vflags, hipStream_t s, in
         attr_done[dev][slot] = true;
     }
     const int tiles = ((d.M + WBM - 1) / WBM) * (d.N / G::BN);
-    const float* phi = GEGLU ? mudg_phi_table() : nullptr;
+    const float* phi = GEGLU ? mudg_phi_table(PLANES == 2) : nullptr;
     hipLaunchKernelGGL((wgemm_kernel<MODE, NREP, GEGLU>), dim3(tiles), dim3(512), G::SMEM, s, d, vflags, phi);
     return mudg_check_launch("mudg_gemm");
 }
@@ -1032,7 +1055,7 @@ static int wgemm_launch_persistent(const MudgGemmDesc& d, int vflags, hipStream_
         attr_done[dev][slot] = true;
     }
     const int tiles = (d.M / WBM) * (d.N / G::BN);
-    const float* phi = GEGLU ? mudg_phi_table() : nullptr;
+    const float* phi = GEGLU ? mudg_phi_table(PLANES == 2) : nullptr;
     hipLaunchKernelGGL((wgemm_pkernel<NREP, GEGLU>), dim3(grid), dim3(512), G::SMEM, s, d, vflags, phi, tiles);
     return mudg_check_launch("mudg_gemm");
 }

@@ -358,6 +358,16 @@ def test_wide288_gemm_and_temporal_conv_in_every_operand_mode(cuda):
     y32 = ops.gemm(x, w, bias=b.to(cuda), out_fp32=True, frame_rows=288)
     assert rel(y32, xv @ wv.t() + b.double()) < TOL_F32
     assert torch.equal(ops.gemm(x[:288 * 2], w, bias=b.to(cuda), out_fp32=True, frame_rows=288), y32[:288 * 2])
+    # GEGLU with a frame hint of whole tiles (16-bit builds: the table lookup; bf16x3: the cubic through the same table)
+    from test_kernels_gpu import pack_geglu
+    C = 128
+    xg, xgv = operand(f32(288 * 3, C, seed=11), cuda)
+    wf, bf_ = f32(8 * C, C, seed=12, scale=0.1), f32(8 * C, seed=13, scale=0.1)
+    wpk, bpk = pack_geglu(wf, bf_)
+    wg, wgv = operand(wpk, cuda)
+    hh = (xgv @ wgv.t() + bpk.double()).reshape(288 * 3, -1, 2, 32)
+    yg = ops.gemm(xg, wg, bias=bpk.to(cuda), geglu=True, frame_rows=288)
+    assert rel(value(yg), (hh[:, :, 0] * F.gelu(hh[:, :, 1])).reshape(288 * 3, -1)) < TOL_OP
     clips, t, hw, c, co = 2, 4, 288, 128, 640
     xt, xtv = operand(f32(clips * t * hw, c, seed=5), cuda)
     wt, wtv = operand(f32(co, 3 * c, seed=6, scale=0.05), cuda)
