@@ -1211,13 +1211,21 @@ static int access_flags(const MudgGemmDesc& d) {
     return vflags;
 }
 
+// The defaults mudg_gemm gives a caller's descriptor before any kernel-selection rule reads it: batch < 1 -> 1, no second source ->
+// csplit = the whole channel axis, alpha == 0 (a zero-initialised C struct) -> 1.  ONE place, so that every query about "which kernel
+// will run this" (mudg_gemm_stats_rows) sees exactly the descriptor mudg_gemm dispatches on.
+static void normalise_desc(MudgGemmDesc& d) {
+    if (d.batch < 1) d.batch = 1;
+    if (!d.X2) d.csplit = d.mode == 0 ? d.K : d.Cin;
+    if (d.alpha == 0.f) d.alpha = 1.f;
+}
+
 // Height of the row blocks `stats` will be written in for this problem (mudg_hip.h): 288 where the 288 x 320 kernel runs it, else 128.
 extern "C" int mudg_gemm_stats_rows(const MudgGemmDesc* dp) {
     if (!dp) return 128;
     MudgGemmDesc d = *dp;
-    if (d.batch < 1) d.batch = 1;
-    if (!d.X2) d.csplit = d.mode == 0 ? d.K : d.Cin;
     if (d.out_fp32 < 0 || d.out_fp32 > 2 || d.res_fp32 < 0 || d.res_fp32 > 2 || d.mode < 0 || d.mode > 2) return 128;
+    normalise_desc(d);
     return mudg_wgemm_ok(d, access_flags(d)) ? 288 : 128;
 }
 
@@ -1241,10 +1249,9 @@ extern "C" int mudg_gemm(const MudgGemmDesc* dp, void* stream) {
     MUDG_REQUIRE(d.ldx % (8 * PLANES) == 0 && d.ldw % (8 * PLANES) == 0, "mudg_gemm: ldx=%d ldw=%d must be multiples of %d", d.ldx, d.ldw, 8 * PLANES);
     MUDG_REQUIRE(aligned16(d.X) && aligned16(d.W), "mudg_gemm: X/W must be 16-byte aligned");
     MUDG_REQUIRE((d.sX & 7) == 0 && (d.sW & 7) == 0, "mudg_gemm: batch strides must be multiples of 8");
-    if (d.batch < 1) d.batch = 1;
+    normalise_desc(d);
     const int cin = d.mode == 0 ? d.K : d.Cin;
-    if (!d.X2) d.csplit = cin;
-    else {
+    if (d.X2) {
         MUDG_REQUIRE(aligned16(d.X2) && d.ldx2 % (8 * PLANES) == 0, "mudg_gemm: X2 alignment");
         MUDG_REQUIRE(d.csplit > 0 && d.csplit < cin && (d.csplit & 7) == 0, "mudg_gemm: csplit=%d", d.csplit);
     }
@@ -1274,7 +1281,6 @@ extern "C" int mudg_gemm(const MudgGemmDesc* dp, void* stream) {
     // the group bias is a second bias (added with it, before nothing): an activation or a GEGLU gate between them is not defined
     MUDG_REQUIRE(!(d.gbias && (d.act || d.geglu)), "mudg_gemm: gbias combines with neither act nor geglu");
     if (d.stats) MUDG_REQUIRE(d.batch == 1 && !d.geglu, "mudg_gemm: stats needs batch == 1 and no GEGLU");
-    if (d.alpha == 0.f) d.alpha = 1.f;
     if (d.Y8) {
         MUDG_REQUIRE(PLANES == 1, "mudg_gemm: the fused fp8 copy belongs to the 16-bit builds");
         MUDG_REQUIRE(d.S8 && d.out_fp32 == KIND_OPERAND && !d.geglu && !d.subpixel && d.batch == 1 && (d.N & 31) == 0 && (d.ldy8 & 7) == 0 &&

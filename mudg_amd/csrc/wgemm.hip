@@ -31,11 +31,16 @@
 // k half in one LOAD section - 7 %; DMA issued between the MFMAs - 13 %; four larger phases per K-tile - 3 %; without any DMA the
 // loop would run at 1780 TFLOP/s (the real-data MFMA rate), without fragment reads + 2 %.
 //
-// Epilogue: accumulators (+ bias + group bias) -> fp32 LDS staging in three passes of 128 columns -> coalesced 16-byte rows
-// (+ residual, any storage kind; GroupNorm partials of what was stored, per 288-ROW BLOCK = per tile: mudg_gemm_stats_rows).
-// Summation order over K is the K-tile order of the other kernels, but v_mfma_f32_16x16x32 adds 32 products per instruction where
-// v_mfma_f32_32x32x16 adds 16: results differ from the 128 x 128 kernels' in the last bits.  The selection rule (wgemm_ok) therefore
-// never looks at M — a clip's result must not depend on the batch it travels in — only at the problem's per-frame geometry.
+// Epilogue: straight from the accumulators, no LDS staging (w_epilogue): a lane owns 8 consecutive channels of each of its 9 rows per
+// fragment pair — one 16-byte piece per row — so value = alpha acc + bias (+ group bias) is rounded and stored from registers; the
+// GroupNorm partials of what was stored go out per 288-ROW BLOCK = per tile (mudg_gemm_stats_rows).  A residual is not fetched by the
+// epilogue at all: it SEEDS the accumulators when the tile starts (w_seed).
+// Bits.  Summation order over K is the K-tile order of the 128 x 128 kernels; without a residual the results are BIT-IDENTICAL to the
+// 128 x 128 kernels' on every shape and epilogue the suite runs (tests/test_gemm_variants_gpu.py::
+// test_wide288_is_bit_identical_to_the_one_tile_kernels — an observation about v_mfma_f32_16x16x32 vs two v_mfma_f32_32x32x16 on gfx950,
+// asserted by that test, not a documented property of the instructions).  With a residual they are not — the sum is ((r + x w) + bias) here
+// and ((x w + bias) + r) there — and that alone is why the selection rule (mudg_wgemm_ok) never looks at M: a clip's result must not
+// depend on the batch it travels in, so whether a residual problem runs on this tile is decided by its per-frame geometry only.
 //
 // bf16x3 build (MUDG_PLANES = 2), same tile, same epilogue: a k half holds both bf16 pieces of both operands (x0, x1, w0, w1: 76 KiB),
 // so the ring is two k halves and a piece is re-staged two phases after its last read.  Per k half h, three phases of 45 MFMAs:

@@ -7,7 +7,6 @@ count (views into wider buffers are fine as long as stride(1) == 1 and rows are 
 from __future__ import annotations
 
 import ctypes as C
-import functools
 import math
 from typing import Optional
 
@@ -238,10 +237,13 @@ def tconv3_slab_ok(t, hw, cin):
     return hip.planes() <= 2 and t == 16 and hw % 8 == 0 and cin % 64 == 0
 
 
-@functools.lru_cache(maxsize=None)
 def tconv3_wide(t, hw, cin, cout):
     """Whether the library runs this temporal conv (plain K order, korder 0) on its 288 x 320-tile kernel — the caller then does not
-    ask for the slab-major order, whose 8-pixel x 16-frame tiles belong to the 128 x 128 kernels.  A dry query: nothing is read."""
+    ask for the slab-major order, whose 8-pixel x 16-frame tiles belong to the 128 x 128 kernels.  A dry query: nothing is read.
+    Not cached: it is one host call, and the variant builds re-read MUDG_GEMM_W288 at every call (a cached answer went stale when a
+    test toggled the switch in-process).  The query assumes what the executor always passes — dense, 16-byte-aligned rows; a caller
+    with other strides gets a correct result either way (ops.tconv3 asks again with the real descriptor for the GroupNorm block
+    height), only possibly the slower of the two K orders."""
     d = hip.GemmDesc()
     d.X, d.W, d.Y = 256, 256, 256                     # aligned placeholders
     d.M, d.N, d.K = 16 * t * hw, cout, 3 * cin

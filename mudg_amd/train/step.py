@@ -181,8 +181,13 @@ class GradientAllReducer:
             self.buckets.append(cur)
         # Persistent flat buckets; every parameter's .grad is a VIEW into its bucket (as DDP's gradient_as_bucket_view): backward
         # accumulates straight into the bucket, the collective runs on it in place, nothing is packed, unpacked or allocated per
-        # step.  (Round 3 allocated 5.8 GB of zeros and issued 2 x 1520 copies per step.)  A parameter that receives no gradient
-        # keeps its zeros — it then sees weight decay only, as under DDP.
+        # step.  (Round 3 allocated 5.8 GB of zeros and issued 2 x 1520 copies per step.)  A parameter that receives no gradient:
+        # with several ranks it keeps its zeros (its contribution to the average; it then sees weight decay only, as under DDP's
+        # bucket views); in a one-rank job it gets .grad = None back (see _touched below).
+        # Gradients must ARRIVE THROUGH AUTOGRAD ACCUMULATION (the post-accumulate hook is what marks a parameter as touched) or be
+        # ASSIGNED as a tensor of their own (p.grad = g: recognised by its address and copied into the bucket).  A gradient written
+        # by hand INTO the bucket view (p.grad.add_(...) without a backward pass) is indistinguishable from the view's zeros
+        # without a device read, and a one-rank job drops it — do not do that.
         self.flats = [torch.zeros(sum(p.numel() for p in b), dtype=torch.float32, device=b[0].device) for b in self.buckets]
         self._views = {}
         for flat, bucket in zip(self.flats, self.buckets):
@@ -258,7 +263,13 @@ class GradientAllReducer:
             return 0
         if not self._active():                            # one rank: nothing to average; untouched parameters get grad None back
             for p in self.params:
-                if id(p) not in self._touched:
+                if id(p) in self._touched:
+                    continue
+                g, v = p.grad, self._views[id(p)]
+                if g is not None and g.data_ptr() != v.data_ptr():      # assigned by hand (no accumulation hook fired): keep it, in the bucket
+                    v.copy_(g)
+                    p.grad = v
+                else:
                     p.grad = None
             self._touched.clear()
             return 0

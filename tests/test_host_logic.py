@@ -56,6 +56,29 @@ def test_kernels_reject_bad_arguments_without_touching_the_gpu():
     assert hip.lib().mudg_ddim_ws_doubles(3) == 3 * 64 * 4
 
 
+def test_stats_rows_query_sees_the_descriptor_mudg_gemm_dispatches_on():
+    """mudg_gemm rewrites alpha == 0 (a zero-initialised C struct) to 1, batch < 1 to 1 and csplit to the whole channel axis before its
+    selection rules read the descriptor; mudg_gemm_stats_rows must answer for that same descriptor — with alpha left at 0 it used to
+    report 128-row GroupNorm blocks for a residual problem the 288 x 320 tile then ran (round-5 advisor finding).  Host logic only:
+    pointers are fake, nothing is launched."""
+    from mudg_amd import hip
+    lib = hip.lib()
+
+    def query(alpha, batch=1):
+        d = hip.GemmDesc()
+        d.X, d.W, d.Y, d.R, d.stats = 4096, 8192, 12288, 16384, 20480
+        d.M, d.N, d.K = 288 * 4, 320, 320
+        d.ldx, d.ldw, d.ldy, d.ldr = 320, 320, 320, 320
+        d.batch, d.alpha, d.mode, d.HW = batch, alpha, 0, 288
+        d.out_fp32, d.res_fp32 = 2, 2
+        return lib.mudg_gemm_stats_rows(ctypes.byref(d))
+
+    assert query(1.0) == 288
+    assert query(0.0) == 288, "the query must apply mudg_gemm's alpha == 0 -> 1 default"
+    assert query(0.0, batch=0) == 288
+    assert query(0.5) == 128              # a scaled product with a residual cannot seed the accumulators: the 128 x 128 kernels
+
+
 @pytest.mark.parametrize("base", [0.3, 0.7])
 def test_product_schedule_matches_reference(base):
     from lvdm.models.samplers.ddim import DDIMSampler
