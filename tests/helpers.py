@@ -86,18 +86,68 @@ def cached_oracle(key, compute):
 
 def record_parity(mode, name, value, **extra):
     """Measured parity figures, merged into gpurun_out/parity_modes.json ({mode: {name: value}}): the record bench.py's
-    `at_tolerance` quotes once it has been copied to profiles/rN/ (tools/collect_profiles.sh)."""
+    `at_tolerance` quotes once it has been copied to profiles/rN/ (tools/collect_profiles.sh).  The operand-mode children run side
+    by side (ChildRuns below), so the read-modify-write is under an advisory file lock."""
+    import fcntl
     import json
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     path = os.path.join(root, "gpurun_out", "parity_modes.json")
     try:
         os.makedirs(os.path.dirname(path), exist_ok=True)
-        rec = {}
-        if os.path.exists(path):
-            with open(path) as f:
-                rec = json.load(f)
-        rec.setdefault(mode, {})[name] = dict(extra, value=float(value)) if extra else float(value)
-        with open(path, "w") as f:
-            json.dump(rec, f, indent=1, sort_keys=True)
+        with open(path + ".lock", "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            rec = {}
+            if os.path.exists(path):
+                with open(path) as f:
+                    rec = json.load(f)
+            rec.setdefault(mode, {})[name] = dict(extra, value=float(value)) if extra else float(value)
+            tmp = path + f".{os.getpid()}.tmp"
+            with open(tmp, "w") as f:
+                json.dump(rec, f, indent=1, sort_keys=True)
+            os.replace(tmp, path)
     except Exception:
         pass
+
+
+class ChildRuns:
+    """Child pytest processes of one test module, up to `workers` of them side by side on the same GPU.  The variant / operand-mode
+    children used to run one after the other — two thirds of the suite's 16 minutes, most of it host time (interpreter and torch
+    start-up, Python dispatch of small launches, reference arithmetic on the fixtures, model construction) with the GPU idle;
+    side by side a block costs about what its longest children do.  Nothing in the suites asserts a time, and every child has its own
+    library instance, streams and allocator.  All children are submitted when the first test of the module asks for its result;
+    MUDG_CHILDREN_SERIAL=1 runs them one at a time (to bisect a failure that only shows under contention)."""
+
+    def __init__(self, workers):
+        from concurrent.futures import ThreadPoolExecutor
+        self.pool = ThreadPoolExecutor(max_workers=1 if os.environ.get("MUDG_CHILDREN_SERIAL") == "1" else workers)
+        self.futures, self.procs, self.cancelled = {}, [], False
+
+    def submit(self, key, cmd, cwd, env, timeout):
+        import subprocess
+
+        def run():
+            if self.cancelled:
+                return -999, "cancelled"
+            proc = subprocess.Popen(cmd, cwd=cwd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            self.procs.append(proc)
+            try:
+                out, _ = proc.communicate(timeout=timeout)
+            except subprocess.TimeoutExpired:
+                proc.kill()
+                out, _ = proc.communicate()
+                return -998, out + f"\n[timed out after {timeout} s]"
+            return proc.returncode, out
+
+        if key not in self.futures:
+            self.futures[key] = self.pool.submit(run)
+
+    def result(self, key):
+        return self.futures[key].result()
+
+    def shutdown(self):
+        """A failed sibling under -x: do not leave the others running on the GPU."""
+        self.cancelled = True
+        for proc in self.procs:
+            if proc.poll() is None:
+                proc.kill()
+        self.pool.shutdown(wait=True)

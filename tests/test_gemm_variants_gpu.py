@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SELECT = "gemm or conv or tconv or resblock or transformer or geglu or fused or attention or attn or wide or persistent or norm or temporal"
 
 
-@pytest.mark.parametrize("env", [
+VARIANTS = [
     {"MUDG_GEMM_FAST": "0"},
     {"MUDG_GEMM_SB": "2"},
     {"MUDG_GEMM_SB": "0"},
@@ -33,26 +33,45 @@ SELECT = "gemm or conv or tconv or resblock or transformer or geglu or fused or 
     {"MUDG_CONV_XSHARE": "0"},
     {"MUDG_GEMM_W288": "2"},
     {"MUDG_GEMM_W288": "2", "MUDG_GEMM_W288P": "2"},
-], ids=lambda e: ",".join(f"{k[5:]}={v}" for k, v in e.items()))
-def test_kernel_parity_under_variant(cuda, env):
+]
+# The bf16x3 build's own debug-variants library (libmudg_hip_x3_dbg.so): its 288 x 320 kernel forced for every problem it can run
+# (short K, GEGLU on the 288 x 256 tile, ragged M — the rule sends none of those to it), and switched off (every conv / temporal conv
+# on the fused-piece 128 x 128 kernels), under the mode-agnostic kernel suite and the UNet parity tests.
+VARIANTS_X3 = [{"MUDG_GEMM_W288": "2"}, {"MUDG_GEMM_W288": "0"}]
+_name = lambda e: ",".join(f"{k[5:]}={v}" for k, v in e.items())
+
+
+@pytest.fixture(scope="module")
+def children():
+    """All variant children of this module, six at a time (helpers.ChildRuns)."""
+    from helpers import ChildRuns
+    runs = ChildRuns(workers=6)
+    for env in VARIANTS:
+        runs.submit(_name(env), [sys.executable, "-m", "pytest", "tests/test_kernels_gpu.py", "tests/test_operand_modes_gpu.py", "tests/test_unet_gpu.py",
+                                 "-m", "gpu", "-q", "-k", SELECT, "-p", "no:cacheprovider"],
+                    ROOT, dict(os.environ, MUDG_DEBUG_VARIANTS="1", **env), 900)
+    for env in VARIANTS_X3:
+        runs.submit("x3:" + _name(env), [sys.executable, "-m", "pytest", "tests/test_operand_modes_gpu.py", "tests/test_unet_gpu.py", "-m", "gpu", "-q",
+                                         "-p", "no:cacheprovider"],
+                    ROOT, dict(os.environ, MUDG_DEBUG_VARIANTS="1", MUDG_OPERAND="bf16x3", MUDG_PARITY_CHILD="1", MUDG_SKIP_FULLSIZE_ORACLE="1",
+                               MUDG_SKIP_CONFIG0_CUT="1", **env), 900)
+    yield runs
+    runs.shutdown()
+
+
+@pytest.mark.parametrize("env", VARIANTS, ids=_name)
+def test_kernel_parity_under_variant(cuda, env, request):
     if os.environ.get("MUDG_DEBUG_VARIANTS") == "1":
         pytest.skip("already running under a variant switch")
-    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_kernels_gpu.py", "tests/test_operand_modes_gpu.py", "tests/test_unet_gpu.py", "-m", "gpu",
-                        "-q", "-k", SELECT, "-p", "no:cacheprovider"],
-                       cwd=ROOT, env=dict(os.environ, MUDG_DEBUG_VARIANTS="1", **env), capture_output=True, text=True, timeout=900)
-    print("\n".join(l for l in r.stdout.splitlines() if "passed" in l or "failed" in l))
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    rc, stdout = request.getfixturevalue("children").result(_name(env))
+    print("\n".join(l for l in stdout.splitlines() if "passed" in l or "failed" in l))
+    assert rc == 0, stdout[-5000:]
 
 
-@pytest.mark.parametrize("env", [{"MUDG_GEMM_W288": "2"}, {"MUDG_GEMM_W288": "0"}], ids=lambda e: ",".join(f"{k[5:]}={v}" for k, v in e.items()))
-def test_kernel_parity_under_variant_in_the_bf16x3_build(cuda, env):
-    """The bf16x3 build's own debug-variants library (libmudg_hip_x3_dbg.so): its 288 x 320 kernel forced for every problem it can run
-    (short K, GEGLU on the 288 x 256 tile, ragged M — the rule sends none of those to it), and switched off (every conv / temporal conv on
-    the fused-piece 128 x 128 kernels), under the mode-agnostic kernel suite and the UNet parity tests."""
+@pytest.mark.parametrize("env", VARIANTS_X3, ids=_name)
+def test_kernel_parity_under_variant_in_the_bf16x3_build(cuda, env, request):
     if os.environ.get("MUDG_DEBUG_VARIANTS") == "1" or os.environ.get("MUDG_PARITY_CHILD") == "1":
         pytest.skip("already running under a variant switch / inside a mode child")
-    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_operand_modes_gpu.py", "tests/test_unet_gpu.py", "-m", "gpu", "-q", "-p", "no:cacheprovider"],
-                       cwd=ROOT, env=dict(os.environ, MUDG_DEBUG_VARIANTS="1", MUDG_OPERAND="bf16x3", MUDG_PARITY_CHILD="1", MUDG_SKIP_FULLSIZE_ORACLE="1",
-                                          MUDG_SKIP_CONFIG0_CUT="1", **env), capture_output=True, text=True, timeout=900)
-    print("\n".join(l for l in r.stdout.splitlines() if "passed" in l or "failed" in l))
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    rc, stdout = request.getfixturevalue("children").result("x3:" + _name(env))
+    print("\n".join(l for l in stdout.splitlines() if "passed" in l or "failed" in l))
+    assert rc == 0, stdout[-5000:]

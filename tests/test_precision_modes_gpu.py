@@ -16,6 +16,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CUT = "tests/test_fullsize_gpu.py::test_config0_cut_one_ddim_step_and_4_frame_decode_at_mdm512_match_the_cpu_oracle"
 FWD512 = "tests/test_fullsize_gpu.py::test_mdm512_unet_forward_matches_the_cpu_oracle_at_full_size"
 FWD1024 = "tests/test_fullsize_gpu.py::test_mdm1024_4_frame_unet_forward_matches_the_cpu_oracle"
+# one guided DDIM step + a 576 x 1024 decoded frame at the benchmarked spatial size: where bf16x3 is held to the literal 1e-3
+STEP1024 = "tests/test_fullsize_gpu.py::test_mdm1024_4_frame_guided_ddim_step_and_one_frame_decode_match_the_cpu_oracle"
 # the MDM1024 property tests (clip independence, determinism, graph replay, guided steps per clip): BASELINE configs[4] is stated at
 # MDM1024, so its switch runs them too
 PROPS1024 = ["tests/test_fullsize_gpu.py::test_unet_clips_are_independent_and_runs_are_deterministic_at_mdm1024",
@@ -32,7 +34,7 @@ MODES = {
     # bf16x3 is the mode that carries the contract: the full-size config-0 cut asserts the literal 1e-3 there
     "bf16x3": ({"MUDG_OPERAND": "bf16x3"},
                ["tests/test_operand_modes_gpu.py", "tests/test_unet_gpu.py", "tests/test_pipeline_gpu.py",
-                "tests/test_sampler_options_gpu.py", "tests/test_training_gpu.py", CUT, FWD512, FWD1024]),
+                "tests/test_sampler_options_gpu.py", "tests/test_training_gpu.py", CUT, FWD512, FWD1024, STEP1024]),
     "bf16x6": ({"MUDG_OPERAND": "bf16x6"},
                ["tests/test_operand_modes_gpu.py", "tests/test_unet_gpu.py", "tests/test_pipeline_gpu.py"]),
     # BASELINE.json configs[4]: MX-fp8 scores in the long self-attention (>= 512 tokens of head width 64: the full-size
@@ -40,19 +42,28 @@ MODES = {
     # cut (guided DDIM step + decode) against the CPU oracle under the switch, the MDM1024 property tests, and the kernel-level
     # test of the fp8 score path
     "bf16+fp8scores": ({"MUDG_OPERAND": "bf16", "MUDG_ATTN_FP8": "1"},
-                       [FWD512, FWD1024, CUT, *PROPS1024, "tests/test_operand_modes_gpu.py::test_mxfp8_quantiser_and_fp8_score_attention"]),
+                       [FWD512, FWD1024, CUT, STEP1024, *PROPS1024, "tests/test_operand_modes_gpu.py::test_mxfp8_quantiser_and_fp8_score_attention"]),
 }
 
 
+@pytest.fixture(scope="module")
+def children():
+    """Every mode child, submitted at once (helpers.ChildRuns): the full-size oracle results they compare against were memoised by
+    the default-mode run of tests/test_fullsize_gpu.py, which pytest collects before this file."""
+    from helpers import ChildRuns
+    runs = ChildRuns(workers=len(MODES))
+    for mode, (env_add, suites) in MODES.items():
+        skip = {} if (CUT in suites or mode == "fp16") else {"MUDG_SKIP_FULLSIZE_ORACLE": "1", "MUDG_SKIP_CONFIG0_CUT": "1"}
+        env = dict(os.environ, MUDG_PARITY_CHILD="1", **env_add, **skip)
+        runs.submit(mode, [sys.executable, "-m", "pytest", *suites, "-m", "gpu", "-q", "-s", "-p", "no:cacheprovider"], ROOT, env, 2700)
+    yield runs
+    runs.shutdown()
+
+
 @pytest.mark.parametrize("mode", list(MODES))
-def test_parity_suites_in_operand_mode(cuda, mode):
-    env_add, suites = MODES[mode]
+def test_parity_suites_in_operand_mode(cuda, mode, request):
     if os.environ.get("MUDG_PARITY_CHILD") == "1":
         pytest.skip("already inside a mode child")
-    skip = {} if (CUT in suites or mode == "fp16") else {"MUDG_SKIP_FULLSIZE_ORACLE": "1", "MUDG_SKIP_CONFIG0_CUT": "1"}
-    env = dict(os.environ, MUDG_PARITY_CHILD="1", **env_add, **skip)
-    r = subprocess.run([sys.executable, "-m", "pytest", *suites, "-m", "gpu", "-q", "-s", "-p", "no:cacheprovider"],
-                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=2700)
-    tail = "\n".join(l for l in r.stdout.splitlines() if "rel-L2" in l or "passed" in l or "failed" in l)
-    print(tail)
-    assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
+    rc, stdout = request.getfixturevalue("children").result(mode)
+    print("\n".join(l for l in stdout.splitlines() if "rel-L2" in l or "passed" in l or "failed" in l))
+    assert rc == 0, stdout[-6000:]
