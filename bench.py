@@ -184,23 +184,43 @@ def at_tolerance(args):
                       {"MUDG_OPERAND": "bf16x3"})
     out["operand"] = "bf16x3"
     out["tolerance"] = "decoded frames within 1e-3 rel-L2 of the reference (BASELINE.json north_star)"
-    recs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "parity_modes.json")))
-    if recs:
-        try:
-            with open(recs[-1]) as f:
-                out["parity_last_measured"] = dict(json.load(f).get("bf16x3", {}), file=os.path.relpath(recs[-1], ROOT))
-        except Exception:
-            pass
+    par = _parity_of("bf16x3")
+    if par:
+        out["parity_last_measured"] = par
     return out
 
 
+def _parity_of(mode):
+    """The last measured parity figures of an operand mode / switch (profiles/rN/parity_modes.json, written by the `-m gpu` suite)."""
+    recs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "parity_modes.json")))
+    if not recs:
+        return None
+    try:
+        with open(recs[-1]) as f:
+            return dict(json.load(f).get(mode, {}), file=os.path.relpath(recs[-1], ROOT))
+    except Exception:
+        return None
+
+
 def other_configs(args):
-    """BASELINE.json's other single-GPU configurations on the driver's clock: configs[1] (MDM512, bf16) and configs[4] (MDM1024
-    with MX-fp8 attention scores; GroupNorm-SiLU is fused and the decode frame-batched in every configuration)."""
-    return {"mdm512": child_bench(args, "BASELINE configs[1]: MDM512 320x512x16f, 50 DDIM steps, bf16", ["--operand", "bf16", "--resolution", "512"],
-                                  {"MUDG_OPERAND": "bf16"}, steps=8, warmup=2),
-            "fp8_scores": child_bench(args, "BASELINE configs[4]: MDM1024 with MX-fp8 scores in the long self-attention (MUDG_ATTN_FP8=1)",
-                                      ["--operand", "bf16", "--resolution", "1024"], {"MUDG_OPERAND": "bf16", "MUDG_ATTN_FP8": "1"})}
+    """The other single-GPU configurations, on the driver's clock: BASELINE configs[1] (MDM512, bf16), configs[4] (MDM1024 with MX-fp8
+    attention scores; GroupNorm-SiLU is fused and the decode frame-batched in every configuration) with its measured parity next to
+    it, and the reference's OWN operating point — fp16 operands (it runs under torch.autocast(fp16),
+    virtual_render/virtual_pose_render.py:218) and its 3-modality batch (colour / depth / semantic clips denoised together, :90-100,
+    206-213; `value` there is CLIP-steps/s: 3 clips advance per step)."""
+    out = {"mdm512": child_bench(args, "BASELINE configs[1]: MDM512 320x512x16f, 50 DDIM steps, bf16", ["--operand", "bf16", "--resolution", "512"],
+                                 {"MUDG_OPERAND": "bf16"}, steps=8, warmup=2),
+           "fp8_scores": child_bench(args, "BASELINE configs[4]: MDM1024 with MX-fp8 scores in the long self-attention (MUDG_ATTN_FP8=1)",
+                                     ["--operand", "bf16", "--resolution", "1024"], {"MUDG_OPERAND": "bf16", "MUDG_ATTN_FP8": "1"}),
+           "fp16": child_bench(args, "MDM1024 with fp16 MFMA operands (the reference's autocast dtype), fp32 residual stream",
+                               ["--operand", "fp16", "--resolution", "1024"], {"MUDG_OPERAND": "fp16"}),
+           "b3": child_bench(args, "MDM1024, the reference driver's 3-modality batch (B = 3 clips per step), bf16; value = clip-steps/s",
+                             ["--operand", "bf16", "--resolution", "1024", "--batch", "3"], {"MUDG_OPERAND": "bf16"}, steps=3, warmup=1)}
+    for key, mode in (("fp8_scores", "bf16+fp8scores"), ("fp16", "fp16")):
+        par = _parity_of(mode)
+        if par:
+            out[key]["parity_last_measured"] = par
+    return out
 
 
 def training_step_record(args):

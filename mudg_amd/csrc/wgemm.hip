@@ -240,7 +240,9 @@ __device__ __forceinline__ void w_seed(const MudgGemmDesc& p, f32x4 (&acc)[9][NR
 // the 8 consecutive output channels wave_pair_col(wc, p) + 8 q .. + 7: one 16-byte piece per row (operand / fp16 result; two for
 // fp32), four lanes = 64 contiguous bytes of the row.  A piece is value = alpha acc + (bias + group bias), GEGLU'd, rounded, summed into the
 // GroupNorm partials, stored.  A residual is already in the accumulators (w_seed): the epilogue fetches nothing.
-template <int NREP, bool GEGLU>
+// LUT: how the Phi table lies in `tail` — 2 = (value, step) pairs (gelu_lut2, 8 KiB), 1 = plain values (gelu_lut, 4 KiB: the two-workgroup
+// kernel below has no room for the pairs); the same bits either way (the step is the same fp32 difference, taken once or per value).
+template <int NREP, bool GEGLU, int LUT = 2>
 __device__ __forceinline__ void w_epilogue(const MudgGemmDesc& p, f32x4 (&acc)[9][NREP], const int m0, const int n0, const int tm, const int wr, const int wc,
                                            const int lane, const int tid, float* tail, const float* __restrict__ phi) {
     constexpr int WBN = 64 * NREP, NPAIR = NREP / 2;
@@ -277,7 +279,7 @@ __device__ __forceinline__ void w_epilogue(const MudgGemmDesc& p, f32x4 (&acc)[9
                 for (int e = 0; e < 8; ++e) {
                     const float val = alpha * acc[i][e >> 2][e & 3] + bv[e];
                     const float gate = alpha * acc[i][2 + (e >> 2)][e & 3] + bg[e];
-                    v[e] = val * (phi ? (PLANES == 2 ? gelu_hermite(gate, phis) : gelu_lut2(gate, phis)) : gelu_fast(gate));
+                    v[e] = val * (phi ? (PLANES == 2 ? gelu_hermite(gate, phis) : (LUT == 1 ? gelu_lut(gate, tail) : gelu_lut2(gate, phis))) : gelu_fast(gate));
                 }
             } else {
 #pragma unroll
@@ -972,6 +974,151 @@ __global__ __launch_bounds__(512, 2) void wgemm_pkernel(const MudgGemmDesc p, co
 }
 #endif
 
+#if MUDG_PLANES == 1
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// The half-height GEGLU tile (round 6): 144 x 256, FOUR waves, TWO workgroups per CU.
+// Why.  The eight-wave tile is alone on its CU: while it runs its epilogue — GEGLU's is the longest, a table lookup and ~12 vector
+// instructions per output value, as long as the whole K loop at K = 320 — and while it waits for its first K-tile, the matrix pipes idle
+// (profiles/r5/pmc_mfma.md: 39 % MFMA-busy in the persistent GEGLU form).  Here a CU holds two INDEPENDENT workgroups of half the height:
+// each SIMD has one wave of either, the per-wave work is the eight-wave kernel's (9 x 4 fragments of 16 x 16, 144 accumulator
+// registers), and nothing couples the two — one multiplies while the other stores, fetches or sits in its barrier.
+// LDS per workgroup (79.0 KiB; 2 x 80 KiB is the CU): a RING OF THREE k halves (32 deep) x {X: 9, W: 16 subtiles of 1 KiB, st_16x32
+// swizzled at the DMA source as above} = 75 KiB + the Phi table as plain values (4 KiB: the pairs of the eight-wave kernel do not fit).
+// Per k half h (slot h % 3), ONE barrier:
+//     s_waitcnt vmcnt(pieces of h + 1)   this wave's pieces of h have landed
+//     s_barrier                          so have everybody's; and everybody has finished reading k half h - 1 ...
+//     DMA of k half h + 2                ... whose slot these pieces go to (two k halves = 72 MFMAs of latency budget)
+//     fragments W (4), X rows 0-2 (3), X rows 3-5 (3) | 12 MFMAs | X rows 6-8 | 12 MFMAs | 12 MFMAs
+// (a wave's own fragment reads of the next row third are in flight under its MFMAs; the compiler's counted lgkmcnt waits order them).
+// Bits: the K order of every other kernel and gelu_lut on the same table — identical to the eight-wave tile and the 128 x 128 kernels,
+// so the selection rule may look at M.
+constexpr int H_NA = 9, H_NB = 16;
+constexpr int H_KS = (H_NA + H_NB) * 1024;               // one k half: 25 KiB
+constexpr int H_RING = 3 * H_KS;
+constexpr int H_SMEM = H_RING + ((PHI_N + 1) * 4 + 15) / 16 * 16;
+
+__global__ __launch_bounds__(256, 2) void hgeglu_kernel(const MudgGemmDesc p, const int vflags, const float* __restrict__ phi) {
+    constexpr int HBM_ = 16 * H_NA, HBN = 256;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wc = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave = wave column: 64 of the tile's 256 W rows
+    float* tail = reinterpret_cast<float*>(smem + H_RING);
+    if (phi) for (int t = tid; t <= PHI_N; t += 256) tail[t] = phi[t];        // visible after the K loop's barriers
+
+    // XCD-aware tile numbering (as wgemm_kernel): every XCD a contiguous tile range, walked in 8-row groups column by column
+    const int ntn = p.N / HBN, ntm = (p.M + HBM_ - 1) / HBM_;
+    int tile;
+    {
+        const int total = gridDim.x, q8 = total >> 3, r8 = total & 7;
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    }
+    int tm, tn;
+    {
+        const int per = 8 * ntn, g = tile / per, first = g * 8;
+        const int gsz = (ntm - first) < 8 ? (ntm - first) : 8;
+        const int r = tile - g * per;
+        tn = r / gsz;
+        tm = first + (r - tn * gsz);
+    }
+    const int m0 = tm * HBM_, n0 = tn * HBN;
+
+    const int pos = lane * 16;
+    const int sbyte = pos ^ (((pos >> 9) & 1) << 5);
+    const int srow = sbyte >> 6, schunk = (sbyte >> 4) & 3;
+    const h16* X = reinterpret_cast<const h16*>(p.X);
+    const h16* X2 = p.X2 ? reinterpret_cast<const h16*>(p.X2) : nullptr;
+    const h16* W = reinterpret_cast<const h16*>(p.W);
+    const __amdgpu_buffer_rsrc_t rX = make_rsrc(X + (int64_t)m0 * p.ldx);
+    const __amdgpu_buffer_rsrc_t rX2 = X2 ? make_rsrc(X2 + (int64_t)m0 * p.ldx2) : rX;
+    const __amdgpu_buffer_rsrc_t rW = make_rsrc(W + (int64_t)n0 * p.ldw);
+    const int ldx2e = X2 ? p.ldx2 : p.ldx;
+    const unsigned va1 = (unsigned)(srow * p.ldx) * 2u + (unsigned)schunk * 16u;
+    const unsigned va2 = (unsigned)(srow * ldx2e) * 2u + (unsigned)schunk * 16u;
+    const unsigned vw_pair = (unsigned)((8 * (srow >> 2) + (srow & 3)) * p.ldw) * 2u + (unsigned)schunk * 16u;     // (permuted W rows: wgemm_kernel)
+    // this wave's pieces per k half: its own 4 W subtiles; of the 9 X subtiles 3 | 2 | 2 | 2
+    const int a_first = wc == 0 ? 0 : 1 + 2 * wc, a_cnt = wc == 0 ? 3 : 2;
+    unsigned alive = 0;                                   // bit q: the lane's source row of X piece q exists
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+        if (q < a_cnt && m0 + (a_first + q) * 16 + srow < p.M) alive |= 1u << q;
+    auto stage = [&](int h, int slot) {
+        char* base = smem + slot * H_KS;
+        const int c = (h >> 1) * BK;
+        const bool s2 = c >= p.csplit;
+        const int cc = s2 ? c - p.csplit : c;
+        const int ld = s2 ? ldx2e : p.ldx;
+        const int soff = (cc + (h & 1) * 32) * 2;
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            if (q < a_cnt) {
+                const int st = a_first + q;
+                const unsigned v = ((alive >> q) & 1u) ? (s2 ? va2 : va1) : OOB;
+                if (s2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rX2, (lptr_t)(base + st * 1024), 16, (int)v, soff + st * 16 * ld * 2, 0, 0);
+                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rX, (lptr_t)(base + st * 1024), 16, (int)v, soff + st * 16 * ld * 2, 0, 0);
+            }
+        const int soffw = h * 64;                          // k half h of W's K axis: 32 elements each
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row0 = wave_pair_col<4>(wc, j >> 1) + 4 * (j & 1);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(base + (H_NA + wc * 4 + j) * 1024), 16, (int)vw_pair, soffw + row0 * p.ldw * 2, 0, 0);
+        }
+    };
+
+    f32x4 acc[9][4];
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int fbyte0 = (lane & 15) * 64 + (lane >> 4) * 16;
+    const int fbyte = fbyte0 ^ (((fbyte0 >> 9) & 1) << 5);
+    const char* a_base = smem + fbyte;
+    const char* b_base = smem + (H_NA + wc * 4) * 1024 + fbyte;
+
+    const int NH = 2 * (p.K / BK);                        // k halves (>= 2)
+    stage(0, 0);
+    stage(1, 1);
+    int slot = 0;
+    h16x8 bf[4], a0[3], a1[3];
+#pragma unroll 1
+    for (int h = 0; h < NH; ++h) {
+        if (h + 1 < NH) { if (a_cnt == 3) W_VMCNT(7); else W_VMCNT(6); }
+        else W_VMCNT(0);
+        W_BARRIER();
+        if (h + 2 < NH) stage(h + 2, slot == 0 ? 2 : slot - 1);
+        const char* ab = a_base + slot * H_KS;
+        const char* bb = b_base + slot * H_KS;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const h16x8*>(bb + j * 1024);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) a0[i] = *reinterpret_cast<const h16x8*>(ab + i * 1024);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) a1[i] = *reinterpret_cast<const h16x8*>(ab + (3 + i) * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(bf[j], a0[i], acc[i][j]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) a0[i] = *reinterpret_cast<const h16x8*>(ab + (6 + i) * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[3 + i][j] = mfma16(bf[j], a1[i], acc[3 + i][j]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[6 + i][j] = mfma16(bf[j], a0[i], acc[6 + i][j]);
+        __builtin_amdgcn_sched_barrier(0);
+        slot = slot == 2 ? 0 : slot + 1;
+    }
+    w_epilogue<4, true, 1>(p, acc, m0, n0, tm, 0, wc, lane, tid, tail, phi);
+}
+#endif
+
 // Variant switch GEMM_W288 (debug-variants build; read at every call so that one process can compare kernels): 0 = never, 1 = the rule
 // below, 2 = every eligible problem.
 int variant() { return mudg_variant("GEMM_W288", 1); }
@@ -980,6 +1127,15 @@ int variant() { return mudg_variant("GEMM_W288", 1); }
 
 #if MUDG_PLANES == 1
 static int persistent_grid(const MudgGemmDesc& d);
+// The half-height GEGLU kernel (hgeglu_kernel).  Variant switch GEMM_H144: 0 = never, 1 = the rule, 2 = every GEGLU problem the 288 x 256
+// tile is eligible for (the callers have checked wgemm_eligible: mode 0, N % 256 == 0, K % 64 == 0, 16-byte Y pieces, no residual / group
+// bias / partials).  Same bits as the kernels it replaces, so the rule may look at M.
+static bool half_height_ok(const MudgGemmDesc& d) {
+    const int hv = mudg_variant("GEMM_H144", 1);
+    if (!hv || !d.geglu) return false;
+    if (hv == 2) return true;
+    return true;
+}
 #endif
 // What the kernel can run at all.
 static bool wgemm_eligible(const MudgGemmDesc& d, int vflags) {
@@ -1008,6 +1164,9 @@ bool mudg_wgemm_ok(const MudgGemmDesc& d, int vflags) {
     const int mode = variant();
     if (!mode || !wgemm_eligible(d, vflags)) return false;
     if (mode == 2) return true;
+#if MUDG_PLANES == 1
+    if (d.geglu && half_height_ok(d)) return true;         // (same bits as every other GEGLU kernel: no frame geometry needed)
+#endif
     const int S = d.mode == 1 ? d.Hout * d.Wout : d.HW;
     if (S <= 0 || S % WBM != 0) return false;
     // Measured per shape against the 128 x 128 kernels (tools/exp_w288.py, profiles/r5/w288_shapes.txt; MI355X, frames of whole tiles):
@@ -1019,7 +1178,8 @@ bool mudg_wgemm_ok(const MudgGemmDesc& d, int vflags) {
     if (d.mode != 0 || PLANES == 2) return true;
 #if MUDG_PLANES == 1
     // GEGLU (bit-identical to the persistent 128 x 128 kernel it replaces, so M may decide): + 7 ... + 16 % in the persistent form (more
-    // tiles than CUs) at every K; the one-tile form + 11 % at K = 1280, - 1 % at K = 640, - 5 ... - 12 % at K = 320.
+    // tiles than CUs) at every K; the one-tile form + 11 % at K = 1280, - 1 % at K = 640, - 5 ... - 12 % at K = 320.  Since round 6 the
+    // two-workgroup half-height kernel (hgeglu_kernel) runs GEGLU wherever its rule says so (half_height_ok).
     if (d.geglu && d.K < 640) return persistent_grid(d) > 0;
 #endif
     return true;
@@ -1084,8 +1244,25 @@ static int persistent_grid(const MudgGemmDesc& d) {
 }
 #endif
 
+#if MUDG_PLANES == 1
+static int hgeglu_launch(const MudgGemmDesc& d, int vflags, hipStream_t s) {
+    static bool attr_done[MAX_DEVICES] = {};
+    const int dev = mudg_current_device();
+    if (dev < 0) MUDG_FAIL(MUDG_ELAUNCH, "gemm: no current device");
+    if (!attr_done[dev]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hgeglu_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, H_SMEM);
+        if (e != hipSuccess) MUDG_FAIL(MUDG_ELAUNCH, "gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_done[dev] = true;
+    }
+    const int tiles = ((d.M + 16 * H_NA - 1) / (16 * H_NA)) * (d.N / 256);
+    hipLaunchKernelGGL(hgeglu_kernel, dim3(tiles), dim3(256), H_SMEM, s, d, vflags, mudg_phi_table(false));
+    return mudg_check_launch("mudg_gemm");
+}
+#endif
+
 int mudg_wgemm_launch(const MudgGemmDesc& d, int vflags, hipStream_t s) {
 #if MUDG_PLANES == 1
+    if (d.geglu && half_height_ok(d)) return hgeglu_launch(d, vflags, s);
     if (const int grid = persistent_grid(d))
         return d.geglu ? wgemm_launch_persistent<4, true>(d, vflags, s, 1, grid) : wgemm_launch_persistent<5, false>(d, vflags, s, 0, grid);
 #endif
