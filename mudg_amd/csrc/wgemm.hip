@@ -83,6 +83,7 @@ template <int NREP> struct WGeo {
         __builtin_amdgcn_sched_barrier(0);     \
     } while (0)
 #define W_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+#define H_LGKM0() __builtin_amdgcn_s_waitcnt(0xC07F)        /* s_waitcnt lgkmcnt(0) (vmcnt, expcnt untouched) as the compiler-visible builtin */
 
 __device__ __forceinline__ f32x4 mfma16(h16x8 a, h16x8 b, f32x4 c) {
 #ifdef MUDG_OPERAND_FP16
@@ -997,6 +998,7 @@ constexpr int H_KS = (H_NA + H_NB) * 1024;               // one k half: 25 KiB
 constexpr int H_RING = 3 * H_KS;
 constexpr int H_SMEM = H_RING + ((PHI_N + 1) * 4 + 15) / 16 * 16;
 
+template <bool PF>
 __global__ __launch_bounds__(256, 2) void hgeglu_kernel(const MudgGemmDesc p, const int vflags, const float* __restrict__ phi) {
     constexpr int HBM_ = 16 * H_NA, HBN = 256;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -1075,45 +1077,92 @@ __global__ __launch_bounds__(256, 2) void hgeglu_kernel(const MudgGemmDesc p, co
     const char* a_base = smem + fbyte;
     const char* b_base = smem + (H_NA + wc * 4) * 1024 + fbyte;
 
-    const int NH = 2 * (p.K / BK);                        // k halves (>= 2)
+    const int NH = 2 * (p.K / BK);                        // k halves (>= 2, even)
     stage(0, 0);
     stage(1, 1);
-    int slot = 0;
-    h16x8 bf[4], a0[3], a1[3];
-#pragma unroll 1
-    for (int h = 0; h < NH; ++h) {
-        if (h + 1 < NH) { if (a_cnt == 3) W_VMCNT(7); else W_VMCNT(6); }
+    auto wait_landed = [&](bool more) {                   // this wave's pieces of the k half about to be read: all but the a_cnt + 4 of the next one
+        if (more) { if (a_cnt == 3) W_VMCNT(7); else W_VMCNT(6); }
         else W_VMCNT(0);
+    };
+    auto mma3 = [&](auto third_tag, const h16x8 (&b)[4], const h16x8 (&a)[3]) {
+        constexpr int third = decltype(third_tag)::value;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[third * 3 + i][j] = mfma16(b[j], a[i], acc[third * 3 + i][j]);
+    };
+    auto read_b = [&](h16x8 (&dst)[4], int sl) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dst[j] = *reinterpret_cast<const h16x8*>(b_base + sl * H_KS + j * 1024);
+    };
+    auto read_a = [&](h16x8 (&dst)[3], int sl, int third) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) dst[i] = *reinterpret_cast<const h16x8*>(a_base + sl * H_KS + (third * 3 + i) * 1024);
+    };
+    using T0 = std::integral_constant<int, 0>; using T1 = std::integral_constant<int, 1>; using T2 = std::integral_constant<int, 2>;
+    if constexpr (!PF) {
+        int slot = 0;
+        h16x8 bf[4], a0[3], a1[3];
+#pragma unroll 1
+        for (int h = 0; h < NH; ++h) {
+            wait_landed(h + 1 < NH);
+            W_BARRIER();
+            if (h + 2 < NH) stage(h + 2, slot == 0 ? 2 : slot - 1);
+            read_b(bf, slot); read_a(a0, slot, 0); read_a(a1, slot, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma3(T0{}, bf, a0);
+            __builtin_amdgcn_sched_barrier(0);
+            read_a(a0, slot, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            mma3(T1{}, bf, a1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma3(T2{}, bf, a0);
+            __builtin_amdgcn_sched_barrier(0);
+            slot = slot == 2 ? 0 : slot + 1;
+        }
+    } else {
+        // The same ring with the NEXT k half's first fragments (W, X rows 0-2) requested before the last row third of this one is
+        // multiplied: the wait for the next k half, the barrier and the DMA issue sit between the second and the third row third, and a
+        // wave never starts a k half by waiting for its own ds_reads.  W fragments alternate between two register sets (k halves come in
+        // pairs), X fragments rotate through three.
+        h16x8 bA[4], bB[4], ax[3], ay[3], az[3];
+        wait_landed(true);
         W_BARRIER();
-        if (h + 2 < NH) stage(h + 2, slot == 0 ? 2 : slot - 1);
-        const char* ab = a_base + slot * H_KS;
-        const char* bb = b_base + slot * H_KS;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bf[j] = *reinterpret_cast<const h16x8*>(bb + j * 1024);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) a0[i] = *reinterpret_cast<const h16x8*>(ab + i * 1024);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) a1[i] = *reinterpret_cast<const h16x8*>(ab + (3 + i) * 1024);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(bf[j], a0[i], acc[i][j]);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) a0[i] = *reinterpret_cast<const h16x8*>(ab + (6 + i) * 1024);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[3 + i][j] = mfma16(bf[j], a1[i], acc[3 + i][j]);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[6 + i][j] = mfma16(bf[j], a0[i], acc[6 + i][j]);
-        __builtin_amdgcn_sched_barrier(0);
-        slot = slot == 2 ? 0 : slot + 1;
+        if (NH > 2) stage(2, 2);
+        read_b(bA, 0); read_a(ax, 0, 0);
+        int slot = 0;                                      // slot of k half h
+        // Every wait is a FULL lgkmcnt(0) for fragments requested one MFMA group (12 MFMAs, ~200 cycles) earlier, placed BEFORE the next
+        // group's reads are issued — the builtin (not inline asm), so that the compiler's own wait insertion knows the fragments have
+        // arrived and adds nothing after the reads (its counted waits merge conservatively across the `last k half` branch).
+        auto half = [&](int h, const h16x8 (&bc)[4], h16x8 (&bn)[4]) {
+            const int nslot = slot == 2 ? 0 : slot + 1;
+            H_LGKM0();                                     // W fragments and X rows 0-2 of this k half
+            read_a(ay, slot, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma3(T0{}, bc, ax);
+            __builtin_amdgcn_sched_barrier(0);
+            H_LGKM0();                                     // X rows 3-5
+            read_a(az, slot, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            mma3(T1{}, bc, ay);
+            __builtin_amdgcn_sched_barrier(0);
+            H_LGKM0();                                     // X rows 6-8: every read of this k half has returned, its slot may be re-staged
+            if (h + 1 < NH) {
+                wait_landed(h + 2 < NH);
+                W_BARRIER();
+                if (h + 3 < NH) stage(h + 3, slot);
+                read_b(bn, nslot); read_a(ax, nslot, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mma3(T2{}, bc, az);
+            __builtin_amdgcn_sched_barrier(0);
+            slot = nslot;
+        };
+#pragma unroll 1
+        for (int h = 0; h < NH; h += 2) {
+            half(h, bA, bB);
+            half(h + 1, bB, bA);
+        }
     }
     w_epilogue<4, true, 1>(p, acc, m0, n0, tm, 0, wc, lane, tid, tail, phi);
 }
@@ -1245,18 +1294,23 @@ static int persistent_grid(const MudgGemmDesc& d) {
 #endif
 
 #if MUDG_PLANES == 1
-static int hgeglu_launch(const MudgGemmDesc& d, int vflags, hipStream_t s) {
+template <bool PF>
+static int hgeglu_launch_one(const MudgGemmDesc& d, int vflags, hipStream_t s) {
     static bool attr_done[MAX_DEVICES] = {};
     const int dev = mudg_current_device();
     if (dev < 0) MUDG_FAIL(MUDG_ELAUNCH, "gemm: no current device");
     if (!attr_done[dev]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hgeglu_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, H_SMEM);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hgeglu_kernel<PF>), hipFuncAttributeMaxDynamicSharedMemorySize, H_SMEM);
         if (e != hipSuccess) MUDG_FAIL(MUDG_ELAUNCH, "gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_done[dev] = true;
     }
     const int tiles = ((d.M + 16 * H_NA - 1) / (16 * H_NA)) * (d.N / 256);
-    hipLaunchKernelGGL(hgeglu_kernel, dim3(tiles), dim3(256), H_SMEM, s, d, vflags, mudg_phi_table(false));
+    hipLaunchKernelGGL(hgeglu_kernel<PF>, dim3(tiles), dim3(256), H_SMEM, s, d, vflags, mudg_phi_table(false));
     return mudg_check_launch("mudg_gemm");
+}
+// Variant switch GEMM_H144PF (measurements): 0 = the plain loop (every k half starts with its own fragment reads), 1 = the prefetching loop.
+static int hgeglu_launch(const MudgGemmDesc& d, int vflags, hipStream_t s) {
+    return mudg_variant("GEMM_H144PF", 1) ? hgeglu_launch_one<true>(d, vflags, s) : hgeglu_launch_one<false>(d, vflags, s);
 }
 #endif
 

@@ -119,16 +119,29 @@ class ChildRuns:
 
     def __init__(self, workers):
         from concurrent.futures import ThreadPoolExecutor
-        self.pool = ThreadPoolExecutor(max_workers=1 if os.environ.get("MUDG_CHILDREN_SERIAL") == "1" else workers)
+        self.workers = 1 if os.environ.get("MUDG_CHILDREN_SERIAL") == "1" else workers
+        self.pool = ThreadPoolExecutor(max_workers=self.workers)
         self.futures, self.procs, self.cancelled = {}, [], False
+        # The children's reference arithmetic is torch on the host: each child gets its share of the cores.  (Six children with the
+        # default of one OpenMP thread per core each — 768 spinning threads on 128 cores — ran the variant block FORTY times slower
+        # than one after the other: round-6 log, gpurun_out/r6/gpu_tests_1.txt.)
+        self.threads = max(2, (os.cpu_count() or 8) // self.workers)
 
-    def submit(self, key, cmd, cwd, env, timeout):
+    def submit(self, key, cmd, cwd, env, timeout, alone=False):
+        """alone=True: nothing else starts before this child has finished — the first child of a module runs so, and leaves warm
+        on-disk caches (MIOpen's kernel database for the torch references, compiled-kernel caches) to the ones that follow instead
+        of having all of them build and lock the same files at once."""
         import subprocess
+        import time
 
         def run():
             if self.cancelled:
                 return -999, "cancelled"
-            proc = subprocess.Popen(cmd, cwd=cwd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            child_env = dict(env)
+            if self.workers > 1:
+                child_env.update(OMP_NUM_THREADS=str(self.threads), MKL_NUM_THREADS=str(self.threads), OMP_WAIT_POLICY="PASSIVE")
+            t0 = time.time()
+            proc = subprocess.Popen(cmd, cwd=cwd, env=child_env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
             self.procs.append(proc)
             try:
                 out, _ = proc.communicate(timeout=timeout)
@@ -136,10 +149,24 @@ class ChildRuns:
                 proc.kill()
                 out, _ = proc.communicate()
                 return -998, out + f"\n[timed out after {timeout} s]"
-            return proc.returncode, out
+            return proc.returncode, out + f"\n[child {key}: {time.time() - t0:.0f} s wall, started {t0 - self.t0:.0f} s after the first]"
 
-        if key not in self.futures:
-            self.futures[key] = self.pool.submit(run)
+        if key in self.futures:
+            return
+        if not self.futures:
+            self.t0 = time.time()
+        if alone:
+            fut = self.pool.submit(run)
+            self.barrier = fut
+            self.futures[key] = fut
+        else:
+            gate = getattr(self, "barrier", None)
+
+            def gated():
+                if gate is not None:
+                    gate.result()
+                return run()
+            self.futures[key] = self.pool.submit(gated)
 
     def result(self, key):
         return self.futures[key].result()

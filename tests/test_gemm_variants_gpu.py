@@ -43,13 +43,13 @@ _name = lambda e: ",".join(f"{k[5:]}={v}" for k, v in e.items())
 
 @pytest.fixture(scope="module")
 def children():
-    """All variant children of this module, six at a time (helpers.ChildRuns)."""
+    """All variant children of this module, four at a time (helpers.ChildRuns)."""
     from helpers import ChildRuns
-    runs = ChildRuns(workers=6)
-    for env in VARIANTS:
+    runs = ChildRuns(workers=4)
+    for i, env in enumerate(VARIANTS):
         runs.submit(_name(env), [sys.executable, "-m", "pytest", "tests/test_kernels_gpu.py", "tests/test_operand_modes_gpu.py", "tests/test_unet_gpu.py",
                                  "-m", "gpu", "-q", "-k", SELECT, "-p", "no:cacheprovider"],
-                    ROOT, dict(os.environ, MUDG_DEBUG_VARIANTS="1", **env), 900)
+                    ROOT, dict(os.environ, MUDG_DEBUG_VARIANTS="1", **env), 900, alone=(i == 0))
     for env in VARIANTS_X3:
         runs.submit("x3:" + _name(env), [sys.executable, "-m", "pytest", "tests/test_operand_modes_gpu.py", "tests/test_unet_gpu.py", "-m", "gpu", "-q",
                                          "-p", "no:cacheprovider"],
@@ -64,7 +64,7 @@ def test_kernel_parity_under_variant(cuda, env, request):
     if os.environ.get("MUDG_DEBUG_VARIANTS") == "1":
         pytest.skip("already running under a variant switch")
     rc, stdout = request.getfixturevalue("children").result(_name(env))
-    print("\n".join(l for l in stdout.splitlines() if "passed" in l or "failed" in l))
+    print("\n".join(l for l in stdout.splitlines() if "passed" in l or "failed" in l or l.startswith("[child")))
     assert rc == 0, stdout[-5000:]
 
 
@@ -73,5 +73,5 @@ def test_kernel_parity_under_variant_in_the_bf16x3_build(cuda, env, request):
     if os.environ.get("MUDG_DEBUG_VARIANTS") == "1" or os.environ.get("MUDG_PARITY_CHILD") == "1":
         pytest.skip("already running under a variant switch / inside a mode child")
     rc, stdout = request.getfixturevalue("children").result("x3:" + _name(env))
-    print("\n".join(l for l in stdout.splitlines() if "passed" in l or "failed" in l))
+    print("\n".join(l for l in stdout.splitlines() if "passed" in l or "failed" in l or l.startswith("[child")))
     assert rc == 0, stdout[-5000:]

@@ -65,5 +65,5 @@ def test_parity_suites_in_operand_mode(cuda, mode, request):
     if os.environ.get("MUDG_PARITY_CHILD") == "1":
         pytest.skip("already inside a mode child")
     rc, stdout = request.getfixturevalue("children").result(mode)
-    print("\n".join(l for l in stdout.splitlines() if "rel-L2" in l or "passed" in l or "failed" in l))
+    print("\n".join(l for l in stdout.splitlines() if "rel-L2" in l or "passed" in l or "failed" in l or l.startswith("[child")))
     assert rc == 0, stdout[-6000:]

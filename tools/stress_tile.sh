@@ -9,7 +9,7 @@ rc=0
 run() {  # name, env...
     local name=$1; shift
     echo "== $name" | tee -a "$OUT/stress_summary.txt"
-    ( env "$@" timeout 1500 python tools/stress_tile.py --launches "$N" --seed "$SEED" > "$OUT/stress_$name.log" 2>&1 ) || rc=1
+    ( env "$@" timeout ${STRESS_TIMEOUT:-1500} python tools/stress_tile.py --launches "$N" --seed "$SEED" > "$OUT/stress_$name.log" 2>&1 ) || rc=1
     grep -E "DONE|FAIL|Error|error|abort" "$OUT/stress_$name.log" | head -20 | tee -a "$OUT/stress_summary.txt"
 }
 SEED=1 run bf16_default MUDG_OPERAND=bf16
