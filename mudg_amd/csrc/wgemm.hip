@@ -156,17 +156,17 @@ template <int NREP> __device__ __forceinline__ int wave_single_col(int wc) { ret
 // 102 -> 83, 18432 x 2560 x 1280 135 -> 121).  The
 // sum is ((r + x w) + bias) instead of ((x w + bias) + r): not the bits of the 128 x 128 one-tile kernels, so whether a problem with a
 // residual runs here never depends on M (mudg_wgemm_ok).
-template <int NREP>
-__device__ __forceinline__ void w_seed(const MudgGemmDesc& p, f32x4 (&acc)[9][NREP], const int m0, const int n0, const int wr, const int wc, const int lane) {
+template <int NREP, int NI>
+__device__ __forceinline__ void w_seed(const MudgGemmDesc& p, f32x4 (&acc)[NI][NREP], const int m0, const int n0, const int wr, const int wc, const int lane) {
     constexpr int NPAIR = NREP / 2;
     const int px = lane & 15, q4 = lane >> 4;
     const int RK = p.res_fp32;
-    const int64_t mrow = (int64_t)m0 + wr * 144 + px;
+    const int64_t mrow = (int64_t)m0 + wr * (16 * NI) + px;
     const int np = n0 + 8 * q4, ns = n0 + wave_single_col<NREP>(wc) + 4 * q4;
     if (RK == KIND_F32) {
         const float* R = reinterpret_cast<const float*>(p.R);
 #pragma unroll
-        for (int i = 0; i < 9; ++i) {
+        for (int i = 0; i < NI; ++i) {
             const int64_t m = mrow + 16 * i;
             const bool live = m < p.M;
 #pragma unroll
@@ -179,10 +179,10 @@ __device__ __forceinline__ void w_seed(const MudgGemmDesc& p, f32x4 (&acc)[9][NR
         }
     } else if (RK == KIND_F16 || PLANES == 1) {           // 16-bit storage: the fp16 stream or a one-piece operand matrix
         const char* R = reinterpret_cast<const char*>(p.R);
-        u32x4 ra[9][NPAIR];
-        u32x2 rs[9];
+        u32x4 ra[NI][NPAIR];
+        u32x2 rs[NI];
 #pragma unroll
-        for (int i = 0; i < 9; ++i) {
+        for (int i = 0; i < NI; ++i) {
             const int64_t m = mrow + 16 * i;
             const bool live = m < p.M;
 #pragma unroll
@@ -190,7 +190,7 @@ __device__ __forceinline__ void w_seed(const MudgGemmDesc& p, f32x4 (&acc)[9][NR
             rs[i] = (live && (NREP & 1)) ? *reinterpret_cast<const u32x2*>(R + (m * p.ldr + ns) * 2) : u32x2{0u, 0u};
         }
 #pragma unroll
-        for (int i = 0; i < 9; ++i) {
+        for (int i = 0; i < NI; ++i) {
 #pragma unroll
             for (int P = 0; P < NPAIR; ++P) {
                 if (RK == KIND_F16) {
@@ -218,7 +218,7 @@ __device__ __forceinline__ void w_seed(const MudgGemmDesc& p, f32x4 (&acc)[9][NR
     } else {                                              // an operand matrix of the bf16x3 build: the sum of its pieces
         const h16* R = reinterpret_cast<const h16*>(p.R);
 #pragma unroll
-        for (int i = 0; i < 9; ++i) {
+        for (int i = 0; i < NI; ++i) {
             const int64_t m = mrow + 16 * i;
             const bool live = m < p.M;
 #pragma unroll
@@ -243,15 +243,15 @@ __device__ __forceinline__ void w_seed(const MudgGemmDesc& p, f32x4 (&acc)[9][NR
 // GroupNorm partials, stored.  A residual is already in the accumulators (w_seed): the epilogue fetches nothing.
 // LUT: how the Phi table lies in `tail` — 2 = (value, step) pairs (gelu_lut2, 8 KiB), 1 = plain values (gelu_lut, 4 KiB: the two-workgroup
 // kernel below has no room for the pairs); the same bits either way (the step is the same fp32 difference, taken once or per value).
-template <int NREP, bool GEGLU, int LUT = 2>
-__device__ __forceinline__ void w_epilogue(const MudgGemmDesc& p, f32x4 (&acc)[9][NREP], const int m0, const int n0, const int tm, const int wr, const int wc,
+template <int NREP, bool GEGLU, int LUT = 2, int NI = 9>
+__device__ __forceinline__ void w_epilogue(const MudgGemmDesc& p, f32x4 (&acc)[NI][NREP], const int m0, const int n0, const int tm, const int wr, const int wc,
                                            const int lane, const int tid, float* tail, const float* __restrict__ phi) {
     constexpr int WBN = 64 * NREP, NPAIR = NREP / 2;
     using T0 = std::integral_constant<int, 0>; using T1 = std::integral_constant<int, 1>;
     const int px = lane & 15, q4 = lane >> 4;
     const float alpha = p.alpha;
     const int OK = p.out_fp32;
-    const int64_t mrow = (int64_t)m0 + wr * 144 + px;    // row of i = 0
+    const int64_t mrow = (int64_t)m0 + wr * (16 * NI) + px;    // row of i = 0
     float* sred = tail;                                  // [M half][tile column][2]: GroupNorm partials meet here
     const f32x2* phis = reinterpret_cast<const f32x2*>(tail);      // GEGLU: the Phi table as pairs
     const int64_t gb0 = p.gbias ? (int64_t)(m0 / p.rows_per_group) * p.N : 0;          // host-checked: one group per tile
@@ -271,7 +271,7 @@ __device__ __forceinline__ void w_epilogue(const MudgGemmDesc& p, f32x4 (&acc)[9
 #pragma unroll
         for (int e = 0; e < 8; ++e) { gs[e] = 0.f; gq[e] = 0.f; }
 #pragma unroll
-        for (int i = 0; i < 9; ++i) {
+        for (int i = 0; i < NI; ++i) {
             const int64_t m = mrow + 16 * i;
             const bool live = m < p.M;
             float v[8];
@@ -331,7 +331,7 @@ __device__ __forceinline__ void w_epilogue(const MudgGemmDesc& p, f32x4 (&acc)[9
 #pragma unroll
         for (int e = 0; e < 4; ++e) { gs[e] = 0.f; gq[e] = 0.f; }
 #pragma unroll
-        for (int i = 0; i < 9; ++i) {
+        for (int i = 0; i < NI; ++i) {
             const int64_t m = mrow + 16 * i;
             const bool live = m < p.M;
             float v[4];
@@ -510,7 +510,7 @@ __global__ __launch_bounds__(512, 2) void wgemm_kernel(const MudgGemmDesc p, con
         k.c = slab ? (wrap ? c1 : k.c) : (wrap ? 0 : c1);
     };
     f32x4 acc[9][NREP];
-    if (!GEGLU && p.R) w_seed<NREP>(p, acc, m0, n0, wr, wc, lane);
+    if (!GEGLU && p.R) w_seed<NREP, 9>(p, acc, m0, n0, wr, wc, lane);
     else {
 #pragma unroll
         for (int i = 0; i < 9; ++i)
@@ -999,10 +999,20 @@ constexpr int H_RING = 3 * H_KS;
 constexpr int H_SMEM = H_RING + ((PHI_N + 1) * 4 + 15) / 16 * 16;
 
 template <bool PF>
-__global__ __launch_bounds__(256, 2) void hgeglu_kernel(const MudgGemmDesc p, const int vflags, const float* __restrict__ phi) {
+__global__ __launch_bounds__(256, 2) void hgeglu_kernel(const MudgGemmDesc p, const int vflags, const float* __restrict__ phi, const int first_round, const int delay) {
     constexpr int HBM_ = 16 * H_NA, HBN = 256;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
+    // ANTI-PHASE START.  All workgroups of a launch take the same time, and the two that share a CU start together: left alone they run
+    // in lockstep for the whole launch — both fetching, both multiplying, both in the epilogue at the same moments — and a CU with two
+    // workgroups behaves like one with a single twice as large.  The workgroup that got the SECOND wave slot of its SIMDs in the first
+    // round of the launch (HW_ID.wave_id odd) therefore starts `delay` x 8128 cycles late; every later workgroup inherits the phase of the
+    // one whose slot it takes over.
+    if (delay > 0 && (int)blockIdx.x < first_round) {
+        const unsigned hw = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4);      // HW_REG_HW_ID (4), offset 0, width 4: wave_id
+        if (hw & 1u)
+            for (int i = 0; i < delay; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     const int wc = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave = wave column: 64 of the tile's 256 W rows
     float* tail = reinterpret_cast<float*>(smem + H_RING);
     if (phi) for (int t = tid; t <= PHI_N; t += 256) tail[t] = phi[t];        // visible after the K loop's barriers
@@ -1305,7 +1315,14 @@ static int hgeglu_launch_one(const MudgGemmDesc& d, int vflags, hipStream_t s) {
         attr_done[dev] = true;
     }
     const int tiles = ((d.M + 16 * H_NA - 1) / (16 * H_NA)) * (d.N / 256);
-    hipLaunchKernelGGL(hgeglu_kernel<PF>, dim3(tiles), dim3(256), H_SMEM, s, d, vflags, mudg_phi_table(false));
+    static int cus[MAX_DEVICES] = {};
+    if (!cus[dev]) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
+        cus[dev] = n;
+    }
+    const int delay = mudg_variant("GEMM_H144DELAY", 0);
+    hipLaunchKernelGGL(hgeglu_kernel<PF>, dim3(tiles), dim3(256), H_SMEM, s, d, vflags, mudg_phi_table(false), 2 * cus[dev], delay);
     return mudg_check_launch("mudg_gemm");
 }
 // Variant switch GEMM_H144PF (measurements): 0 = the plain loop (every k half starts with its own fragment reads), 1 = the prefetching loop.

@@ -51,4 +51,25 @@ if what in ("time", "all"):
         fl = 2.0 * M * N * K
         print(f"geglu {M} {N} {K}: round-5 rule {ts[0]*1e6:8.1f} us {fl/ts[0]/1e12:7.1f} TF | 288x256 one-tile {ts[1]*1e6:8.1f} us | 144x256 x2 {ts[2]*1e6:8.1f} us "
               f"{fl/ts[2]/1e12:7.1f} TF  x{ts[0]/ts[2]:.3f}", flush=True)
+if what == "delay":
+    # the anti-phase start of the two workgroups of a CU (GEMM_H144DELAY, units of 8128 cycles)
+    for (M, N, K, hw) in [(294912, 2560, 320, 9216), (73728, 5120, 640, 2304), (18432, 10240, 1280, 576), (81920, 2560, 320, 2560)]:
+        x, w, b = rn(M, K), rn(N, K), torch.randn(N, device="cuda")
+        line = f"geglu {M} {N} {K}:"
+        setv("1", "0")
+        line += f" round-5 rule {timeit(lambda: ops.gemm(x, w, bias=b, geglu=True, frame_rows=hw), iters=20)*1e6:7.1f} us |"
+        setv("2", "2")
+        for d in (0, 1, 2, 3, 4, 6):
+            os.environ["MUDG_GEMM_H144DELAY"] = str(d)
+            line += f" delay {d}: {timeit(lambda: ops.gemm(x, w, bias=b, geglu=True, frame_rows=hw), iters=20)*1e6:7.1f}"
+        print(line, flush=True)
+if what == "one":
+    # one launch per form of the level-0 shape, for rocprofv3 --pmc (read the LAST dispatch of each kernel)
+    M, N, K, hw = 294912, 2560, 320, 9216
+    x, w, b = rn(M, K), rn(N, K), torch.randn(N, device="cuda")
+    for name, v, h in (("rule-r5", "1", "0"), ("h144", "2", "2")):
+        setv(v, h)
+        for _ in range(3):
+            ops.gemm(x, w, bias=b, geglu=True, frame_rows=hw)
+        torch.cuda.synchronize()
 setv("1", "1")
