@@ -621,11 +621,20 @@ __global__ __launch_bounds__(G::NTH, G::WIDE ? 2 : ((SB && !fused_planes(FAST)) 
                     for (int g = 0; g < 4; ++g) {
                         const int nb = q * 128 + wn * 64 + 8 * g + 4 * hi;                 // value columns inside the tile
                         f32x4 v;
+                        float gate[4];
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
-                            const float val = alpha * acc[2 * q][mi][4 * g + j] + sbias[nb + j];
-                            const float gate = alpha * acc[2 * q + 1][mi][4 * g + j] + sbias[nb + 32 + j];
-                            v[j] = val * (phi ? gelu_lut(gate, phis) : gelu_fast(gate));
+                            v[j] = alpha * acc[2 * q][mi][4 * g + j] + sbias[nb + j];
+                            gate[j] = alpha * acc[2 * q + 1][mi][4 * g + j] + sbias[nb + 32 + j];
+                        }
+                        // (table or polynomial: decided per group, not inside the per-value expression — there the compiler kept a branch
+                        // and a serialised LDS round trip per value; wgemm.hip, w_epilogue)
+                        if (phi) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] *= gelu_lut(gate[j], phis);
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] *= gelu_fast(gate[j]);
                         }
                         *reinterpret_cast<f32x4*>(&stg[ml * WSTG + wn * 32 + 8 * g + 4 * hi]) = v;
                     }
@@ -839,11 +848,21 @@ __global__ __launch_bounds__(G::NTH, G::WIDE ? 2 : ((SB && !fused_planes(FAST)) 
             for (int g = 0; g < 4; ++g) {
                 const int nl = wn * (32 * NI) + q * 64 + 8 * g + 4 * hi;      // value columns of pair q; its gates sit 32 further
                 f32x4 v;
+                float gate[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float val = alpha * acc[2 * q][mi][4 * g + j] + sbias[nl + j];
-                    const float gate = alpha * acc[2 * q + 1][mi][4 * g + j] + sbias[nl + 32 + j];
-                    v[j] = val * (PLANES > 2 ? gelu_erf_f(gate) : (phi ? gelu_lut(gate, phis) : gelu_fast(gate)));
+                    v[j] = alpha * acc[2 * q][mi][4 * g + j] + sbias[nl + j];
+                    gate[j] = alpha * acc[2 * q + 1][mi][4 * g + j] + sbias[nl + 32 + j];
+                }
+                if (PLANES > 2) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] *= gelu_erf_f(gate[j]);
+                } else if (phi) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] *= gelu_lut(gate[j], phis);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] *= gelu_fast(gate[j]);
                 }
                 *reinterpret_cast<f32x4*>(&stg[ml * STGLD + wn * (16 * NI) + q * 32 + 8 * g + 4 * hi]) = v;
             }

@@ -436,10 +436,15 @@ __global__ __launch_bounds__(256, FUSEDP ? 2 : WGS) void pgemm_kernel(const Mudg
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = alpha * acc[GEGLU ? 0 : NIX][mi][8 * Q + j] + bv[j];
                 if constexpr (GEGLU) {
+                    float gate[8];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float gate = alpha * acc[1][mi][8 * Q + j] + bg[j];
-                        v[j] *= phi ? gelu_lut(gate, phis) : gelu_fast(gate);
+                    for (int j = 0; j < 8; ++j) gate[j] = alpha * acc[1][mi][8 * Q + j] + bg[j];
+                    if (phi) {                            // (decided per row, not per value: wgemm.hip, w_epilogue)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] *= gelu_lut(gate[j], phis);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] *= gelu_fast(gate[j]);
                     }
                 } else if (RS && p.stats) {
                     // partial sums over what is stored: the lane's two rows here, the 32 pixels of the half-wave below

@@ -243,7 +243,8 @@ __device__ __forceinline__ void w_seed(const MudgGemmDesc& p, f32x4 (&acc)[NI][N
 // GroupNorm partials, stored.  A residual is already in the accumulators (w_seed): the epilogue fetches nothing.
 // LUT: how the Phi table lies in `tail` — 2 = (value, step) pairs (gelu_lut2, 8 KiB), 1 = plain values (gelu_lut, 4 KiB: the two-workgroup
 // kernel below has no room for the pairs); the same bits either way (the step is the same fp32 difference, taken once or per value).
-template <int NREP, bool GEGLU, int LUT = 2, int NI = 9>
+// UASPEC = false: no alpha == 1 copy of the plain epilogue (the persistent plain kernel has no registers for two).
+template <int NREP, bool GEGLU, int LUT = 2, bool UASPEC = true, int NI = 9>
 __device__ __forceinline__ void w_epilogue(const MudgGemmDesc& p, f32x4 (&acc)[NI][NREP], const int m0, const int n0, const int tm, const int wr, const int wc,
                                            const int lane, const int tid, float* tail, const float* __restrict__ phi) {
     constexpr int WBN = 64 * NREP, NPAIR = NREP / 2;
@@ -256,8 +257,13 @@ __device__ __forceinline__ void w_epilogue(const MudgGemmDesc& p, f32x4 (&acc)[N
     const f32x2* phis = reinterpret_cast<const f32x2*>(tail);      // GEGLU: the Phi table as pairs
     const int64_t gb0 = p.gbias ? (int64_t)(m0 / p.rows_per_group) * p.N : 0;          // host-checked: one group per tile
 
-    auto piece8 = [&](auto ptag) __attribute__((always_inline)) {
+    // uatag: alpha == 1 (the product is not scaled: one v_add instead of v_mul + v_add per value, the same bits); tabtag: GEGLU's Phi from the
+    // table.  Both are decided ONCE per tile, outside the loops: with `phi ? table : polynomial` inside the per-value expression the
+    // compiler kept a branch per value and every table read was followed by its own s_waitcnt — 72 serialised LDS round trips per lane,
+    // the longest part of a K = 320 tile (round 6: profiles/r6/geglu_epilogue.md).  Here a row's eight reads are in flight together.
+    auto piece8 = [&](auto ptag, auto uatag, auto tabtag) __attribute__((always_inline)) {
         constexpr int P = decltype(ptag)::value;         // fragment pair: accumulator fragments 2 P (channels + 0..3) and 2 P + 1 (+ 4..7)
+        constexpr bool UA = decltype(uatag)::value != 0, TAB = decltype(tabtag)::value != 0;
         const int cw = n0 + wave_pair_col<NREP>(wc, GEGLU ? 0 : P) + 8 * q4;          // first W row (bias index) of the value
         const int n = GEGLU ? (n0 >> 1) + wc * 32 + 8 * q4 : cw;                        // first output channel
         float bv[8], bg[8];
@@ -276,15 +282,38 @@ __device__ __forceinline__ void w_epilogue(const MudgGemmDesc& p, f32x4 (&acc)[N
             const bool live = m < p.M;
             float v[8];
             if constexpr (GEGLU) {
+                float val[8], gate[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float val = alpha * acc[i][e >> 2][e & 3] + bv[e];
-                    const float gate = alpha * acc[i][2 + (e >> 2)][e & 3] + bg[e];
-                    v[e] = val * (phi ? (PLANES == 2 ? gelu_hermite(gate, phis) : (LUT == 1 ? gelu_lut(gate, tail) : gelu_lut2(gate, phis))) : gelu_fast(gate));
+                    const float a = acc[i][e >> 2][e & 3], b = acc[i][2 + (e >> 2)][e & 3];
+                    val[e] = UA ? a + bv[e] : alpha * a + bv[e];
+                    gate[e] = UA ? b + bg[e] : alpha * b + bg[e];
+                }
+                if constexpr (!TAB) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = val[e] * gelu_fast(gate[e]);
+                } else if constexpr (PLANES == 2) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = val[e] * gelu_hermite(gate[e], phis);
+                } else if constexpr (LUT == 1) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = val[e] * gelu_lut(gate[e], tail);
+                } else {                                  // gelu_lut2 in stages: eight indices, eight reads, eight interpolations
+                    float u[8];
+                    f32x2 t[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) u[e] = __builtin_amdgcn_fmed3f(fmaf(gate[e], 64.0f, 512.0f), 0.0f, 1023.99f);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) t[e] = phis[(int)u[e]];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = val[e] * (gate[e] * fmaf(__builtin_amdgcn_fractf(u[e]), t[e][1], t[e][0]));
                 }
             } else {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = alpha * acc[i][2 * P + (e >> 2)][e & 3] + bv[e];
+                for (int e = 0; e < 8; ++e) {
+                    const float a = acc[i][2 * P + (e >> 2)][e & 3];
+                    v[e] = UA ? a + bv[e] : alpha * a + bv[e];
+                }
             }
             if (!GEGLU && p.stats) {
 #pragma unroll
@@ -318,8 +347,9 @@ __device__ __forceinline__ void w_epilogue(const MudgGemmDesc& p, f32x4 (&acc)[N
         }
     };
     // the unpaired fifth fragment of the 320-wide tile: 4 consecutive channels per lane (8-byte operand / fp16 pieces)
-    auto piece4 = [&]() __attribute__((always_inline)) {
+    auto piece4 = [&](auto uatag) __attribute__((always_inline)) {
         constexpr int J = 2 * NPAIR;
+        constexpr bool UA = decltype(uatag)::value != 0;
         const int n = n0 + wave_single_col<NREP>(wc) + 4 * q4;
         float bv[4];
 #pragma unroll
@@ -336,7 +366,7 @@ __device__ __forceinline__ void w_epilogue(const MudgGemmDesc& p, f32x4 (&acc)[N
             const bool live = m < p.M;
             float v[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = alpha * acc[i][J < NREP ? J : 0][e] + bv[e];
+            for (int e = 0; e < 4; ++e) { const float a = acc[i][J < NREP ? J : 0][e]; v[e] = UA ? a + bv[e] : alpha * a + bv[e]; }
             if (p.stats) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -377,12 +407,20 @@ __device__ __forceinline__ void w_epilogue(const MudgGemmDesc& p, f32x4 (&acc)[N
             }
         }
     };
+    const bool ua = UASPEC && alpha == 1.f;
     if constexpr (GEGLU) {
-        piece8(T0{});
+        if (phi) { if (ua) piece8(T0{}, T1{}, T1{}); else piece8(T0{}, T0{}, T1{}); }
+        else { if (ua) piece8(T0{}, T1{}, T0{}); else piece8(T0{}, T0{}, T0{}); }
     } else {
-        piece8(T0{});
-        if constexpr (NPAIR > 1) piece8(T1{});
-        if constexpr (NREP & 1) piece4();
+        if (ua) {
+            piece8(T0{}, T1{}, T0{});
+            if constexpr (NPAIR > 1) piece8(T1{}, T1{}, T0{});
+            if constexpr (NREP & 1) piece4(T1{});
+        } else {
+            piece8(T0{}, T0{}, T0{});
+            if constexpr (NPAIR > 1) piece8(T1{}, T0{}, T0{});
+            if constexpr (NREP & 1) piece4(T0{});
+        }
         if (p.stats) {
             // per 288-row block (= this tile) and channel: M half 0 + M half 1
             __syncthreads();
@@ -963,7 +1001,7 @@ __global__ __launch_bounds__(512, 2) void wgemm_pkernel(const MudgGemmDesc p, co
         }
         if (wr == 0) W_BARRIER();                          // evens out the stagger
         __builtin_amdgcn_sched_barrier(0);
-        w_epilogue<NREP, GEGLU>(p, acc, cur.m0, cur.n0, cur.tm, wr, wc, lane, tid, tail, phi);
+        w_epilogue<NREP, GEGLU, 2, GEGLU>(p, acc, cur.m0, cur.n0, cur.tm, wr, wc, lane, tid, tail, phi);
         __builtin_amdgcn_sched_barrier(0);
         if (!has_next) break;
         cur = nxt;
