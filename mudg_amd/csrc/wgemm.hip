@@ -83,6 +83,13 @@ template <int NREP> struct WGeo {
         __builtin_amdgcn_sched_barrier(0);     \
     } while (0)
 #define W_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+// Debug-variants build only: s_memtime stamps of wave 0 of every workgroup at the phase boundaries of the GEGLU kernels (tools/exp_stamps.py).
+#ifdef MUDG_DEBUG_VARIANTS
+__device__ unsigned long long* g_stamps = nullptr;         // [workgroup][64]
+#define W_STAMP(slot) do { if (tid == 0 && g_stamps && (slot) < 64) g_stamps[(size_t)blockIdx.x * 64 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define W_STAMP(slot) do { } while (0)
+#endif
 #define H_LGKM0() __builtin_amdgcn_s_waitcnt(0xC07F)        /* s_waitcnt lgkmcnt(0) (vmcnt, expcnt untouched) as the compiler-visible builtin */
 
 __device__ __forceinline__ f32x4 mfma16(h16x8 a, h16x8 b, f32x4 c) {
@@ -945,6 +952,8 @@ __global__ __launch_bounds__(512, 2) void wgemm_pkernel(const MudgGemmDesc p, co
     using T0 = std::integral_constant<int, 0>; using T1 = std::integral_constant<int, 1>; using T2 = std::integral_constant<int, 2>;
     const int nk = p.K / BK;                               // >= 2 (host)
 
+    W_STAMP(0);
+    int stamp_tile = 0;
     stage(0, 0, 0, 0, 0);
     stage(0, 0, 1, 0, 0);
     stage(0, 1, 0, 1, 0);
@@ -1001,8 +1010,11 @@ __global__ __launch_bounds__(512, 2) void wgemm_pkernel(const MudgGemmDesc p, co
         }
         if (wr == 0) W_BARRIER();                          // evens out the stagger
         __builtin_amdgcn_sched_barrier(0);
+        W_STAMP(1 + 2 * stamp_tile);
         w_epilogue<NREP, GEGLU, 2, GEGLU>(p, acc, cur.m0, cur.n0, cur.tm, wr, wc, lane, tid, tail, phi);
         __builtin_amdgcn_sched_barrier(0);
+        W_STAMP(2 + 2 * stamp_tile);
+        ++stamp_tile;
         if (!has_next) break;
         cur = nxt;
         li += stride;
@@ -1126,6 +1138,7 @@ __global__ __launch_bounds__(256, 2) void hgeglu_kernel(const MudgGemmDesc p, co
     const char* b_base = smem + (H_NA + wc * 4) * 1024 + fbyte;
 
     const int NH = 2 * (p.K / BK);                        // k halves (>= 2, even)
+    W_STAMP(0);
     stage(0, 0);
     stage(1, 1);
     auto wait_landed = [&](bool more) {                   // this wave's pieces of the k half about to be read: all but the a_cnt + 4 of the next one
@@ -1176,6 +1189,7 @@ __global__ __launch_bounds__(256, 2) void hgeglu_kernel(const MudgGemmDesc p, co
         h16x8 bA[4], bB[4], ax[3], ay[3], az[3];
         wait_landed(true);
         W_BARRIER();
+        W_STAMP(1);
         if (NH > 2) stage(2, 2);
         read_b(bA, 0); read_a(ax, 0, 0);
         int slot = 0;                                      // slot of k half h
@@ -1212,7 +1226,9 @@ __global__ __launch_bounds__(256, 2) void hgeglu_kernel(const MudgGemmDesc p, co
             half(h + 1, bB, bA);
         }
     }
+    W_STAMP(2);
     w_epilogue<4, true, 1>(p, acc, m0, n0, tm, 0, wc, lane, tid, tail, phi);
+    W_STAMP(3);
 }
 #endif
 
@@ -1366,6 +1382,13 @@ static int hgeglu_launch_one(const MudgGemmDesc& d, int vflags, hipStream_t s) {
 // Variant switch GEMM_H144PF (measurements): 0 = the plain loop (every k half starts with its own fragment reads), 1 = the prefetching loop.
 static int hgeglu_launch(const MudgGemmDesc& d, int vflags, hipStream_t s) {
     return mudg_variant("GEMM_H144PF", 1) ? hgeglu_launch_one<true>(d, vflags, s) : hgeglu_launch_one<false>(d, vflags, s);
+}
+#endif
+
+#if defined(MUDG_DEBUG_VARIANTS) && MUDG_PLANES == 1
+// tools/exp_stamps.py (debug-variants build; not part of the ABI of include/mudg_hip.h)
+extern "C" int mudg_debug_set_stamps(void* buf) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &buf, sizeof(buf)) == hipSuccess ? 0 : 1;
 }
 #endif
 
