@@ -1058,10 +1058,10 @@ __global__ __launch_bounds__(256, 2) void hgeglu_kernel(const MudgGemmDesc p, co
     // workgroups behaves like one with a single twice as large.  The workgroup that got the SECOND wave slot of its SIMDs in the first
     // round of the launch (HW_ID.wave_id odd) therefore starts `delay` x 8128 cycles late; every later workgroup inherits the phase of the
     // one whose slot it takes over.
-    if (delay > 0 && (int)blockIdx.x < first_round) {
+    if ((delay & 0xffff) > 0 && (int)blockIdx.x < first_round) {
         const unsigned hw = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4);      // HW_REG_HW_ID (4), offset 0, width 4: wave_id
         if (hw & 1u)
-            for (int i = 0; i < delay; ++i) __builtin_amdgcn_s_sleep(127);
+            for (int i = 0; i < (delay & 0xffff); ++i) __builtin_amdgcn_s_sleep(127);
     }
     const int wc = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave = wave column: 64 of the tile's 256 W rows
     float* tail = reinterpret_cast<float*>(smem + H_RING);
@@ -1137,10 +1137,17 @@ __global__ __launch_bounds__(256, 2) void hgeglu_kernel(const MudgGemmDesc p, co
     const char* a_base = smem + fbyte;
     const char* b_base = smem + (H_NA + wc * 4) * 1024 + fbyte;
 
+#ifdef MUDG_DEBUG_VARIANTS
+    const int abl = (delay >> 16) & 3;                    // measurements only (GEMM_H144ABL): 1 = no K loop, 2 = no epilogue, 3 = neither
+    const int NH = (abl & 1) ? 0 : 2 * (p.K / BK);
+#else
     const int NH = 2 * (p.K / BK);                        // k halves (>= 2, even)
+#endif
     W_STAMP(0);
-    stage(0, 0);
-    stage(1, 1);
+    if (NH > 0) {
+        stage(0, 0);
+        stage(1, 1);
+    }
     auto wait_landed = [&](bool more) {                   // this wave's pieces of the k half about to be read: all but the a_cnt + 4 of the next one
         if (more) { if (a_cnt == 3) W_VMCNT(7); else W_VMCNT(6); }
         else W_VMCNT(0);
@@ -1161,6 +1168,9 @@ __global__ __launch_bounds__(256, 2) void hgeglu_kernel(const MudgGemmDesc p, co
         for (int i = 0; i < 3; ++i) dst[i] = *reinterpret_cast<const h16x8*>(a_base + sl * H_KS + (third * 3 + i) * 1024);
     };
     using T0 = std::integral_constant<int, 0>; using T1 = std::integral_constant<int, 1>; using T2 = std::integral_constant<int, 2>;
+    // The K loop runs at raised priority: when both workgroups of a CU have an instruction ready, the one that feeds the matrix pipe goes
+    // first and the other one's epilogue arithmetic fills the slots in between (GEMM_H144PRIO = 0 in the variant build: off).
+    if ((delay >> 20) == 0) __builtin_amdgcn_s_setprio(3);
     if constexpr (!PF) {
         int slot = 0;
         h16x8 bf[4], a0[3], a1[3];
@@ -1187,11 +1197,13 @@ __global__ __launch_bounds__(256, 2) void hgeglu_kernel(const MudgGemmDesc p, co
         // wave never starts a k half by waiting for its own ds_reads.  W fragments alternate between two register sets (k halves come in
         // pairs), X fragments rotate through three.
         h16x8 bA[4], bB[4], ax[3], ay[3], az[3];
-        wait_landed(true);
-        W_BARRIER();
-        W_STAMP(1);
-        if (NH > 2) stage(2, 2);
-        read_b(bA, 0); read_a(ax, 0, 0);
+        if (NH > 0) {
+            wait_landed(true);
+            W_BARRIER();
+            W_STAMP(1);
+            if (NH > 2) stage(2, 2);
+            read_b(bA, 0); read_a(ax, 0, 0);
+        }
         int slot = 0;                                      // slot of k half h
         // Every wait is a FULL lgkmcnt(0) for fragments requested one MFMA group (12 MFMAs, ~200 cycles) earlier, placed BEFORE the next
         // group's reads are issued — the builtin (not inline asm), so that the compiler's own wait insertion knows the fragments have
@@ -1226,7 +1238,20 @@ __global__ __launch_bounds__(256, 2) void hgeglu_kernel(const MudgGemmDesc p, co
             half(h + 1, bB, bA);
         }
     }
+    __builtin_amdgcn_s_setprio(0);
     W_STAMP(2);
+#ifdef MUDG_DEBUG_VARIANTS
+    if (abl & 2) {                                         // keep the accumulators alive without an epilogue
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 9; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (t == 12345.678f) reinterpret_cast<float*>(p.Y)[0] = t;
+        return;
+    }
+    if (NH == 0) __syncthreads();                          // (the table copy is otherwise made visible by the K loop's barriers)
+#endif
     w_epilogue<4, true, 1>(p, acc, m0, n0, tm, 0, wc, lane, tid, tail, phi);
     W_STAMP(3);
 }
@@ -1247,7 +1272,10 @@ static bool half_height_ok(const MudgGemmDesc& d) {
     const int hv = mudg_variant("GEMM_H144", 1);
     if (!hv || !d.geglu) return false;
     if (hv == 2) return true;
-    return true;
+    // Measured (tools/exp_h144.py, profiles/r6/h144.txt; MI355X): x 0.93 ... 1.07 against the persistent 288 x 256 form on the benchmark's
+    // GEGLU shapes — + 2 ... 7 % where the eight-wave tile has fewer tiles than one round of CUs (M = 4608) or at K = 320 on the level-0
+    // rows, - 4 ... - 7 % from K = 512 (92 instead of 136 FLOP per staged byte).  The rule takes it where it won.
+    return d.K <= 320 ? d.M >= 200000 : (d.K >= 1280 && (int64_t)(d.M / 288) * (d.N / 256) < 768);
 }
 #endif
 // What the kernel can run at all.
@@ -1375,7 +1403,7 @@ static int hgeglu_launch_one(const MudgGemmDesc& d, int vflags, hipStream_t s) {
         if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
         cus[dev] = n;
     }
-    const int delay = mudg_variant("GEMM_H144DELAY", 0);
+    const int delay = mudg_variant("GEMM_H144DELAY", 0) | (mudg_variant("GEMM_H144ABL", 0) << 16) | (mudg_variant("GEMM_H144PRIO", 1) ? 0 : 1 << 20);
     hipLaunchKernelGGL(hgeglu_kernel<PF>, dim3(tiles), dim3(256), H_SMEM, s, d, vflags, mudg_phi_table(false), 2 * cus[dev], delay);
     return mudg_check_launch("mudg_gemm");
 }

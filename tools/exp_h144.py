@@ -63,6 +63,27 @@ if what == "delay":
             os.environ["MUDG_GEMM_H144DELAY"] = str(d)
             line += f" delay {d}: {timeit(lambda: ops.gemm(x, w, bias=b, geglu=True, frame_rows=hw), iters=20)*1e6:7.1f}"
         print(line, flush=True)
+if what == "ablate":
+    # the two-workgroup kernel with parts switched off (GEMM_H144ABL: 1 = no K loop, 2 = no epilogue, 3 = neither; wrong results, timing only)
+    for (M, N, K, hw) in [(294912, 2560, 320, 9216), (73728, 5120, 640, 2304), (18432, 10240, 1280, 576)]:
+        x, w, b = rn(M, K), rn(N, K), torch.randn(N, device="cuda")
+        setv("2", "2")
+        line = f"geglu {M} {N} {K}:"
+        for a, name in ((0, "full"), (1, "no K loop"), (2, "no epilogue"), (3, "launch + table copy only")):
+            os.environ["MUDG_GEMM_H144ABL"] = str(a)
+            line += f" {name} {timeit(lambda: ops.gemm(x, w, bias=b, geglu=True, frame_rows=hw), iters=20)*1e6:7.1f} us |"
+        os.environ["MUDG_GEMM_H144ABL"] = "0"
+        print(line, flush=True)
+if what == "prio":
+    for (M, N, K, hw) in [(294912, 2560, 320, 9216), (73728, 5120, 640, 2304), (18432, 10240, 1280, 576), (81920, 2560, 320, 2560)]:
+        x, w, b = rn(M, K), rn(N, K), torch.randn(N, device="cuda")
+        setv("1", "0")
+        line = f"geglu {M} {N} {K}: persistent 288x256 {timeit(lambda: ops.gemm(x, w, bias=b, geglu=True, frame_rows=hw), iters=20)*1e6:7.1f} us |"
+        setv("2", "2")
+        for pr in ("0", "1"):
+            os.environ["MUDG_GEMM_H144PRIO"] = pr
+            line += f" 144x256 x2 prio {pr}: {timeit(lambda: ops.gemm(x, w, bias=b, geglu=True, frame_rows=hw), iters=20)*1e6:7.1f} us |"
+        print(line, flush=True)
 if what == "one":
     # one launch per form of the level-0 shape, for rocprofv3 --pmc (read the LAST dispatch of each kernel)
     M, N, K, hw = 294912, 2560, 320, 9216

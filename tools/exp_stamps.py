@@ -31,8 +31,10 @@ def run(M, N, K, hw, w288, h144, nwg):
     st = buf.cpu().reshape(nwg, 64)
     used = st[:, 0] > 0
     st = st[used]
-    span = int(st[st > 0].max() - st[st > 0].min())
-    tick_ns = us * 1e3 / span            # (the launch itself is a few us of the event time: an upper bound on the tick)
+    # s_memtime counters of different XCDs are not aligned: only differences inside one workgroup mean anything.  The tick is calibrated on
+    # the persistent kernel, whose workgroups live for (nearly) the whole launch.
+    last = st.max(dim=1).values
+    tick_ns = float((us * 1e3 / (last - st[:, 0]).double()).median())
     return st, us, tick_ns
 
 
@@ -48,7 +50,7 @@ for (M, N, K, hw) in [(294912, 2560, 320, 9216), (73728, 5120, 640, 2304)]:
     print(f"   start -> first epilogue {first.mean():.2f} us (first-fetch latency + one K loop); K loop of a later tile {loop.mean():.2f} us (min {loop.min():.2f}, max {loop.max():.2f}); "
           f"epilogue {epi.mean():.2f} us (min {epi.min():.2f}, max {epi.max():.2f}); {nt} tiles stamped per workgroup")
     tiles2 = ((M + 143) // 144) * (N // 256)
-    st, us, tick = run(M, N, K, hw, "2", "2", tiles2)
+    st, us, _ = run(M, N, K, hw, "2", "2", tiles2)
     d = st.double()
     pro, loop, epi = (d[:, 1] - d[:, 0]) * tick / 1e3, (d[:, 2] - d[:, 1]) * tick / 1e3, (d[:, 3] - d[:, 2]) * tick / 1e3
     life = (d[:, 3] - d[:, 0]) * tick / 1e3
