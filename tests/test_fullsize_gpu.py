@@ -183,26 +183,90 @@ def _forward_vs_oracle(model, res, seed, frames=None):
     assert got.shape == want.shape and err < tol
 
 
+def _step_reference(weights_model, res, frames, seed, decode_frames):
+    """The CPU-oracle side of ONE guided DDIM step (S = 1, uniform_trailing -> t = 999; CFG 7.5, rescale 0.7, eta 0: conditional +
+    unconditional UNet forward, the fused update) on MDM<res> latents (1, 4, frames, h, w) and the decode of the first `decode_frames`
+    frames, memoised on disk (helpers.cached_oracle) for every test and operand-mode child that compares against it:
+        {"samples", "decoded", "e_c"}      e_c = the oracle's CONDITIONAL UNet output of that step — the reference of the forward-only
+                                           tests, which used to pay for an oracle forward of their own (a minute each).
+    Weights come from `weights_model` (synthetic, seed 7: the UNet and VAE weights do not depend on the resolution the model object was
+    built for), the schedule constants from the `res` configuration.  -> (inputs on the GPU, reference dict, cache hit, seconds)."""
+    import time
+    from helpers import cached_oracle
+    from mudg_amd import configs, factory
+    from oracle import ddim as o_ddim, schedule as o_sched, unet as o_unet, vae as o_vae
+    unet = weights_model.model.diffusion_model
+    dev = next(unet.parameters()).device
+    c, _, h, w = configs.LATENT_SHAPE[res]
+    inp = factory.synthetic_inputs(weights_model, res, 1, dev, seed=seed, latent_shape=(c, frames, h, w))
+
+    def oracle():
+        usd = {k: v.detach().float().cpu() for k, v in unet.state_dict().items()}
+        vsd = {k: v.detach().float().cpu() for k, v in weights_model.first_stage_model.state_dict().items()}
+        kw = configs.latent_visual_diffusion(res)
+        sched = o_sched.model_schedule(kw["timesteps"], kw["linear_start"], kw["linear_end"], kw["rescale_betas_zero_snr"], kw["base_scale"])
+        concat, lab, fs = inp["cond"]["c_concat"][0].cpu(), inp["class_label"][:, 0].cpu(), inp["fs"].cpu()
+        cfg = dict(configs.UNET_MDM, temporal_length=frames)
+        apply_model = lambda x, t, ctx: o_unet.unet_forward(usd, cfg, torch.cat([x, concat], 1), t, lab, ctx, fs, head_chunk=8)
+        trace = []
+        want = o_ddim.ddim_sample(apply_model, sched, inp["x_T"].cpu(), inp["cond"]["c_crossattn"][0].cpu(), inp["uc"]["c_crossattn"][0].cpu(),
+                                  1, None, 0.0, 7.5, 0.7, "uniform_trailing", trace=trace)
+        want_dec = o_vae.decode_first_stage(vsd, configs.VAE_DDCONFIG, want[:, :, :decode_frames].contiguous(), kw["scale_factor"])
+        return {"samples": want, "decoded": want_dec, "e_c": trace[0]["e_c"]}
+
+    t0 = time.perf_counter()
+    want, hit = cached_oracle(f"guided_step_v2_mdm{res}_{frames}frames_model7_seed{seed}_s1_eta0_{decode_frames}decoded", oracle)
+    return inp, want, hit, time.perf_counter() - t0
+
+
+# (resolution, frames, input seed, decoded frames) of the two default-on guided-step references
+CUT512 = ("512", 16, 31, 4)
+STEP1024 = ("1024", 4, 37, 1)
+
+
+def _forward_vs_step_reference(model, ref):
+    """One UNet forward on the HIP path — the conditional pass of the guided step `ref`: x_T with the concat channels at t = 999 —
+    against the oracle's output of that same pass (_step_reference: e_c)."""
+    from helpers import record_parity
+    from mudg_amd import hip
+    res, frames = ref[0], ref[1]
+    inp, want, hit, dt = _step_reference(model, *ref)
+    unet = model.model.diffusion_model
+    x = torch.cat([inp["x_T"], inp["cond"]["c_concat"][0]], dim=1)
+    ts = torch.full((1,), 999, device=x.device, dtype=torch.long)
+    with torch.no_grad():
+        got = unet(x, ts, c_label=inp["class_label"][:, 0], context=inp["cond"]["c_crossattn"][0], fs=inp["fs"]).float().cpu()
+    err = ((got - want["e_c"]).double().norm() / want["e_c"].double().norm()).item()
+    tol = {"bf16": 2.5e-2, "fp16": 4e-3, "bf16x3": 2e-4, "bf16x6": 2e-5}[hip.operand_name()]
+    took = "cached" if hit else f"{dt:.0f} s on {torch.get_num_threads()} threads (the whole guided step + decode)"
+    tag = "" if frames == 16 else f"_{frames}frames"
+    what = "full-size" if frames == 16 else f"{frames}-frame"
+    print(f"[{_mode()}] MDM{res} {what} UNet forward (t = 999) vs CPU oracle: rel-L2 {err:.3e} (bound {tol:g}); oracle {took}")
+    record_parity(_mode(), f"mdm{res}{tag}_unet_forward_vs_cpu_oracle", err)
+    assert got.shape == want["e_c"].shape and err < tol
+
+
 def test_mdm512_unet_forward_matches_the_cpu_oracle_at_full_size(big):
     """Full-size NUMERICAL parity (not a property): one UNet forward of the real 1.44 B-parameter topology at MDM512
-    (latents (1, 12, 16, 40, 64), context (1, 333, 1024); 12.6 TFLOP) on the HIP path against the CPU oracle on the GPU
-    box's host cores (fp32 eager, about a minute on the 128-thread host).  Same bound as the small-topology UNet tests:
-    the operand mode's per-forward floor.  MUDG_SKIP_FULLSIZE_ORACLE=1 skips it."""
+    (latents (1, 12, 16, 40, 64), context (1, 333, 1024); 12.6 TFLOP) on the HIP path against the CPU oracle on the GPU box's host
+    cores (fp32 eager) — the conditional pass of the config-0 cut below, whose memoised oracle run provides the reference (round 6: the
+    forward tests no longer pay for an oracle forward of their own).  Bound: the operand mode's per-forward floor.
+    MUDG_SKIP_FULLSIZE_ORACLE=1 skips it."""
     import os
     if os.environ.get("MUDG_SKIP_FULLSIZE_ORACLE") == "1":
         pytest.skip("MUDG_SKIP_FULLSIZE_ORACLE=1")
-    _forward_vs_oracle(big[0], "512", 21)
+    _forward_vs_step_reference(big[0], CUT512)
 
 
 def test_mdm1024_4_frame_unet_forward_matches_the_cpu_oracle(big):
-    """NUMERICAL parity at the benchmarked spatial size, cheap enough to run by default: the real 1.44 B-parameter UNet on MDM1024
-    latents (1, 12, T = 4, 72, 128) — 9216-token spatial self-attention, every level-0 shape of the benchmark — with context
-    (1, 77 + 64, 1024): 13 TFLOP, about a minute of CPU oracle (memoised for the operand-mode children, where bf16x3 is held to
-    2e-4).  MUDG_SKIP_FULLSIZE_ORACLE=1 skips it.  The 16-frame forward below stays opt-in (four minutes)."""
+    """NUMERICAL parity at the benchmarked spatial size: the real 1.44 B-parameter UNet on MDM1024 latents (1, 12, T = 4, 72, 128) —
+    9216-token spatial self-attention, every level-0 shape of the benchmark — with context (1, 77 + 64, 1024): 13 TFLOP; the conditional
+    pass of the 4-frame guided step below (bf16x3 child: 2e-4).  MUDG_SKIP_FULLSIZE_ORACLE=1 skips it.  The 16-frame forward stays
+    opt-in (four minutes)."""
     import os
     if os.environ.get("MUDG_SKIP_FULLSIZE_ORACLE") == "1":
         pytest.skip("MUDG_SKIP_FULLSIZE_ORACLE=1")
-    _forward_vs_oracle(big[0], "1024", 27, frames=4)
+    _forward_vs_step_reference(big[0], STEP1024)
 
 
 def test_mdm1024_unet_forward_matches_the_cpu_oracle_at_the_benchmark_size(big):
@@ -265,18 +329,14 @@ def test_config0_two_ddim_steps_and_decode_at_mdm512_match_the_cpu_oracle(cuda, 
         assert e_d <= 1e-3 and e_s <= 1e-3
 
 
-def _guided_step_vs_oracle(model, frames):
-    """One guided DDIM step (S = 1, uniform_trailing -> t = 999; CFG 7.5, rescale 0.7, eta 0: the two UNet forwards of a bench step + the
-    fused update) on MDM1024 latents (1, 4, frames, 72, 128) and the decode of the first frame at 576 x 1024 — HIP path against the fp32
-    CPU oracle.  In the precision modes the literal 1e-3 is asserted on latents and on the decoded frame."""
-    import time
-    from helpers import cached_oracle, record_parity
+def _guided_step_vs_oracle(model, ref, weights_model=None):
+    """One guided DDIM step + decode on the HIP path (`model`: built for ref's resolution) against _step_reference(ref).  In the
+    precision modes the literal 1e-3 is asserted on latents and on the decoded frames."""
+    from helpers import record_parity
     from lvdm.models.samplers import ddim as my_ddim
-    from mudg_amd import configs, factory, hip
-    from oracle import ddim as o_ddim, schedule as o_sched, unet as o_unet, vae as o_vae
-    dev = next(model.model.diffusion_model.parameters()).device
-    c, _, h, w = configs.LATENT_SHAPE["1024"]
-    inp = factory.synthetic_inputs(model, "1024", 1, dev, seed=37, latent_shape=(c, frames, h, w))
+    from mudg_amd import hip
+    res, frames, _, nd = ref
+    inp, want, hit, dt = _step_reference(weights_model or model, *ref)
     sampler = my_ddim.DDIMSampler(model)
     with torch.no_grad():
         samples, _ = sampler.sample(S=1, conditioning=inp["cond"], batch_size=1, shape=list(inp["x_T"].shape[1:]), verbose=False,
@@ -285,40 +345,34 @@ def _guided_step_vs_oracle(model, frames):
                                     sparse_x=inp["sparse_x"], class_label=inp["class_label"], cfg_img=None,
                                     unconditional_conditioning_img_nonetext=None)
         assert list(sampler.ddim_timesteps) == [999]
-        decoded = model.decode_first_stage(samples[:, :, :1].contiguous())
-
-    def oracle():
-        unet = model.model.diffusion_model
-        usd = {k: v.detach().float().cpu() for k, v in unet.state_dict().items()}
-        vsd = {k: v.detach().float().cpu() for k, v in model.first_stage_model.state_dict().items()}
-        kw = configs.latent_visual_diffusion("1024")
-        sched = o_sched.model_schedule(kw["timesteps"], kw["linear_start"], kw["linear_end"], kw["rescale_betas_zero_snr"], kw["base_scale"])
-        concat, lab, fs = inp["cond"]["c_concat"][0].cpu(), inp["class_label"][:, 0].cpu(), inp["fs"].cpu()
-        cfg = dict(configs.UNET_MDM, temporal_length=frames)
-        apply_model = lambda x, t, ctx: o_unet.unet_forward(usd, cfg, torch.cat([x, concat], 1), t, lab, ctx, fs, head_chunk=8)
-        want = o_ddim.ddim_sample(apply_model, sched, inp["x_T"].cpu(), inp["cond"]["c_crossattn"][0].cpu(), inp["uc"]["c_crossattn"][0].cpu(),
-                                  1, None, 0.0, 7.5, 0.7, "uniform_trailing")
-        want_dec = o_vae.decode_first_stage(vsd, configs.VAE_DDCONFIG, want[:, :, :1].contiguous(), kw["scale_factor"])
-        return {"samples": want, "decoded": want_dec}
-
-    tag = "" if frames == 16 else f"_{frames}frames"
-    t0 = time.perf_counter()
-    want, hit = cached_oracle(f"guided_step_mdm1024{tag}_model7_seed37_s1_eta0_1frame", oracle)
-    dt = time.perf_counter() - t0
+        decoded = model.decode_first_stage(samples[:, :, :nd].contiguous())
     rel = lambda a, b: ((a.double().cpu() - b.double()).norm() / b.double().norm()).item()
     e_s, e_d = rel(samples, want["samples"]), rel(decoded, want["decoded"])
     took = "cached" if hit else f"{dt:.0f} s on {torch.get_num_threads()} threads"
+    return e_s, e_d, took, decoded
+
+
+def _check_step(e_s, e_d):
+    from mudg_amd import hip
+    if hip.operand_name() in ("bf16x3", "bf16x6"):
+        assert e_d <= 1e-3 and e_s <= 1e-3          # THE CONTRACT (north_star: decoded frames within 1e-3 rel-L2 of the reference)
+    else:
+        guard = 3e-2 if hip.operand_name() == "fp16" else 1.5e-1       # regression guards, not the contract (DESIGN §5)
+        assert e_d < guard and e_s < guard
+
+
+def _mdm1024_step(model, frames):
+    from helpers import record_parity
+    ref = STEP1024 if frames == 4 else ("1024", 16, 37, 1)
+    e_s, e_d, took, decoded = _guided_step_vs_oracle(model, ref)
+    tag = "" if frames == 16 else f"_{frames}frames"
     size = "the benchmarked size" if frames == 16 else f"the benchmarked spatial size, {frames} frames"
     print(f"[{_mode()}] MDM1024 ({size}): 1 guided DDIM step + 1-frame 576 x 1024 decode vs CPU oracle: latents {e_s:.3e}  "
           f"decoded frame {e_d:.3e}; oracle {took}")
     record_parity(_mode(), f"mdm1024{tag}_guided_step_latents_vs_cpu_oracle", e_s)
     record_parity(_mode(), f"mdm1024{tag}_guided_step_decoded_vs_cpu_oracle", e_d)
     assert decoded.shape == (1, 3, 1, 576, 1024) and torch.isfinite(decoded).all()
-    if hip.operand_name() in ("bf16x3", "bf16x6"):
-        assert e_d <= 1e-3 and e_s <= 1e-3          # THE CONTRACT, at the benchmarked spatial size
-    else:
-        guard = 3e-2 if hip.operand_name() == "fp16" else 1.5e-1       # regression guards, not the contract (DESIGN §5)
-        assert e_d < guard and e_s < guard
+    _check_step(e_s, e_d)
 
 
 def test_mdm1024_4_frame_guided_ddim_step_and_one_frame_decode_match_the_cpu_oracle(big):
@@ -332,7 +386,7 @@ def test_mdm1024_4_frame_guided_ddim_step_and_one_frame_decode_match_the_cpu_ora
     import os
     if os.environ.get("MUDG_SKIP_FULLSIZE_ORACLE") == "1":
         pytest.skip("MUDG_SKIP_FULLSIZE_ORACLE=1")
-    _guided_step_vs_oracle(big[0], 4)
+    _mdm1024_step(big[0], 4)
 
 
 def test_mdm1024_guided_ddim_step_and_one_frame_decode_match_the_cpu_oracle(big):
@@ -341,61 +395,26 @@ def test_mdm1024_guided_ddim_step_and_one_frame_decode_match_the_cpu_oracle(big)
     import os
     if os.environ.get("MUDG_RUN_MDM1024_STEP") != "1":
         pytest.skip("opt-in: MUDG_RUN_MDM1024_STEP=1 (nine minutes of CPU oracle)")
-    _guided_step_vs_oracle(big[0], 16)
+    _mdm1024_step(big[0], 16)
 
 
 def test_config0_cut_one_ddim_step_and_4_frame_decode_at_mdm512_match_the_cpu_oracle(cuda):
     """A cut of BASELINE.json configs[0] that is cheap enough to run by default: MDM512 latents (1, 4, 16, 40, 64), the real
     1.44 B-parameter UNet, ONE guided DDIM step (S = 1, uniform_trailing -> t = 999; CFG 7.5, rescale 0.7, eta 0: two full
     UNet forwards + the fused update), then the decode of the first 4 frames at 320 x 512 — HIP path against the fp32 CPU
-    oracle (2 UNet forwards + 4 decoder frames on the host, about two minutes on 128 threads; memoised for the
-    operand-mode child runs).  In the precision modes the literal 1e-3 is asserted on latents and decoded frames; the
+    oracle (2 UNet forwards + 4 decoder frames on the host, about two minutes on 128 threads; memoised for the forward test above and
+    for the operand-mode child runs).  In the precision modes the literal 1e-3 is asserted on latents and decoded frames; the
     16-bit modes (bf16, fp16, bf16 with fp8 scores) are held to regression guards and their errors are printed."""
     import os
-    import time
     if os.environ.get("MUDG_SKIP_CONFIG0_CUT") == "1":
         pytest.skip("MUDG_SKIP_CONFIG0_CUT=1")
-    from helpers import cached_oracle, record_parity
-    from lvdm.models.samplers import ddim as my_ddim
-    from mudg_amd import configs, factory, hip
-    from oracle import ddim as o_ddim, schedule as o_sched, unet as o_unet, vae as o_vae
+    from helpers import record_parity
+    from mudg_amd import factory
     model = factory.build_synthetic_model("512", cuda, seed=7)
-    inp = factory.synthetic_inputs(model, "512", 1, cuda, seed=31)
-    sampler = my_ddim.DDIMSampler(model)
-    samples, _ = sampler.sample(S=1, conditioning=inp["cond"], batch_size=1, shape=list(inp["x_T"].shape[1:]), verbose=False,
-                                unconditional_guidance_scale=7.5, unconditional_conditioning=inp["uc"], eta=0.0, mask=None, x0=None,
-                                fs=inp["fs"], x_T=inp["x_T"], timestep_spacing="uniform_trailing", guidance_rescale=0.7,
-                                sparse_x=inp["sparse_x"], class_label=inp["class_label"], cfg_img=None,
-                                unconditional_conditioning_img_nonetext=None)
-    assert list(sampler.ddim_timesteps) == [999]
-    decoded = model.decode_first_stage(samples[:, :, :4].contiguous())
-
-    def oracle():
-        unet = model.model.diffusion_model
-        usd = {k: v.detach().float().cpu() for k, v in unet.state_dict().items()}
-        vsd = {k: v.detach().float().cpu() for k, v in model.first_stage_model.state_dict().items()}
-        kw = configs.latent_visual_diffusion("512")
-        sched = o_sched.model_schedule(kw["timesteps"], kw["linear_start"], kw["linear_end"], kw["rescale_betas_zero_snr"], kw["base_scale"])
-        concat, lab, fs = inp["cond"]["c_concat"][0].cpu(), inp["class_label"][:, 0].cpu(), inp["fs"].cpu()
-        apply_model = lambda x, t, ctx: o_unet.unet_forward(usd, dict(configs.UNET_MDM), torch.cat([x, concat], 1), t, lab, ctx, fs, head_chunk=8)
-        want = o_ddim.ddim_sample(apply_model, sched, inp["x_T"].cpu(), inp["cond"]["c_crossattn"][0].cpu(), inp["uc"]["c_crossattn"][0].cpu(),
-                                  1, None, 0.0, 7.5, 0.7, "uniform_trailing")
-        want_dec = o_vae.decode_first_stage(vsd, configs.VAE_DDCONFIG, want[:, :, :4].contiguous(), kw["scale_factor"])
-        return {"samples": want, "decoded": want_dec}
-
-    t0 = time.perf_counter()
-    want, hit = cached_oracle("config0_cut_mdm512_model7_seed31_s1_eta0_4frames", oracle)
-    dt = time.perf_counter() - t0
-    rel = lambda a, b: ((a.double().cpu() - b.double()).norm() / b.double().norm()).item()
-    e_s, e_d = rel(samples, want["samples"]), rel(decoded, want["decoded"])
-    took = "cached" if hit else f"{dt:.0f} s on {torch.get_num_threads()} threads"
+    e_s, e_d, took, decoded = _guided_step_vs_oracle(model, CUT512)
     print(f"[{_mode()}] config-0 cut at full size (MDM512, 1 guided DDIM step + 4-frame decode) vs CPU oracle: latents {e_s:.3e}  "
           f"decoded frames {e_d:.3e}; oracle {took}")
     record_parity(_mode(), "config0_cut_latents_vs_cpu_oracle", e_s)
     record_parity(_mode(), "config0_cut_decoded_vs_cpu_oracle", e_d)
     assert decoded.shape == (1, 3, 4, 320, 512) and torch.isfinite(decoded).all()
-    if hip.operand_name() in ("bf16x3", "bf16x6"):
-        assert e_d <= 1e-3 and e_s <= 1e-3          # THE CONTRACT, at full width and depth
-    else:
-        guard = 3e-2 if hip.operand_name() == "fp16" else 1.5e-1       # regression guards, not the contract (DESIGN §5)
-        assert e_d < guard and e_s < guard
+    _check_step(e_s, e_d)

@@ -923,3 +923,38 @@ def test_wide288_is_bit_identical_to_the_one_tile_kernels(cuda):
             os.environ["MUDG_GEMM_W288"] = saved
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+def test_half_height_geglu_kernel_is_bit_identical_to_the_kernels_it_replaces(cuda):
+    """Debug-variants build only: the two-workgroup 144 x 256 GEGLU kernel of round 6 (csrc/wgemm.hip: hgeglu_kernel, both K-loop forms)
+    against the persistent / one-tile 288 x 256 tile and the 128 x 128 kernels on the same inputs — same K order, the same Phi table
+    arithmetic: the same bits, which is what lets its selection rule look at M.  Ragged M (a last tile of 13 rows, a single row), two
+    activation sources, K from one K-tile up, fp32 and operand results."""
+    import os
+    if os.environ.get("MUDG_DEBUG_VARIANTS") != "1" or os.environ.get("MUDG_GEMM_PERSIST", "1") not in ("0", "1"):
+        pytest.skip("needs the debug-variants build with the default kernel rule (tests/test_gemm_variants_gpu.py runs it)")
+    from mudg_amd import hip, ops
+    if hip.planes() != 1:
+        pytest.skip("the 16-bit builds' kernel")
+    cases = [(144 * 5, 512, 320, False, 0), (144 * 7 + 13, 256, 64, False, 0), (1, 256, 128, True, 0), (288 * 40 + 100, 2560, 320, False, 0),
+             (144 * 33, 1024, 1280, True, 0), (5000, 768, 192, False, 64)]
+    saved = {k: os.environ.get(k) for k in ("MUDG_GEMM_W288", "MUDG_GEMM_H144", "MUDG_GEMM_H144PF")}
+    try:
+        for i, (M, N, K, f32, split) in enumerate(cases):
+            x, w, b = rnd(M, K - split, seed=10 + i).to(cuda), rnd(N, K, seed=20 + i, scale=0.1).to(cuda), torch.randn(N, device=cuda)
+            x2 = rnd(M, split, seed=30 + i).to(cuda) if split else None
+            outs = []
+            for w288, h144, pf in (("0", "0", "1"), ("2", "0", "1"), ("2", "2", "1"), ("2", "2", "0")):
+                os.environ.update(MUDG_GEMM_W288=w288, MUDG_GEMM_H144=h144, MUDG_GEMM_H144PF=pf)
+                outs.append(ops.gemm(x, w, x2=x2, bias=b, geglu=True, out_fp32=f32, frame_rows=288))
+            torch.cuda.synchronize()
+            assert torch.isfinite(outs[0].float()).all() and float(outs[0].float().abs().max()) > 1e-3
+            for o in outs[1:]:
+                assert torch.equal(o, outs[0]), (M, N, K)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
