@@ -22,6 +22,11 @@ MUDG_DEBUG_VARIANTS=1 MUDG_GEMM_W288=0 python bench.py --no-cpu-baseline --no-ch
 MUDG_DEBUG_VARIANTS=1 MUDG_GEMM_W288=1 python bench.py --no-cpu-baseline --no-children --steps 10 --warmup 3 2>/dev/null | tail -1 > $OUT/bench_w288_rule.json
 MUDG_DEBUG_VARIANTS=1 MUDG_GEMM_W288=0 python bench.py --no-cpu-baseline --no-children --operand bf16x3 --steps 4 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_bf16x3_w288_off.json
 MUDG_DEBUG_VARIANTS=1 MUDG_GEMM_W288=1 python bench.py --no-cpu-baseline --no-children --operand bf16x3 --steps 4 --warmup 1 2>/dev/null | tail -1 > $OUT/bench_bf16x3_w288_rule.json
+# round 6: the two-workgroup 144 x 256 GEGLU kernel off / by its rule (same box, same library), its per-shape timings, ablation and counters
+MUDG_DEBUG_VARIANTS=1 MUDG_GEMM_H144=0 python bench.py --no-cpu-baseline --no-children --steps 10 --warmup 3 2>/dev/null | tail -1 > $OUT/bench_h144_off.json
+MUDG_DEBUG_VARIANTS=1 MUDG_GEMM_H144=1 python bench.py --no-cpu-baseline --no-children --steps 10 --warmup 3 2>/dev/null | tail -1 > $OUT/bench_h144_rule.json
+MUDG_DEBUG_VARIANTS=1 python tools/exp_h144.py time 2>/dev/null | grep geglu > $OUT/h144.txt
+MUDG_DEBUG_VARIANTS=1 python tools/exp_h144.py ablate 2>/dev/null | grep geglu > $OUT/h144_ablate.txt
 # every contraction shape of the step on the tile and on the 128 x 128 kernels (the measurement behind the rule in wgemm.hip), both builds
 MUDG_DEBUG_VARIANTS=1 python tools/exp_w288.py time > $OUT/w288_shapes.txt 2>/dev/null
 MUDG_DEBUG_VARIANTS=1 MUDG_OPERAND=bf16x3 python tools/exp_w288.py time > $OUT/w288_x3_shapes.txt 2>/dev/null
@@ -41,6 +46,11 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pw -- python bench.py --steps 
 python tools/rocprof_summary.py pmc $(find /tmp/pw -name "*.db" | head -1) > $OUT/pmc_write.md
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d /tmp/pm -- python bench.py --steps 1 --warmup 0 --no-graph --no-cpu-baseline --no-profile --no-decode --no-children > /tmp/pm.log 2>&1
 python tools/rocprof_summary.py mfma $(find /tmp/pm -name "*.db" | head -1) > $OUT/pmc_mfma.md
+# the mode that meets the tolerance: kernel trace and MFMA-busy counters of the bf16x3 step
+rocprofv3 --kernel-trace --stats -d /tmp/pt3 -- python bench.py --steps 2 --warmup 1 --operand bf16x3 --no-cpu-baseline --no-profile --no-children > /tmp/pt3.log 2>&1
+python tools/rocprof_summary.py trace $(find /tmp/pt3 -name "*.db" | head -1) > $OUT/kernel_trace_bf16x3.md
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d /tmp/pm3 -- python bench.py --steps 1 --warmup 0 --operand bf16x3 --no-graph --no-cpu-baseline --no-profile --no-decode --no-children > /tmp/pm3.log 2>&1
+python tools/rocprof_summary.py mfma $(find /tmp/pm3 -name "*.db" | head -1) > $OUT/pmc_mfma_bf16x3.md
 # the training step of the full UNet: seconds per step, peak memory
 timeout 900 python tools/train_bench.py 512 3 2>/dev/null | tail -1 > $OUT/train_bench.log
 timeout 900 python tools/train_bench.py 1024 2 2>/dev/null | tail -1 >> $OUT/train_bench.log

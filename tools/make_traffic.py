@@ -16,6 +16,13 @@ def table(path, counter):
         # kernel names: gemm_kernel<Geo<4, 2>, MODE, FAST, SB> (round 3 on; the tile geometry comes first) or gemm_kernel<MODE, ...>
         # (round 5: wgemm_kernel<MODE, NREP, GEGLU> — the 288 x 320 tile — and its persistent plain-GEMM form wgemm_pkernel<NREP, GEGLU>)
         m = re.match(r"\| `([pw]?gemm\w*_p?kernel)<(?:\(anonymous namespace\)::)?(?:Geo<\d+, \d+>, )?(\d)[^`]*` \| " + counter + r" \| (\d+) \| ([0-9.e+]+) \|", line)
+        h = re.match(r"\| `(?:\(anonymous namespace\)::)?(hgeglu_kernel)<[^`]*` \| " + counter + r" \| (\d+) \| ([0-9.e+]+) \|", line)
+        if h:           # round 6: the two-workgroup 144 x 256 GEGLU kernel (plain GEMM family)
+            e = out.setdefault("gemm", {"kernels": [], "launches": 0, "kib": 0.0})
+            e["kernels"].append("hgeglu_kernel<..>")
+            e["launches"] += int(h.group(2))
+            e["kib"] += float(h.group(3))
+            continue
         if m:
             fam = "gemm" if m.group(1) == "wgemm_pkernel" else FAM[m.group(2)]
             e = out.setdefault(fam, {"kernels": [], "launches": 0, "kib": 0.0})
