@@ -1272,10 +1272,14 @@ static bool half_height_ok(const MudgGemmDesc& d) {
     const int hv = mudg_variant("GEMM_H144", 1);
     if (!hv || !d.geglu) return false;
     if (hv == 2) return true;
-    // Measured (tools/exp_h144.py, profiles/r6/h144.txt; MI355X): x 0.93 ... 1.07 against the persistent 288 x 256 form on the benchmark's
-    // GEGLU shapes — + 2 ... 7 % where the eight-wave tile has fewer tiles than one round of CUs (M = 4608) or at K = 320 on the level-0
-    // rows, - 4 ... - 7 % from K = 512 (92 instead of 136 FLOP per staged byte).  The rule takes it where it won.
-    return d.K <= 320 ? d.M >= 200000 : (d.K >= 1280 && (int64_t)(d.M / 288) * (d.N / 256) < 768);
+    // Measured (MI355X; profiles/r6/h144*.txt, bench_h144_off / _rule.json): per launch x 0.90 ... 1.08 of the persistent 288 x 256 form in
+    // isolated timings (+ 3 ... 7 % at K = 320 on the level-0 rows and where the eight-wave tile has less than a round of tiles, - 5 ...
+    // - 10 % from K = 512: 92 instead of 136 FLOP per staged byte), and INSIDE the step — the same library, the same box, the rule "where
+    // it won in isolation" against never — 122.39 against 121.53 ms: the rocprofv3 trace of that step has its level-0 launches at 710 us
+    // where the persistent form's were 681.  The rule is therefore: never.  The kernel stays, tested (tests/test_gemm_variants_gpu.py
+    // runs the parity suites with it forced, test_half_height_geglu_kernel_is_bit_identical...), as the measured answer to "two
+    // workgroups per CU" (DESIGN §3.2).
+    return false;
 }
 #endif
 // What the kernel can run at all.

@@ -958,3 +958,27 @@ def test_half_height_geglu_kernel_is_bit_identical_to_the_kernels_it_replaces(cu
             else:
                 os.environ[k] = v
 
+
+def test_zero_initialised_alpha_is_one_for_the_kernel_choice_and_the_groupnorm_blocks(cuda):
+    """Round-5 advisor finding, on the GPU: a descriptor with alpha = 0 (a zero-initialised C struct: mudg_gemm reads it as 1), a residual
+    and GroupNorm partials.  mudg_gemm_stats_rows used to answer for the un-normalised descriptor (128-row blocks) while mudg_gemm ran
+    the 288 x 320 tile and wrote 288-row blocks.  Now both see the same descriptor: the block height the query reports is the one the
+    partials were written in (they equal the column sums of the stored result taken in blocks of that height), and the result is the
+    alpha = 1 result bit for bit."""
+    from mudg_amd import ops
+    M, N, K = 288 * 6, 320, 320
+    x, w = rnd(M, K, seed=1).to(cuda), rnd(N, K, seed=2, scale=0.05).to(cuda)
+    b = torch.randn(N, device=cuda)
+    r = rnd(M, N, seed=3).to(ops.STREAM()).to(cuda)
+    outs = []
+    for alpha in (0.0, 1.0):
+        y = ops.gemm(x, w, bias=b, residual=r, stats=True, out_stream=True, alpha=alpha, frame_rows=288)
+        outs.append((y, getattr(y, ops.GN_ATTR), getattr(y, ops.GN_ATTR + "_rows")))
+    torch.cuda.synchronize()
+    (y0, p0, r0), (y1, p1, r1) = outs
+    assert r0 == r1 and torch.equal(y0, y1) and torch.equal(p0, p1)
+    v = y0.double().reshape(M // r0, r0, N)
+    want = torch.stack([v.sum(1), (v ** 2).sum(1)], -1)
+    assert p0.shape == (M // r0, N, 2)
+    assert rel_l2(p0, want.cpu()) < 1e-5
+
