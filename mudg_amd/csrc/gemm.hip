@@ -711,10 +711,21 @@ __global__ __launch_bounds__(G::NTH, G::WIDE ? 2 : ((SB && !fused_planes(FAST)) 
                         }
                     }
                     if (p.stats) {
+                        float t[8];                     // what the store will hold — the storage kind decided once per row (wgemm.hip, w_epilogue)
+                        if (OK == KIND_F32) {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) t[j] = v[u][j];
+                        } else if (OK == KIND_F16) {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) t[j] = (float)f16_sat(v[u][j]);
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) t[j] = (float)(h16)v[u][j];
+                        }
 #pragma unroll
                         for (int j = 0; j < 8; ++j) {
-                            const float t = (j < nvalid) ? (OK == KIND_F32 ? v[u][j] : (OK == KIND_F16 ? (float)f16_sat(v[u][j]) : (float)(h16)v[u][j])) : 0.f;
-                            gs[j] += t; gq[j] = fmaf(t, t, gq[j]);
+                            const float tt = (j < nvalid) ? t[j] : 0.f;
+                            gs[j] += tt; gq[j] = fmaf(tt, tt, gq[j]);
                         }
                     }
                     int64_t yoff;
@@ -955,10 +966,21 @@ __global__ __launch_bounds__(G::NTH, G::WIDE ? 2 : ((SB && !fused_planes(FAST)) 
             }
         }
         if (p.stats) {
+            float t[8];
+            if (p.out_fp32 == KIND_F32) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) t[j] = v[j];
+            } else if (p.out_fp32 == KIND_F16) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) t[j] = (float)f16_sat(v[j]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) t[j] = operand_round(v[j]);
+            }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float t = (j < nvalid) ? (p.out_fp32 == KIND_F32 ? v[j] : (p.out_fp32 == KIND_F16 ? (float)f16_sat(v[j]) : operand_round(v[j]))) : 0.f;
-                gs[j] += t; gq[j] = fmaf(t, t, gq[j]);
+                const float tt = (j < nvalid) ? t[j] : 0.f;
+                gs[j] += tt; gq[j] = fmaf(tt, tt, gq[j]);
             }
         }
         const int64_t yoff = bz * p.sY + mp * p.ldy + n;

@@ -448,9 +448,20 @@ __global__ __launch_bounds__(256, FUSEDP ? 2 : WGS) void pgemm_kernel(const Mudg
                     }
                 } else if (RS && p.stats) {
                     // partial sums over what is stored: the lane's two rows here, the 32 pixels of the half-wave below
+                    float tk[8];                        // the storage kind decided once per row (wgemm.hip, w_epilogue)
+                    if (OK == KIND_F32) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) tk[j] = v[j];
+                    } else if (OK == KIND_F16) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) tk[j] = (float)f16_sat(v[j]);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) tk[j] = operand_round(v[j]);
+                    }
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const float t = live ? (OK == KIND_F32 ? v[j] : (OK == KIND_F16 ? (float)f16_sat(v[j]) : operand_round(v[j]))) : 0.f;
+                        const float t = live ? tk[j] : 0.f;
                         if (mi == 0) t0[j] = t;
                         else { gs[j] = t0[j] + t; gq[j] = fmaf(t, t, t0[j] * t0[j]); }
                     }

@@ -323,10 +323,23 @@ __device__ __forceinline__ void w_epilogue(const MudgGemmDesc& p, f32x4 (&acc)[N
                 }
             }
             if (!GEGLU && p.stats) {
+                // what the store will hold, per storage kind — the kind decided once per row, not inside the per-value expression (there
+                // it was a chain of scalar compares and branches per VALUE: round 6)
+                float t[8];
+                if (OK == KIND_F32) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) t[e] = v[e];
+                } else if (OK == KIND_F16) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) t[e] = (float)f16_sat(v[e]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) t[e] = operand_round(v[e]);
+                }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    const float t = live ? (OK == KIND_F32 ? v[e] : (OK == KIND_F16 ? (float)f16_sat(v[e]) : operand_round(v[e]))) : 0.f;
-                    gs[e] += t; gq[e] = fmaf(t, t, gq[e]);
+                    const float tt = live ? t[e] : 0.f;
+                    gs[e] += tt; gq[e] = fmaf(tt, tt, gq[e]);
                 }
             }
             if (live) {
@@ -375,10 +388,21 @@ __device__ __forceinline__ void w_epilogue(const MudgGemmDesc& p, f32x4 (&acc)[N
 #pragma unroll
             for (int e = 0; e < 4; ++e) { const float a = acc[i][J < NREP ? J : 0][e]; v[e] = UA ? a + bv[e] : alpha * a + bv[e]; }
             if (p.stats) {
+                float t[4];
+                if (OK == KIND_F32) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t[e] = v[e];
+                } else if (OK == KIND_F16) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t[e] = (float)f16_sat(v[e]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t[e] = operand_round(v[e]);
+                }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float t = live ? (OK == KIND_F32 ? v[e] : (OK == KIND_F16 ? (float)f16_sat(v[e]) : operand_round(v[e]))) : 0.f;
-                    gs[e] += t; gq[e] = fmaf(t, t, gq[e]);
+                    const float tt = live ? t[e] : 0.f;
+                    gs[e] += tt; gq[e] = fmaf(tt, tt, gq[e]);
                 }
             }
             if (live) {
