@@ -1261,13 +1261,14 @@ static void normalise_desc(MudgGemmDesc& d) {
     if (d.alpha == 0.f) d.alpha = 1.f;
 }
 
-// Height of the row blocks `stats` will be written in for this problem (mudg_hip.h): 288 where the 288 x 320 kernel runs it, else 128.
+// Height of the row blocks `stats` will be written in for this problem (mudg_hip.h): 288 / 160 where a tile kernel of wgemm.hip runs it, else 128.
 extern "C" int mudg_gemm_stats_rows(const MudgGemmDesc* dp) {
     if (!dp) return 128;
     MudgGemmDesc d = *dp;
     if (d.out_fp32 < 0 || d.out_fp32 > 2 || d.res_fp32 < 0 || d.res_fp32 > 2 || d.mode < 0 || d.mode > 2) return 128;
     normalise_desc(d);
-    return mudg_wgemm_ok(d, access_flags(d)) ? 288 : 128;
+    const int rows = mudg_wgemm_rows(d, access_flags(d));
+    return rows ? rows : 128;
 }
 
 extern "C" int mudg_conv_subpixel_ok(const MudgGemmDesc* dp) {

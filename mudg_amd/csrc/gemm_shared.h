@@ -59,4 +59,5 @@ const float* mudg_phi_table(bool split_ok = false);      // device Phi table, or
 int mudg_pgemm_launch(const MudgGemmDesc& d, int vflags, int wgs, hipStream_t s);
 // wgemm.hip: the 288 x 320 eight-wave tile (16-bit builds); _ok = eligible AND selected by its M-independent rule
 bool mudg_wgemm_ok(const MudgGemmDesc& d, int vflags);
+int mudg_wgemm_rows(const MudgGemmDesc& d, int vflags);      // 288 | 160 (w160_kernel, 16-bit builds) | 0
 int mudg_wgemm_launch(const MudgGemmDesc& d, int vflags, hipStream_t s);

@@ -187,7 +187,7 @@ __global__ __launch_bounds__(256) void gn_finalize_ch_kernel(const float* __rest
     const int cpg = C / groups, c0 = g * cpg;
     double a = 0.0, b = 0.0;
     if (blocks_per_sample2 != blocks_per_sample) {
-        // the two sources' producers wrote blocks of different heights (128 | 288): each source's blocks on their own, source 1 first
+        // the two sources' producers wrote blocks of different heights (128 | 160 | 288): each source's blocks on their own, source 1 first
         for (int src = 0; src < 2; ++src) {
             const int bps = src ? blocks_per_sample2 : blocks_per_sample;
             const int lo = src ? (c0 > csplit ? c0 : csplit) : c0, hi = src ? c0 + cpg : (c0 + cpg < csplit ? c0 + cpg : csplit);
@@ -658,7 +658,8 @@ extern "C" int mudg_groupnorm_fused_rows(const void* X, const void* X2, int cspl
                                          int groups, float eps, int silu, const float* P1, int p1_rows, const float* P2, int p2_rows,
                                          float* ws, void* stream) {
     MUDG_REQUIRE(X && Y && gamma && beta && ws && P1, "mudg_groupnorm_fused: null pointer");
-    MUDG_REQUIRE((p1_rows == 128 || p1_rows == 288) && (!X2 || p2_rows == 128 || p2_rows == 288), "mudg_groupnorm_fused: partial blocks are 128 or 288 rows high");
+    MUDG_REQUIRE((p1_rows == 128 || p1_rows == 160 || p1_rows == 288) && (!X2 || p2_rows == 128 || p2_rows == 160 || p2_rows == 288),
+                 "mudg_groupnorm_fused: partial blocks are 128, 160 or 288 rows high");
     if (!X2) p2_rows = p1_rows;
     MUDG_REQUIRE(rows % p1_rows == 0 && rows % p2_rows == 0, "mudg_groupnorm_fused: rows=%d per sample must be whole partial blocks (%d / %d rows)", rows, p1_rows, p2_rows);
     MUDG_REQUIRE(samples > 0 && rows > 0 && C > 0 && groups > 0, "mudg_groupnorm_fused: empty problem");

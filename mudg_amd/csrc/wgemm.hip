@@ -1281,6 +1281,270 @@ __global__ __launch_bounds__(256, 2) void hgeglu_kernel(const MudgGemmDesc p, co
 }
 #endif
 
+#if MUDG_PLANES == 1
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// The 160-row tile (round 6): 160 x 320 (GEGLU: 160 x 256), eight waves as 2 (M) x 4 (N), one workgroup per CU — for the resolutions whose
+// frames are no multiple of 288 rows but of 160: MDM512 (BASELINE configs[1]) has 2560 / 640 / 160 pixels per frame = 16 / 4 / 1 tiles, a
+// guidance batch of 2 x 16 frames 512 / 128 / 32 tiles per 320 columns — whole rounds of the 256 CUs at level 0 where the 288-row tile
+// would leave 1.11 rounds and the 128 x 128 kernels run 1920 tiles of which every third column is half empty (N = 320 = 2.5 x 128).
+// A wave owns 80 x 80 = 5 x 5 fragments (100 accumulators); 107 FLOP per staged byte (288 x 320: 151, 128 x 128: 64).
+// LDS: a RING OF FIVE k halves (32 deep) x {X: 10, W: 4 NREP subtiles of 1 KiB, st_16x32 swizzled at the DMA source as in wgemm_kernel}
+// = 150 KiB (GEGLU: 130 + the Phi pairs).  The 30 | 26 pieces of a k half go over the eight waves as pieces wave, wave + 8, wave + 16,
+// wave + 24: four per wave (pieces beyond the 30 | 26 zero-fill a spare KiB).  Per k half h, ONE barrier (the skeleton of hgeglu_kernel, with the fragments double-buffered):
+//     s_waitcnt vmcnt(4 c)       this wave's pieces of k half h + 1 have landed (c = k halves issued after it: 2, at the end of K 1, 0)
+//     s_barrier                  so have everybody's; and everybody's fragment reads of k half h - 1 have returned ...
+//     DMA of k half h + 4        ... whose slot these pieces go to: three k halves (75 MFMAs per wave, ~ 5000 cycles) to land
+//     s_waitcnt lgkmcnt(0)       the fragments of k half h (requested under the MFMAs of k half h - 1)
+//     fragments of k half h + 1  (5 W + 5 X reads into the other register set) | 25 MFMAs of k half h
+// Bits: the K order and the per-row arithmetic of every other contraction kernel; without a residual identical to the 128 x 128 kernels,
+// with one the sum is ((r + x w) + bias) as on the 288-row tile — so the rule (mudg_wgemm_rows) looks at the frame geometry, never at M.
+constexpr int QBM = 160, Q_NA = QBM / 16, Q_NI = 5;
+template <int NREP> struct QGeo {
+    static constexpr int BN = 64 * NREP;
+    static constexpr int NB = BN / 16;
+    static constexpr int NP = Q_NA + NB;                 // pieces of a k half: 30 | 26
+    static constexpr int KS = NP * 1024;
+    static constexpr int R = 5;                          // ring slots
+    static constexpr int LOOP = R * KS;                  // 153600 | 133120
+    static constexpr int SMEM = LOOP + (NREP == 4 ? W_TAIL_GEGLU : W_TAIL) + 1024;         // + the dummy pieces' KiB
+};
+
+template <int MODE, int NREP, bool GEGLU, bool RS>
+__global__ __launch_bounds__(512, 2) void w160_kernel(const MudgGemmDesc p, const int vflags, const float* __restrict__ phi) {
+    using G = QGeo<NREP>;
+    constexpr int WBN = G::BN, KS = G::KS, R = G::R, NPAIR = NREP / 2;
+    static_assert(!GEGLU || (MODE == 0 && NREP == 4), "GEGLU: plain GEMM on the 256-wide tile");
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;             // waves wc and wc + 4 share a SIMD: the two M halves
+    float* tail = reinterpret_cast<float*>(smem + G::LOOP);
+    if (GEGLU && phi) {                                  // (value, step) pairs: gelu_lut2; visible after the K loop's barriers
+        for (int t = tid; t <= PHI_N; t += 512) {
+            const float a = phi[t], b = phi[t < PHI_N ? t + 1 : t];
+            *reinterpret_cast<f32x2*>(&tail[2 * t]) = f32x2{a, b - a};
+        }
+    }
+    // XCD-aware tile numbering (as wgemm_kernel)
+    const int ntn = p.N / WBN, ntm = (p.M + QBM - 1) / QBM;
+    int tile;
+    {
+        const int total = gridDim.x, q8 = total >> 3, r8 = total & 7;
+        const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+    }
+    int tm, tn;
+    {
+        const int per = 8 * ntn, g = tile / per, first = g * 8;
+        const int gsz = (ntm - first) < 8 ? (ntm - first) : 8;
+        const int r = tile - g * per;
+        tn = r / gsz;
+        tm = first + (r - tn * gsz);
+    }
+    const int m0 = tm * QBM, n0 = tn * WBN;
+    constexpr int ntaps = MODE == 0 ? 1 : (MODE == 1 ? 9 : 3);
+
+    const int pos = lane * 16;
+    const int sbyte = pos ^ (((pos >> 9) & 1) << 5);
+    const int srow = sbyte >> 6, schunk = (sbyte >> 4) & 3;
+    const h16* X = reinterpret_cast<const h16*>(p.X);
+    const h16* X2 = p.X2 ? reinterpret_cast<const h16*>(p.X2) : nullptr;
+    const h16* W = reinterpret_cast<const h16*>(p.W);
+    const int64_t shift = MODE == 1 ? -(int64_t)(p.Win + 1) : (MODE == 2 ? -(int64_t)p.HW : 0);
+    const __amdgpu_buffer_rsrc_t rX = make_rsrc(X + ((int64_t)m0 + shift) * p.ldx);
+    const __amdgpu_buffer_rsrc_t rX2 = X2 ? make_rsrc(X2 + ((int64_t)m0 + shift) * p.ldx2) : rX;
+    const __amdgpu_buffer_rsrc_t rW = make_rsrc(W + (int64_t)n0 * p.ldw);
+    const int ldx2e = X2 ? p.ldx2 : p.ldx;
+    const unsigned va1 = (unsigned)(srow * p.ldx) * 2u + (unsigned)schunk * 16u;
+    const unsigned va2 = (unsigned)(srow * ldx2e) * 2u + (unsigned)schunk * 16u;
+    const unsigned vw_pair = (unsigned)((8 * (srow >> 2) + (srow & 3)) * p.ldw) * 2u + (unsigned)schunk * 16u;     // (permuted W rows: wgemm_kernel)
+    const unsigned vw_single = (unsigned)(srow * p.ldw) * 2u + (unsigned)schunk * 16u;
+    // This wave's pieces of a k half: piece indices wave + 8 q (q = 0 .. 3); a piece below Q_NA is an X subtile, below NP the W subtile
+    // piece - Q_NA, and beyond NP (the last pieces of some waves) a DUMMY: the same instruction with every lane out of range, zero-filling a
+    // spare KiB behind the tail — every wave issues exactly FOUR operations per k half, so the counted waits are the same for all.
+    // Piece 0 is always X, piece 2 always W; what pieces 1 and 3 are is wave-uniform and loop-invariant.
+    const bool x1 = wave + 8 < Q_NA;
+    int wdst[4], wso[4];                                  // per W piece: LDS offset inside a k half, scalar offset of its first W row
+    unsigned wv[4];                                       // ... and the lanes' offsets (permuted rows for paired fragments; OOB: dummy)
+#pragma unroll
+    for (int q = 1; q < 4; ++q) {
+        const int pc = wave + 8 * q;
+        const bool live = pc >= Q_NA && pc < G::NP;
+        const int st = live ? pc - Q_NA : 0, wcol = st / NREP, j = st - wcol * NREP;
+        const bool single = j >= 2 * NPAIR;
+        const int row0 = single ? wave_single_col<NREP>(wcol) : wave_pair_col<NREP>(wcol, j >> 1) + 4 * (j & 1);       // first channel of the piece
+        wdst[q] = pc * 1024;
+        wso[q] = row0 * p.ldw * 2;
+        wv[q] = live ? (single ? vw_single : vw_pair) : OOB;
+    }
+    const bool dummy3 = !(wave + 24 < G::NP);
+    unsigned amask[2];                                    // tap validity of the lane's source row in X subtiles `wave` and `wave + 8`
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int st = wave + 8 * q;
+        const int m = m0 + st * 16 + srow;
+        unsigned mask = 0;
+        if (st < Q_NA && m < p.M) {
+            if (MODE == 0) mask = 1;
+            else if (MODE == 1) {
+                const int hw = p.Hout * p.Wout;
+                const int f = m / hw, r = m - f * hw;
+                const int oy = r / p.Wout, ox = r - oy * p.Wout;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int iy = oy - 1 + t / 3, ix = ox - 1 + t % 3;
+                    if (iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win) mask |= 1u << t;
+                }
+            } else {
+                const int fr = (m / p.HW) % p.T;
+#pragma unroll
+                for (int t = 0; t < 3; ++t) if (fr + t - 1 >= 0 && fr + t - 1 < p.T) mask |= 1u << t;
+            }
+        }
+        amask[q] = mask;
+    }
+    auto advance = [&](KPos& k) {
+        k.kt += 1;
+        if (MODE == 0) { k.c += BK; return; }
+        const int t1 = k.tap + 1, c1 = k.c + BK;
+        const bool slab = p.korder != 0;
+        const bool wrap = slab ? (t1 == ntaps) : (c1 == p.Cin);
+        k.tap = slab ? (wrap ? 0 : t1) : (wrap ? t1 : k.tap);
+        k.c = slab ? (wrap ? c1 : k.c) : (wrap ? 0 : c1);
+    };
+    auto stage = [&](const KPos& k, int ks, int slot) {
+        char* base = smem + slot * KS;
+        const bool s2 = k.c >= p.csplit;
+        const int cc = s2 ? k.c - p.csplit : k.c;
+        const int ld = s2 ? ldx2e : p.ldx;
+        int soff = (cc + ks * 32) * 2;
+        if (MODE == 1) { const int dy = k.tap / 3, dx = k.tap - 3 * dy; soff += (dy * p.Win + dx) * ld * 2; }
+        if (MODE == 2) soff += k.tap * p.HW * ld * 2;
+        const int soffw = (k.kt * BK + ks * 32) * 2;
+        // No branch in here (a taken scalar branch costs the wave its instruction buffer, and both waves of a SIMD run this right after the
+        // same barrier with the matrix pipe idle): the second source and "piece 1 is an X piece" are selects of descriptor and offsets.
+        const __amdgpu_buffer_rsrc_t rA = s2 ? rX2 : rX;
+        const unsigned vx0 = ((amask[0] >> k.tap) & 1u) ? (s2 ? va2 : va1) : OOB;
+        const unsigned vx1 = ((amask[1] >> k.tap) & 1u) ? (s2 ? va2 : va1) : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lptr_t)(base + wave * 1024), 16, (int)vx0, soff + wave * 16 * ld * 2, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(x1 ? rA : rW, (lptr_t)(base + (wave + 8) * 1024), 16, (int)(x1 ? vx1 : wv[1]),
+                                                 x1 ? soff + (wave + 8) * 16 * ld * 2 : soffw + wso[1], 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(base + wdst[2]), 16, (int)wv[2], soffw + wso[2], 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(dummy3 ? smem + G::SMEM - 1024 : base + wdst[3]), 16, (int)wv[3], soffw + wso[3], 0, 0);
+    };
+    auto wait_pieces = [&](int c) {                       // at most c k halves' worth of this wave's pieces (four each) still in flight
+        if (c <= 0) W_VMCNT(0);
+        else if (c == 1) W_VMCNT(4);
+        else if (c == 2) W_VMCNT(8);
+        else W_VMCNT(12);
+    };
+
+    const int NH = 2 * (p.K / BK);                        // k halves (>= 2, even)
+    KPos kS{0, 0, 0};
+    int hs = 0, sslot = 0;                                // the next k half to stage and its slot
+    auto stage_next = [&]() {
+        stage(kS, hs & 1, sslot);
+        ++hs;
+        sslot = sslot == R - 1 ? 0 : sslot + 1;
+        if (!(hs & 1)) advance(kS);
+    };
+#pragma unroll
+    for (int i = 0; i < R - 1; ++i)
+        if (i < NH) stage_next();
+
+    // RS (a residual seeds the accumulators) is a template parameter: as a run-time branch its merge point carried a vmcnt(0) — every tile
+    // waited for all four prefetched k halves before its first MFMA, residual or not.
+    f32x4 acc[Q_NI][NREP];
+    if constexpr (RS) w_seed<NREP, Q_NI>(p, acc, m0, n0, wr, wc, lane);
+    else {
+#pragma unroll
+        for (int i = 0; i < Q_NI; ++i)
+#pragma unroll
+            for (int j = 0; j < NREP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int fbyte0 = (lane & 15) * 64 + (lane >> 4) * 16;
+    const int fbyte = fbyte0 ^ (((fbyte0 >> 9) & 1) << 5);
+    const char* a_base = smem + (wr * Q_NI) * 1024 + fbyte;
+    const char* b_base = smem + (Q_NA + wc * NREP) * 1024 + fbyte;
+    auto read_frags = [&](h16x8 (&b)[NREP], h16x8 (&a)[Q_NI], int slot) {
+#pragma unroll
+        for (int j = 0; j < NREP; ++j) b[j] = *reinterpret_cast<const h16x8*>(b_base + slot * KS + j * 1024);
+#pragma unroll
+        for (int i = 0; i < Q_NI; ++i) a[i] = *reinterpret_cast<const h16x8*>(a_base + slot * KS + i * 1024);
+    };
+    h16x8 bA[NREP], aA[Q_NI], bB[NREP], aB[Q_NI];
+    wait_pieces((NH < R - 1 ? NH : R - 1) - 1);           // k half 0 has landed
+    W_BARRIER();
+    read_frags(bA, aA, 0);
+    int slot = 0;                                         // slot of k half h
+    auto half = [&](int h, const h16x8 (&bc)[NREP], const h16x8 (&ac)[Q_NI], h16x8 (&bn)[NREP], h16x8 (&an)[Q_NI]) {
+        const int nslot = slot == R - 1 ? 0 : slot + 1;
+        const bool more = h + 1 < NH;
+        if (more) {
+            const int last = NH - 1 < h + R - 2 ? NH - 1 : h + R - 2;          // the youngest k half issued so far
+            wait_pieces(last - (h + 1));
+        }
+        W_BARRIER();
+        if (hs < NH) stage_next();
+        H_LGKM0();
+        __builtin_amdgcn_sched_barrier(0);
+        // The next k half's ten fragment reads go out BETWEEN this one's MFMAs, one per two: a wave issues in order, and ten reads in front
+        // of the MFMAs — while the other seven waves' reads queue at the same LDS — kept the matrix pipe idle until the last was issued
+        // (first version: 2650 cycles per k half where the MFMAs need 1600).  After the last k half the reads fetch a stale slot: unused.
+        read_frags(bn, an, nslot);
+#pragma unroll
+        for (int i = 0; i < Q_NI; ++i)
+#pragma unroll
+            for (int j = 0; j < NREP; ++j) acc[i][j] = mfma16(bc[j], ac[i], acc[i][j]);
+#pragma unroll
+        for (int g = 0; g < NREP + Q_NI; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);          // 2 MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);          // 1 DS read
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, Q_NI * NREP - 2 * (NREP + Q_NI), 0);
+        __builtin_amdgcn_sched_barrier(0);
+        slot = nslot;
+    };
+    // Steady state — while a k half is staged in every iteration and two younger ones are in flight (h <= NH - 5): no condition inside.
+    auto steady = [&](int ks, const h16x8 (&bc)[NREP], const h16x8 (&ac)[Q_NI], h16x8 (&bn)[NREP], h16x8 (&an)[Q_NI]) {
+        const int nslot = slot == R - 1 ? 0 : slot + 1;
+        W_VMCNT(8);
+        W_BARRIER();
+        stage(kS, ks, sslot);
+        sslot = sslot == R - 1 ? 0 : sslot + 1;
+        if (ks) advance(kS);
+        H_LGKM0();
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(bn, an, nslot);
+#pragma unroll
+        for (int i = 0; i < Q_NI; ++i)
+#pragma unroll
+            for (int j = 0; j < NREP; ++j) acc[i][j] = mfma16(bc[j], ac[i], acc[i][j]);
+#pragma unroll
+        for (int g = 0; g < NREP + Q_NI; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, Q_NI * NREP - 2 * (NREP + Q_NI), 0);
+        __builtin_amdgcn_sched_barrier(0);
+        slot = nslot;
+    };
+    int h = 0;
+#pragma unroll 1
+    for (; h + 6 <= NH; h += 2) {                        // both k halves of the pair are steady: h + 1 <= NH - 5
+        steady(0, bA, aA, bB, aB);
+        steady(1, bB, aB, bA, aA);
+    }
+    hs = h + R - 1 < NH ? h + R - 1 : NH;                 // (what the steady iterations staged)
+#pragma unroll 1
+    for (; h < NH; h += 2) {
+        half(h, bA, aA, bB, aB);
+        half(h + 1, bB, aB, bA, aA);
+    }
+    w_epilogue<NREP, GEGLU, 2, true, Q_NI>(p, acc, m0, n0, tm, wr, wc, lane, tid, tail, phi);
+}
+#endif
+
 // Variant switch GEMM_W288 (debug-variants build; read at every call so that one process can compare kernels): 0 = never, 1 = the rule
 // below, 2 = every eligible problem.
 int variant() { return mudg_variant("GEMM_W288", 1); }
@@ -1307,7 +1571,7 @@ static bool half_height_ok(const MudgGemmDesc& d) {
 }
 #endif
 // What the kernel can run at all.
-static bool wgemm_eligible(const MudgGemmDesc& d, int vflags) {
+static bool wgemm_eligible(const MudgGemmDesc& d, int vflags, int bm = WBM) {
     if (d.batch != 1 || d.act || d.Y8 || d.subpixel || (d.mode == 1 && d.upsample)) return false;
     if (d.geglu ? (d.mode != 0 || d.N % 256 != 0 || d.R || d.gbias || d.stats) : d.N % 320 != 0) return false;
     if (!(vflags & VF_Y) || (d.R && !(vflags & VF_R))) return false;
@@ -1315,12 +1579,12 @@ static bool wgemm_eligible(const MudgGemmDesc& d, int vflags) {
     if ((d.K & 63) || (cin & 63) || (d.csplit & 63)) return false;
     if (d.mode == 1 && (d.stride != 1 || d.pad != 1 || d.Hin != d.Hout || d.Win != d.Wout || d.K != 9 * d.Cin)) return false;
     if (d.mode == 2 && (d.korder || d.K != 3 * d.Cin)) return false;       // (korder 1 means tiles of 8 pixels x 16 frames to the callers: gemm.hip)
-    if (d.gbias && (d.rows_per_group % WBM != 0)) return false;            // one group per tile: the group bias rides in the column constants
+    if (d.gbias && (d.rows_per_group % bm != 0)) return false;             // one group per tile: the group bias rides in the column constants
     if (d.R && d.alpha != 1.f) return false;                               // the residual seeds the accumulators (w_seed)
     if ((d.ldy & 7) || (d.R && (d.ldr & 7))) return false;                 // 8-byte pieces of the unpaired fragment
     // 32-bit reach of the descriptor offsets
     const int64_t ld = d.X2 && d.ldx2 > d.ldx ? d.ldx2 : d.ldx;
-    int64_t rows = WBM + 16 + (PLANES > 1);                                // (the second piece of a row: ld / 2 elements further)
+    int64_t rows = bm + 16 + (PLANES > 1);                                 // (the second piece of a row: ld / 2 elements further)
     if (d.mode == 1) rows += 2 * (int64_t)d.Win + 2;
     if (d.mode == 2) rows += 2 * (int64_t)d.HW;
     const int64_t lim = (int64_t)1 << 31;
@@ -1329,7 +1593,7 @@ static bool wgemm_eligible(const MudgGemmDesc& d, int vflags) {
 
 // Where it is used.  The rule never looks at M (see the header): `S`, the rows of one frame (mode 0: the caller's hint in d.HW), must be
 // whole tiles — then every frame batch of the benchmarked resolution fills whole rounds of the 256 CUs.
-bool mudg_wgemm_ok(const MudgGemmDesc& d, int vflags) {
+static bool wgemm288_ok(const MudgGemmDesc& d, int vflags) {
     const int mode = variant();
     if (!mode || !wgemm_eligible(d, vflags)) return false;
     if (mode == 2) return true;
@@ -1353,6 +1617,36 @@ bool mudg_wgemm_ok(const MudgGemmDesc& d, int vflags) {
 #endif
     return true;
 }
+
+#if MUDG_PLANES == 1
+// The 160-row tile (w160_kernel): frames of whole 160-row tiles that are not whole 288-row tiles.  Variant switch GEMM_W160: 0 = never,
+// 1 = the rule, 2 = every eligible problem (as GEMM_W288 = 2; the 288-row tile's own rule is asked first).
+static bool w160_ok(const MudgGemmDesc& d, int vflags) {
+    const int mode = mudg_variant("GEMM_W160", 1);
+    if (!mode || !wgemm_eligible(d, vflags, QBM)) return false;
+    if (mode == 2) return true;
+    const int S = d.mode == 1 ? d.Hout * d.Wout : d.HW;
+    if (S <= 0 || S % QBM != 0) return false;
+    // Measured per shape against the 128 x 128 kernels (tools/exp_w160.py, profiles/r6/w160_shapes.txt; MI355X, MDM512's frame batches):
+    // 3x3 convs + 30 ... + 45 %, temporal convs + 19 ... + 27 % at 2560- and 640-pixel frames; plain GEMMs + 13 ... + 35 % from K = 640 with
+    // N <= K, + 0 ... + 9 % for N = 2 ... 3 K, at K = 320 + 11 ... + 14 % without and - 2 ... - 3 % with a residual, - 2 ... - 6 % for N = 3 K;
+    // GEGLU - 9 ... - 22 % against the persistent 128 x 128 kernel (whose epilogue runs beside other workgroups' K loops).  One workgroup
+    // per CU wants a frame batch to bring enough tiles: the 160-pixel level (32 frames = 32 tile rows x 4 ... 8 columns: half the CUs)
+    // stays on the 128 x 128 kernels (- 20 ... - 30 % there).  Never M: S, K, N, the mode and whether there is a residual.
+    if (S < 640 || d.geglu) return false;
+    if (d.mode != 0) return true;
+    return d.K >= 640 || (!d.R && d.N <= 2 * d.K);
+}
+#endif
+// Height of the tile that will run the problem: 288, 160 or 0 (none of the kernels of this file).
+int mudg_wgemm_rows(const MudgGemmDesc& d, int vflags) {
+    if (wgemm288_ok(d, vflags)) return WBM;
+#if MUDG_PLANES == 1
+    if (w160_ok(d, vflags)) return QBM;
+#endif
+    return 0;
+}
+bool mudg_wgemm_ok(const MudgGemmDesc& d, int vflags) { return mudg_wgemm_rows(d, vflags) != 0; }
 
 template <int MODE, int NREP, bool GEGLU>
 static int wgemm_launch_one(const MudgGemmDesc& d, int vflags, hipStream_t s, int slot) {
@@ -1448,8 +1742,33 @@ extern "C" int mudg_debug_set_stamps(void* buf) {
 }
 #endif
 
+#if MUDG_PLANES == 1
+template <int MODE, int NREP, bool GEGLU, bool RS>
+static int w160_launch_one(const MudgGemmDesc& d, int vflags, hipStream_t s, int slot) {
+    static bool attr_done[MAX_DEVICES][8] = {};
+    const int dev = mudg_current_device();
+    if (dev < 0) MUDG_FAIL(MUDG_ELAUNCH, "gemm: no current device");
+    using G = QGeo<NREP>;
+    if (!attr_done[dev][slot]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&w160_kernel<MODE, NREP, GEGLU, RS>), hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM);
+        if (e != hipSuccess) MUDG_FAIL(MUDG_ELAUNCH, "gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_done[dev][slot] = true;
+    }
+    const int tiles = ((d.M + QBM - 1) / QBM) * (d.N / G::BN);
+    const float* phi = GEGLU ? mudg_phi_table(false) : nullptr;
+    hipLaunchKernelGGL((w160_kernel<MODE, NREP, GEGLU, RS>), dim3(tiles), dim3(512), G::SMEM, s, d, vflags, phi);
+    return mudg_check_launch("mudg_gemm");
+}
+#endif
+
 int mudg_wgemm_launch(const MudgGemmDesc& d, int vflags, hipStream_t s) {
 #if MUDG_PLANES == 1
+    if (mudg_wgemm_rows(d, vflags) == QBM) {
+        if (d.geglu) return w160_launch_one<0, 4, true, false>(d, vflags, s, 6);
+        if (d.mode == 0) return d.R ? w160_launch_one<0, 5, false, true>(d, vflags, s, 0) : w160_launch_one<0, 5, false, false>(d, vflags, s, 1);
+        if (d.mode == 1) return d.R ? w160_launch_one<1, 5, false, true>(d, vflags, s, 2) : w160_launch_one<1, 5, false, false>(d, vflags, s, 3);
+        return d.R ? w160_launch_one<2, 5, false, true>(d, vflags, s, 4) : w160_launch_one<2, 5, false, false>(d, vflags, s, 5);
+    }
     if (d.geglu && half_height_ok(d)) return hgeglu_launch(d, vflags, s);
     if (const int grid = persistent_grid(d))
         return d.geglu ? wgemm_launch_persistent<4, true>(d, vflags, s, 1, grid) : wgemm_launch_persistent<5, false>(d, vflags, s, 0, grid);
@@ -1461,5 +1780,6 @@ int mudg_wgemm_launch(const MudgGemmDesc& d, int vflags, hipStream_t s) {
 }
 #else
 bool mudg_wgemm_ok(const MudgGemmDesc&, int) { return false; }
+int mudg_wgemm_rows(const MudgGemmDesc&, int) { return 0; }
 int mudg_wgemm_launch(const MudgGemmDesc&, int, hipStream_t) { MUDG_FAIL(MUDG_EINVAL, "gemm: no 288 x 320 kernel in this build"); }
 #endif

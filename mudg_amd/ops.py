@@ -238,7 +238,7 @@ def tconv3_slab_ok(t, hw, cin):
 
 
 def tconv3_wide(t, hw, cin, cout):
-    """Whether the library runs this temporal conv (plain K order, korder 0) on its 288 x 320-tile kernel — the caller then does not
+    """Whether the library runs this temporal conv (plain K order, korder 0) on a tile kernel of wgemm.hip (288 x 320 or 160 x 320) — the caller then does not
     ask for the slab-major order, whose 8-pixel x 16-frame tiles belong to the 128 x 128 kernels.  A dry query: nothing is read.
     Not cached: it is one host call, and the variant builds re-read MUDG_GEMM_W288 at every call (a cached answer went stale when a
     test toggled the switch in-process).  The query assumes what the executor always passes — dense, 16-byte-aligned rows; a caller
@@ -251,7 +251,7 @@ def tconv3_wide(t, hw, cin, cout):
     d.ldx, d.ldw, d.ldy = pl * cin, pl * 3 * cin, pl * cout
     d.csplit, d.batch, d.alpha, d.mode = cin, 1, 1.0, 2
     d.Cin, d.T, d.HW = cin, t, hw
-    return hip.lib().mudg_gemm_stats_rows(C.byref(d)) == 288
+    return hip.lib().mudg_gemm_stats_rows(C.byref(d)) != 128       # 288 or 160: a tile kernel of wgemm.hip
 
 
 def tconv3(x, w, *, clips, t, hw, cin, out=None, bias=None, residual=None, out_fp32=False, stats=False, out_stream=False, korder=0):

@@ -6,7 +6,8 @@ off / forced at 4, 3 and 2 workgroups per CU for every problem it accepts (its r
 flash-attention kernels (32 / 64 queries per wave) forced, the LDS-table GroupNorm apply kernel and the VALU temporal-attention kernel
 (the defaults are the register-table kernel and the MFMA kernel), the 3x3 convs without the shared activation stage of their dx taps, the 288 x 320 tile forced for every problem it can run (and, in
 that child, its bit-identity with the 128 x 128 kernels: test_wide288_is_bit_identical_to_the_one_tile_kernels), the two-workgroup
-144 x 256 GEGLU kernel of round 6 forced for every GEGLU problem (both K-loop forms) and switched off."""
+144 x 256 GEGLU kernel of round 6 forced for every GEGLU problem (both K-loop forms) and switched off, the 160 x 320 tile of round 6 forced
+for every problem it can run (test_wide160_is_bit_identical_to_the_one_tile_kernels runs in the children)."""
 import os
 import subprocess
 import sys
@@ -37,6 +38,7 @@ VARIANTS = [
     {"MUDG_GEMM_H144": "2"},                                  # the two-workgroup 144 x 256 GEGLU kernel for every GEGLU problem it can run
     {"MUDG_GEMM_H144": "2", "MUDG_GEMM_H144PF": "0"},         # ... its plain (non-prefetching) K loop
     {"MUDG_GEMM_H144": "0"},                                  # ... and never (round 5's selection)
+    {"MUDG_GEMM_W160": "2"},                                  # the 160 x 320 tile (round 6) for every problem it can run that the 288-row tile's rule does not take
 ]
 # The bf16x3 build's own debug-variants library (libmudg_hip_x3_dbg.so): its 288 x 320 kernel forced for every problem it can run
 # (short K, GEGLU on the 288 x 256 tile, ragged M — the rule sends none of those to it), and switched off (every conv / temporal conv

@@ -2,6 +2,7 @@
 bf16-rounded inputs.  Tolerances: a bf16 result carries one rounding (relative 2^-9, rms ~1.1e-3), so bf16 outputs
 are held to rel-L2 <= 3e-3; fp32 outputs to 2e-5 (accumulation order only)."""
 import math
+import os
 
 import pytest
 import torch
@@ -748,7 +749,7 @@ def test_persistent_plain_gemm_with_residual_seed_and_groupnorm_partials(cuda, k
     assert tuple(stats.shape) == ((M + rows - 1) // rows, N, 2)
     yf = torch.nn.functional.pad(y.float().cpu(), (0, 0, 0, (-M) % rows)).reshape(-1, rows, N)
     assert rel_l2(stats[..., 0], yf.sum(1)) < 1e-5 and rel_l2(stats[..., 1], (yf * yf).sum(1)) < 1e-5
-    sub = 128 * 36                                         # whole blocks of either height
+    sub = 5760                                             # whole blocks of every height (45 x 128 = 36 x 160 = 20 x 288)
     part = ops.gemm(x[:sub].to(cuda), w.to(cuda), bias=b.to(cuda), residual=res[:sub].to(cuda), stats=True, **kw)
     assert torch.equal(part, y[:sub]) and torch.equal(getattr(part, ops.GN_ATTR), stats[:sub // rows])
 
@@ -784,6 +785,15 @@ def _wide_build():
     return _hip.planes() <= 2           # the kernel belongs to the 16-bit builds and bf16x3 (this file runs in the 16-bit builds)
 
 
+def _rows_ok(rows, by_rule):
+    """The partial-block height the library reported against what its RULE gives for the case; a variant child (debug-variants build) may
+    have forced another tile kernel or switched one off: then any of the three heights is the library's to choose."""
+    import os
+    if os.environ.get("MUDG_DEBUG_VARIANTS") == "1":
+        return rows in (128, 160, 288)
+    return rows == by_rule
+
+
 @pytest.mark.parametrize("kind,korder", [("operand", 1), ("stream", 0), ("f32", 1)])
 def test_wide288_conv_group_bias_residual_two_sources_and_partials(cuda, kind, korder):
     """Frames of 576 = 2 x 288 pixels: the library's rule sends the conv to the 288 x 320 tile (16-bit builds).  Bias + per-frame
@@ -803,7 +813,7 @@ def test_wide288_conv_group_bias_residual_two_sources_and_partials(cuda, kind, k
                     rows_per_group=h * wd, residual=res.to(cuda), stats=True, **kw)
     assert rel_l2(y, ref) < (TOL_F32 if kind == "f32" else TOL_BF16)
     rows = getattr(y, ops.GN_ATTR + "_rows")
-    assert rows == (288 if _wide_build() else 128)
+    assert _rows_ok(rows, 288 if _wide_build() else 128)
     stats = getattr(y, ops.GN_ATTR)
     assert tuple(stats.shape) == (M // rows if M % rows == 0 else M // rows + 1, cout, 2)
     if M % rows == 0:
@@ -825,7 +835,7 @@ def test_wide288_plain_gemm_ragged_rows_and_temporal_conv(cuda):
     y = ops.gemm(x.to(cuda), w.to(cuda), bias=b.to(cuda), residual=r.to(cuda), out_stream=True, stats=True, frame_rows=288)
     assert rel_l2(y, ref) < TOL_BF16
     rows = getattr(y, ops.GN_ATTR + "_rows")
-    assert rows == (288 if _wide_build() else 128) and getattr(y, ops.GN_ATTR).shape[0] == (M + rows - 1) // rows
+    assert _rows_ok(rows, 288 if _wide_build() else 128) and getattr(y, ops.GN_ATTR).shape[0] == (M + rows - 1) // rows
     # no hint: the 128 x 128 kernels, the same bits (compared without the residual: the persistent 128 x 128 kernel, which a variant child
     # forces, adds a residual first instead of last)
     assert torch.equal(ops.gemm(x.to(cuda), w.to(cuda), bias=b.to(cuda), out_fp32=True), ops.gemm(x.to(cuda), w.to(cuda), bias=b.to(cuda), out_fp32=True, frame_rows=288))
@@ -854,7 +864,7 @@ def test_wide288_partials_feed_the_groupnorm_also_next_to_128_row_partials(cuda)
     a = ops.conv3x3(x.to(cuda), w1.to(cuda), frames=f, hin=h, win=wd, cin=cin, korder=1, stats=True, out_stream=True)
     bsrc = ops.gemm(x.to(cuda), rnd(160, cin, seed=3, scale=0.1).to(cuda), stats=True, out_stream=True)     # N = 160: the 128 x 128 kernels
     if _wide_build():
-        assert getattr(a, ops.GN_ATTR + "_rows") == 288 and getattr(bsrc, ops.GN_ATTR + "_rows") == 128
+        assert _rows_ok(getattr(a, ops.GN_ATTR + "_rows"), 288) and getattr(bsrc, ops.GN_ATTR + "_rows") == 128
     g = torch.randn(480, generator=torch.Generator().manual_seed(4)).to(cuda)
     bt = torch.randn(480, generator=torch.Generator().manual_seed(5)).to(cuda)
     for x1, x2 in ((a, None), (a, bsrc), (bsrc, a)):
@@ -923,6 +933,113 @@ def test_wide288_is_bit_identical_to_the_one_tile_kernels(cuda):
             os.environ["MUDG_GEMM_W288"] = saved
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+# ---------------------------------------------------------------------------------------------- the 160 x 320 tile (csrc/wgemm.hip: w160_kernel)
+def _w160_build():
+    return _hip.planes() == 1            # 16-bit builds only
+
+
+def test_wide160_conv_gemm_and_temporal_conv_by_the_rule(cuda):
+    """Frames of 20 x 32 = 640 pixels (MDM512's second level: whole 160-row tiles, no whole 288-row tiles): the library's rule sends the 3x3
+    conv, the long-K plain GEMM and the temporal conv to the 160 x 320 tile (16-bit builds).  Conv with bias + per-frame group bias, an
+    fp16-stream residual, two channel sources and GroupNorm partials per 160-row block; GEMM with ragged rows; against fp32 references;
+    a frame's rows and partial blocks do not depend on what else is in the launch."""
+    from mudg_amd import ops
+    f, h, wd, c1, c2, cout = 3, 20, 32, 64, 128, 320
+    cin, M = c1 + c2, 3 * 20 * 32
+    xa, xb = rnd(M, c1, seed=1), rnd(M, c2, seed=2)
+    w = rnd(cout, 9 * cin, seed=3, scale=0.03)
+    b = torch.randn(cout, generator=torch.Generator().manual_seed(4)) * 0.1
+    gb = torch.randn(f, cout, generator=torch.Generator().manual_seed(5))
+    res = torch.randn(M, cout, generator=torch.Generator().manual_seed(6)).to(ops.STREAM())
+    ref = _conv_ref(torch.cat([xa, xb], 1), w, f, h, wd, cin, cout, 1) + b + gb.repeat_interleave(h * wd, 0) + res.float()
+    y = ops.conv3x3(xa.to(cuda), w.to(cuda), x2=xb.to(cuda), frames=f, hin=h, win=wd, cin=cin, korder=1, bias=b.to(cuda), gbias=gb.to(cuda),
+                    rows_per_group=h * wd, residual=res.to(cuda), stats=True, out_stream=True)
+    assert rel_l2(y, ref) < TOL_BF16
+    rows = getattr(y, ops.GN_ATTR + "_rows")
+    assert _rows_ok(rows, 160 if _w160_build() else 128)
+    stats = getattr(y, ops.GN_ATTR)
+    yf = y.float().cpu().reshape(-1, rows, cout)
+    assert tuple(stats.shape) == (M // rows, cout, 2)
+    assert rel_l2(stats[..., 0], yf.sum(1)) < 1e-5 and rel_l2(stats[..., 1], (yf * yf).sum(1)) < 1e-5
+    one = ops.conv3x3(xa[:h * wd].to(cuda), w.to(cuda), x2=xb[:h * wd].to(cuda), frames=1, hin=h, win=wd, cin=cin, korder=1, bias=b.to(cuda),
+                      gbias=gb[:1].to(cuda), rows_per_group=h * wd, residual=res[:h * wd].to(cuda), stats=True, out_stream=True)
+    assert torch.equal(one, y[:h * wd]) and torch.equal(getattr(one, ops.GN_ATTR), stats[:h * wd // rows])
+    # the partials feed the fused GroupNorm (160-row blocks next to a 128-row source)
+    other = ops.gemm(xa.to(cuda), rnd(160, c1, seed=7, scale=0.1).to(cuda), stats=True, out_stream=True)       # N = 160: the 128 x 128 kernels
+    g = torch.randn(480, generator=torch.Generator().manual_seed(8)).to(cuda)
+    bt = torch.randn(480, generator=torch.Generator().manual_seed(9)).to(cuda)
+    fused = ops.groupnorm(y, g, bt, samples=f, rows=h * wd, eps=1e-5, silu=True, groups=32, x2=other)
+    plain = ops.groupnorm(y, g, bt, samples=f, rows=h * wd, eps=1e-5, silu=True, groups=32, x2=other, fused=False)
+    assert rel_l2(fused, plain.float().cpu()) < 2e-3
+    # plain GEMM, K = 1280, ragged rows, frame hint 640; without the hint the 128 x 128 kernels: the same bits without a residual
+    Mg, N, K = 160 * 9 + 100, 320, 1280
+    x, wg = rnd(Mg, K, seed=11), rnd(N, K, seed=12, scale=0.03)
+    bg = torch.randn(N, generator=torch.Generator().manual_seed(13)) * 0.1
+    r = rnd(Mg, N, seed=14).to(ops.STREAM())
+    yg = ops.gemm(x.to(cuda), wg.to(cuda), bias=bg.to(cuda), residual=r.to(cuda), out_stream=True, stats=True, frame_rows=640)
+    assert rel_l2(yg, x.float() @ wg.float().t() + bg + r.float()) < TOL_BF16
+    rows = getattr(yg, ops.GN_ATTR + "_rows")
+    assert _rows_ok(rows, 160 if _w160_build() else 128) and getattr(yg, ops.GN_ATTR).shape[0] == (Mg + rows - 1) // rows
+    assert torch.equal(ops.gemm(x.to(cuda), wg.to(cuda), bias=bg.to(cuda), out_fp32=True), ops.gemm(x.to(cuda), wg.to(cuda), bias=bg.to(cuda), out_fp32=True, frame_rows=640))
+    # temporal conv (plain K order): clips of 4 frames x 640 pixels
+    clips, t, hw, c, co = 2, 4, 640, 128, 640
+    xt, wt = rnd(clips * t * hw, c, seed=15), rnd(co, 3 * c, seed=16, scale=0.05)
+    btc = torch.randn(co, generator=torch.Generator().manual_seed(17)) * 0.1
+    xi = xt.float().reshape(clips, t, hw, c).permute(0, 3, 1, 2)
+    wk = wt.float().reshape(co, 3, c).permute(0, 2, 1)
+    ref = F.conv2d(xi, wk[..., None], padding=(1, 0)).permute(0, 2, 3, 1).reshape(clips * t * hw, co) + btc
+    assert ops.tconv3_wide(t, hw, c, co) == _w160_build() or os.environ.get("MUDG_DEBUG_VARIANTS") == "1"
+    yt = ops.tconv3(xt.to(cuda), wt.to(cuda), clips=clips, t=t, hw=hw, cin=c, bias=btc.to(cuda), stats=True)
+    assert rel_l2(yt, ref) < TOL_BF16
+    rows = getattr(yt, ops.GN_ATTR + "_rows")
+    yf = yt.float().cpu().reshape(-1, rows, co)
+    assert rel_l2(getattr(yt, ops.GN_ATTR)[..., 0], yf.sum(1)) < 1e-5
+
+
+def test_wide160_is_bit_identical_to_the_one_tile_kernels(cuda):
+    """Debug-variants build only: the same problem on the 128 x 128 kernels and on the 160 x 320 tile forced for everything it can run
+    (GEGLU on its 160 x 256 form, K from one K-tile — shorter than the ring — up, ragged M, one-tile frames whose every row touches an image
+    border) gives the same bits without a residual; with one the tile adds it first (fp32 rounding apart); repeated launches reproduce."""
+    import os
+    if os.environ.get("MUDG_DEBUG_VARIANTS") != "1" or os.environ.get("MUDG_GEMM_PERSIST", "1") not in ("0", "1"):
+        pytest.skip("needs the debug-variants build with the default kernel rule (tests/test_gemm_variants_gpu.py runs it)")
+    from mudg_amd import hip, ops
+    if hip.planes() != 1:
+        pytest.skip("the 16-bit builds' kernel")
+    f, h, wd, cin, cout = 2, 10, 16, 128, 640
+    x, w = rnd(f * h * wd, cin, seed=1).to(cuda), rnd(cout, 9 * cin, seed=2, scale=0.03).to(cuda)
+    r = rnd(f * h * wd, cout, seed=3).to(ops.STREAM()).to(cuda)
+    xm, wm = rnd(160 * 7 + 31, 640, seed=4).to(cuda), rnd(960, 640, seed=5, scale=0.03).to(cuda)
+    xs, ws = rnd(160 * 3 + 1, 64, seed=6).to(cuda), rnd(320, 64, seed=7, scale=0.1).to(cuda)          # one K-tile: two k halves, a ring of five
+    xk, wk = rnd(500, 192, seed=8).to(cuda), rnd(320, 192, seed=9, scale=0.1).to(cuda)                # three K-tiles: no steady-state iteration
+    xg, wg, bg = rnd(160 * 5 + 7, 320, seed=10).to(cuda), rnd(1024, 320, seed=11, scale=0.1).to(cuda), torch.randn(1024, device=cuda)
+    outs = []
+    saved = {k: os.environ.get(k) for k in ("MUDG_GEMM_W288", "MUDG_GEMM_W160")}
+    try:
+        for v in ("0", "2", "2"):
+            os.environ["MUDG_GEMM_W288"], os.environ["MUDG_GEMM_W160"] = "0", v
+            outs.append((ops.conv3x3(x, w, frames=f, hin=h, win=wd, cin=cin, korder=1, out_stream=True, stats=True),
+                         ops.conv3x3(x, w, frames=f, hin=h, win=wd, cin=cin, korder=0, out_fp32=True),
+                         ops.gemm(xm, wm, out_fp32=True), ops.tconv3(x, w[:, :3 * cin].contiguous(), clips=1, t=2, hw=h * wd, cin=cin),
+                         ops.gemm(xs, ws, out_stream=True), ops.gemm(xk, wk), ops.gemm(xg, wg, bias=bg, geglu=True), ops.gemm(xg, wg, bias=bg, geglu=True, out_fp32=True)))
+            rows = getattr(outs[-1][0], ops.GN_ATTR + "_rows")
+            assert rows == (128 if v == "0" else 160)
+            res_out = ops.conv3x3(x, w, frames=f, hin=h, win=wd, cin=cin, korder=1, residual=r, out_stream=True)
+            if v == "0":
+                res_ref = res_out
+            else:
+                assert rel_l2(res_out, res_ref.float().cpu()) < 2e-3 and float((res_out.float() - res_ref.float()).abs().max()) < 0.05
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    for a, b, c in zip(*outs):
+        assert torch.isfinite(a.float()).all() and float(a.float().abs().max()) > 1e-3
+        assert torch.equal(a, b) and torch.equal(b, c)
 
 
 def test_half_height_geglu_kernel_is_bit_identical_to_the_kernels_it_replaces(cuda):

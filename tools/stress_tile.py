@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Randomised stress of the 288 x 320 tile (csrc/wgemm.hip: hand-counted s_waitcnt vmcnt rings, inline-asm MFMAs, buffer descriptors
+"""Randomised stress of the 288 x 320 tile and (--tile 160, round 6) of the 160 x 320 tile (csrc/wgemm.hip: hand-counted s_waitcnt vmcnt rings, inline-asm MFMAs, buffer descriptors
 based before the tile's first row) — the tool the round-5 review asked for after an unexplained abort in 2 of ~100 suite runs.
 
 Every case is a random problem the tile can run (plain GEMM / GEGLU / same-size 3x3 conv / temporal 3-tap conv; ragged M, K = 64 ...
@@ -40,9 +40,12 @@ ap.add_argument("--launches", type=int, default=2000, help="tile launches to rea
 ap.add_argument("--seed", type=int, default=0)
 ap.add_argument("--repeat", type=int, default=3)
 ap.add_argument("--no-poison", action="store_true")
+ap.add_argument("--tile", type=int, default=288, choices=(288, 160), help="288: wgemm_kernel / wgemm_pkernel; 160: w160_kernel (16-bit builds)")
 args = ap.parse_args()
 
 CANARY = 0x5A5B
+TILE = args.tile
+SWITCH = "MUDG_GEMM_W288" if TILE == 288 else "MUDG_GEMM_W160"      # the variant switch that forces the stressed tile
 G = 16                                  # canary rows before and after every result
 
 
@@ -152,7 +155,7 @@ def make_case(rng, g):
         K = 64 * ri(rng, 1, 24 if not big else 8)
         tiles_m = ri(rng, 60, 300) if big else ri(rng, 1, 12)
         whole = ri(rng, 0, 2) > 0
-        M = 288 * tiles_m - (0 if whole else ri(rng, 1, 287))
+        M = TILE * tiles_m - (0 if whole else ri(rng, 1, TILE - 1))
         two = (not geglu) and K >= 128 and ri(rng, 0, 3) == 0
         c1 = 64 * ri(rng, 1, K // 64 - 1) if two else K
         x = rn(g, M, c1)
@@ -171,19 +174,21 @@ def make_case(rng, g):
         gb, rpg, stats = None, 0, 0
         if not geglu and whole and ri(rng, 0, 2) == 0:
             per = pick(rng, [d for d in (1, 2, 3, 4, 6) if tiles_m % d == 0])
-            rpg = 288 * per
+            rpg = TILE * per
             gb = torch.randn(M // rpg, N, generator=g, device="cuda")
         if not geglu and ri(rng, 0, 1):
-            stats = 288 * pick(rng, [d for d in (1, 2, 3, 4) if tiles_m % d == 0]) if whole else 0
+            stats = TILE * pick(rng, [d for d in (1, 2, 3, 4) if tiles_m % d == 0]) if whole else 0
         desc = f"{kind} M={M} N={N} K={K}" + (f" split {c1}" if two else "") + f" out={out_kind} res={res_kind} bias={int(bias_on)} gbias={rpg} stats={stats}"
 
         def run(out):
-            return ops.gemm(x, w, out=out, x2=x2, bias=b, gbias=gb, rows_per_group=rpg, residual=r, geglu=geglu, stats=bool(stats), frame_rows=288)
-        pers = hip.planes() == 1 and whole and K >= 128 and r is None
+            return ops.gemm(x, w, out=out, x2=x2, bias=b, gbias=gb, rows_per_group=rpg, residual=r, geglu=geglu, stats=bool(stats), frame_rows=TILE)
+        pers = TILE == 288 and hip.planes() == 1 and whole and K >= 128 and r is None
         return desc, run, M, nout, odt, r is not None, stats, pers
     if kind == "conv":
         f = ri(rng, 1, 3) if not big else ri(rng, 8, 16)
         h, wd = ri(rng, 3, 40), ri(rng, 3, 40)
+        if TILE == 160 and ri(rng, 0, 1):                    # half the cases: frames of whole 160-row tiles (partials per tile)
+            h, wd = pick(rng, [(10, 16), (16, 10), (20, 32), (32, 20), (8, 20), (20, 8), (5, 32), (32, 5), (25, 32), (15, 32), (30, 16), (40, 24)])
         cin, cout = 64 * ri(rng, 1, 6), 320 * ri(rng, 1, 2)
         two = cin >= 128 and ri(rng, 0, 3) == 0
         c1 = 64 * ri(rng, 1, cin // 64 - 1) if two else cin
@@ -197,7 +202,7 @@ def make_case(rng, g):
         if res_kind:
             rdt = {"operand": ops.H16(), "stream": ops.STREAM(), "fp32": torch.float32}[res_kind]
             r = rn(g, M, cout) if rdt == ops.H16() else (torch.randn(M, cout, generator=g, device="cuda") * 0.5).to(rdt)
-        stats = h * wd if ri(rng, 0, 1) and (h * wd) % 288 == 0 else 0
+        stats = h * wd if ri(rng, 0, 1) and (h * wd) % TILE == 0 else 0
         desc = f"conv f={f} {h}x{wd} cin={cin} cout={cout}" + (f" split {c1}" if two else "") + f" korder={korder} out={out_kind} res={res_kind} bias={int(bias_on)} stats={stats}"
 
         def run(out):
@@ -226,25 +231,25 @@ def main():
     g = torch.Generator(device="cuda").manual_seed(args.seed + 1)
     launches = cases = skipped = 0
     env = {k: os.environ.get(k) for k in ("MUDG_OPERAND", "PYTORCH_NO_CUDA_MEMORY_CACHING", "AMD_SERIALIZE_KERNEL", "HSA_XNACK")}
-    print(f"[stress] build {hip.operand_name()} planes {hip.planes()} seed {args.seed} target {args.launches} tile launches, repeat {args.repeat}, "
+    print(f"[stress] tile {TILE} build {hip.operand_name()} planes {hip.planes()} seed {args.seed} target {args.launches} tile launches, repeat {args.repeat}, "
           f"LDS poison {'on' if POISON else 'off'}, env {env}", flush=True)
     t0 = time.time()
     while launches < args.launches:
         desc, run, M, nout, odt, has_res, stats_rows, pers = make_case(rng, g)
         pad = pick(rng, [0, 0, 8, 24, 64])
-        os.environ["MUDG_GEMM_W288"], os.environ["MUDG_GEMM_W288P"] = "0", "0"
+        os.environ["MUDG_GEMM_W288"], os.environ["MUDG_GEMM_W288P"], os.environ["MUDG_GEMM_W160"] = "0", "0", "0"
         ref_whole, ref_view = guarded(M, nout, odt, pad)
         ref = run(ref_view)
         assert LAST["rows"] == 128, "MUDG_GEMM_W288=0 must not select the tile"
         forms = [("tile", "2", "0")] + ([("persistent", "2", "2")] if pers else [])
         first = None
         for form, v, pv in forms:
-            os.environ["MUDG_GEMM_W288"], os.environ["MUDG_GEMM_W288P"] = v, pv
+            os.environ[SWITCH], os.environ["MUDG_GEMM_W288P"] = v, pv
             for i in range(args.repeat):
                 poison(launches)
                 whole, view = guarded(M, nout, odt, pad)
                 y = run(view)
-                if LAST["rows"] != 288:                  # the library declined the tile for this descriptor: nothing to stress
+                if LAST["rows"] != TILE:                 # the library declined the tile for this descriptor: nothing to stress
                     break
                 launches += 1
                 torch.cuda.synchronize()
@@ -266,7 +271,7 @@ def main():
                         fail(f"tile bits != 128x128 bits (rel-L2 {rel(values(y), values(ref)):.2e}): {desc} [{form}]")
                     if stats_rows:
                         p = getattr(y, ops.GN_ATTR)
-                        s = p.reshape(-1, stats_rows // 288, nout, 2).double().sum(1)
+                        s = p.reshape(-1, stats_rows // TILE, nout, 2).double().sum(1)
                         v64 = values(y).reshape(-1, stats_rows, nout)
                         want = torch.stack([v64.sum(1), (v64 ** 2).sum(1)], -1)
                         e = rel(s, want)
@@ -283,6 +288,7 @@ def main():
         if cases % 100 == 0:
             print(f"[stress] {cases} cases, {launches} tile launches clean, {skipped} declined, {time.time() - t0:.0f} s; last: {desc}", flush=True)
     os.environ["MUDG_GEMM_W288"] = "1"
+    os.environ["MUDG_GEMM_W160"] = "1"
     os.environ.pop("MUDG_GEMM_W288P", None)
     verdict = "all bit-reproducible, canaries intact" if not FAILURES else f"{len(FAILURES)} FAILURES"
     print(f"[stress] DONE: {cases} cases, {launches} tile launches (one-tile and persistent forms), {verdict}, "
