@@ -27,6 +27,14 @@ MUDG_DEBUG_VARIANTS=1 MUDG_GEMM_H144=0 python bench.py --no-cpu-baseline --no-ch
 MUDG_DEBUG_VARIANTS=1 MUDG_GEMM_H144=1 python bench.py --no-cpu-baseline --no-children --steps 10 --warmup 3 2>/dev/null | tail -1 > $OUT/bench_h144_rule.json
 MUDG_DEBUG_VARIANTS=1 python tools/exp_h144.py time 2>/dev/null | grep geglu > $OUT/h144.txt
 MUDG_DEBUG_VARIANTS=1 python tools/exp_h144.py ablate 2>/dev/null | grep geglu > $OUT/h144_ablate.txt
+MUDG_DEBUG_VARIANTS=1 python tools/exp_stamps.py > $OUT/stamps.txt 2>/dev/null
+# round 6: the 160 x 320 tile (MDM512's frames): per-shape timings, parity, MDM512 with the tile off / by its rule (same box, same library), kernel trace
+MUDG_DEBUG_VARIANTS=1 python tools/exp_w160.py parity > $OUT/w160_parity.txt 2>/dev/null
+MUDG_DEBUG_VARIANTS=1 python tools/exp_w160.py time 2>/dev/null | grep -v amdgpu.ids > $OUT/w160_shapes.txt
+MUDG_DEBUG_VARIANTS=1 MUDG_GEMM_W160=0 python bench.py --no-cpu-baseline --no-children --resolution 512 2>/dev/null | tail -1 > $OUT/bench_m512_w160_off.json
+MUDG_DEBUG_VARIANTS=1 MUDG_GEMM_W160=1 python bench.py --no-cpu-baseline --no-children --resolution 512 2>/dev/null | tail -1 > $OUT/bench_m512_w160_rule.json
+rocprofv3 --kernel-trace --stats -d /tmp/pt5 -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-profile --no-children --resolution 512 > /tmp/pt5.log 2>&1
+python tools/rocprof_summary.py trace $(find /tmp/pt5 -name "*.db" | head -1) > $OUT/kernel_trace_m512.md
 # every contraction shape of the step on the tile and on the 128 x 128 kernels (the measurement behind the rule in wgemm.hip), both builds
 MUDG_DEBUG_VARIANTS=1 python tools/exp_w288.py time > $OUT/w288_shapes.txt 2>/dev/null
 MUDG_DEBUG_VARIANTS=1 MUDG_OPERAND=bf16x3 python tools/exp_w288.py time > $OUT/w288_x3_shapes.txt 2>/dev/null
