@@ -101,9 +101,9 @@ typedef struct MudgGemmDesc {
     /* mode 2 */
     int T, HW;            /* mode 0: HW may carry a HINT — the rows of one frame of the matrix (0 = none): it lets the library choose a tile
                              height that divides a frame (mudg_gemm_stats_rows).  Never M decides, so a row's result does not depend on
-                             the batch it travels in; with a residual R the 288-row tile adds R first instead of last (last-bit
+                             the batch it travels in; with a residual R the 288- and 160-row tiles add R first instead of last (last-bit
                              differences against the un-hinted call), without one the bits are the same */
-    float* stats;         /* NULL, or fp32 [ceil(M/rows)][Nout][2], rows = mudg_gemm_stats_rows(d) (128 | 288): the epilogue also writes, per row block and output
+    float* stats;         /* NULL, or fp32 [ceil(M/rows)][Nout][2], rows = mudg_gemm_stats_rows(d) (128 | 160 | 288): the epilogue also writes, per row block and output
                              channel, the sum and the sum of squares of the values it stored (as stored: after rounding to
                              bf16 when Y is bf16) — the first pass of the GroupNorm that consumes Y
                              (mudg_groupnorm_fused).  Needs batch == 1 and no GEGLU. */
@@ -122,9 +122,11 @@ typedef struct MudgGemmDesc {
     int ldy8, lds8;
 } MudgGemmDesc;
 int mudg_gemm(const MudgGemmDesc* d, void* stream);
-/* Height of the row blocks in which mudg_gemm will write `stats` for this problem: 128, or 288 where the 288 x 320-tile kernel of
- * the 16-bit builds runs it (same-size 3x3 convs, temporal convs with korder 0 and plain GEMMs with N % 320 == 0 whose frames are
- * whole 288-row tiles: Hout * Wout, HW — for mode 0 the caller's hint in HW — a multiple of 288).  `stats` then holds
+/* Height of the row blocks in which mudg_gemm will write `stats` for this problem: 128, or 288 where the 288 x 320-tile kernel
+ * runs it (same-size 3x3 convs, temporal convs with korder 0 and plain GEMMs with N % 320 == 0 whose frames are
+ * whole 288-row tiles: Hout * Wout, HW — for mode 0 the caller's hint in HW — a multiple of 288), or 160 where the 160 x 320-tile
+ * kernel of the 16-bit builds does (round 6: the same problems when a frame is whole 160-row tiles but not whole 288-row ones and
+ * has at least 640 rows — MDM512's 2560- and 640-pixel frames; plain GEMMs there from K = 640, or without a residual).  `stats` then holds
  * fp32 [ceil(M / rows)][Nout][2], and the consumer (mudg_groupnorm_fused) is told the same height.  The answer depends on the
  * descriptor's geometry, strides and pointer alignment, never on M: a clip's results do not depend on the batch it travels in. */
 int mudg_gemm_stats_rows(const MudgGemmDesc* d);
@@ -207,7 +209,7 @@ int mudg_groupnorm_fused(const void* X, const void* X2, int csplit, int ldx, int
                          int samples, int rows, int C, int groups, float eps, int silu,
                          const float* P1, const float* P2, float* ws, void* stream);
 
-/* The same with the height of the partial blocks stated per source (mudg_gemm_stats_rows of the producer: 128 | 288; `rows` must be
+/* The same with the height of the partial blocks stated per source (mudg_gemm_stats_rows of the producer: 128 | 160 | 288; `rows` must be
  * a multiple of both; mudg_groupnorm_fused = 128, 128). */
 int mudg_groupnorm_fused_rows(const void* X, const void* X2, int csplit, int ldx, int ldx2, int x_fp32,
                               const float* gamma, const float* beta, void* Y, int ldy,

@@ -267,7 +267,7 @@ __device__ __forceinline__ void w_epilogue(const MudgGemmDesc& p, f32x4 (&acc)[N
     // uatag: alpha == 1 (the product is not scaled: one v_add instead of v_mul + v_add per value, the same bits); tabtag: GEGLU's Phi from the
     // table.  Both are decided ONCE per tile, outside the loops: with `phi ? table : polynomial` inside the per-value expression the
     // compiler kept a branch per value and every table read was followed by its own s_waitcnt — 72 serialised LDS round trips per lane,
-    // the longest part of a K = 320 tile (round 6: profiles/r6/geglu_epilogue.md).  Here a row's eight reads are in flight together.
+    // the longest part of a K = 320 tile (round 6: DESIGN §3.2).  Here a row's eight reads are in flight together.
     auto piece8 = [&](auto ptag, auto uatag, auto tabtag) __attribute__((always_inline)) {
         constexpr int P = decltype(ptag)::value;         // fragment pair: accumulator fragments 2 P (channels + 0..3) and 2 P + 1 (+ 4..7)
         constexpr bool UA = decltype(uatag)::value != 0, TAB = decltype(tabtag)::value != 0;
