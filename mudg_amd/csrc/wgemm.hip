@@ -1298,25 +1298,44 @@ __global__ __launch_bounds__(256, 2) void hgeglu_kernel(const MudgGemmDesc p, co
 //     fragments of k half h + 1  (5 W + 5 X reads into the other register set) | 25 MFMAs of k half h
 // Bits: the K order and the per-row arithmetic of every other contraction kernel; without a residual identical to the 128 x 128 kernels,
 // with one the sum is ((r + x w) + bias) as on the 288-row tile — so the rule (mudg_wgemm_rows) looks at the frame geometry, never at M.
-constexpr int QBM = 160, Q_NA = QBM / 16, Q_NI = 5;
-template <int NREP> struct QGeo {
+// The same skeleton carries TWO tile heights (NI = 16-row fragments per wave and M half): NI = 5 — 160 rows, above — and, in the variant
+// builds only (GEMM_W288Q, a measurement: mudg_wgemm_launch), NI = 9 — 288 rows, the tile of wgemm_kernel on this loop: what took the 160-row
+// loop from 1050 to 1290 TFLOP/s (fragment reads between the MFMAs, no branch in the steady state, one barrier per k half) applied to the
+// tile with 151 FLOP per staged byte — same bits, same speed as the six-phase loop (profiles/r6/w288q_shapes.txt).  At 180
+// accumulators there is no room for a second fragment set, so the fragments are refreshed IN PLACE: a row's X fragment is requested for
+// the next k half as soon as its five MFMAs are issued, a W fragment after its last use in the last row — each has at least five MFMAs
+// (plus the barrier and the DMA issue) to arrive.  Ring of FOUR k halves of 38 | 34 KiB (five pieces per wave).
+constexpr int QBM = 160;
+template <int NREP, int NI> struct QGeo {
+    static constexpr int BM = 32 * NI;                   // 160 | 288
+    static constexpr int NA = 2 * NI;                    // X subtiles of a k half
     static constexpr int BN = 64 * NREP;
     static constexpr int NB = BN / 16;
-    static constexpr int NP = Q_NA + NB;                 // pieces of a k half: 30 | 26
+    static constexpr int NP = NA + NB;                   // pieces of a k half: 30 | 26 (160 rows), 38 | 34 (288 rows)
+    static constexpr int PW = (NP + 7) / 8;              // ... per wave: 4 | 5
     static constexpr int KS = NP * 1024;
-    static constexpr int R = 5;                          // ring slots
-    static constexpr int LOOP = R * KS;                  // 153600 | 133120
+    static constexpr int R = NI == 5 ? 5 : 4;            // ring slots
+    static constexpr int LOOP = R * KS;                  // 153600 | 133120; 155648 | 139264
     static constexpr int SMEM = LOOP + (NREP == 4 ? W_TAIL_GEGLU : W_TAIL) + 1024;         // + the dummy pieces' KiB
+    static constexpr bool DB = NI == 5;                  // two fragment sets (else refreshed in place)
 };
+template <int N> __device__ __forceinline__ void w_vmcnt_pieces(int c) {       // at most c k halves' worth of a wave's N pieces still in flight (c wave-uniform)
+    if (c <= 0) W_VMCNT(0);
+    else if (c == 1) { if constexpr (N == 4) W_VMCNT(4); else W_VMCNT(5); }
+    else if (c == 2) { if constexpr (N == 4) W_VMCNT(8); else W_VMCNT(10); }
+    else if (c == 3) { if constexpr (N == 4) W_VMCNT(12); else W_VMCNT(15); }
+    else { if constexpr (N == 4) W_VMCNT(16); else W_VMCNT(20); }
+}
 
-template <int MODE, int NREP, bool GEGLU, bool RS>
-__global__ __launch_bounds__(512, 2) void w160_kernel(const MudgGemmDesc p, const int vflags, const float* __restrict__ phi) {
-    using G = QGeo<NREP>;
-    constexpr int WBN = G::BN, KS = G::KS, R = G::R, NPAIR = NREP / 2;
+template <int MODE, int NREP, bool GEGLU, bool RS, int NI>
+__global__ __launch_bounds__(512, 2) void wq_kernel(const MudgGemmDesc p, const int vflags, const float* __restrict__ phi) {
+    using G = QGeo<NREP, NI>;
+    constexpr int WBN = G::BN, KS = G::KS, R = G::R, NPAIR = NREP / 2, BMq = G::BM, NA = G::NA, PW = G::PW;
     static_assert(!GEGLU || (MODE == 0 && NREP == 4), "GEGLU: plain GEMM on the 256-wide tile");
+    static_assert(PW == 4 || PW == 5, "pieces per wave");
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6) & 7;
     const int wr = wave >> 2, wc = wave & 3;             // waves wc and wc + 4 share a SIMD: the two M halves
     float* tail = reinterpret_cast<float*>(smem + G::LOOP);
     if (GEGLU && phi) {                                  // (value, step) pairs: gelu_lut2; visible after the K loop's barriers
@@ -1326,7 +1345,7 @@ __global__ __launch_bounds__(512, 2) void w160_kernel(const MudgGemmDesc p, cons
         }
     }
     // XCD-aware tile numbering (as wgemm_kernel)
-    const int ntn = p.N / WBN, ntm = (p.M + QBM - 1) / QBM;
+    const int ntn = p.N / WBN, ntm = (p.M + BMq - 1) / BMq;
     int tile;
     {
         const int total = gridDim.x, q8 = total >> 3, r8 = total & 7;
@@ -1341,7 +1360,7 @@ __global__ __launch_bounds__(512, 2) void w160_kernel(const MudgGemmDesc p, cons
         tn = r / gsz;
         tm = first + (r - tn * gsz);
     }
-    const int m0 = tm * QBM, n0 = tn * WBN;
+    const int m0 = tm * BMq, n0 = tn * WBN;
     constexpr int ntaps = MODE == 0 ? 1 : (MODE == 1 ? 9 : 3);
 
     const int pos = lane * 16;
@@ -1359,32 +1378,34 @@ __global__ __launch_bounds__(512, 2) void w160_kernel(const MudgGemmDesc p, cons
     const unsigned va2 = (unsigned)(srow * ldx2e) * 2u + (unsigned)schunk * 16u;
     const unsigned vw_pair = (unsigned)((8 * (srow >> 2) + (srow & 3)) * p.ldw) * 2u + (unsigned)schunk * 16u;     // (permuted W rows: wgemm_kernel)
     const unsigned vw_single = (unsigned)(srow * p.ldw) * 2u + (unsigned)schunk * 16u;
-    // This wave's pieces of a k half: piece indices wave + 8 q (q = 0 .. 3); a piece below Q_NA is an X subtile, below NP the W subtile
-    // piece - Q_NA, and beyond NP (the last pieces of some waves) a DUMMY: the same instruction with every lane out of range, zero-filling a
-    // spare KiB behind the tail — every wave issues exactly FOUR operations per k half, so the counted waits are the same for all.
-    // Piece 0 is always X, piece 2 always W; what pieces 1 and 3 are is wave-uniform and loop-invariant.
-    const bool x1 = wave + 8 < Q_NA;
-    int wdst[4], wso[4];                                  // per W piece: LDS offset inside a k half, scalar offset of its first W row
-    unsigned wv[4];                                       // ... and the lanes' offsets (permuted rows for paired fragments; OOB: dummy)
+    // This wave's pieces of a k half: piece indices wave + 8 q (q = 0 .. PW - 1); a piece below NA is an X subtile, below NP the W subtile
+    // piece - NA, and beyond NP (the last pieces of some waves) a DUMMY: the same instruction with every lane out of range, zero-filling a
+    // spare KiB behind the tail — every wave issues exactly PW operations per k half, so the counted waits are the same for all.
+    // What piece q is — X for every wave (XQ leading pieces), W for every wave, or wave-dependent — is loop-invariant.
+    constexpr int XQ = NA / 8;                            // pieces 0 .. XQ - 1 are X pieces of every wave (1 | 2)
+    constexpr int XMAX = (NA + 7) / 8;                    // a wave has at most XMAX X pieces (2 | 3)
+    const bool xmix = wave + 8 * XQ < NA;                 // piece XQ: X for the first NA - 8 XQ waves, W for the others
+    int wso[5];                                           // per W piece: the scalar offset of its first W row  (fixed bounds: with [PW] — a
+                                                          // constexpr local of the template — hipcc 7.2 silently drops the kernel's HOST stub)
+    unsigned wv[5];                                       // ... and the lanes' offsets (permuted rows for paired fragments; OOB: dummy)
 #pragma unroll
-    for (int q = 1; q < 4; ++q) {
+    for (int q = XQ; q < PW; ++q) {
         const int pc = wave + 8 * q;
-        const bool live = pc >= Q_NA && pc < G::NP;
-        const int st = live ? pc - Q_NA : 0, wcol = st / NREP, j = st - wcol * NREP;
+        const bool live = pc >= NA && pc < G::NP;
+        const int st = live ? pc - NA : 0, wcol = st / NREP, j = st - wcol * NREP;
         const bool single = j >= 2 * NPAIR;
         const int row0 = single ? wave_single_col<NREP>(wcol) : wave_pair_col<NREP>(wcol, j >> 1) + 4 * (j & 1);       // first channel of the piece
-        wdst[q] = pc * 1024;
         wso[q] = row0 * p.ldw * 2;
         wv[q] = live ? (single ? vw_single : vw_pair) : OOB;
     }
-    const bool dummy3 = !(wave + 24 < G::NP);
-    unsigned amask[2];                                    // tap validity of the lane's source row in X subtiles `wave` and `wave + 8`
+    const bool dummy_last = !(wave + 8 * (PW - 1) < G::NP);
+    unsigned amask[3];                                    // tap validity of the lane's source row in this wave's X subtiles
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
+    for (int q = 0; q < XMAX; ++q) {
         const int st = wave + 8 * q;
         const int m = m0 + st * 16 + srow;
         unsigned mask = 0;
-        if (st < Q_NA && m < p.M) {
+        if (st < NA && m < p.M) {
             if (MODE == 0) mask = 1;
             else if (MODE == 1) {
                 const int hw = p.Hout * p.Wout;
@@ -1422,21 +1443,25 @@ __global__ __launch_bounds__(512, 2) void w160_kernel(const MudgGemmDesc p, cons
         if (MODE == 2) soff += k.tap * p.HW * ld * 2;
         const int soffw = (k.kt * BK + ks * 32) * 2;
         // No branch in here (a taken scalar branch costs the wave its instruction buffer, and both waves of a SIMD run this right after the
-        // same barrier with the matrix pipe idle): the second source and "piece 1 is an X piece" are selects of descriptor and offsets.
+        // same barrier with the matrix pipe idle): the second source and "piece XQ is an X piece" are selects of descriptor and offsets.
         const __amdgpu_buffer_rsrc_t rA = s2 ? rX2 : rX;
-        const unsigned vx0 = ((amask[0] >> k.tap) & 1u) ? (s2 ? va2 : va1) : OOB;
-        const unsigned vx1 = ((amask[1] >> k.tap) & 1u) ? (s2 ? va2 : va1) : OOB;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lptr_t)(base + wave * 1024), 16, (int)vx0, soff + wave * 16 * ld * 2, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(x1 ? rA : rW, (lptr_t)(base + (wave + 8) * 1024), 16, (int)(x1 ? vx1 : wv[1]),
-                                                 x1 ? soff + (wave + 8) * 16 * ld * 2 : soffw + wso[1], 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(base + wdst[2]), 16, (int)wv[2], soffw + wso[2], 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(dummy3 ? smem + G::SMEM - 1024 : base + wdst[3]), 16, (int)wv[3], soffw + wso[3], 0, 0);
-    };
-    auto wait_pieces = [&](int c) {                       // at most c k halves' worth of this wave's pieces (four each) still in flight
-        if (c <= 0) W_VMCNT(0);
-        else if (c == 1) W_VMCNT(4);
-        else if (c == 2) W_VMCNT(8);
-        else W_VMCNT(12);
+        const unsigned vxa = s2 ? va2 : va1;
+        static_assert(PW == XQ + 3, "pieces of a wave: XQ X pieces, one X-or-W piece, one W piece, one W-or-dummy piece");
+        const unsigned v0 = ((amask[0] >> k.tap) & 1u) ? vxa : OOB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lptr_t)(base + wave * 1024), 16, (int)v0, soff + wave * 16 * ld * 2, 0, 0);
+        if constexpr (XQ == 2) {
+            const unsigned v1 = ((amask[1] >> k.tap) & 1u) ? vxa : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lptr_t)(base + (wave + 8) * 1024), 16, (int)v1, soff + (wave + 8) * 16 * ld * 2, 0, 0);
+        }
+        {
+            const int pc = wave + 8 * XQ;
+            const unsigned vm = ((amask[XQ] >> k.tap) & 1u) ? vxa : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xmix ? rA : rW, (lptr_t)(base + pc * 1024), 16, (int)(xmix ? vm : wv[XQ]),
+                                                     xmix ? soff + pc * 16 * ld * 2 : soffw + wso[XQ], 0, 0);
+        }
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(base + (wave + 8 * (XQ + 1)) * 1024), 16, (int)wv[XQ + 1], soffw + wso[XQ + 1], 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (lptr_t)(dummy_last ? smem + G::SMEM - 1024 : base + (wave + 8 * (XQ + 2)) * 1024), 16, (int)wv[XQ + 2],
+                                                 soffw + wso[XQ + 2], 0, 0);
     };
 
     const int NH = 2 * (p.K / BK);                        // k halves (>= 2, even)
@@ -1448,100 +1473,119 @@ __global__ __launch_bounds__(512, 2) void w160_kernel(const MudgGemmDesc p, cons
         sslot = sslot == R - 1 ? 0 : sslot + 1;
         if (!(hs & 1)) advance(kS);
     };
-#pragma unroll
-    for (int i = 0; i < R - 1; ++i)
-        if (i < NH) stage_next();
-
     // RS (a residual seeds the accumulators) is a template parameter: as a run-time branch its merge point carried a vmcnt(0) — every tile
-    // waited for all four prefetched k halves before its first MFMA, residual or not.
-    f32x4 acc[Q_NI][NREP];
-    if constexpr (RS) w_seed<NREP, Q_NI>(p, acc, m0, n0, wr, wc, lane);
+    // waited for all the prefetched k halves before its first MFMA, residual or not.  The seeds are requested before the first k halves
+    // (as in wgemm_kernel): what the first MFMA needs — seeds and k half 0 — is then at the head of the queue.
+    f32x4 acc[NI][NREP];
+    if constexpr (RS) w_seed<NREP, NI>(p, acc, m0, n0, wr, wc, lane);
     else {
 #pragma unroll
-        for (int i = 0; i < Q_NI; ++i)
+        for (int i = 0; i < NI; ++i)
 #pragma unroll
             for (int j = 0; j < NREP; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    // R - 1 k halves are staged ahead: in iteration h the fragments of k half h are in registers, those of h + 1 are read from their slot,
+    // and k half h + R - 1 goes to the slot of k half h - 1.  (Filling the whole ring — k half h + R into k half h's own slot, which needs
+    // an lgkmcnt(0) in front of the barrier — was measured: - 3 ... - 4 % on the convs at either height; profiles/r6/w288q_shapes_d4.txt.)
+#pragma unroll
+    for (int i = 0; i < R - 1; ++i)
+        if (i < NH) stage_next();
     const int fbyte0 = (lane & 15) * 64 + (lane >> 4) * 16;
     const int fbyte = fbyte0 ^ (((fbyte0 >> 9) & 1) << 5);
-    const char* a_base = smem + (wr * Q_NI) * 1024 + fbyte;
-    const char* b_base = smem + (Q_NA + wc * NREP) * 1024 + fbyte;
-    auto read_frags = [&](h16x8 (&b)[NREP], h16x8 (&a)[Q_NI], int slot) {
-#pragma unroll
-        for (int j = 0; j < NREP; ++j) b[j] = *reinterpret_cast<const h16x8*>(b_base + slot * KS + j * 1024);
-#pragma unroll
-        for (int i = 0; i < Q_NI; ++i) a[i] = *reinterpret_cast<const h16x8*>(a_base + slot * KS + i * 1024);
-    };
-    h16x8 bA[NREP], aA[Q_NI], bB[NREP], aB[Q_NI];
-    wait_pieces((NH < R - 1 ? NH : R - 1) - 1);           // k half 0 has landed
+    const char* a_base = smem + (wr * NI) * 1024 + fbyte;
+    const char* b_base = smem + (NA + wc * NREP) * 1024 + fbyte;
+    auto frag_a = [&](int slot, int i) { return *reinterpret_cast<const h16x8*>(a_base + slot * KS + i * 1024); };
+    auto frag_b = [&](int slot, int j) { return *reinterpret_cast<const h16x8*>(b_base + slot * KS + j * 1024); };
+    constexpr int NSET = G::DB ? 2 : 1;
+    h16x8 fb[NSET][NREP], fa[NSET][NI];
+    w_vmcnt_pieces<PW>((NH < R - 1 ? NH : R - 1) - 1);    // k half 0 has landed
     W_BARRIER();
-    read_frags(bA, aA, 0);
+#pragma unroll
+    for (int j = 0; j < NREP; ++j) fb[0][j] = frag_b(0, j);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) fa[0][i] = frag_a(0, i);
     int slot = 0;                                         // slot of k half h
-    auto half = [&](int h, const h16x8 (&bc)[NREP], const h16x8 (&ac)[Q_NI], h16x8 (&bn)[NREP], h16x8 (&an)[Q_NI]) {
-        const int nslot = slot == R - 1 ? 0 : slot + 1;
-        const bool more = h + 1 < NH;
-        if (more) {
-            const int last = NH - 1 < h + R - 2 ? NH - 1 : h + R - 2;          // the youngest k half issued so far
-            wait_pieces(last - (h + 1));
+    // The MFMAs of the k half whose fragments are in set `cur`, with the NEXT k half's fragment reads (slot nslot) between them: a wave
+    // issues in order, and all the reads in front of the MFMAs — while the other seven waves' reads queue at the same LDS — kept the matrix
+    // pipe idle until the last was issued (first version of the 160-row loop: 2650 cycles per k half where the MFMAs need 1600).  After the
+    // last k half the reads fetch a stale slot: unused.
+    auto multiply = [&](auto cur_tag, int nslot) {
+        constexpr int cur = decltype(cur_tag)::value;
+        if constexpr (G::DB) {                            // into the other set, one read per two MFMAs
+            constexpr int nxt = cur ^ 1;
+            H_LGKM0();                                    // this k half's fragments (requested under the previous one's MFMAs)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < NREP; ++j) fb[nxt][j] = frag_b(nslot, j);
+#pragma unroll
+            for (int i = 0; i < NI; ++i) fa[nxt][i] = frag_a(nslot, i);
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < NREP; ++j) acc[i][j] = mfma16(fb[cur][j], fa[cur][i], acc[i][j]);
+#pragma unroll
+            for (int g = 0; g < NREP + NI; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);          // 2 MFMA
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);          // 1 DS read
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, NI * NREP - 2 * (NREP + NI), 0);
+            __builtin_amdgcn_sched_barrier(0);
+        } else {                                          // in place: X fragment i after row i, W fragment j after its MFMA of the last row
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+#pragma unroll
+                for (int j = 0; j < NREP; ++j) {
+                    acc[i][j] = mfma16(fb[0][j], fa[0][i], acc[i][j]);
+                    if (i == NI - 1) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        fb[0][j] = frag_b(nslot, j);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                fa[0][i] = frag_a(nslot, i);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
-        W_BARRIER();
-        if (hs < NH) stage_next();
-        H_LGKM0();
-        __builtin_amdgcn_sched_barrier(0);
-        // The next k half's ten fragment reads go out BETWEEN this one's MFMAs, one per two: a wave issues in order, and ten reads in front
-        // of the MFMAs — while the other seven waves' reads queue at the same LDS — kept the matrix pipe idle until the last was issued
-        // (first version: 2650 cycles per k half where the MFMAs need 1600).  After the last k half the reads fetch a stale slot: unused.
-        read_frags(bn, an, nslot);
-#pragma unroll
-        for (int i = 0; i < Q_NI; ++i)
-#pragma unroll
-            for (int j = 0; j < NREP; ++j) acc[i][j] = mfma16(bc[j], ac[i], acc[i][j]);
-#pragma unroll
-        for (int g = 0; g < NREP + Q_NI; ++g) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);          // 2 MFMA
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);          // 1 DS read
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, Q_NI * NREP - 2 * (NREP + Q_NI), 0);
-        __builtin_amdgcn_sched_barrier(0);
-        slot = nslot;
     };
-    // Steady state — while a k half is staged in every iteration and two younger ones are in flight (h <= NH - 5): no condition inside.
-    auto steady = [&](int ks, const h16x8 (&bc)[NREP], const h16x8 (&ac)[Q_NI], h16x8 (&bn)[NREP], h16x8 (&an)[Q_NI]) {
+    using C0 = std::integral_constant<int, 0>; using C1 = std::integral_constant<int, G::DB ? 1 : 0>;
+    // Steady state — while a k half is staged in every iteration (h + R - 1 <= NH - 1) and R - 3 younger ones than h + 1 are in flight: no
+    // condition inside.  `ks`: which half of its K-tile the staged k half h + R - 1 is.
+    auto steady = [&](int ks, auto cur_tag) {
         const int nslot = slot == R - 1 ? 0 : slot + 1;
-        W_VMCNT(8);
+        w_vmcnt_pieces<PW>(R - 3);
         W_BARRIER();
         stage(kS, ks, sslot);
         sslot = sslot == R - 1 ? 0 : sslot + 1;
         if (ks) advance(kS);
-        H_LGKM0();
-        __builtin_amdgcn_sched_barrier(0);
-        read_frags(bn, an, nslot);
-#pragma unroll
-        for (int i = 0; i < Q_NI; ++i)
-#pragma unroll
-            for (int j = 0; j < NREP; ++j) acc[i][j] = mfma16(bc[j], ac[i], acc[i][j]);
-#pragma unroll
-        for (int g = 0; g < NREP + Q_NI; ++g) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        multiply(cur_tag, nslot);
+        slot = nslot;
+    };
+    auto half = [&](int h, auto cur_tag) {
+        const int nslot = slot == R - 1 ? 0 : slot + 1;
+        if (h + 1 < NH) {
+            const int last = NH - 1 < h + R - 2 ? NH - 1 : h + R - 2;          // the youngest k half issued so far
+            w_vmcnt_pieces<PW>(last - (h + 1));
         }
-        __builtin_amdgcn_sched_group_barrier(0x008, Q_NI * NREP - 2 * (NREP + Q_NI), 0);
-        __builtin_amdgcn_sched_barrier(0);
+        W_BARRIER();
+        if (hs < NH) stage_next();
+        multiply(cur_tag, nslot);
         slot = nslot;
     };
     int h = 0;
 #pragma unroll 1
-    for (; h + 6 <= NH; h += 2) {                        // both k halves of the pair are steady: h + 1 <= NH - 5
-        steady(0, bA, aA, bB, aB);
-        steady(1, bB, aB, bA, aA);
+    for (; h + R + 1 <= NH; h += 2) {                    // both k halves of the pair are steady: h + 1 <= NH - R
+        steady((R - 1) & 1, C0{});
+        steady(R & 1, C1{});
     }
-    hs = h + R - 1 < NH ? h + R - 1 : NH;                 // (what the steady iterations staged)
+    hs = h + R - 1 < NH ? h + R - 1 : NH;                 // (what the steady iterations staged; sslot followed them)
 #pragma unroll 1
     for (; h < NH; h += 2) {
-        half(h, bA, aA, bB, aB);
-        half(h + 1, bB, aB, bA, aA);
+        half(h, C0{});
+        half(h + 1, C1{});
     }
-    w_epilogue<NREP, GEGLU, 2, true, Q_NI>(p, acc, m0, n0, tm, wr, wc, lane, tid, tail, phi);
+    w_epilogue<NREP, GEGLU, 2, true, NI>(p, acc, m0, n0, tm, wr, wc, lane, tid, tail, phi);
 }
 #endif
 
@@ -1743,32 +1787,46 @@ extern "C" int mudg_debug_set_stamps(void* buf) {
 #endif
 
 #if MUDG_PLANES == 1
-template <int MODE, int NREP, bool GEGLU, bool RS>
-static int w160_launch_one(const MudgGemmDesc& d, int vflags, hipStream_t s, int slot) {
-    static bool attr_done[MAX_DEVICES][8] = {};
+template <int MODE, int NREP, bool GEGLU, bool RS, int NI>
+static int wq_launch_one(const MudgGemmDesc& d, int vflags, hipStream_t s, int slot) {
+    static bool attr_done[MAX_DEVICES][16] = {};
     const int dev = mudg_current_device();
     if (dev < 0) MUDG_FAIL(MUDG_ELAUNCH, "gemm: no current device");
-    using G = QGeo<NREP>;
+    using G = QGeo<NREP, NI>;
     if (!attr_done[dev][slot]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&w160_kernel<MODE, NREP, GEGLU, RS>), hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wq_kernel<MODE, NREP, GEGLU, RS, NI>), hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM);
         if (e != hipSuccess) MUDG_FAIL(MUDG_ELAUNCH, "gemm: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_done[dev][slot] = true;
     }
-    const int tiles = ((d.M + QBM - 1) / QBM) * (d.N / G::BN);
+    const int tiles = ((d.M + G::BM - 1) / G::BM) * (d.N / G::BN);
     const float* phi = GEGLU ? mudg_phi_table(false) : nullptr;
-    hipLaunchKernelGGL((w160_kernel<MODE, NREP, GEGLU, RS>), dim3(tiles), dim3(512), G::SMEM, s, d, vflags, phi);
+    hipLaunchKernelGGL((wq_kernel<MODE, NREP, GEGLU, RS, NI>), dim3(tiles), dim3(512), G::SMEM, s, d, vflags, phi);
     return mudg_check_launch("mudg_gemm");
 }
 #endif
 
 int mudg_wgemm_launch(const MudgGemmDesc& d, int vflags, hipStream_t s) {
 #if MUDG_PLANES == 1
-    if (mudg_wgemm_rows(d, vflags) == QBM) {
-        if (d.geglu) return w160_launch_one<0, 4, true, false>(d, vflags, s, 6);
-        if (d.mode == 0) return d.R ? w160_launch_one<0, 5, false, true>(d, vflags, s, 0) : w160_launch_one<0, 5, false, false>(d, vflags, s, 1);
-        if (d.mode == 1) return d.R ? w160_launch_one<1, 5, false, true>(d, vflags, s, 2) : w160_launch_one<1, 5, false, false>(d, vflags, s, 3);
-        return d.R ? w160_launch_one<2, 5, false, true>(d, vflags, s, 4) : w160_launch_one<2, 5, false, false>(d, vflags, s, 5);
+    const int rows = mudg_wgemm_rows(d, vflags);
+    if (rows == QBM) {
+        if (d.geglu) return wq_launch_one<0, 4, true, false, 5>(d, vflags, s, 6);
+        if (d.mode == 0) return d.R ? wq_launch_one<0, 5, false, true, 5>(d, vflags, s, 0) : wq_launch_one<0, 5, false, false, 5>(d, vflags, s, 1);
+        if (d.mode == 1) return d.R ? wq_launch_one<1, 5, false, true, 5>(d, vflags, s, 2) : wq_launch_one<1, 5, false, false, 5>(d, vflags, s, 3);
+        return d.R ? wq_launch_one<2, 5, false, true, 5>(d, vflags, s, 4) : wq_launch_one<2, 5, false, false, 5>(d, vflags, s, 5);
     }
+#ifdef MUDG_DEBUG_VARIANTS
+    // The 288-row tile on the loop of the 160-row one (wq_kernel<..., 9>), variant builds only.  Variant switch GEMM_W288Q: 0 = never (the
+    // rule: wgemm_kernel's six-phase loop), 2 = every one-tile problem of the 288-row tile (GEGLU included).  Measured per shape against the
+    // six-phase loop (tools/exp_w288.py q, profiles/r6/w288q_shapes.txt): 3x3 convs x 0.96 ... 1.04, temporal convs x 1.00 ... 1.02, plain
+    // GEMMs x 0.85 ... 1.07, GEGLU (one-tile against the persistent six-phase form) x 0.90 ... 0.98 — the same bits and no gain: two
+    // different schedules of the same 45 MFMAs, 14 fragment reads and 38 DMA pieces per k half end at the same 1300 - 1430 TFLOP/s.
+    if (mudg_variant("GEMM_W288P", 1) != 2 && mudg_variant("GEMM_W288Q", 0) == 2) {
+        if (d.geglu) return wq_launch_one<0, 4, true, false, 9>(d, vflags, s, 13);
+        if (d.mode == 0) return d.R ? wq_launch_one<0, 5, false, true, 9>(d, vflags, s, 7) : wq_launch_one<0, 5, false, false, 9>(d, vflags, s, 8);
+        if (d.mode == 1) return d.R ? wq_launch_one<1, 5, false, true, 9>(d, vflags, s, 9) : wq_launch_one<1, 5, false, false, 9>(d, vflags, s, 10);
+        return d.R ? wq_launch_one<2, 5, false, true, 9>(d, vflags, s, 11) : wq_launch_one<2, 5, false, false, 9>(d, vflags, s, 12);
+    }
+#endif
     if (d.geglu && half_height_ok(d)) return hgeglu_launch(d, vflags, s);
     if (const int grid = persistent_grid(d))
         return d.geglu ? wgemm_launch_persistent<4, true>(d, vflags, s, 1, grid) : wgemm_launch_persistent<5, false>(d, vflags, s, 0, grid);

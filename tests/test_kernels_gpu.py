@@ -933,6 +933,25 @@ def test_wide288_is_bit_identical_to_the_one_tile_kernels(cuda):
             os.environ["MUDG_GEMM_W288"] = saved
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+    # the same tile on the loop of the 160-row kernel (wq_kernel<..., 9>, GEMM_W288Q = 2: a measurement kept in the variant builds): the
+    # same bits as the six-phase loop, a residual included (both seed the accumulators with it)
+    if _hip.planes() == 1:
+        saved = {k: os.environ.get(k) for k in ("MUDG_GEMM_W288", "MUDG_GEMM_W288Q")}
+        try:
+            pair = []
+            for q in ("0", "2"):
+                os.environ["MUDG_GEMM_W288"], os.environ["MUDG_GEMM_W288Q"] = "2", q
+                pair.append((ops.conv3x3(x, w, frames=f, hin=h, win=wd, cin=cin, korder=1, residual=r, out_stream=True, stats=True),
+                             ops.gemm(xm, wm, out_fp32=True), ops.tconv3(x, w[:, :3 * cin].contiguous(), clips=1, t=2, hw=h * wd, cin=cin),
+                             ops.gemm(xl[:288 * 9], wm, residual=rnd(288 * 9, 960, seed=9).to(ops.STREAM()).to(cuda), out_stream=True, stats=True, frame_rows=288)))
+        finally:
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        for a, b in zip(*pair):
+            assert torch.equal(a, b) and torch.equal(getattr(a, ops.GN_ATTR, torch.zeros(1)), getattr(b, ops.GN_ATTR, torch.zeros(1)))
 
 
 # ---------------------------------------------------------------------------------------------- the 160 x 320 tile (csrc/wgemm.hip: w160_kernel)

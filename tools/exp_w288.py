@@ -184,3 +184,84 @@ if what in ("time", "all"):
         fl = 2.0 * M * cout * 9 * cin
         print(f"conv {M} {cout} {9*cin}: 128x128 {ts[0]*1e6:8.1f} us {fl/ts[0]/1e12:7.1f} TF | 288x320 {ts[1]*1e6:8.1f} us {fl/ts[1]/1e12:7.1f} TF  x{ts[0]/ts[1]:.3f}", flush=True)
     os.environ["MUDG_GEMM_W288"] = "1"
+
+if what in ("q", "qparity", "qtime") and hip.planes() == 1:
+    # Round 6: the 288-row tile on the loop of the 160-row tile (wq_kernel<..., 9>: one barrier per k half, fragments refreshed in place
+    # between the MFMAs, branch-free steady state) against wgemm_kernel's six-phase loop — MUDG_GEMM_W288Q = 0 / 2, both under MUDG_GEMM_W288 = 2.
+    os.environ["MUDG_GEMM_W288"] = "2"
+
+    def qboth(fn):
+        out = []
+        for v in ("0", "2"):
+            os.environ["MUDG_GEMM_W288Q"] = v
+            y = fn()
+            torch.cuda.synchronize()
+            out.append((y, getattr(y, ops.GN_ATTR, None)))
+        os.environ["MUDG_GEMM_W288Q"] = "0"
+        return out
+
+    bad = 0
+    if what in ("q", "qparity"):
+        torch.manual_seed(2)
+        cases = []
+        for M, N, K in ((288 * 5, 640, 320), (288 * 3 + 100, 320, 1280), (288 * 9, 960, 64), (288 * 2 + 1, 320, 128), (288 * 4, 320, 192), (288 * 300, 320, 320)):
+            x, w, b, r = rn(M, K), rn(N, K), torch.randn(N, device="cuda"), rs(M, N)
+            cases.append((f"gemm {M}x{N}x{K} residual stream stats", lambda x=x, w=w, b=b, r=r: ops.gemm(x, w, bias=b, residual=r, out_stream=True, stats=True, frame_rows=288)))
+            cases.append((f"gemm {M}x{N}x{K} fp32", lambda x=x, w=w, b=b: ops.gemm(x, w, bias=b, out_fp32=True, frame_rows=288)))
+        for korder in (0, 1):
+            f, h, wd, cin, cout = 3, 24, 36, 128, 320
+            x, w, b = rn(f * h * wd, cin), rn(cout, 9 * cin), torch.randn(cout, device="cuda")
+            emb, r = torch.randn(f, cout, device="cuda"), rs(f * h * wd, cout)
+            xa, xb = rn(f * h * wd, 64), rn(f * h * wd, 64)
+            cases.append((f"conv korder {korder} gbias stats", lambda x=x, w=w, b=b, emb=emb, korder=korder: ops.conv3x3(x, w, frames=f, hin=h, win=wd, cin=cin, korder=korder, bias=b, gbias=emb, rows_per_group=h * wd, stats=True)))
+            cases.append((f"conv korder {korder} residual", lambda x=x, w=w, b=b, r=r, korder=korder: ops.conv3x3(x, w, frames=f, hin=h, win=wd, cin=cin, korder=korder, bias=b, residual=r, out_stream=True, stats=True)))
+            cases.append((f"conv korder {korder} two sources", lambda xa=xa, xb=xb, w=w, b=b, korder=korder: ops.conv3x3(xa, w, x2=xb, frames=f, hin=h, win=wd, cin=cin, korder=korder, bias=b, out_fp32=True)))
+        for M, N, K in ((288 * 4 + 40, 512, 320), (288 * 2, 2560, 128), (288 * 6, 1024, 64)):
+            x, w, b = rn(M, K), rn(N, K), torch.randn(N, device="cuda")
+            cases.append((f"geglu {M}x{N}x{K}", lambda x=x, w=w, b=b: ops.gemm(x, w, bias=b, geglu=True, frame_rows=288)))
+        clips, t, hw, c, co = 2, 4, 288, 128, 320
+        x, w, b, r = rn(clips * t * hw, c), rn(co, 3 * c), torch.randn(co, device="cuda"), rs(clips * t * hw, co)
+        cases.append(("tconv stats", lambda: ops.tconv3(x, w, clips=clips, t=t, hw=hw, cin=c, bias=b, stats=True)))
+        cases.append(("tconv residual", lambda: ops.tconv3(x, w, clips=clips, t=t, hw=hw, cin=c, bias=b, residual=r, out_stream=True)))
+        for name, fn in cases:
+            (y0, p0), (y1, p1) = qboth(fn)
+            (y2, p2) = qboth(fn)[1]
+            same = torch.equal(y0, y1) and (p0 is None or torch.equal(p0, p1)) and torch.equal(y1, y2) and bool(torch.isfinite(y1.float()).all())
+            bad += not same
+            print(f"{name}: new loop == six-phase loop (bits, partials, repeat): {same}" + ("" if same else f"   <-- FAIL rel-L2 {rel(y1, y0):.2e}"), flush=True)
+        print(f"QPARITY {'OK' if not bad else 'FAILED: %d' % bad}", flush=True)
+    if what in ("q", "qtime"):
+        def tq(fn, pers=None):
+            ts = []
+            for v in ("0", "2"):
+                os.environ["MUDG_GEMM_W288Q"] = v
+                ts.append(timeit(fn, iters=10))
+            os.environ["MUDG_GEMM_W288Q"] = "0"
+            return ts
+        G = [(294912, 320, 320, 9216), (294912, 320, 1280, 9216), (294912, 960, 320, 9216), (294912, 640, 320, 9216), (73728, 640, 640, 2304), (73728, 640, 2560, 2304),
+             (73728, 1920, 640, 2304), (73728, 1280, 640, 2304), (18432, 1280, 5120, 576), (18432, 3840, 1280, 576), (18432, 1280, 1280, 576), (18432, 2560, 1280, 576)]
+        for resid in (1, 0):
+            for (M, N, K, hw) in G:
+                x, w, b = rn(M, K), rn(N, K), torch.randn(N, device="cuda")
+                r = rs(M, N) if resid else None
+                ts = tq(lambda: ops.gemm(x, w, bias=b, residual=r, out_stream=bool(resid), frame_rows=hw))
+                print(f"gemm {M} {N} {K} residual={resid}: six-phase {ts[0]*1e6:8.1f} us {2.0*M*N*K/ts[0]/1e12:7.1f} TF | new loop {ts[1]*1e6:8.1f} us {2.0*M*N*K/ts[1]/1e12:7.1f} TF  x{ts[0]/ts[1]:.3f}", flush=True)
+        for (M, N, K, hw) in [(294912, 2560, 320, 9216), (73728, 5120, 640, 2304), (18432, 10240, 1280, 576), (147456, 2560, 320, 9216)]:
+            x, w, b = rn(M, K), rn(N, K), torch.randn(N, device="cuda")
+            ts = tq(lambda: ops.gemm(x, w, bias=b, geglu=True, frame_rows=hw))
+            print(f"geglu {M} {N} {K}: six-phase (persistent where it applies) {ts[0]*1e6:8.1f} us {2.0*M*N*K/ts[0]/1e12:7.1f} TF | new loop, one tile {ts[1]*1e6:8.1f} us {2.0*M*N*K/ts[1]/1e12:7.1f} TF  x{ts[0]/ts[1]:.3f}", flush=True)
+        for (clips, t, hw, c) in [(2, 16, 9216, 320), (2, 16, 2304, 640), (2, 16, 576, 1280)]:
+            x, w = rn(clips * t * hw, c), rn(c, 3 * c)
+            M = clips * t * hw
+            ts = tq(lambda: ops.tconv3(x, w, clips=clips, t=t, hw=hw, cin=c, stats=True, korder=0))
+            print(f"tconv {M} {c} {3*c}: six-phase {ts[0]*1e6:8.1f} us | new loop {ts[1]*1e6:8.1f} us {2.0*M*c*3*c/ts[1]/1e12:7.1f} TF  x{ts[0]/ts[1]:.3f}", flush=True)
+        C = [(32, 72, 128, 320, 320), (32, 72, 128, 640, 320), (32, 72, 128, 960, 320), (16, 72, 128, 320, 320), (32, 36, 64, 640, 640), (32, 36, 64, 1280, 640),
+             (32, 36, 64, 1920, 640), (32, 18, 32, 1280, 1280), (32, 18, 32, 2560, 1280), (32, 18, 32, 1920, 1280)]
+        for (f, h, w_, cin, cout) in C:
+            x, w = rn(f * h * w_, cin), rn(cout, 9 * cin)
+            M = f * h * w_
+            ts = tq(lambda: ops.conv3x3(x, w, frames=f, hin=h, win=w_, cin=cin, korder=1, stats=True))
+            fl = 2.0 * M * cout * 9 * cin
+            print(f"conv {M} {cout} {9*cin}: six-phase {ts[0]*1e6:8.1f} us {fl/ts[0]/1e12:7.1f} TF | new loop {ts[1]*1e6:8.1f} us {fl/ts[1]/1e12:7.1f} TF  x{ts[0]/ts[1]:.3f}", flush=True)
+    os.environ["MUDG_GEMM_W288"] = "1"
+    sys.exit(1 if bad else 0)
