@@ -979,12 +979,13 @@ def test_wide160_conv_gemm_and_temporal_conv_by_the_rule(cuda):
     rows = getattr(y, ops.GN_ATTR + "_rows")
     assert _rows_ok(rows, 160 if _w160_build() else 128)
     stats = getattr(y, ops.GN_ATTR)
-    yf = y.float().cpu().reshape(-1, rows, cout)
-    assert tuple(stats.shape) == (M // rows, cout, 2)
+    blocks = lambda t, r: torch.nn.functional.pad(t.float().cpu(), (0, 0, 0, (-t.shape[0]) % r)).reshape(-1, r, t.shape[1])     # (a variant child may force another height)
+    yf = blocks(y, rows)
+    assert tuple(stats.shape) == ((M + rows - 1) // rows, cout, 2)
     assert rel_l2(stats[..., 0], yf.sum(1)) < 1e-5 and rel_l2(stats[..., 1], (yf * yf).sum(1)) < 1e-5
     one = ops.conv3x3(xa[:h * wd].to(cuda), w.to(cuda), x2=xb[:h * wd].to(cuda), frames=1, hin=h, win=wd, cin=cin, korder=1, bias=b.to(cuda),
                       gbias=gb[:1].to(cuda), rows_per_group=h * wd, residual=res[:h * wd].to(cuda), stats=True, out_stream=True)
-    assert torch.equal(one, y[:h * wd]) and torch.equal(getattr(one, ops.GN_ATTR), stats[:h * wd // rows])
+    assert torch.equal(one, y[:h * wd]) and ((h * wd) % rows or torch.equal(getattr(one, ops.GN_ATTR), stats[:h * wd // rows]))
     # the partials feed the fused GroupNorm (160-row blocks next to a 128-row source)
     other = ops.gemm(xa.to(cuda), rnd(160, c1, seed=7, scale=0.1).to(cuda), stats=True, out_stream=True)       # N = 160: the 128 x 128 kernels
     g = torch.randn(480, generator=torch.Generator().manual_seed(8)).to(cuda)
@@ -1013,8 +1014,7 @@ def test_wide160_conv_gemm_and_temporal_conv_by_the_rule(cuda):
     yt = ops.tconv3(xt.to(cuda), wt.to(cuda), clips=clips, t=t, hw=hw, cin=c, bias=btc.to(cuda), stats=True)
     assert rel_l2(yt, ref) < TOL_BF16
     rows = getattr(yt, ops.GN_ATTR + "_rows")
-    yf = yt.float().cpu().reshape(-1, rows, co)
-    assert rel_l2(getattr(yt, ops.GN_ATTR)[..., 0], yf.sum(1)) < 1e-5
+    assert rel_l2(getattr(yt, ops.GN_ATTR)[..., 0], blocks(yt, rows).sum(1)) < 1e-5
 
 
 def test_wide160_is_bit_identical_to_the_one_tile_kernels(cuda):
