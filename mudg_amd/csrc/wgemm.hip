@@ -1,6 +1,8 @@
 // wgemm.hip — the 288 x 320 tile of the contraction family (round 5): eight waves, v_mfma_f32_16x16x32, one workgroup per CU,
 // LDS-DMA ring managed per k half, six barrier-delimited phases per K-tile with the two wave groups of a SIMD in anti-phase.
 // Plain GEMM, same-size 3x3 conv and temporal 3-tap conv (descriptor loader, 16-bit builds).  MudgGemmDesc semantics: mudg_hip.h.
+// Also in this file: the persistent form of the tile (wgemm_pkernel), the two-workgroup 144 x 256 GEGLU kernel (hgeglu_kernel, round 6: a
+// measured negative, rule "never") and the 160 x 320 tile for frames of whole 160-row tiles (wq_kernel, round 6) — each under its own header.
 //
 // Why this tile.  (1) One workgroup per CU wants the tile count to be a multiple of the 256 CUs, and 288 rows make it one at
 // every level of the benchmarked resolution: a frame is 9216 / 2304 / 576 pixels = 32 / 8 / 2 x 288, so a guidance batch of
