@@ -87,7 +87,7 @@ template <int NREP> struct WGeo {
 #define W_VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 // Debug-variants build only: s_memtime stamps of wave 0 of every workgroup at the phase boundaries of the GEGLU kernels (tools/exp_stamps.py).
 #ifdef MUDG_DEBUG_VARIANTS
-__device__ unsigned long long* g_stamps = nullptr;         // [workgroup][64]
+[[maybe_unused]] __device__ unsigned long long* g_stamps = nullptr;         // [workgroup][64]
 #define W_STAMP(slot) do { if (tid == 0 && g_stamps && (slot) < 64) g_stamps[(size_t)blockIdx.x * 64 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define W_STAMP(slot) do { } while (0)
@@ -979,7 +979,7 @@ __global__ __launch_bounds__(512, 2) void wgemm_pkernel(const MudgGemmDesc p, co
     const int nk = p.K / BK;                               // >= 2 (host)
 
     W_STAMP(0);
-    int stamp_tile = 0;
+    [[maybe_unused]] int stamp_tile = 0;
     stage(0, 0, 0, 0, 0);
     stage(0, 0, 1, 0, 0);
     stage(0, 1, 0, 1, 0);
