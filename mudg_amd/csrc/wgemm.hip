@@ -580,6 +580,7 @@ __global__ __launch_bounds__(512, 2) void wgemm_kernel(const MudgGemmDesc p, con
         k.tap = slab ? (wrap ? 0 : t1) : (wrap ? t1 : k.tap);
         k.c = slab ? (wrap ? c1 : k.c) : (wrap ? 0 : c1);
     };
+    W_STAMP(0);
     f32x4 acc[9][NREP];
     if (!GEGLU && p.R) w_seed<NREP, 9>(p, acc, m0, n0, wr, wc, lane);
     else {
@@ -667,6 +668,7 @@ __global__ __launch_bounds__(512, 2) void wgemm_kernel(const MudgGemmDesc p, con
         advance(kB);
         if (nk <= 1) W_VMCNT(0); else if (a_cnt + b_cnt == 5) W_VMCNT(10); else W_VMCNT(8);      // ks 0 of tile 0 has landed
         W_BARRIER();
+        W_STAMP(1);
         if (wr == 1) W_BARRIER();                            // the stagger: M-half 1 runs one barrier behind M-half 0
 
         for (int t = 0; t < nk; ++t) {
@@ -837,8 +839,10 @@ __global__ __launch_bounds__(512, 2) void wgemm_kernel(const MudgGemmDesc p, con
         asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     }
     if (wr == 0) W_BARRIER();                            // evens out the stagger: every fragment read has retired, every DMA has landed
+    W_STAMP(2);
 
     w_epilogue<NREP, GEGLU>(p, acc, m0, n0, tm, wr, wc, lane, tid, tail, phi);
+    W_STAMP(3);
 }
 
 #if MUDG_PLANES == 1
@@ -1466,6 +1470,7 @@ __global__ __launch_bounds__(512, 2) void wq_kernel(const MudgGemmDesc p, const 
                                                  soffw + wso[XQ + 2], 0, 0);
     };
 
+    W_STAMP(0);
     const int NH = 2 * (p.K / BK);                        // k halves (>= 2, even)
     KPos kS{0, 0, 0};
     int hs = 0, sslot = 0;                                // the next k half to stage and its slot
@@ -1502,6 +1507,7 @@ __global__ __launch_bounds__(512, 2) void wq_kernel(const MudgGemmDesc p, const 
     h16x8 fb[NSET][NREP], fa[NSET][NI];
     w_vmcnt_pieces<PW>((NH < R - 1 ? NH : R - 1) - 1);    // k half 0 has landed
     W_BARRIER();
+    W_STAMP(1);
 #pragma unroll
     for (int j = 0; j < NREP; ++j) fb[0][j] = frag_b(0, j);
 #pragma unroll
@@ -1587,7 +1593,9 @@ __global__ __launch_bounds__(512, 2) void wq_kernel(const MudgGemmDesc p, const 
         half(h, C0{});
         half(h + 1, C1{});
     }
+    W_STAMP(2);
     w_epilogue<NREP, GEGLU, 2, true, NI>(p, acc, m0, n0, tm, wr, wc, lane, tid, tail, phi);
+    W_STAMP(3);
 }
 #endif
 

@@ -325,6 +325,9 @@ def test_config0_two_ddim_steps_and_decode_at_mdm512_match_the_cpu_oracle(cuda, 
     print(f"[{hip.operand_name()}] config 0 at full size (MDM512, {steps} DDIM steps + 16-frame decode) vs CPU oracle: latents {e_s:.3e}  "
           f"decoded frames {e_d:.3e}; oracle {dt:.0f} s on {torch.get_num_threads()} threads")
     assert decoded.shape == (1, 3, 16, 320, 512) and torch.isfinite(decoded).all()
+    from helpers import record_parity
+    record_parity(hip.operand_name(), f"config0_{steps}_steps_latents_vs_cpu_oracle", e_s)
+    record_parity(hip.operand_name(), f"config0_{steps}_steps_decoded_vs_cpu_oracle", e_d)
     if hip.operand_name() in ("bf16x3", "bf16x6"):
         assert e_d <= 1e-3 and e_s <= 1e-3
 

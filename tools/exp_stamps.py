@@ -59,3 +59,55 @@ for (M, N, K, hw) in [(294912, 2560, 320, 9216), (73728, 5120, 640, 2304)]:
           f"(min {epi.min():.2f}, max {epi.max():.2f}), stamped lifetime {life.mean():.2f}; slots x lifetime = {512 * us / tiles2:.2f} us per workgroup "
           f"=> {512 * us / tiles2 - life.mean():.2f} us per workgroup outside the stamps (launch, table copy, store drain)")
 os.environ["MUDG_GEMM_W288"], os.environ["MUDG_GEMM_H144"] = "1", "1"
+
+# Round 6, second half: where a one-tile workgroup of the plain contraction tiles spends its life, and what a CU spends BETWEEN two
+# workgroups (launch, descriptor set-up, the drain of the stores): slots x launch time / tiles - stamped lifetime.
+rs = lambda *s: (torch.randn(*s, device="cuda") * 0.5).to(ops.STREAM())
+
+
+def run_plain(fn, nwg):
+    for _ in range(3):
+        fn()
+    buf = torch.zeros(nwg * 64, dtype=torch.int64, device="cuda")
+    assert lib.mudg_debug_set_stamps(ctypes.c_void_p(buf.data_ptr())) == 0
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    fn()
+    e1.record()
+    torch.cuda.synchronize()
+    assert lib.mudg_debug_set_stamps(ctypes.c_void_p(0)) == 0
+    return buf.cpu().reshape(nwg, 64).double(), e0.elapsed_time(e1) * 1e3
+
+
+def report(name, fn, tiles, tick):
+    d, us = run_plain(fn, tiles)
+    d = d[d[:, 0] > 0]
+    pro, loop, epi = (d[:, 1] - d[:, 0]) * tick / 1e3, (d[:, 2] - d[:, 1]) * tick / 1e3, (d[:, 3] - d[:, 2]) * tick / 1e3
+    life = (d[:, 3] - d[:, 0]) * tick / 1e3
+    slot = 256 * us / tiles if tiles >= 256 else us
+    print(f"{name}: {us:.0f} us, {tiles} one-tile workgroups = {slot:.2f} us of a CU each; stamped: first k half (+ residual) landed after {pro.mean():.2f} us "
+          f"(min {pro.min():.2f}, max {pro.max():.2f}), K loop {loop.mean():.2f} (min {loop.min():.2f}, max {loop.max():.2f}), epilogue {epi.mean():.2f} "
+          f"(min {epi.min():.2f}, max {epi.max():.2f}), lifetime {life.mean():.2f} => {slot - life.mean():.2f} us per workgroup outside the stamps", flush=True)
+
+
+tick = 0.6          # ns per s_memtime tick, re-calibrated on a long persistent launch below
+st, us, tick = run(294912, 2560, 320, 9216, "1", "0", 256)
+print(f"tick {tick:.3f} ns")
+os.environ["MUDG_GEMM_W288"] = "2"
+for (M, N, K, hw, resid) in [(294912, 320, 320, 9216, 1), (294912, 320, 320, 9216, 0), (294912, 320, 1280, 9216, 1), (294912, 960, 320, 9216, 0), (73728, 640, 640, 2304, 1),
+                              (73728, 640, 2560, 2304, 1), (18432, 1280, 5120, 576, 1)]:
+    x, w, b = rn(M, K), rn(N, K), torch.randn(N, device="cuda")
+    r = rs(M, N) if resid else None
+    report(f"gemm {M}x{N}x{K} residual={resid} on the 288 x 320 tile", lambda: ops.gemm(x, w, bias=b, residual=r, out_stream=bool(resid), frame_rows=hw), (M // 288) * (N // 320), tick)
+for (f, h, w_, cin, cout) in [(32, 72, 128, 320, 320), (32, 36, 64, 1280, 640)]:
+    x, w = rn(f * h * w_, cin), rn(cout, 9 * cin)
+    report(f"conv {f * h * w_}x{cout}x{9 * cin} on the 288 x 320 tile", lambda: ops.conv3x3(x, w, frames=f, hin=h, win=w_, cin=cin, korder=1, stats=True), (f * h * w_ // 288) * (cout // 320), tick)
+os.environ["MUDG_GEMM_W288"], os.environ["MUDG_GEMM_W160"] = "0", "2"
+for (M, N, K, hw, resid) in [(81920, 320, 320, 2560, 1), (81920, 320, 1280, 2560, 1), (20480, 640, 2560, 640, 1)]:
+    x, w, b = rn(M, K), rn(N, K), torch.randn(N, device="cuda")
+    r = rs(M, N) if resid else None
+    report(f"gemm {M}x{N}x{K} residual={resid} on the 160 x 320 tile", lambda: ops.gemm(x, w, bias=b, residual=r, out_stream=bool(resid), frame_rows=hw), (M // 160) * (N // 320), tick)
+for (f, h, w_, cin, cout) in [(32, 40, 64, 320, 320), (32, 20, 32, 1280, 640)]:
+    x, w = rn(f * h * w_, cin), rn(cout, 9 * cin)
+    report(f"conv {f * h * w_}x{cout}x{9 * cin} on the 160 x 320 tile", lambda: ops.conv3x3(x, w, frames=f, hin=h, win=w_, cin=cin, korder=1, stats=True), (f * h * w_ // 160) * (cout // 320), tick)
+os.environ["MUDG_GEMM_W288"], os.environ["MUDG_GEMM_W160"] = "1", "1"
