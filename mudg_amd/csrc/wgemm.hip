@@ -253,9 +253,13 @@ __device__ __forceinline__ void w_seed(const MudgGemmDesc& p, f32x4 (&acc)[NI][N
 // LUT: how the Phi table lies in `tail` — 2 = (value, step) pairs (gelu_lut2, 8 KiB), 1 = plain values (gelu_lut, 4 KiB: the two-workgroup
 // kernel below has no room for the pairs); the same bits either way (the step is the same fp32 difference, taken once or per value).
 // UASPEC = false: no alpha == 1 copy of the plain epilogue (the persistent plain kernel has no registers for two).
-template <int NREP, bool GEGLU, int LUT = 2, bool UASPEC = true, int NI = 9>
+// DR (wq_kernel's deferred residual): the residual of the lane's pieces is in registers, RAW (sraw: the two 16-byte pieces of a row's
+// fragment pairs, srs: the 8-byte piece of its unpaired fragment; fp16 stream or 16-bit operand storage), and is added HERE, after the bias —
+// ((x w + bias) + r), the order of the 128 x 128 kernels.
+template <int NREP, bool GEGLU, int LUT = 2, bool UASPEC = true, int NI = 9, bool DR = false>
 __device__ __forceinline__ void w_epilogue(const MudgGemmDesc& p, f32x4 (&acc)[NI][NREP], const int m0, const int n0, const int tm, const int wr, const int wc,
-                                           const int lane, const int tid, float* tail, const float* __restrict__ phi) {
+                                           const int lane, const int tid, float* tail, const float* __restrict__ phi,
+                                           const u32x4 (*sraw)[2] = nullptr, const u32x2* srs = nullptr) {
     constexpr int WBN = 64 * NREP, NPAIR = NREP / 2;
     using T0 = std::integral_constant<int, 0>; using T1 = std::integral_constant<int, 1>;
     const int px = lane & 15, q4 = lane >> 4;
@@ -270,7 +274,7 @@ __device__ __forceinline__ void w_epilogue(const MudgGemmDesc& p, f32x4 (&acc)[N
     // table.  Both are decided ONCE per tile, outside the loops: with `phi ? table : polynomial` inside the per-value expression the
     // compiler kept a branch per value and every table read was followed by its own s_waitcnt — 72 serialised LDS round trips per lane,
     // the longest part of a K = 320 tile (round 6: DESIGN §3.2).  Here a row's eight reads are in flight together.
-    auto piece8 = [&](auto ptag, auto uatag, auto tabtag) __attribute__((always_inline)) {
+    auto piece8 = [&](auto ptag, auto uatag, auto tabtag, auto rtag) __attribute__((always_inline)) {
         constexpr int P = decltype(ptag)::value;         // fragment pair: accumulator fragments 2 P (channels + 0..3) and 2 P + 1 (+ 4..7)
         constexpr bool UA = decltype(uatag)::value != 0, TAB = decltype(tabtag)::value != 0;
         const int cw = n0 + wave_pair_col<NREP>(wc, GEGLU ? 0 : P) + 8 * q4;          // first W row (bias index) of the value
@@ -323,6 +327,18 @@ __device__ __forceinline__ void w_epilogue(const MudgGemmDesc& p, f32x4 (&acc)[N
                     const float a = acc[i][2 * P + (e >> 2)][e & 3];
                     v[e] = UA ? a + bv[e] : alpha * a + bv[e];
                 }
+                if constexpr (DR) {
+                    constexpr int RT = decltype(rtag)::value;             // 1: fp16 stream, 2: operand storage
+                    if constexpr (RT == 1) {
+                        union { u32x4 w; f16x8 hh; } t; t.w = sraw[i][P];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += (float)t.hh[e];
+                    } else {
+                        const h16x8 t = as_h16x8(sraw[i][P]);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += (float)t[e];
+                    }
+                }
             }
             if (!GEGLU && p.stats) {
                 // what the store will hold, per storage kind — the kind decided once per row, not inside the per-value expression (there
@@ -369,7 +385,7 @@ __device__ __forceinline__ void w_epilogue(const MudgGemmDesc& p, f32x4 (&acc)[N
         }
     };
     // the unpaired fifth fragment of the 320-wide tile: 4 consecutive channels per lane (8-byte operand / fp16 pieces)
-    auto piece4 = [&](auto uatag) __attribute__((always_inline)) {
+    auto piece4 = [&](auto uatag, auto rtag) __attribute__((always_inline)) {
         constexpr int J = 2 * NPAIR;
         constexpr bool UA = decltype(uatag)::value != 0;
         const int n = n0 + wave_single_col<NREP>(wc) + 4 * q4;
@@ -389,6 +405,17 @@ __device__ __forceinline__ void w_epilogue(const MudgGemmDesc& p, f32x4 (&acc)[N
             float v[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) { const float a = acc[i][J < NREP ? J : 0][e]; v[e] = UA ? a + bv[e] : alpha * a + bv[e]; }
+            if constexpr (DR) {
+                if constexpr (decltype(rtag)::value == 1) {
+                    union { u32x2 w; _Float16 hh[4]; } t; t.w = srs[i];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += (float)t.hh[e];
+                } else {
+                    Pack8 t; t.u = srs[i];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += (float)t.h[e];
+                }
+            }
             if (p.stats) {
                 float t[4];
                 if (OK == KIND_F32) {
@@ -441,19 +468,20 @@ __device__ __forceinline__ void w_epilogue(const MudgGemmDesc& p, f32x4 (&acc)[N
         }
     };
     const bool ua = UASPEC && alpha == 1.f;
+    using R0 = std::integral_constant<int, 0>; using R1 = std::integral_constant<int, 1>; using R2 = std::integral_constant<int, 2>;
     if constexpr (GEGLU) {
-        if (phi) { if (ua) piece8(T0{}, T1{}, T1{}); else piece8(T0{}, T0{}, T1{}); }
-        else { if (ua) piece8(T0{}, T1{}, T0{}); else piece8(T0{}, T0{}, T0{}); }
+        if (phi) { if (ua) piece8(T0{}, T1{}, T1{}, R0{}); else piece8(T0{}, T0{}, T1{}, R0{}); }
+        else { if (ua) piece8(T0{}, T1{}, T0{}, R0{}); else piece8(T0{}, T0{}, T0{}, R0{}); }
     } else {
-        if (ua) {
-            piece8(T0{}, T1{}, T0{});
-            if constexpr (NPAIR > 1) piece8(T1{}, T1{}, T0{});
-            if constexpr (NREP & 1) piece4(T1{});
-        } else {
-            piece8(T0{}, T0{}, T0{});
-            if constexpr (NPAIR > 1) piece8(T1{}, T0{}, T0{});
-            if constexpr (NREP & 1) piece4(T0{});
-        }
+        auto pieces = [&](auto uatag, auto rtag) __attribute__((always_inline)) {
+            piece8(T0{}, uatag, T0{}, rtag);
+            if constexpr (NPAIR > 1) piece8(T1{}, uatag, T0{}, rtag);
+            if constexpr (NREP & 1) piece4(uatag, rtag);
+        };
+        if constexpr (DR) {               // (alpha == 1: host-checked for every problem with a residual)
+            if (p.res_fp32 == KIND_F16) pieces(T1{}, R1{}); else pieces(T1{}, R2{});
+        } else if (ua) pieces(T1{}, R0{});
+        else pieces(T0{}, R0{});
         if (p.stats) {
             // per 288-row block (= this tile) and channel: M half 0 + M half 1
             __syncthreads();
@@ -1333,7 +1361,30 @@ template <int N> __device__ __forceinline__ void w_vmcnt_pieces(int c) {       /
     else { if constexpr (N == 4) W_VMCNT(16); else W_VMCNT(20); }
 }
 
-template <int MODE, int NREP, bool GEGLU, bool RS, int NI>
+// The same with EXTRA younger operations of the wave known to be in flight (the deferred residual pieces of wq_kernel).
+template <int N, int EXTRA> __device__ __forceinline__ void w_vmcnt_pieces_plus(int c) {
+    static_assert(N == 4 && EXTRA == 15, "literal counts below");
+    if (c <= 0) W_VMCNT(15);
+    else if (c == 1) W_VMCNT(19);
+    else if (c == 2) W_VMCNT(23);
+    else W_VMCNT(27);
+}
+// One residual piece requested WITHOUT the compiler's knowledge (inline assembly: its own bookkeeping would put a vmcnt(0) — the whole
+// DMA ring — in front of the first use); the caller guarantees arrival by a counted wait and pins the use behind it (w_pin).
+__device__ __forceinline__ u32x4 w_load16_async(const void* base, unsigned off) {          // base: wave-uniform (SGPR pair), off: the lane's byte offset
+    u32x4 r;
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(r) : "v"(off), "s"(base) : "memory");
+    return r;
+}
+__device__ __forceinline__ u32x2 w_load8_async(const void* base, unsigned off) {
+    u32x2 r;
+    asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(r) : "v"(off), "s"(base) : "memory");
+    return r;
+}
+__device__ __forceinline__ void w_pin(u32x4& r) { asm volatile("" : "+v"(r)); }
+__device__ __forceinline__ void w_pin(u32x2& r) { asm volatile("" : "+v"(r)); }
+
+template <int MODE, int NREP, bool GEGLU, int RS, int NI>          // RS: 0 = no residual, 1 = it seeds the accumulators, 2 = deferred (below)
 __global__ __launch_bounds__(512, 2) void wq_kernel(const MudgGemmDesc p, const int vflags, const float* __restrict__ phi) {
     using G = QGeo<NREP, NI>;
     constexpr int WBN = G::BN, KS = G::KS, R = G::R, NPAIR = NREP / 2, BMq = G::BM, NA = G::NA, PW = G::PW;
@@ -1430,6 +1481,7 @@ __global__ __launch_bounds__(512, 2) void wq_kernel(const MudgGemmDesc p, const 
         }
         amask[q] = mask;
     }
+    const int NH = 2 * (p.K / BK);                        // k halves (>= 2, even)
     auto advance = [&](KPos& k) {
         k.kt += 1;
         if (MODE == 0) { k.c += BK; return; }
@@ -1471,7 +1523,6 @@ __global__ __launch_bounds__(512, 2) void wq_kernel(const MudgGemmDesc p, const 
     };
 
     W_STAMP(0);
-    const int NH = 2 * (p.K / BK);                        // k halves (>= 2, even)
     KPos kS{0, 0, 0};
     int hs = 0, sslot = 0;                                // the next k half to stage and its slot
     auto stage_next = [&]() {
@@ -1481,10 +1532,23 @@ __global__ __launch_bounds__(512, 2) void wq_kernel(const MudgGemmDesc p, const 
         if (!(hs & 1)) advance(kS);
     };
     // RS (a residual seeds the accumulators) is a template parameter: as a run-time branch its merge point carried a vmcnt(0) — every tile
-    // waited for all the prefetched k halves before its first MFMA, residual or not.  The seeds are requested before the first k halves
-    // (as in wgemm_kernel): what the first MFMA needs — seeds and k half 0 — is then at the head of the queue.
+    // waited for all the prefetched k halves before its first MFMA, residual or not.
+    // DEFERRED RESIDUAL (RS = 2: the 160-row tile, 16-bit residual kinds).  The first k halves are requested FIRST, then the 15 residual pieces
+    // of the lane — raw, by loads the compiler does not track (w_load16_async), into 50 registers this loop leaves free — and the MFMAs
+    // start on zeroed accumulators; the waits for k halves 1 .. 3 (older than the pieces) allow 15 more operations in flight, the wait for
+    // k half 4 (younger) retires them, and the EPILOGUE adds them: ((x w + bias) + r), the order of the 128 x 128 one-tile kernels — with a
+    // 16-bit residual the tile's results are BIT-IDENTICAL to theirs (tools/exp_w160.py parity).  Built to take the residual off the
+    // path to the first MFMA (vector-memory results return in issue order, and profiles/r6/stamps.txt has a K = 320 workgroup spend 43 % of
+    // its life in front of it); measured: x 0.97 ... 1.03 of the seeded form on every shape (w160_shapes.txt) — the residual's bytes cost
+    // their bandwidth wherever they are requested.  Kept for the bits.  tests/test_isa_rules.py checks on the generated code that nothing
+    // touches the 50 pending registers before the counted wait in front of the epilogue.
+    constexpr bool DEFER = RS == 2;
+    static_assert(!DEFER || (G::DB && NREP == 5 && PLANES == 1), "deferred residual: the 160 x 320 tile of the 16-bit builds");
+    constexpr int NSEED = DEFER ? NI : 1;
+    u32x4 sraw[NSEED][2];
+    u32x2 srs[NSEED];
     f32x4 acc[NI][NREP];
-    if constexpr (RS) w_seed<NREP, NI>(p, acc, m0, n0, wr, wc, lane);
+    if constexpr (RS == 1) w_seed<NREP, NI>(p, acc, m0, n0, wr, wc, lane);
     else {
 #pragma unroll
         for (int i = 0; i < NI; ++i)
@@ -1497,6 +1561,27 @@ __global__ __launch_bounds__(512, 2) void wq_kernel(const MudgGemmDesc p, const 
 #pragma unroll
     for (int i = 0; i < R - 1; ++i)
         if (i < NH) stage_next();
+    constexpr int SEED_OPS = 3 * NI;                      // per lane: two 16-byte pieces and one 8-byte piece per row fragment
+    if constexpr (DEFER) {
+        {                     // every lane of every wave issues all of them (rows beyond M read the last row: never stored): the counts below rely on it
+            // addresses as wave-uniform bases (the tile's first row and the wave's columns) + one 32-bit offset per lane and row: 64-bit
+            // lane addresses for 15 requests at once spilled (and a spilled destination of an untracked load is garbage)
+            const int px = lane & 15, q4 = lane >> 4;
+            const char* Rt = reinterpret_cast<const char*>(p.R) + ((int64_t)m0 * p.ldr + n0) * 2;
+            const char* b0 = Rt + wave_pair_col<NREP>(wc, 0) * 2;
+            const char* b1 = Rt + wave_pair_col<NREP>(wc, 1) * 2;
+            const char* bs = Rt + wave_single_col<NREP>(wc) * 2;
+            const int rlast = (int)(p.M - 1 - m0);         // rows beyond M read the last row (never stored)
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int r = wr * (16 * NI) + 16 * i + px;
+                const unsigned off = (unsigned)((r < rlast ? r : rlast) * p.ldr) * 2u;
+                sraw[i][0] = w_load16_async(b0, off + 16u * q4);
+                sraw[i][1] = w_load16_async(b1, off + 16u * q4);
+                srs[i] = w_load8_async(bs, off + 8u * q4);
+            }
+        }
+    }
     const int fbyte0 = (lane & 15) * 64 + (lane >> 4) * 16;
     const int fbyte = fbyte0 ^ (((fbyte0 >> 9) & 1) << 5);
     const char* a_base = smem + (wr * NI) * 1024 + fbyte;
@@ -1505,7 +1590,8 @@ __global__ __launch_bounds__(512, 2) void wq_kernel(const MudgGemmDesc p, const 
     auto frag_b = [&](int slot, int j) { return *reinterpret_cast<const h16x8*>(b_base + slot * KS + j * 1024); };
     constexpr int NSET = G::DB ? 2 : 1;
     h16x8 fb[NSET][NREP], fa[NSET][NI];
-    w_vmcnt_pieces<PW>((NH < R - 1 ? NH : R - 1) - 1);    // k half 0 has landed
+    if constexpr (DEFER) w_vmcnt_pieces_plus<PW, SEED_OPS>((NH < R - 1 ? NH : R - 1) - 1);
+    else w_vmcnt_pieces<PW>((NH < R - 1 ? NH : R - 1) - 1);     // k half 0 has landed
     W_BARRIER();
     W_STAMP(1);
 #pragma unroll
@@ -1570,18 +1656,32 @@ __global__ __launch_bounds__(512, 2) void wq_kernel(const MudgGemmDesc p, const 
         multiply(cur_tag, nslot);
         slot = nslot;
     };
-    auto half = [&](int h, auto cur_tag) {
+    auto half = [&](int h, auto cur_tag, auto plus_tag) {
         const int nslot = slot == R - 1 ? 0 : slot + 1;
         if (h + 1 < NH) {
             const int last = NH - 1 < h + R - 2 ? NH - 1 : h + R - 2;          // the youngest k half issued so far
-            w_vmcnt_pieces<PW>(last - (h + 1));
+            if constexpr (decltype(plus_tag)::value != 0) w_vmcnt_pieces_plus<PW, SEED_OPS>(last - (h + 1));
+            else w_vmcnt_pieces<PW>(last - (h + 1));
         }
         W_BARRIER();
         if (hs < NH) stage_next();
         multiply(cur_tag, nslot);
         slot = nslot;
     };
+    using P0 = std::integral_constant<int, 0>; using P1 = std::integral_constant<int, DEFER ? 1 : 0>;
     int h = 0;
+    if constexpr (DEFER) {
+        // k halves 1 .. 3 were requested before the residual pieces: the waits of iterations 0 .. 2 leave the pieces in flight; k half 4
+        // after them: its wait (iteration 3) retires them (a shorter K: the vmcnt(0) in front of the epilogue does).
+        half(0, C0{}, P1{});
+        half(1, C1{}, P1{});
+        h = 2;
+        if (NH > 2) {
+            half(2, C0{}, P1{});
+            half(3, C1{}, P0{});
+            h = 4;
+        }
+    }
 #pragma unroll 1
     for (; h + R + 1 <= NH; h += 2) {                    // both k halves of the pair are steady: h + 1 <= NH - R
         steady((R - 1) & 1, C0{});
@@ -1590,11 +1690,16 @@ __global__ __launch_bounds__(512, 2) void wq_kernel(const MudgGemmDesc p, const 
     hs = h + R - 1 < NH ? h + R - 1 : NH;                 // (what the steady iterations staged; sslot followed them)
 #pragma unroll 1
     for (; h < NH; h += 2) {
-        half(h, C0{});
-        half(h + 1, C1{});
+        half(h, C0{}, P0{});
+        half(h + 1, C1{}, P0{});
     }
     W_STAMP(2);
-    w_epilogue<NREP, GEGLU, 2, true, NI>(p, acc, m0, n0, tm, wr, wc, lane, tid, tail, phi);
+    if constexpr (DEFER) {
+        W_VMCNT(0);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) { w_pin(sraw[i][0]); w_pin(sraw[i][1]); w_pin(srs[i]); }
+        w_epilogue<NREP, GEGLU, 2, true, NI, true>(p, acc, m0, n0, tm, wr, wc, lane, tid, tail, phi, sraw, srs);
+    } else w_epilogue<NREP, GEGLU, 2, true, NI>(p, acc, m0, n0, tm, wr, wc, lane, tid, tail, phi);
     W_STAMP(3);
 }
 #endif
@@ -1681,15 +1786,19 @@ static bool w160_ok(const MudgGemmDesc& d, int vflags) {
     if (mode == 2) return true;
     const int S = d.mode == 1 ? d.Hout * d.Wout : d.HW;
     if (S <= 0 || S % QBM != 0) return false;
-    // Measured per shape against the 128 x 128 kernels (tools/exp_w160.py, profiles/r6/w160_shapes.txt; MI355X, MDM512's frame batches):
-    // 3x3 convs + 30 ... + 45 %, temporal convs + 19 ... + 27 % at 2560- and 640-pixel frames; plain GEMMs + 13 ... + 35 % from K = 640 with
-    // N <= K, + 0 ... + 9 % for N = 2 ... 3 K, at K = 320 + 11 ... + 14 % without and - 2 ... - 3 % with a residual, - 2 ... - 6 % for N = 3 K;
-    // GEGLU - 9 ... - 22 % against the persistent 128 x 128 kernel (whose epilogue runs beside other workgroups' K loops).  One workgroup
-    // per CU wants a frame batch to bring enough tiles: the 160-pixel level (32 frames = 32 tile rows x 4 ... 8 columns: half the CUs)
-    // stays on the 128 x 128 kernels (- 20 ... - 30 % there).  Never M: S, K, N, the mode and whether there is a residual.
+    // Measured per shape against the 128 x 128 kernels, twice.  In isolation (tools/exp_w160.py, profiles/r6/w160_shapes.txt; MI355X, MDM512's
+    // frame batches, every operand hot in the 256-MiB Infinity Cache after the first repeat): 3x3 convs + 28 ... + 45 %, temporal convs + 14 ...
+    // + 27 % at 2560- and 640-pixel frames; plain GEMMs + 13 ... + 35 % from K = 640 with N <= K, + 0 ... + 9 % for N = 2 ... 3 K, at K = 320
+    // + 7 ... + 14 % without and - 2 ... - 3 % with a residual; GEGLU - 9 ... - 22 % against the persistent 128 x 128 kernel.  And INSIDE
+    // the step (tools/shape_profile.py 512 with GEMM_W160 = 0 / 1 / 2, profiles/r6/shapes_m512_w160_*.md), where a kernel's operands come
+    // from HBM or from its producer: convs + 12 ... + 27 %, temporal convs + 5 ... + 14 %, plain GEMMs + 11 ... + 16 % at K >= 1280 — and
+    // - 3 ... - 13 % at K = 320 / 640, where the one workgroup of a CU waits for its first k half alone while the 128 x 128 kernels have
+    // four workgroups per CU to cover for each other (the isolated timing hides it: its operands never leave the cache).  The rule follows
+    // the step.  One workgroup per CU wants a frame batch to bring enough tiles: the 160-pixel level (32 frames = 32 tile rows x 4 ... 8
+    // columns: half the CUs) stays on the 128 x 128 kernels (- 20 ... - 45 % there).  Never M: S, K, the mode.
     if (S < 640 || d.geglu) return false;
     if (d.mode != 0) return true;
-    return d.K >= 640 || (!d.R && d.N <= 2 * d.K);
+    return d.K >= 1280;
 }
 #endif
 // Height of the tile that will run the problem: 288, 160 or 0 (none of the kernels of this file).
@@ -1797,9 +1906,9 @@ extern "C" int mudg_debug_set_stamps(void* buf) {
 #endif
 
 #if MUDG_PLANES == 1
-template <int MODE, int NREP, bool GEGLU, bool RS, int NI>
+template <int MODE, int NREP, bool GEGLU, int RS, int NI>
 static int wq_launch_one(const MudgGemmDesc& d, int vflags, hipStream_t s, int slot) {
-    static bool attr_done[MAX_DEVICES][16] = {};
+    static bool attr_done[MAX_DEVICES][20] = {};
     const int dev = mudg_current_device();
     if (dev < 0) MUDG_FAIL(MUDG_ELAUNCH, "gemm: no current device");
     using G = QGeo<NREP, NI>;
@@ -1819,10 +1928,13 @@ int mudg_wgemm_launch(const MudgGemmDesc& d, int vflags, hipStream_t s) {
 #if MUDG_PLANES == 1
     const int rows = mudg_wgemm_rows(d, vflags);
     if (rows == QBM) {
-        if (d.geglu) return wq_launch_one<0, 4, true, false, 5>(d, vflags, s, 6);
-        if (d.mode == 0) return d.R ? wq_launch_one<0, 5, false, true, 5>(d, vflags, s, 0) : wq_launch_one<0, 5, false, false, 5>(d, vflags, s, 1);
-        if (d.mode == 1) return d.R ? wq_launch_one<1, 5, false, true, 5>(d, vflags, s, 2) : wq_launch_one<1, 5, false, false, 5>(d, vflags, s, 3);
-        return d.R ? wq_launch_one<2, 5, false, true, 5>(d, vflags, s, 4) : wq_launch_one<2, 5, false, false, 5>(d, vflags, s, 5);
+        if (d.geglu) return wq_launch_one<0, 4, true, 0, 5>(d, vflags, s, 6);
+        // a residual of 16-bit storage (the fp16 stream, an operand matrix) is deferred to the epilogue, an fp32 one seeds the accumulators.
+        // Variant switch GEMM_W160DEFER = 0: every residual seeds.
+        const int rs = !d.R ? 0 : ((d.res_fp32 != KIND_F32 && mudg_variant("GEMM_W160DEFER", 1)) ? 2 : 1);
+        if (d.mode == 0) return rs == 0 ? wq_launch_one<0, 5, false, 0, 5>(d, vflags, s, 0) : (rs == 1 ? wq_launch_one<0, 5, false, 1, 5>(d, vflags, s, 1) : wq_launch_one<0, 5, false, 2, 5>(d, vflags, s, 14));
+        if (d.mode == 1) return rs == 0 ? wq_launch_one<1, 5, false, 0, 5>(d, vflags, s, 2) : (rs == 1 ? wq_launch_one<1, 5, false, 1, 5>(d, vflags, s, 3) : wq_launch_one<1, 5, false, 2, 5>(d, vflags, s, 15));
+        return rs == 0 ? wq_launch_one<2, 5, false, 0, 5>(d, vflags, s, 4) : (rs == 1 ? wq_launch_one<2, 5, false, 1, 5>(d, vflags, s, 5) : wq_launch_one<2, 5, false, 2, 5>(d, vflags, s, 16));
     }
 #ifdef MUDG_DEBUG_VARIANTS
     // The 288-row tile on the loop of the 160-row one (wq_kernel<..., 9>), variant builds only.  Variant switch GEMM_W288Q: 0 = never (the
@@ -1831,10 +1943,10 @@ int mudg_wgemm_launch(const MudgGemmDesc& d, int vflags, hipStream_t s) {
     // GEMMs x 0.85 ... 1.07, GEGLU (one-tile against the persistent six-phase form) x 0.90 ... 0.98 — the same bits and no gain: two
     // different schedules of the same 45 MFMAs, 14 fragment reads and 38 DMA pieces per k half end at the same 1300 - 1430 TFLOP/s.
     if (mudg_variant("GEMM_W288P", 1) != 2 && mudg_variant("GEMM_W288Q", 0) == 2) {
-        if (d.geglu) return wq_launch_one<0, 4, true, false, 9>(d, vflags, s, 13);
-        if (d.mode == 0) return d.R ? wq_launch_one<0, 5, false, true, 9>(d, vflags, s, 7) : wq_launch_one<0, 5, false, false, 9>(d, vflags, s, 8);
-        if (d.mode == 1) return d.R ? wq_launch_one<1, 5, false, true, 9>(d, vflags, s, 9) : wq_launch_one<1, 5, false, false, 9>(d, vflags, s, 10);
-        return d.R ? wq_launch_one<2, 5, false, true, 9>(d, vflags, s, 11) : wq_launch_one<2, 5, false, false, 9>(d, vflags, s, 12);
+        if (d.geglu) return wq_launch_one<0, 4, true, 0, 9>(d, vflags, s, 13);
+        if (d.mode == 0) return d.R ? wq_launch_one<0, 5, false, 1, 9>(d, vflags, s, 7) : wq_launch_one<0, 5, false, 0, 9>(d, vflags, s, 8);
+        if (d.mode == 1) return d.R ? wq_launch_one<1, 5, false, 1, 9>(d, vflags, s, 9) : wq_launch_one<1, 5, false, 0, 9>(d, vflags, s, 10);
+        return d.R ? wq_launch_one<2, 5, false, 1, 9>(d, vflags, s, 11) : wq_launch_one<2, 5, false, 0, 9>(d, vflags, s, 12);
     }
 #endif
     if (d.geglu && half_height_ok(d)) return hgeglu_launch(d, vflags, s);

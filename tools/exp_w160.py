@@ -138,6 +138,20 @@ if what in ("parity", "all"):
     print(f"20 repeats bit-identical: gemm {same}, conv {same_c}", flush=True)
     if not (same and same_c):
         fails += 1
+    # the deferred residual (the default) against the residual as seeds: the same values up to the order of one fp32 addition
+    os.environ["MUDG_GEMM_W288"] = "0"
+    for M, N, K in ((160 * 5 + 3, 640, 320), (160 * 3, 320, 64), (160 * 4, 320, 128), (160 * 6, 960, 1280)):
+        x, w, b, r = rn(M, K), rn(N, K), torch.randn(N, device="cuda"), rs(M, N)
+        ys = []
+        for dv in ("1", "0"):
+            os.environ["MUDG_GEMM_W160"], os.environ["MUDG_GEMM_W160DEFER"] = "2", dv
+            ys.append(ops.gemm(x, w, bias=b, residual=r, out_stream=True, stats=True, frame_rows=160))
+        e = rel(ys[0], ys[1])
+        ok = e < 2e-3 and bool(torch.isfinite(ys[0].float()).all())
+        fails += not ok
+        print(f"gemm {M}x{N}x{K} residual deferred vs seeded: rel-L2 {e:.2e}" + ("" if ok else "   <-- FAIL"), flush=True)
+    os.environ["MUDG_GEMM_W160"], os.environ["MUDG_GEMM_W288"] = "1", "1"
+    os.environ.pop("MUDG_GEMM_W160DEFER", None)
     print(f"PARITY {'OK' if not fails else 'FAILED: %d' % fails}", flush=True)
 
 if what in ("time", "all"):
@@ -157,8 +171,15 @@ if what in ("time", "all"):
             b = torch.randn(N, device="cuda")
             r = rs(M, N) if resid else None
             ts = t2(lambda: ops.gemm(x, w, bias=b, residual=r, out_stream=bool(resid), frame_rows=hw))
+            extra = ""
+            if resid:               # the residual seeding the accumulators (GEMM_W160DEFER = 0) instead of deferred to the epilogue
+                os.environ["MUDG_GEMM_W160"], os.environ["MUDG_GEMM_W160DEFER"] = "2", "0"
+                tsd = timeit(lambda: ops.gemm(x, w, bias=b, residual=r, out_stream=True, frame_rows=hw), iters=10)
+                os.environ["MUDG_GEMM_W160"] = "1"
+                os.environ.pop("MUDG_GEMM_W160DEFER", None)
+                extra = f" | residual as seeds {tsd*1e6:8.1f} us (deferral x{tsd/ts[1]:.3f})"
             print(f"gemm {M} {N} {K} residual={resid}: 128x128 {ts[0]*1e6:8.1f} us {2.0*M*N*K/ts[0]/1e12:7.1f} TF | 160x320 {ts[1]*1e6:8.1f} us {2.0*M*N*K/ts[1]/1e12:7.1f} TF"
-                  f"  x{ts[0]/ts[1]:.3f}", flush=True)
+                  f"  x{ts[0]/ts[1]:.3f}{extra}", flush=True)
     for (M, N, K, hw) in [(81920, 2560, 320, 2560), (20480, 5120, 640, 640), (5120, 10240, 1280, 160)]:
         x, w, b = rn(M, K), rn(N, K), torch.randn(N, device="cuda")
         ts = t2(lambda: ops.gemm(x, w, bias=b, geglu=True, frame_rows=hw))
