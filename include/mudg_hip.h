@@ -101,7 +101,7 @@ typedef struct MudgGemmDesc {
     /* mode 2 */
     int T, HW;            /* mode 0: HW may carry a HINT — the rows of one frame of the matrix (0 = none): it lets the library choose a tile
                              height that divides a frame (mudg_gemm_stats_rows).  Never M decides, so a row's result does not depend on
-                             the batch it travels in; with a residual R the 288- and 160-row tiles add R first instead of last (last-bit
+                             the batch it travels in; with a residual R the 288-row tile (and the 160-row tile for an fp32 R) adds R first instead of last (last-bit
                              differences against the un-hinted call), without one the bits are the same */
     float* stats;         /* NULL, or fp32 [ceil(M/rows)][Nout][2], rows = mudg_gemm_stats_rows(d) (128 | 160 | 288): the epilogue also writes, per row block and output
                              channel, the sum and the sum of squares of the values it stored (as stored: after rounding to

@@ -1331,7 +1331,8 @@ __global__ __launch_bounds__(256, 2) void hgeglu_kernel(const MudgGemmDesc p, co
 //     s_waitcnt lgkmcnt(0)       the fragments of k half h (requested under the MFMAs of k half h - 1)
 //     fragments of k half h + 1  (5 W + 5 X reads into the other register set) | 25 MFMAs of k half h
 // Bits: the K order and the per-row arithmetic of every other contraction kernel; without a residual identical to the 128 x 128 kernels,
-// with one the sum is ((r + x w) + bias) as on the 288-row tile — so the rule (mudg_wgemm_rows) looks at the frame geometry, never at M.
+// and with a 16-bit one too (it is added by the epilogue, after the bias: RS = 2 below); an fp32 residual seeds the accumulators as on the
+// 288-row tile — ((r + x w) + bias) — so the rule (mudg_wgemm_rows) looks at the frame geometry, never at M.
 // The same skeleton carries TWO tile heights (NI = 16-row fragments per wave and M half): NI = 5 — 160 rows, above — and, in the variant
 // builds only (GEMM_W288Q, a measurement: mudg_wgemm_launch), NI = 9 — 288 rows, the tile of wgemm_kernel on this loop: what took the 160-row
 // loop from 1050 to 1290 TFLOP/s (fragment reads between the MFMAs, no branch in the steady state, one barrier per k half) applied to the
