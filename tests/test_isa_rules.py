@@ -66,13 +66,15 @@ def test_deferred_residual_registers_are_untouched_until_the_counted_wait(wgemm_
 
 
 def test_tile_kernels_of_wgemm_do_not_spill(wgemm_asm):
-    """A scratch reload inside a K loop is a vector-memory operation the hand-counted vmcnt waits do not know (and it carries its own
-    vmcnt(0): the DMA ring drains)."""
+    """A scratch reload inside a K loop is a vector-memory operation the hand-counted vmcnt waits of these kernels do not know (and it
+    carries its own vmcnt(0): the DMA ring drains).  Every kernel of the file — the 288-row tile in its one-tile and persistent forms, the
+    half-height GEGLU kernel, the 160-row tile — is held to zero scratch in the release build."""
     md = wgemm_asm[wgemm_asm.index("amdhsa.kernels"):]
-    seen = 0
+    seen = {}
     for m in re.finditer(r"\.name:\s+(\S+).*?\.private_segment_fixed_size:\s+(\d+)", md, re.S):
         name, scratch = m.group(1), int(m.group(2))
-        if "wq_kernel" in name and "ELi5EEE" in name:          # the 160-row instantiations (release builds)
-            seen += 1
-            assert scratch == 0, (name, scratch)
-    assert seen >= 10
+        for family in ("wq_kernel", "wgemm_kernel", "wgemm_pkernel", "hgeglu_kernel"):
+            if family in name:
+                seen[family] = seen.get(family, 0) + 1
+                assert scratch == 0, (name, scratch)
+    assert seen.get("wq_kernel", 0) >= 10 and seen.get("wgemm_kernel", 0) >= 4 and seen.get("wgemm_pkernel", 0) >= 2 and seen.get("hgeglu_kernel", 0) >= 2, seen
